@@ -1,0 +1,128 @@
+"""ctypes binding of libhallucidet_hip.so (the C ABI in include/hallucidet_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails the
+product path raises.  torch is used here only to obtain device pointers and the
+current HIP stream.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhallucidet_hip.so")
+
+HD_ACT_NONE, HD_ACT_RELU, HD_ACT_SIGMOID = 0, 1, 2
+HD_OUT_NHWC_F16, HD_OUT_NCHW_F32 = 0, 1
+
+c_i32 = C.c_int32
+c_i64 = C.c_int64
+c_f = C.c_float
+c_d = C.c_double
+vp = C.c_void_p
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipCallError(RuntimeError):
+    pass
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x2", vp), ("w", vp), ("bias", vp), ("res", vp), ("y", vp), ("stats", vp),
+        ("N", c_i32), ("Hsrc", c_i32), ("Wsrc", c_i32), ("Hin", c_i32), ("Win", c_i32),
+        ("C1", c_i32), ("C2", c_i32), ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
+        ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32),
+        ("up1", c_i32), ("in_dil", c_i32), ("act", c_i32), ("out_mode", c_i32),
+    ]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [
+        ("x", vp), ("x2", vp), ("dy", vp), ("slab", vp),
+        ("N", c_i32), ("Hsrc", c_i32), ("Wsrc", c_i32), ("Hin", c_i32), ("Win", c_i32),
+        ("C1", c_i32), ("C2", c_i32), ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
+        ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32), ("up1", c_i32),
+        ("nsplit", c_i32),
+    ]
+
+
+# name -> (restype, argtypes).  Must list every symbol include/hallucidet_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+PROTOTYPES = {
+    "hd_abi_version": (C.c_int, []),
+    "hd_last_error": (C.c_char_p, []),
+    "hd_arch": (C.c_char_p, []),
+    "hd_conv2d": (C.c_int, [C.POINTER(ConvArgs), vp]),
+    "hd_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvArgs)]),
+    "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
+    "hd_wgrad_reduce": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
+    "hd_weight_prep": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_colsum": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
+    "hd_bn_finalize": (C.c_int, [vp, C.c_int, c_d, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),
+    "hd_bn_eval_scale_shift": (C.c_int, [vp, vp, vp, vp, c_f, C.c_int, vp, vp, vp]),
+    "hd_bn_apply": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, C.c_int, vp]),
+    "hd_bn_bwd_reduce": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, C.c_int, C.c_int, vp]),
+    "hd_bn_bwd_apply": (C.c_int, [vp] * 11 + [c_f, C.c_int, c_i64, C.c_int, C.c_int, vp]),
+    "hd_maxpool3x3s2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_maxpool3x3s2_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_subsample2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_subsample2_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
+    "hd_nchw_to_nhwc_resize": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
+    "hd_nchw_to_nhwc_resize_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, vp]),
+    "hd_nhwc_to_nchw": (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp]),
+    "hd_upsample_add": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_upsample_add_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
+    "hd_upsample2_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
+    "hd_add_f16": (C.c_int, [vp, vp, vp, c_i64, vp]),
+    "hd_slice_channels": (C.c_int, [vp, vp, c_i64, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "hd_sigmoid_bwd_nchw_to_nhwc": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [c_f, vp]),
+    "hd_relu_bwd": (C.c_int, [vp, vp, vp, c_i64, vp]),
+    "hd_f32_to_f16": (C.c_int, [vp, vp, c_i64, c_f, vp]),
+    "hd_f16_to_f32": (C.c_int, [vp, vp, c_i64, c_f, vp]),
+    "hd_channel_sum_f16": (C.c_int, [vp, c_i64, C.c_int, vp, C.c_int, vp]),
+    "hd_scale_store": (C.c_int, [vp, vp, C.c_int, c_f, C.c_int, vp]),
+    "hd_nms_sorted_batched": (C.c_int, [vp, vp, C.c_int, C.c_int, c_f, vp, vp, vp]),
+    "hd_roi_align": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
+    "hd_roi_align_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
+    "hd_box_iou": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
+    "hd_adam_step": (C.c_int, [vp, vp, vp, vp, c_i64] + [c_f] * 9 + [vp, vp]),
+    "hd_check_finite": (C.c_int, [vp, c_i64, vp, vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises HipLibraryMissing when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            "libhallucidet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python hallucidet_amd/build.py`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().hd_last_error().decode("utf-8", "replace")
+        raise HipCallError("%s failed with status %d: %s" % (what, rc, msg))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,15 @@
+#include "hd_common.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+
+void hd_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" int hd_abi_version(void) { return 1; }
+extern "C" const char* hd_last_error(void) { return g_err; }
+extern "C" const char* hd_arch(void) { return "gfx950"; }

@@ -1,0 +1,261 @@
+// Detection kernels: batched greedy NMS (64-wide bitmask rows: one wavefront lane per
+// mask bit), RoIAlign forward/backward, pairwise IoU.  fp32 box maths with FMA
+// contraction disabled so the keep decisions match the scalar CPU oracle bit for bit.
+#include "hd_common.h"
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float box_iou_dev(const float* a, const float* b) {
+  float area_a = (a[2] - a[0]) * (a[3] - a[1]);
+  float area_b = (b[2] - b[0]) * (b[3] - b[1]);
+  float xx1 = fmaxf(a[0], b[0]), yy1 = fmaxf(a[1], b[1]);
+  float xx2 = fminf(a[2], b[2]), yy2 = fminf(a[3], b[3]);
+  float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+  float inter = w * h;
+  return inter / (area_a + area_b - inter);
+}
+
+// grid (colblk, rowblk, B), block 64.  mask[b][i][colblk] bit j set <=> IoU(box i, box col*64+j) > thr, j-index > i
+__global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __restrict__ counts, int nmax, float thr,
+                                uint64_t* __restrict__ mask) {
+  const int b = blockIdx.z;
+  const int n = counts[b];
+  const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+  if (row0 >= n || col0 >= n || blockIdx.x < blockIdx.y) return;
+  const int cb = (nmax + 63) / 64;
+  __shared__ float cbx[64 * 4];
+  const float* bb = boxes + (size_t)b * nmax * 4;
+  int t = threadIdx.x;
+  int ncol = min(64, n - col0);
+  if (t < ncol) {
+    cbx[t * 4 + 0] = bb[(col0 + t) * 4 + 0];
+    cbx[t * 4 + 1] = bb[(col0 + t) * 4 + 1];
+    cbx[t * 4 + 2] = bb[(col0 + t) * 4 + 2];
+    cbx[t * 4 + 3] = bb[(col0 + t) * 4 + 3];
+  }
+  __syncthreads();
+  int i = row0 + t;
+  if (i < n) {
+    float me[4] = {bb[i * 4], bb[i * 4 + 1], bb[i * 4 + 2], bb[i * 4 + 3]};
+    uint64_t m = 0;
+    int start = (row0 == col0) ? t + 1 : 0;
+    for (int j = start; j < ncol; ++j)
+      if (box_iou_dev(me, cbx + j * 4) > thr) m |= (1ull << j);
+    mask[((size_t)b * nmax + i) * cb + blockIdx.x] = m;
+  }
+}
+
+// one wavefront per image: lane w owns removed-word w (and w+64, ... for n > 4096)
+__global__ void nms_reduce_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ counts, int nmax,
+                                  uint8_t* __restrict__ keep) {
+  const int b = blockIdx.x;
+  const int n = counts[b];
+  const int cb = (nmax + 63) / 64;
+  const int lane = threadIdx.x;  // 64
+  constexpr int MAXW = 4;        // supports nmax <= 64*64*4 = 16384
+  uint64_t remv[MAXW];
+#pragma unroll
+  for (int k = 0; k < MAXW; ++k) remv[k] = 0;
+  const uint64_t* mb = mask + (size_t)b * nmax * cb;
+  uint8_t* kb = keep + (size_t)b * nmax;
+  const int nchunks = (n + 63) / 64;
+  for (int c = 0; c < nchunks; ++c) {
+    // removed word for this chunk lives in lane (c & 63), slot c >> 6
+    uint64_t word = 0;
+#pragma unroll
+    for (int k = 0; k < MAXW; ++k)
+      if ((c >> 6) == k) word = __shfl(remv[k], c & 63);
+    const int i = c * 64 + lane;
+    // diagonal word of my row
+    uint64_t diag = (i < n) ? mb[(size_t)i * cb + c] : 0;
+    // serial resolve inside the chunk (ALU only)
+    uint64_t alive = ~word;
+    int lim = min(64, n - c * 64);
+    uint64_t keepbits = 0;
+    for (int j = 0; j < lim; ++j) {
+      uint64_t dj = __shfl(diag, j);
+      if ((alive >> j) & 1ull) {
+        keepbits |= (1ull << j);
+        alive &= ~dj;
+      }
+    }
+    if (i < n) kb[i] = (uint8_t)((keepbits >> lane) & 1ull);
+    // OR the rows of every kept box of this chunk into the removed words (beyond this chunk)
+    for (int j = 0; j < lim; ++j) {
+      if (!((keepbits >> j) & 1ull)) continue;
+      const uint64_t* row = mb + (size_t)(c * 64 + j) * cb;
+#pragma unroll
+      for (int k = 0; k < MAXW; ++k) {
+        int w = k * 64 + lane;
+        if (w > c && w < nchunks) remv[k] |= row[w];
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ RoIAlign
+struct Bilin {
+  int yl, xl, yh, xh;
+  float w1, w2, w3, w4;
+  bool valid;
+};
+
+__device__ __forceinline__ Bilin bilin_setup(float y, float x, int H, int W) {
+  Bilin b;
+  b.valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
+  if (y <= 0.f) y = 0.f;
+  if (x <= 0.f) x = 0.f;
+  int yl = (int)y, xl = (int)x, yh, xh;
+  if (yl >= H - 1) {
+    yh = yl = H - 1;
+    y = (float)yl;
+  } else
+    yh = yl + 1;
+  if (xl >= W - 1) {
+    xh = xl = W - 1;
+    x = (float)xl;
+  } else
+    xh = xl + 1;
+  float ly = y - (float)yl, lx = x - (float)xl;
+  float hy = 1.f - ly, hx = 1.f - lx;
+  b.yl = yl; b.xl = xl; b.yh = yh; b.xh = xh;
+  b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
+  return b;
+}
+
+__global__ void roi_align_kernel(const f16* __restrict__ feat, const float* __restrict__ rois, f16* __restrict__ out, int R,
+                                 int H, int W, int C, int PH, int PW, float scale, int sr) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)R * PH * PW * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t q = i / vecs;
+    int pw = (int)(q % PW);
+    int ph = (int)((q / PW) % PH);
+    int r = (int)(q / ((int64_t)PW * PH));
+    const float* roi = rois + (size_t)r * 5;
+    int n = (int)roi[0];
+    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+    float bh = rh / (float)PH, bw = rw / (float)PW;
+    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
+    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
+    float count = fmaxf((float)(gh * gw), 1.f);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const f16* fb = feat + (size_t)n * H * W * C + v * 8;
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
+        Bilin b = bilin_setup(y, x, H, W);
+        if (!b.valid) continue;
+        f16x8 v1 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xl) * C);
+        f16x8 v2 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xh) * C);
+        f16x8 v3 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xl) * C);
+        f16x8 v4 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xh) * C);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += b.w1 * (float)v1[k] + b.w2 * (float)v2[k] + b.w3 * (float)v3[k] + b.w4 * (float)v4[k];
+      }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] / count);
+    *reinterpret_cast<f16x8*>(out + (size_t)q * C + v * 8) = o;
+  }
+}
+
+__global__ void roi_align_bwd_kernel(const f16* __restrict__ dout, const float* __restrict__ rois, float* __restrict__ dfeat, int R,
+                                     int H, int W, int C, int PH, int PW, float scale, int sr) {
+  const int64_t total = (int64_t)R * PH * PW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    int64_t q = i / C;
+    int pw = (int)(q % PW);
+    int ph = (int)((q / PW) % PH);
+    int r = (int)(q / ((int64_t)PW * PH));
+    const float* roi = rois + (size_t)r * 5;
+    int n = (int)roi[0];
+    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+    float bh = rh / (float)PH, bw = rw / (float)PW;
+    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
+    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
+    float count = fmaxf((float)(gh * gw), 1.f);
+    float g = (float)dout[i] / count;
+    if (g == 0.f) continue;
+    float* fb = dfeat + (size_t)n * H * W * C + c;
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
+        Bilin b = bilin_setup(y, x, H, W);
+        if (!b.valid) continue;
+        atomicAdd(fb + ((size_t)b.yl * W + b.xl) * C, g * b.w1);
+        atomicAdd(fb + ((size_t)b.yl * W + b.xh) * C, g * b.w2);
+        atomicAdd(fb + ((size_t)b.yh * W + b.xl) * C, g * b.w3);
+        atomicAdd(fb + ((size_t)b.yh * W + b.xh) * C, g * b.w4);
+      }
+    }
+  }
+}
+
+__global__ void box_iou_kernel(const float* __restrict__ gt, int G, const float* __restrict__ boxes, int A, float* __restrict__ iou) {
+  const int64_t total = (int64_t)G * A;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int a = (int)(i % A), g = (int)(i / A);
+    iou[i] = box_iou_dev(gt + g * 4, boxes + (size_t)a * 4);
+  }
+}
+
+}  // namespace
+
+extern "C" int hd_nms_sorted_batched(const float* boxes, const int* counts, int B, int nmax, float iou_thr, uint64_t* mask_ws,
+                                     uint8_t* keep, void* stream) {
+  HD_CHECK_ARG(boxes && counts && mask_ws && keep && B > 0 && nmax > 0 && nmax <= 16384, "hd_nms_sorted_batched: bad args (nmax<=16384)");
+  hipStream_t s = (hipStream_t)stream;
+  int cb = (nmax + 63) / 64;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(64), 0, s, boxes, counts, nmax, iou_thr, mask_ws);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask_ws, counts, nmax, keep);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_align(const void* feat, const float* rois, void* out, int R, int N, int H, int W, int C, int PH, int PW,
+                            float spatial_scale, int sampling_ratio, void* stream) {
+  HD_CHECK_ARG(feat && rois && out && R >= 0 && C % 8 == 0 && N > 0, "hd_roi_align: bad args");
+  if (R == 0) return HD_OK;
+  int64_t total = (int64_t)R * PH * PW * C / 8;
+  int g = (int)((total + 255) / 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(roi_align_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const f16*)feat, rois, (f16*)out, R, H, W, C, PH, PW,
+                     spatial_scale, sampling_ratio);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int R, int N, int H, int W, int C, int PH,
+                                int PW, float spatial_scale, int sampling_ratio, void* stream) {
+  HD_CHECK_ARG(dout && rois && dfeat_f32 && R >= 0 && N > 0, "hd_roi_align_bwd: bad args");
+  if (R == 0) return HD_OK;
+  int64_t total = (int64_t)R * PH * PW * C;
+  int g = (int)((total + 255) / 256);
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, rois, dfeat_f32, R, H, W, C, PH,
+                     PW, spatial_scale, sampling_ratio);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream) {
+  HD_CHECK_ARG(gt && boxes && iou && G >= 0 && A >= 0, "hd_box_iou: bad args");
+  if (G == 0 || A == 0) return HD_OK;
+  int64_t total = (int64_t)G * A;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(box_iou_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, gt, G, boxes, A, iou);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}

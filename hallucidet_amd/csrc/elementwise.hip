@@ -1,0 +1,751 @@
+// Bandwidth-bound kernels of the hot path: BatchNorm pieces, pooling, resampling,
+// layout conversion.  All activations NHWC f16, 8 halves (16 B) per lane.
+#include "hd_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+
+__device__ __forceinline__ f16x8 ld8(const f16* p) { return *reinterpret_cast<const f16x8*>(p); }
+__device__ __forceinline__ void st8(f16* p, f16x8 v) { *reinterpret_cast<f16x8*>(p) = v; }
+
+inline int grid_for(int64_t work, int per_block = TB, int cap = 256 * 16) {
+  int64_t g = (work + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- column sum
+// in [rows][W] fp32 -> out[r2][W]; grid (ceil(W/64), R2), block 256 = 4 row lanes x 64 cols
+__global__ void colsum_stage(const float* __restrict__ in, int rows, int W, float* __restrict__ out, int R2) {
+  __shared__ double red[4][64];
+  int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  int rl = threadIdx.x >> 6;
+  int per = (rows + R2 - 1) / R2;
+  int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  double s = 0.0;
+  if (c < W)
+    for (int r = r0 + rl; r < r1; r += 4) s += (double)in[(size_t)r * W + c];
+  red[rl][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rl == 0 && c < W) out[(size_t)blockIdx.y * W + c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---------------------------------------------------------------- BN finalize
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
+                                   float eps, float* mean, float* invstd, float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double m = (double)sums[c] / count;
+  double var = (double)sums[C + c] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  float is = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  if (mean) mean[c] = (float)m;
+  if (invstd) invstd[c] = is;
+  scale[c] = g * is;
+  shift[c] = b - (float)m * g * is;
+  if (running_mean) {
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
+                               float* scale, float* shift) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float is = 1.f / sqrtf(rv[c] + eps);
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - rm[c] * g * is;
+}
+
+// ---------------------------------------------------------------- BN apply (+res) (+relu)
+__global__ void bn_apply_kernel(const f16* __restrict__ y, const f16* __restrict__ res, const float* __restrict__ scale,
+                                const float* __restrict__ shift, f16* __restrict__ z, int64_t nvec, int C, int relu) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    int c0 = (int)((i * 8) % C);
+    f16x8 v = ld8(y + i * 8);
+    f16x8 r;
+    if (res) r = ld8(res + i * 8);
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float f = (float)v[k] * scale[c0 + k] + shift[c0 + k];
+      if (res) f += (float)r[k];
+      if (relu) f = fmaxf(f, 0.f);
+      o[k] = (f16)f;
+    }
+    st8(z + i * 8, o);
+  }
+}
+
+// ---------------------------------------------------------------- BN backward
+// thread tid = pl*vecs + v ; v = channel vector (8 ch), pl = pixel lane
+__global__ void bn_bwd_reduce_kernel(const f16* __restrict__ dz, const f16* __restrict__ z, const f16* __restrict__ y,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     float* __restrict__ part, int64_t npix, int C, int relu) {
+  extern __shared__ float sm[];  // [256][16]
+  const int vecs = C / 8;
+  const int plan = TB / vecs;
+  const int v = threadIdx.x % vecs, pl = threadIdx.x / vecs;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * per, p1 = min(npix, p0 + per);
+  float sg[8], sgx[8], mu[8], is[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sg[k] = sgx[k] = 0.f;
+    mu[k] = mean[v * 8 + k];
+    is[k] = invstd[v * 8 + k];
+  }
+  if (pl < plan) {
+    for (int64_t p = p0 + pl; p < p1; p += plan) {
+      size_t off = (size_t)p * C + v * 8;
+      f16x8 g = ld8(dz + off), yy = ld8(y + off), zz;
+      if (relu) zz = ld8(z + off);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float gk = (float)g[k];
+        if (relu && !((float)zz[k] > 0.f)) gk = 0.f;
+        float xh = ((float)yy[k] - mu[k]) * is[k];
+        sg[k] += gk;
+        sgx[k] += gk * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sm[threadIdx.x * 16 + k] = sg[k];
+    sm[threadIdx.x * 16 + 8 + k] = sgx[k];
+  }
+  __syncthreads();
+  // 2*C outputs: index o = which*C + c
+  for (int o = threadIdx.x; o < 2 * C; o += TB) {
+    int which = o / C, c = o - which * C;
+    int vv = c / 8, k = c & 7;
+    float s = 0.f;
+    for (int q = 0; q < plan; ++q) s += sm[(q * vecs + vv) * 16 + which * 8 + k];
+    part[(size_t)blockIdx.x * 2 * C + o] = s;
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const f16* __restrict__ dz, const f16* __restrict__ z, const f16* __restrict__ y,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const float* __restrict__ sums, f16* __restrict__ dy,
+                                    f16* __restrict__ dres, float* dgamma, float* dbeta, float gscale, int accumulate,
+                                    int64_t npix, int C, int relu) {
+  const float invM = 1.f / (float)npix;
+  const int64_t nvec = npix * C / 8;
+  if (blockIdx.x == 0) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float dg = sums[C + c] * gscale, db = sums[c] * gscale;
+      if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+      if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+    }
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    int c0 = (int)((i * 8) % C);
+    f16x8 g = ld8(dz + i * 8), yy = ld8(y + i * 8), zz;
+    if (relu) zz = ld8(z + i * 8);
+    f16x8 o, gr;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int c = c0 + k;
+      float gk = (float)g[k];
+      if (relu && !((float)zz[k] > 0.f)) gk = 0.f;
+      float xh = ((float)yy[k] - mean[c]) * invstd[c];
+      float ga = gamma ? gamma[c] : 1.f;
+      float d = ga * invstd[c] * (gk - sums[c] * invM - xh * sums[C + c] * invM);
+      o[k] = (f16)d;
+      gr[k] = (f16)gk;
+    }
+    st8(dy + i * 8, o);
+    if (dres) st8(dres + i * 8, gr);
+  }
+}
+
+// ---------------------------------------------------------------- maxpool 3x3 s2 p1
+__global__ void maxpool_kernel(const f16* __restrict__ x, f16* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * Ho * Wo * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int wo = (int)(p % Wo);
+    int ho = (int)((p / Wo) % Ho);
+    int n = (int)(p / ((int64_t)Wo * Ho));
+    float m[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[k] = -INFINITY;
+    for (int kh = 0; kh < 3; ++kh) {
+      int h = ho * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        int w = wo * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        f16x8 t = ld8(x + ((size_t)(n * H + h) * W + w) * C + v * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m[k] = fmaxf(m[k], (float)t[k]);
+      }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)m[k];
+    st8(y + (size_t)p * C + v * 8, o);
+  }
+}
+
+// gather-form backward: first maximal element in (kh,kw) scan order receives the gradient (ATen rule: strict >)
+__global__ void maxpool_bwd_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, f16* __restrict__ dx, int N, int H,
+                                   int W, int C, int Ho, int Wo) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * H * W * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int w = (int)(p % W);
+    int h = (int)((p / W) % H);
+    int n = (int)(p / ((int64_t)W * H));
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    int ho0 = max(0, h / 2), ho1 = min(Ho - 1, (h + 1) / 2);
+    int wo0 = max(0, w / 2), wo1 = min(Wo - 1, (w + 1) / 2);
+    for (int ho = ho0; ho <= ho1; ++ho)
+      for (int wo = wo0; wo <= wo1; ++wo) {
+        // my position inside this window
+        int mykh = h - (ho * 2 - 1), mykw = w - (wo * 2 - 1);
+        if (mykh < 0 || mykh > 2 || mykw < 0 || mykw > 2) continue;
+        int mypos = mykh * 3 + mykw;
+        float best[8];
+        int bidx[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          best[k] = -INFINITY;
+          bidx[k] = -1;
+        }
+        for (int kh = 0; kh < 3; ++kh) {
+          int hh = ho * 2 - 1 + kh;
+          if ((unsigned)hh >= (unsigned)H) continue;
+          for (int kw = 0; kw < 3; ++kw) {
+            int ww = wo * 2 - 1 + kw;
+            if ((unsigned)ww >= (unsigned)W) continue;
+            f16x8 t = ld8(x + ((size_t)(n * H + hh) * W + ww) * C + v * 8);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              float f = (float)t[k];
+              if (f > best[k] || bidx[k] < 0) {
+                best[k] = f;
+                bidx[k] = kh * 3 + kw;
+              }
+            }
+          }
+        }
+        f16x8 g = ld8(dy + ((size_t)(n * Ho + ho) * Wo + wo) * C + v * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (bidx[k] == mypos) acc[k] += (float)g[k];
+      }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+    st8(dx + (size_t)p * C + v * 8, o);
+  }
+}
+
+__global__ void subsample2_kernel(const f16* __restrict__ x, f16* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * Ho * Wo * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int wo = (int)(p % Wo);
+    int ho = (int)((p / Wo) % Ho);
+    int n = (int)(p / ((int64_t)Wo * Ho));
+    st8(y + (size_t)p * C + v * 8, ld8(x + ((size_t)(n * H + ho * 2) * W + wo * 2) * C + v * 8));
+  }
+}
+
+__global__ void subsample2_bwd_kernel(const f16* __restrict__ dy, f16* __restrict__ dx, int N, int H, int W, int C, int Ho,
+                                      int Wo, int accumulate) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * H * W * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int w = (int)(p % W);
+    int h = (int)((p / W) % H);
+    int n = (int)(p / ((int64_t)W * H));
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)0.f;
+    if ((h & 1) == 0 && (w & 1) == 0 && h / 2 < Ho && w / 2 < Wo)
+      o = ld8(dy + ((size_t)(n * Ho + h / 2) * Wo + w / 2) * C + v * 8);
+    f16* d = dx + (size_t)p * C + v * 8;
+    if (accumulate) {
+      f16x8 e = ld8(d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (f16)((float)o[k] + (float)e[k]);
+    }
+    st8(d, o);
+  }
+}
+
+// ---------------------------------------------------------------- nearest index (ATen legacy 'nearest')
+__device__ __forceinline__ int nn_src(int dst, float scale, int in_size) {
+  int s = (int)floorf((float)dst * scale);
+  return s < in_size - 1 ? s : in_size - 1;
+}
+
+__global__ void nchw_to_nhwc_resize_kernel(const float* __restrict__ x, f16* __restrict__ y, int N, int Cr, int H, int W,
+                                           int Ho, int Wo, int Cp, float sh, float sw) {
+  const int64_t total = (int64_t)N * Ho * Wo;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    int wo = (int)(p % Wo);
+    int ho = (int)((p / Wo) % Ho);
+    int n = (int)(p / ((int64_t)Wo * Ho));
+    int hs = nn_src(ho, sh, H), ws = nn_src(wo, sw, W);
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      f16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int c = c0 + k;
+        o[k] = c < Cr ? (f16)x[((size_t)(n * Cr + c) * H + hs) * W + ws] : (f16)0.f;
+      }
+      st8(y + (size_t)p * Cp + c0, o);
+    }
+  }
+}
+
+__global__ void nchw_to_nhwc_resize_bwd_kernel(const f16* __restrict__ dy, float* __restrict__ dx, int N, int Cr, int H, int W,
+                                               int Ho, int Wo, int Cp, float sh, float sw, float gscale) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    int w = (int)(p % W);
+    int h = (int)((p / W) % H);
+    int n = (int)(p / ((int64_t)W * H));
+    float acc[8];
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    int ho_lo = max(0, (int)floorf((float)h / sh) - 1), ho_hi = min(Ho - 1, (int)floorf((float)(h + 1) / sh) + 1);
+    int wo_lo = max(0, (int)floorf((float)w / sw) - 1), wo_hi = min(Wo - 1, (int)floorf((float)(w + 1) / sw) + 1);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+      if (nn_src(ho, sh, H) != h) continue;
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        if (nn_src(wo, sw, W) != w) continue;
+        const f16* g = dy + ((size_t)(n * Ho + ho) * Wo + wo) * Cp;
+        for (int c = 0; c < Cr && c < 8; ++c) acc[c] += (float)g[c];
+      }
+    }
+    for (int c = 0; c < Cr && c < 8; ++c) dx[((size_t)(n * Cr + c) * H + h) * W + w] = acc[c] * gscale;
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const f16* __restrict__ x, float* __restrict__ y, int N, int Cr, int H, int W, int Cp) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t hw = p % ((int64_t)H * W);
+    int n = (int)(p / ((int64_t)H * W));
+    for (int c = 0; c < Cr; ++c) y[((size_t)n * Cr + c) * H * W + hw] = (float)x[(size_t)p * Cp + c];
+  }
+}
+
+// y = a + nearest(b)
+__global__ void upsample_add_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ y, int N, int H,
+                                    int W, int C, int Hb, int Wb, float sh, float sw) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * H * W * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int w = (int)(p % W);
+    int h = (int)((p / W) % H);
+    int n = (int)(p / ((int64_t)W * H));
+    int hs = nn_src(h, sh, Hb), ws = nn_src(w, sw, Wb);
+    f16x8 va = ld8(a + (size_t)p * C + v * 8);
+    f16x8 vb = ld8(b + ((size_t)(n * Hb + hs) * Wb + ws) * C + v * 8);
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)((float)va[k] + (float)vb[k]);
+    st8(y + (size_t)p * C + v * 8, o);
+  }
+}
+
+__global__ void upsample_add_bwd_kernel(const f16* __restrict__ dy, f16* __restrict__ db, int N, int H, int W, int C, int Hb,
+                                        int Wb, float sh, float sw, int accumulate) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * Hb * Wb * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int wb = (int)(p % Wb);
+    int hb = (int)((p / Wb) % Hb);
+    int n = (int)(p / ((int64_t)Wb * Hb));
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    int h_lo = max(0, (int)floorf((float)hb / sh) - 1), h_hi = min(H - 1, (int)floorf((float)(hb + 1) / sh) + 1);
+    int w_lo = max(0, (int)floorf((float)wb / sw) - 1), w_hi = min(W - 1, (int)floorf((float)(wb + 1) / sw) + 1);
+    for (int h = h_lo; h <= h_hi; ++h) {
+      if (nn_src(h, sh, Hb) != hb) continue;
+      for (int w = w_lo; w <= w_hi; ++w) {
+        if (nn_src(w, sw, Wb) != wb) continue;
+        f16x8 g = ld8(dy + ((size_t)(n * H + h) * W + w) * C + v * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (float)g[k];
+      }
+    }
+    f16* d = db + (size_t)p * C + v * 8;
+    f16x8 o;
+    if (accumulate) {
+      f16x8 e = ld8(d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += (float)e[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+    st8(d, o);
+  }
+}
+
+__global__ void upsample2_bwd_kernel(const f16* __restrict__ dy, f16* __restrict__ dx, int N, int Hl, int Wl, int C, int Ctot,
+                                     int c_off, int accumulate) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * Hl * Wl * vecs;
+  const int Hu = Hl * 2, Wu = Wl * 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int w = (int)(p % Wl);
+    int h = (int)((p / Wl) % Hl);
+    int n = (int)(p / ((int64_t)Wl * Hl));
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        f16x8 g = ld8(dy + ((size_t)(n * Hu + 2 * h + a) * Wu + 2 * w + b) * Ctot + c_off + v * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += (float)g[k];
+      }
+    f16* d = dx + (size_t)p * C + v * 8;
+    if (accumulate) {
+      f16x8 e = ld8(d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] += (float)e[k];
+    }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+    st8(d, o);
+  }
+}
+
+__global__ void add_kernel(const f16* __restrict__ a, const f16* __restrict__ b, f16* __restrict__ o, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    f16x8 x = ld8(a + i * 8), y = ld8(b + i * 8), r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = (f16)((float)x[k] + (float)y[k]);
+    st8(o + i * 8, r);
+  }
+}
+
+__global__ void slice_channels_kernel(const f16* __restrict__ x, f16* __restrict__ y, int64_t npix, int Ctot, int c_off, int C,
+                                      int accumulate) {
+  const int vecs = C / 8;
+  const int64_t total = npix * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    f16x8 g = ld8(x + (size_t)p * Ctot + c_off + v * 8);
+    f16* d = y + (size_t)p * C + v * 8;
+    if (accumulate) {
+      f16x8 e = ld8(d);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = (f16)((float)g[k] + (float)e[k]);
+    }
+    st8(d, g);
+  }
+}
+
+__global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s, f16* __restrict__ dl, int N,
+                                   int Cr, int H, int W, int Cp, float gscale) {
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+    int64_t hw = p % ((int64_t)H * W);
+    int n = (int)(p / ((int64_t)H * W));
+    for (int c0 = 0; c0 < Cp; c0 += 8) {
+      f16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        int c = c0 + k;
+        float v = 0.f;
+        if (c < Cr) {
+          size_t idx = ((size_t)n * Cr + c) * H * W + hw;
+          float sv = s[idx];
+          v = dy[idx] * sv * (1.f - sv) * gscale;
+        }
+        o[k] = (f16)v;
+      }
+      st8(dl + (size_t)p * Cp + c0, o);
+    }
+  }
+}
+
+__global__ void relu_bwd_kernel(const f16* __restrict__ dy, const f16* __restrict__ z, f16* __restrict__ dx, int64_t nvec) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
+    f16x8 g = ld8(dy + i * 8), zz = ld8(z + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (!((float)zz[k] > 0.f)) g[k] = (f16)0.f;
+    st8(dx + i * 8, g);
+  }
+}
+
+__global__ void f32_to_f16_kernel(const float* __restrict__ x, f16* __restrict__ y, int64_t n, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (f16)(x[i] * scale);
+}
+__global__ void f16_to_f32_kernel(const f16* __restrict__ x, float* __restrict__ y, int64_t n, float scale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = (float)x[i] * scale;
+}
+
+// per-channel sum of an NHWC f16 tensor -> part[rows][C]  (bias gradients)
+__global__ void channel_sum_kernel(const f16* __restrict__ x, int64_t npix, int C, float* __restrict__ part) {
+  extern __shared__ float sm[];  // [256][8]
+  const int vecs = C / 8;
+  const int plan = TB / vecs;
+  const int v = threadIdx.x % vecs, pl = threadIdx.x / vecs;
+  const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
+  const int64_t p0 = (int64_t)blockIdx.x * per, p1 = min(npix, p0 + per);
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  if (pl < plan)
+    for (int64_t p = p0 + pl; p < p1; p += plan) {
+      f16x8 g = ld8(x + (size_t)p * C + v * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += (float)g[k];
+    }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sm[threadIdx.x * 8 + k] = s[k];
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += TB) {
+    int vv = c / 8, k = c & 7;
+    float t = 0.f;
+    for (int q = 0; q < plan; ++q) t += sm[(q * vecs + vv) * 8 + k];
+    part[(size_t)blockIdx.x * C + c] = t;
+  }
+}
+
+__global__ void scale_store_kernel(const float* __restrict__ in, float* __restrict__ out, int n, float scale, int accumulate) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = accumulate ? out[i] + in[i] * scale : in[i] * scale;
+}
+
+bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+#define S_ ((hipStream_t)stream)
+
+extern "C" int hd_colsum(const float* in, int rows, int W, float* out, float* ws, void* stream) {
+  HD_CHECK_ARG(in && out && rows > 0 && W > 0, "hd_colsum: bad args");
+  int R2 = rows > 512 ? 128 : (rows > 32 ? 16 : 1);
+  HD_CHECK_ARG(R2 == 1 || ws, "hd_colsum: workspace required for rows > 32");
+  dim3 g(hd_cdiv(W, 64), R2);
+  if (R2 == 1) {
+    hipLaunchKernelGGL(colsum_stage, g, dim3(256), 0, S_, in, rows, W, out, 1);
+  } else {
+    hipLaunchKernelGGL(colsum_stage, g, dim3(256), 0, S_, in, rows, W, ws, R2);
+    hipLaunchKernelGGL(colsum_stage, dim3(hd_cdiv(W, 64), 1), dim3(256), 0, S_, (const float*)ws, R2, W, out, 1);
+  }
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_bn_finalize(const float* sums, int C, double count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                              float* scale, float* shift, void* stream) {
+  HD_CHECK_ARG(sums && scale && shift && C > 0 && count > 0, "hd_bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 64)), dim3(64), 0, S_, sums, C, count, gamma, beta, running_mean,
+                     running_var, momentum, eps, mean, invstd, scale, shift);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                      float eps, int C, float* scale, float* shift, void* stream) {
+  HD_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "hd_bn_eval_scale_shift: bad args");
+  hipLaunchKernelGGL(bn_eval_kernel, dim3(hd_cdiv(C, 64)), dim3(64), 0, S_, gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_bn_apply(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C,
+                           int relu, void* stream) {
+  HD_CHECK_ARG(y && z && scale && shift && n > 0 && C % 8 == 0 && n % 8 == 0, "hd_bn_apply: bad args");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n / 8)), dim3(TB), 0, S_, (const f16*)y, (const f16*)res, scale, shift, (f16*)z, n / 8, C, relu);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, float* part,
+                                int rows, int64_t npix, int C, int relu, void* stream) {
+  HD_CHECK_ARG(dz && y && mean && invstd && part && rows > 0 && npix > 0, "hd_bn_bwd_reduce: bad args");
+  HD_CHECK_ARG(C % 8 == 0 && pow2(C / 8) && C / 8 <= TB, "hd_bn_bwd_reduce: C/8 must be a power of two <= 256 (C=%d)", C);
+  HD_CHECK_ARG(!relu || z, "hd_bn_bwd_reduce: relu needs z");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(TB), TB * 16 * sizeof(float), S_, (const f16*)dz, (const f16*)z,
+                     (const f16*)y, mean, invstd, part, npix, C, relu);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                               const float* gamma, const float* sums, void* dy, void* dres, float* dgamma, float* dbeta,
+                               float gscale, int accumulate, int64_t npix, int C, int relu, void* stream) {
+  HD_CHECK_ARG(dz && y && mean && invstd && sums && dy && npix > 0 && C % 8 == 0, "hd_bn_bwd_apply: bad args");
+  HD_CHECK_ARG(!relu || z, "hd_bn_bwd_apply: relu needs z");
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C / 8)), dim3(TB), 0, S_, (const f16*)dz, (const f16*)z,
+                     (const f16*)y, mean, invstd, gamma, sums, (f16*)dy, (f16*)dres, dgamma, dbeta, gscale, accumulate, npix, C, relu);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  HD_CHECK_ARG(x && y && C % 8 == 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "hd_maxpool3x3s2: bad args");
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, N, H, W, C, Ho, Wo);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  HD_CHECK_ARG(x && dy && dx && C % 8 == 0, "hd_maxpool3x3s2_bwd: bad args");
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const f16*)x, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_subsample2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  HD_CHECK_ARG(x && y && C % 8 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "hd_subsample2: bad args");
+  hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, N, H, W, C, Ho, Wo);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_subsample2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream) {
+  HD_CHECK_ARG(dy && dx && C % 8 == 0, "hd_subsample2_bwd: bad args");
+  hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_nchw_to_nhwc_resize(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream) {
+  HD_CHECK_ARG(x && y && Cp % 8 == 0 && Cr <= Cp && Cr > 0, "hd_nchw_to_nhwc_resize: bad args");
+  float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  hipLaunchKernelGGL(nchw_to_nhwc_resize_kernel, dim3(grid_for((int64_t)N * Ho * Wo)), dim3(TB), 0, S_, x, (f16*)y, N, Cr, H, W, Ho, Wo, Cp, sh, sw);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_nchw_to_nhwc_resize_bwd(const void* dy, float* dx, int N, int Cr, int H, int W, int Ho, int Wo, int Cp,
+                                          float gscale, void* stream) {
+  HD_CHECK_ARG(dy && dx && Cp % 8 == 0 && Cr <= 8 && Cr > 0, "hd_nchw_to_nhwc_resize_bwd: bad args (Cr<=8)");
+  float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  hipLaunchKernelGGL(nchw_to_nhwc_resize_bwd_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TB), 0, S_, (const f16*)dy, dx, N, Cr, H, W, Ho, Wo, Cp, sh, sw, gscale);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_nhwc_to_nchw(const void* x, float* y, int N, int Cr, int H, int W, int Cp, void* stream) {
+  HD_CHECK_ARG(x && y && Cr <= Cp, "hd_nhwc_to_nchw: bad args");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TB), 0, S_, (const f16*)x, y, N, Cr, H, W, Cp);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_upsample_add(const void* a, const void* b, void* y, int N, int H, int W, int C, int Hb, int Wb, void* stream) {
+  HD_CHECK_ARG(a && b && y && C % 8 == 0, "hd_upsample_add: bad args");
+  float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const f16*)a, (const f16*)b, (f16*)y, N, H, W, C, Hb, Wb, sh, sw);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_upsample_add_bwd(const void* dy, void* db, int N, int H, int W, int C, int Hb, int Wb, int accumulate, void* stream) {
+  HD_CHECK_ARG(dy && db && C % 8 == 0, "hd_upsample_add_bwd: bad args");
+  float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
+  hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for((int64_t)N * Hb * Wb * C / 8)), dim3(TB), 0, S_, (const f16*)dy, (f16*)db, N, H, W, C, Hb, Wb, sh, sw, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_upsample2_bwd(const void* dy_up, void* dx_low, int N, int Hl, int Wl, int C, int Ctot, int c_off, int accumulate, void* stream) {
+  HD_CHECK_ARG(dy_up && dx_low && C % 8 == 0 && Ctot % 8 == 0 && c_off % 8 == 0 && c_off + C <= Ctot, "hd_upsample2_bwd: bad args");
+  hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for((int64_t)N * Hl * Wl * C / 8)), dim3(TB), 0, S_, (const f16*)dy_up, (f16*)dx_low, N, Hl, Wl, C, Ctot, c_off, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  HD_CHECK_ARG(a && b && out && n % 8 == 0, "hd_add_f16: bad args");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(TB), 0, S_, (const f16*)a, (const f16*)b, (f16*)out, n / 8);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_slice_channels(const void* x, void* y, int64_t npix, int Ctot, int c_off, int C, int accumulate, void* stream) {
+  HD_CHECK_ARG(x && y && C % 8 == 0 && Ctot % 8 == 0 && c_off % 8 == 0 && c_off + C <= Ctot, "hd_slice_channels: bad args");
+  hipLaunchKernelGGL(slice_channels_kernel, dim3(grid_for(npix * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, npix, Ctot, c_off, C, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_sigmoid_bwd_nchw_to_nhwc(const float* dy, const float* s, void* dlogit, int N, int Cr, int H, int W, int Cp,
+                                           float gscale, void* stream) {
+  HD_CHECK_ARG(dy && s && dlogit && Cp % 8 == 0 && Cr <= Cp, "hd_sigmoid_bwd_nchw_to_nhwc: bad args");
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TB), 0, S_, dy, s, (f16*)dlogit, N, Cr, H, W, Cp, gscale);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_relu_bwd(const void* dy, const void* z, void* dx, int64_t n, void* stream) {
+  HD_CHECK_ARG(dy && z && dx && n % 8 == 0, "hd_relu_bwd: bad args");
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(TB), 0, S_, (const f16*)dy, (const f16*)z, (f16*)dx, n / 8);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_f32_to_f16(const float* x, void* y, int64_t n, float scale, void* stream) {
+  HD_CHECK_ARG(x && y && n > 0, "hd_f32_to_f16: bad args");
+  hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid_for(n)), dim3(TB), 0, S_, x, (f16*)y, n, scale);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream) {
+  HD_CHECK_ARG(x && y && n > 0, "hd_f16_to_f32: bad args");
+  hipLaunchKernelGGL(f16_to_f32_kernel, dim3(grid_for(n)), dim3(TB), 0, S_, (const f16*)x, y, n, scale);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_channel_sum_f16(const void* x, int64_t npix, int C, float* part, int rows, void* stream) {
+  HD_CHECK_ARG(x && part && rows > 0 && C % 8 == 0 && pow2(C / 8) && C / 8 <= TB, "hd_channel_sum_f16: bad args");
+  hipLaunchKernelGGL(channel_sum_kernel, dim3(rows), dim3(TB), TB * 8 * sizeof(float), S_, (const f16*)x, npix, C, part);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_scale_store(const float* in, float* out, int n, float scale, int accumulate, void* stream) {
+  HD_CHECK_ARG(in && out && n > 0, "hd_scale_store: bad args");
+  hipLaunchKernelGGL(scale_store_kernel, dim3(hd_cdiv(n, 256)), dim3(256), 0, S_, in, out, n, scale, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}

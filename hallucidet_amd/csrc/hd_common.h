@@ -1,0 +1,37 @@
+// Shared device/host helpers for libhallucidet_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/hallucidet_hip.h"
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+void hd_set_error(const char* fmt, ...);
+
+#define HD_CHECK_ARG(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      hd_set_error(__VA_ARGS__);       \
+      return HD_E_ARG;                 \
+    }                                  \
+  } while (0)
+
+#define HD_CHECK_LAUNCH()                                                   \
+  do {                                                                      \
+    hipError_t e_ = hipGetLastError();                                      \
+    if (e_ != hipSuccess) {                                                 \
+      hd_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,           \
+                   hipGetErrorString(e_));                                  \
+      return HD_E_LAUNCH;                                                   \
+    }                                                                       \
+  } while (0)
+
+static inline int hd_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,291 @@
+// Weight-gradient implicit GEMM on MFMA:  dW[co][kk] = sum_pix dY[pix][co] * Xg[pix][kk]
+// (kk = (kh*KW+kw)*Cin + ci walks the same 16-byte chunk order as conv_igemm).
+//
+// Both operands live in memory as [pixel][channel] (NHWC), i.e. the reduction index
+// is the SLOW axis.  Tiles are staged to LDS in that natural layout and the MFMA
+// fragments (8 consecutive reduction elements per lane) are produced by the gfx950
+// transposing LDS read ds_read_b64_tr_b16 -- no software transpose anywhere.
+// Row strides are odd multiples of 64 B so the four k-rows a 32-lane half touches
+// fall in distinct bank quarters.
+//
+// The pixel range is split over gridDim.z; each slice writes its fp32 partial tile to
+// a slab and hd_wgrad_reduce sums the slices in a fixed order (deterministic, no
+// float atomics) while converting to the OIHW fp32 layout of the master gradient.
+#include "hd_common.h"
+
+namespace {
+
+constexpr int BP = 32;    // pixels per reduction tile
+constexpr int TN = 128;   // kk columns per block
+
+struct WgP {
+  const f16* x;
+  const f16* x2;
+  const f16* dy;
+  float* slab;
+  int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1;
+  int M, cin8, nchunks, Ktot, per_split;
+};
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ __forceinline__ f16x8 tr_frag(const f16* row0_ptr, int row_stride) {
+  // two transposed 4x16 block reads: k rows [0,4) and [4,8) relative to row0_ptr
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row0_ptr));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row0_ptr + 4 * row_stride));
+  f16x4 fa = __builtin_bit_cast(f16x4, a), fb = __builtin_bit_cast(f16x4, b);
+  f16x8 r = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
+  return r;
+}
+
+template <int TM, int WM, int WN>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
+  constexpr int MT = TM / (WM * 32);
+  constexpr int NT = TN / (WN * 32);
+  constexpr int RSA = (TM == 128) ? 160 : (TM == 64 ? 96 : 32);  // halves; bytes = odd multiple of 64
+  constexpr int RSB = 160;
+  constexpr int A_CH = TM / 8;                       // chunks per pixel row of dY tile
+  constexpr int B_CH = TN / 8;                       // 16
+  constexpr int A_LOADS = (BP * A_CH + 255) / 256;   // 2,1,1
+  constexpr int B_LOADS = BP * B_CH / 256;           // 2
+  constexpr int STAGE = BP * RSA + BP * RSB;
+  __shared__ __attribute__((aligned(16))) f16 lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int co0 = blockIdx.y * TM;
+  const int kk0 = blockIdx.x * TN;  // first kk column of this block
+  const int HoWo = p.Ho * p.Wo;
+  const int pbeg = blockIdx.z * p.per_split;
+  const int pend = min(p.M, pbeg + p.per_split);
+  const int nk = (pend - pbeg + BP - 1) / BP;
+
+  // ---- B (gathered input) assignment: fixed chunk column, 2 pixel rows
+  const int bcc = tid % B_CH;
+  const int bpr = tid / B_CH;  // 0..15
+  const int bq = kk0 / 8 + bcc;
+  const bool bq_valid = bq < p.nchunks;
+  int btap = bq_valid ? bq / p.cin8 : 0;
+  const int bc = (bq_valid ? bq - btap * p.cin8 : 0) * 8;
+  const int bkh = btap / p.KW, bkw = btap - bkh * p.KW;
+  // ---- A (dY) assignment
+  const int acc_ = tid % A_CH;
+  const int apr = tid / A_CH;
+  const bool a_active = apr < BP;  // TM=32: 4 chunks/pixel -> 64 rows of threads, only 32 used per load
+  const bool aco_valid = (co0 + acc_ * 8) < p.Cout;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int a = 0; a < MT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  u32x4 ra[A_LOADS], rb[B_LOADS];
+  constexpr int A_ROWS_PER_LOAD = 256 / A_CH;  // 16, 32, 64
+
+  auto gload = [&](int kt) {
+    const int pb = pbeg + kt * BP;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      int prow = apr + i * A_ROWS_PER_LOAD;
+      int pix = pb + prow;
+      if (prow < BP && pix < pend && aco_valid) v = *reinterpret_cast<const u32x4*>(p.dy + (size_t)pix * p.Cout + co0 + acc_ * 8);
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      int pix = pb + bpr + i * 16;
+      if (pix < pend && bq_valid) {
+        int n = pix / HoWo;
+        int rem = pix - n * HoWo;
+        int ho = rem / p.Wo;
+        int wo = rem - ho * p.Wo;
+        int hi = ho * p.stride - p.pad + bkh, wi = wo * p.stride - p.pad + bkw;
+        if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) {
+          if (bc < p.C1) {
+            if (p.up1) {
+              hi >>= 1;
+              wi >>= 1;
+            }
+            v = *reinterpret_cast<const u32x4*>(p.x + ((size_t)(n * p.Hsrc + hi) * p.Wsrc + wi) * p.C1 + bc);
+          } else {
+            v = *reinterpret_cast<const u32x4*>(p.x2 + ((size_t)(n * p.Hin + hi) * p.Win + wi) * p.C2 + (bc - p.C1));
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    f16* sa = lds + buf * STAGE;
+    f16* sb = sa + BP * RSA;
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      int prow = apr + i * A_ROWS_PER_LOAD;
+      if (prow < BP) *reinterpret_cast<u32x4*>(sa + prow * RSA + acc_ * 8) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) *reinterpret_cast<u32x4*>(sb + (bpr + i * 16) * RSB + bcc * 8) = rb[i];
+  };
+  (void)a_active;
+
+  if (nk > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+
+  // transposed-read lane geometry (see header comment): 16-lane group g, lane-in-group li
+  const int li = lane & 15, g = lane >> 4;
+  const int tq = li >> 2, tp = li & 3;
+  const int th = g >> 1, thalf = g & 1;
+  const int krow = 8 * th + tq;                 // + ks*16 (+4 for the second read)
+  const int coff = 16 * thalf + 4 * tp;         // + tile column base
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    const bool more = (kt + 1) < nk;
+    if (more) gload(kt + 1);
+    const f16* sa = lds + buf * STAGE;
+    const f16* sb = sa + BP * RSA;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 af[MT], bf[NT];
+#pragma unroll
+      for (int a = 0; a < MT; ++a) af[a] = tr_frag(sa + (ks * 16 + krow) * RSA + (wm * MT * 32 + a * 32) + coff, RSA);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bf[b] = tr_frag(sb + (ks * 16 + krow) * RSB + (wn * NT * 32 + b * 32) + coff, RSB);
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: fp32 partial tile -> slab[z][co][kk]
+  float* out = p.slab + (size_t)blockIdx.z * p.Cout * p.Ktot;
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const int kk = kk0 + wn * NT * 32 + b * 32 + (lane & 31);
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * MT * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (co < p.Cout && kk < p.Ktot) out[(size_t)co * p.Ktot + kk] = acc[a][b][r];
+      }
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab, int Cout,
+                                    int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
+  // one thread per OIHW element
+  const int taps = KH * KW;
+  const int64_t total = (int64_t)Cout * Cin_real * taps;
+  const int64_t Ktot = (int64_t)taps * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int t = (int)(i % taps);
+    int ci = (int)((i / taps) % Cin_real);
+    int co = (int)(i / ((int64_t)taps * Cin_real));
+    const float* s = slab + (size_t)co * Ktot + (size_t)t * Cin + ci;
+    float acc = 0.f;
+    for (int k = 0; k < nsplit; ++k) acc += s[(size_t)k * Cout_slab * Ktot];
+    acc *= scale;
+    dw[i] = accumulate ? dw[i] + acc : acc;
+  }
+}
+
+__global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ oscale, f16* __restrict__ wf,
+                                   f16* __restrict__ wd, int Cout, int Cin, int KH, int KW, int Cin_pad, int Cout_pad) {
+  const int taps = KH * KW;
+  // forward layout [Cout][tap][Cin_pad]
+  if (wf) {
+    const int64_t total = (int64_t)Cout * taps * Cin_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int ci = (int)(i % Cin_pad);
+      int t = (int)((i / Cin_pad) % taps);
+      int co = (int)(i / ((int64_t)Cin_pad * taps));
+      float v = 0.f;
+      if (ci < Cin) {
+        v = w[((size_t)co * Cin + ci) * taps + t];
+        if (oscale) v *= oscale[co];
+      }
+      wf[i] = (f16)v;
+    }
+  }
+  // data-gradient layout [Cin_pad][flipped tap][Cout_pad]
+  if (wd) {
+    const int64_t total = (int64_t)Cin_pad * taps * Cout_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int co = (int)(i % Cout_pad);
+      int t = (int)((i / Cout_pad) % taps);
+      int ci = (int)(i / ((int64_t)Cout_pad * taps));
+      float v = 0.f;
+      if (ci < Cin && co < Cout) {
+        v = w[((size_t)co * Cin + ci) * taps + (taps - 1 - t)];
+        if (oscale) v *= oscale[co];
+      }
+      wd[i] = (f16)v;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
+  HD_CHECK_ARG(a && a->x && a->dy && a->slab, "hd_wgrad: null pointer");
+  HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->Cout % 8 == 0, "hd_wgrad: channels must be multiples of 8");
+  HD_CHECK_ARG((a->C2 == 0) == (a->x2 == nullptr), "hd_wgrad: x2/C2 mismatch");
+  HD_CHECK_ARG(a->nsplit >= 1, "hd_wgrad: nsplit");
+  WgP p;
+  p.x = (const f16*)a->x; p.x2 = (const f16*)a->x2; p.dy = (const f16*)a->dy; p.slab = a->slab;
+  p.N = a->N; p.Hsrc = a->Hsrc; p.Wsrc = a->Wsrc; p.Hin = a->Hin; p.Win = a->Win; p.C1 = a->C1; p.C2 = a->C2;
+  p.Cin = a->C1 + a->C2; p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW;
+  p.stride = a->stride; p.pad = a->pad; p.up1 = a->up1;
+  p.M = a->N * a->Ho * a->Wo;
+  p.cin8 = p.Cin / 8;
+  p.nchunks = a->KH * a->KW * p.cin8;
+  p.Ktot = a->KH * a->KW * p.Cin;
+  int per = hd_cdiv(p.M, a->nsplit);
+  per = hd_cdiv(per, BP) * BP;
+  p.per_split = per;
+  hipStream_t s = (hipStream_t)stream;
+  const int tm = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
+  dim3 grid(hd_cdiv(p.Ktot, TN), hd_cdiv(p.Cout, tm), a->nsplit);
+  if (tm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 2, 2>), grid, dim3(256), 0, s, p);
+  else if (tm == 64) hipLaunchKernelGGL((wgrad_kernel<64, 2, 2>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((wgrad_kernel<32, 1, 4>), grid, dim3(256), 0, s, p);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW, int Cin,
+                               int Cin_real, float scale, int accumulate, void* stream) {
+  HD_CHECK_ARG(slab && dw_oihw && nsplit >= 1 && Cout <= Cout_slab && Cin_real <= Cin, "hd_wgrad_reduce: bad args");
+  int64_t total = (int64_t)Cout * Cin_real * KH * KW;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin,
+                     Cin_real, scale, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_weight_prep(const float* w_oihw, const float* out_scale, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH,
+                              int KW, int Cin_pad, int Cout_pad, void* stream) {
+  HD_CHECK_ARG(w_oihw && (w_fwd || w_dgrad) && Cin_pad >= Cin && Cout_pad >= Cout && Cin_pad % 8 == 0 && Cout_pad % 8 == 0,
+               "hd_weight_prep: bad args");
+  int64_t total = (int64_t)Cout_pad * Cin_pad * KH * KW;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, w_oihw, out_scale, (f16*)w_fwd, (f16*)w_dgrad,
+                     Cout, Cin, KH, KW, Cin_pad, Cout_pad);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}

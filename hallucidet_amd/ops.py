@@ -1,0 +1,376 @@
+"""Thin tensor-level wrappers over the C ABI (one function per entry point family).
+
+Inputs/outputs are torch tensors living on the GPU; activations are NHWC float16.
+Nothing here computes on the host and nothing falls back to ATen: a missing library
+or a failing launch raises (``_abi.HipLibraryMissing`` / ``_abi.HipCallError``).
+"""
+import ctypes as C
+
+import torch
+
+from . import _abi
+from ._abi import ConvArgs, WgradArgs, check, ptr
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("hallucidet_amd.ops: tensors must live on the GPU (got %s); there is no CPU path" % t.device)
+
+
+def conv_out_size(h, k, stride, pad):
+    return (h + 2 * pad - k) // stride + 1
+
+
+def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
+           out_nchw_f32=False, want_stats=False, out_hw=None, cout=None, out=None):
+    """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
+
+    ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
+    Returns y or (y, stats_slab[rows,2,Cout]).
+    """
+    _need_cuda(x, w, x2, bias, res)
+    lib = _abi.load()
+    N, Hs, Ws, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    Cout = w.shape[0] if cout is None else cout
+    assert w.dtype == torch.float16 and x.dtype == torch.float16 and x.is_contiguous() and w.is_contiguous()
+    assert w.numel() >= Cout * KH * KW * (C1 + C2), "weight tensor too small"
+    if in_dil > 1:
+        Hin, Win = 0, 0
+        assert out_hw is not None
+        Ho, Wo = out_hw
+    else:
+        Hin, Win = (Hs * 2, Ws * 2) if up1 else (Hs, Ws)
+        if x2 is not None:
+            assert x2.shape[1] == Hin and x2.shape[2] == Win and x2.is_contiguous()
+        if out_hw is None:
+            Ho, Wo = conv_out_size(Hin, KH, stride, pad), conv_out_size(Win, KW, stride, pad)
+        else:
+            Ho, Wo = out_hw
+    if out is not None:
+        y = out
+    elif out_nchw_f32:
+        y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    else:
+        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
+    a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(y), None,
+                 N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
+                 1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else 0)
+    stats = None
+    if want_stats:
+        rows = lib.hd_conv2d_stats_rows(C.byref(a))
+        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
+        a.stats = ptr(stats)
+    check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
+    return (y, stats) if want_stats else y
+
+
+def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None):
+    """Returns fp32 slab [nsplit, Cout, KH*KW*(C1+C2)] of partial weight gradients."""
+    _need_cuda(x, dy, x2)
+    lib = _abi.load()
+    N, Hs, Ws, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    _, Ho, Wo, Cout = dy.shape
+    Hin, Win = (Hs * 2, Ws * 2) if up1 else (Hs, Ws)
+    K = KH * KW * (C1 + C2)
+    M = N * Ho * Wo
+    if nsplit is None:
+        nsplit = pick_nsplit(M, Cout, K)
+    slab = torch.empty((nsplit, Cout, K), dtype=torch.float32, device=x.device)
+    a = WgradArgs(ptr(x), ptr(x2), ptr(dy), ptr(slab), N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
+                  1 if up1 else 0, nsplit)
+    check(lib.hd_wgrad(C.byref(a), _stream()), "hd_wgrad")
+    return slab
+
+
+def pick_nsplit(M, Cout, K, target_blocks=1024):
+    tm = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+    tiles = ((K + 127) // 128) * ((Cout + tm - 1) // tm)
+    ns = max(1, min(target_blocks // max(tiles, 1), M // 256))
+    # bound slab size to 64 MiB
+    while ns > 1 and ns * Cout * K * 4 > (64 << 20):
+        ns //= 2
+    return max(1, ns)
+
+
+def wgrad_reduce(slab, dw, KH, KW, Cin, Cin_real=None, Cout=None, scale=1.0, accumulate=False):
+    _need_cuda(slab, dw)
+    nsplit, Cout_slab, K = slab.shape
+    Cout = Cout_slab if Cout is None else Cout
+    Cin_real = Cin if Cin_real is None else Cin_real
+    assert dw.numel() == Cout * Cin_real * KH * KW and dw.dtype == torch.float32 and dw.is_contiguous()
+    check(_abi.load().hd_wgrad_reduce(ptr(slab), ptr(dw), nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale,
+                                      1 if accumulate else 0, _stream()), "hd_wgrad_reduce")
+    return dw
+
+
+def weight_prep(w_oihw, *, out_scale=None, cin_pad=None, cout_pad=None, want_fwd=True, want_dgrad=False):
+    """fp32 OIHW -> (f16 [Cout, KH*KW*Cin_pad], f16 [Cin_pad, KH*KW*Cout_pad] flipped)."""
+    _need_cuda(w_oihw)
+    Cout, Cin, KH, KW = w_oihw.shape
+    cin_pad = cin_pad or ((Cin + 7) // 8 * 8)
+    cout_pad = cout_pad or ((Cout + 7) // 8 * 8)
+    wf = torch.empty((Cout, KH * KW * cin_pad), dtype=torch.float16, device=w_oihw.device) if want_fwd else None
+    wd = torch.empty((cin_pad, KH * KW * cout_pad), dtype=torch.float16, device=w_oihw.device) if want_dgrad else None
+    check(_abi.load().hd_weight_prep(ptr(w_oihw.contiguous()), ptr(out_scale), ptr(wf), ptr(wd), Cout, Cin, KH, KW,
+                                     cin_pad, cout_pad, _stream()), "hd_weight_prep")
+    return wf, wd
+
+
+def colsum(slab2d):
+    """[rows, W] fp32 -> [W] (deterministic)."""
+    _need_cuda(slab2d)
+    rows, W = slab2d.shape
+    out = torch.empty((W,), dtype=torch.float32, device=slab2d.device)
+    ws = torch.empty((128 * W,), dtype=torch.float32, device=slab2d.device) if rows > 32 else None
+    check(_abi.load().hd_colsum(ptr(slab2d), rows, W, ptr(out), ptr(ws), _stream()), "hd_colsum")
+    return out
+
+
+def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps):
+    C_ = sums.numel() // 2
+    dev = sums.device
+    mean = torch.empty(C_, dtype=torch.float32, device=dev)
+    invstd = torch.empty_like(mean)
+    scale = torch.empty_like(mean)
+    shift = torch.empty_like(mean)
+    check(_abi.load().hd_bn_finalize(ptr(sums), C_, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                                     ptr(running_var), momentum, eps, ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                     _stream()), "hd_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
+    C_ = running_mean.numel()
+    scale = torch.empty(C_, dtype=torch.float32, device=running_mean.device)
+    shift = torch.empty_like(scale)
+    check(_abi.load().hd_bn_eval_scale_shift(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), eps, C_,
+                                             ptr(scale), ptr(shift), _stream()), "hd_bn_eval_scale_shift")
+    return scale, shift
+
+
+def bn_apply(y, scale, shift, *, res=None, relu=True, out=None):
+    _need_cuda(y, scale, shift, res)
+    z = torch.empty_like(y) if out is None else out
+    check(_abi.load().hd_bn_apply(ptr(y), ptr(res), ptr(scale), ptr(shift), ptr(z), y.numel(), y.shape[-1],
+                                  1 if relu else 0, _stream()), "hd_bn_apply")
+    return z
+
+
+def bn_backward(dz, z, y, mean, invstd, gamma, *, relu=True, want_dres=False, gscale=1.0, dgamma=None, dbeta=None,
+                accumulate=False, rows=None):
+    """Backward of z = relu(bn_train(y) (+res)).  Returns (dy, dres|None, dgamma, dbeta)."""
+    _need_cuda(dz, y)
+    C_ = y.shape[-1]
+    npix = y.numel() // C_
+    if rows is None:
+        rows = int(max(1, min(1024, npix // 64)))
+    lib = _abi.load()
+    part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
+    check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(part), rows, npix, C_,
+                               1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
+    sums = colsum(part)
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_dres else None
+    if dgamma is None:
+        dgamma = torch.empty(C_, dtype=torch.float32, device=y.device)
+    if dbeta is None:
+        dbeta = torch.empty(C_, dtype=torch.float32, device=y.device)
+    check(lib.hd_bn_bwd_apply(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(sums), ptr(dy),
+                              ptr(dres), ptr(dgamma), ptr(dbeta), gscale, 1 if accumulate else 0, npix, C_,
+                              1 if relu else 0, _stream()), "hd_bn_bwd_apply")
+    return dy, dres, dgamma, dbeta
+
+
+def maxpool3x3s2(x):
+    N, H, W, C_ = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C_), dtype=torch.float16, device=x.device)
+    check(_abi.load().hd_maxpool3x3s2(ptr(x), ptr(y), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2")
+    return y
+
+
+def maxpool3x3s2_bwd(x, dy):
+    N, H, W, C_ = x.shape
+    _, Ho, Wo, _ = dy.shape
+    dx = torch.empty_like(x)
+    check(_abi.load().hd_maxpool3x3s2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd")
+    return dx
+
+
+def subsample2(x):
+    N, H, W, C_ = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C_), dtype=torch.float16, device=x.device)
+    check(_abi.load().hd_subsample2(ptr(x), ptr(y), N, H, W, C_, Ho, Wo, _stream()), "hd_subsample2")
+    return y
+
+
+def subsample2_bwd(dy, dx, accumulate=True):
+    N, H, W, C_ = dx.shape
+    _, Ho, Wo, _ = dy.shape
+    check(_abi.load().hd_subsample2_bwd(ptr(dy), ptr(dx), N, H, W, C_, Ho, Wo, 1 if accumulate else 0, _stream()),
+          "hd_subsample2_bwd")
+    return dx
+
+
+def nchw_to_nhwc_resize(x, Ho, Wo, Cp=8):
+    _need_cuda(x)
+    N, Cr, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty((N, Ho, Wo, Cp), dtype=torch.float16, device=x.device)
+    check(_abi.load().hd_nchw_to_nhwc_resize(ptr(x), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()), "hd_nchw_to_nhwc_resize")
+    return y
+
+
+def nchw_to_nhwc_resize_bwd(dy, N, Cr, H, W, gscale=1.0):
+    _, Ho, Wo, Cp = dy.shape
+    dx = torch.empty((N, Cr, H, W), dtype=torch.float32, device=dy.device)
+    check(_abi.load().hd_nchw_to_nhwc_resize_bwd(ptr(dy), ptr(dx), N, Cr, H, W, Ho, Wo, Cp, gscale, _stream()),
+          "hd_nchw_to_nhwc_resize_bwd")
+    return dx
+
+
+def nhwc_to_nchw(x, Cr=None):
+    N, H, W, Cp = x.shape
+    Cr = Cp if Cr is None else Cr
+    y = torch.empty((N, Cr, H, W), dtype=torch.float32, device=x.device)
+    check(_abi.load().hd_nhwc_to_nchw(ptr(x), ptr(y), N, Cr, H, W, Cp, _stream()), "hd_nhwc_to_nchw")
+    return y
+
+
+def upsample_add(a, b):
+    N, H, W, C_ = a.shape
+    _, Hb, Wb, _ = b.shape
+    y = torch.empty_like(a)
+    check(_abi.load().hd_upsample_add(ptr(a), ptr(b), ptr(y), N, H, W, C_, Hb, Wb, _stream()), "hd_upsample_add")
+    return y
+
+
+def upsample_add_bwd(dy, db, accumulate):
+    N, H, W, C_ = dy.shape
+    _, Hb, Wb, _ = db.shape
+    check(_abi.load().hd_upsample_add_bwd(ptr(dy), ptr(db), N, H, W, C_, Hb, Wb, 1 if accumulate else 0, _stream()),
+          "hd_upsample_add_bwd")
+    return db
+
+
+def upsample2_bwd(dy_up, dx_low, c_off, accumulate):
+    N, Hl, Wl, C_ = dx_low.shape
+    Ctot = dy_up.shape[3]
+    check(_abi.load().hd_upsample2_bwd(ptr(dy_up), ptr(dx_low), N, Hl, Wl, C_, Ctot, c_off, 1 if accumulate else 0,
+                                       _stream()), "hd_upsample2_bwd")
+    return dx_low
+
+
+def add_f16(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    check(_abi.load().hd_add_f16(ptr(a), ptr(b), ptr(out), a.numel(), _stream()), "hd_add_f16")
+    return out
+
+
+def slice_channels(x, y, c_off, accumulate):
+    Ctot = x.shape[-1]
+    C_ = y.shape[-1]
+    npix = y.numel() // C_
+    check(_abi.load().hd_slice_channels(ptr(x), ptr(y), npix, Ctot, c_off, C_, 1 if accumulate else 0, _stream()),
+          "hd_slice_channels")
+    return y
+
+
+def sigmoid_bwd_nchw_to_nhwc(dy, s, Cp=8, gscale=1.0):
+    N, Cr, H, W = s.shape
+    dl = torch.empty((N, H, W, Cp), dtype=torch.float16, device=s.device)
+    check(_abi.load().hd_sigmoid_bwd_nchw_to_nhwc(ptr(dy.contiguous()), ptr(s), ptr(dl), N, Cr, H, W, Cp, gscale,
+                                                  _stream()), "hd_sigmoid_bwd_nchw_to_nhwc")
+    return dl
+
+
+def relu_bwd(dy, z):
+    dx = torch.empty_like(dy)
+    check(_abi.load().hd_relu_bwd(ptr(dy), ptr(z), ptr(dx), dy.numel(), _stream()), "hd_relu_bwd")
+    return dx
+
+
+def f32_to_f16(x, scale=1.0):
+    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    check(_abi.load().hd_f32_to_f16(ptr(x.contiguous()), ptr(y), x.numel(), scale, _stream()), "hd_f32_to_f16")
+    return y
+
+
+def f16_to_f32(x, scale=1.0):
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_abi.load().hd_f16_to_f32(ptr(x.contiguous()), ptr(y), x.numel(), scale, _stream()), "hd_f16_to_f32")
+    return y
+
+
+def channel_sum(x, rows=None):
+    C_ = x.shape[-1]
+    npix = x.numel() // C_
+    if rows is None:
+        rows = int(max(1, min(512, npix // 64)))
+    part = torch.empty((rows, C_), dtype=torch.float32, device=x.device)
+    check(_abi.load().hd_channel_sum_f16(ptr(x), npix, C_, ptr(part), rows, _stream()), "hd_channel_sum_f16")
+    return colsum(part)
+
+
+def scale_store(src, dst, scale=1.0, accumulate=False):
+    check(_abi.load().hd_scale_store(ptr(src), ptr(dst), dst.numel(), scale, 1 if accumulate else 0, _stream()),
+          "hd_scale_store")
+    return dst
+
+
+def nms_sorted_batched(boxes, counts, iou_thr):
+    """boxes [B, nmax, 4] fp32 sorted by descending score per image; counts [B] int32.  Returns keep [B, nmax] bool."""
+    _need_cuda(boxes, counts)
+    B, nmax, _ = boxes.shape
+    cb = (nmax + 63) // 64
+    ws = torch.empty((B, nmax, cb), dtype=torch.int64, device=boxes.device)
+    keep = torch.zeros((B, nmax), dtype=torch.uint8, device=boxes.device)
+    check(_abi.load().hd_nms_sorted_batched(ptr(boxes.contiguous()), ptr(counts), B, nmax, iou_thr, ptr(ws), ptr(keep),
+                                            _stream()), "hd_nms_sorted_batched")
+    return keep.bool()
+
+
+def roi_align(feat, rois, PH, PW, spatial_scale, sampling_ratio):
+    N, H, W, C_ = feat.shape
+    R = rois.shape[0]
+    out = torch.empty((R, PH, PW, C_), dtype=torch.float16, device=feat.device)
+    check(_abi.load().hd_roi_align(ptr(feat), ptr(rois.contiguous()), ptr(out), R, N, H, W, C_, PH, PW, spatial_scale,
+                                   sampling_ratio, _stream()), "hd_roi_align")
+    return out
+
+
+def roi_align_bwd(dout, rois, feat_shape, spatial_scale, sampling_ratio):
+    N, H, W, C_ = feat_shape
+    R, PH, PW, _ = dout.shape
+    dfeat = torch.zeros((N, H, W, C_), dtype=torch.float32, device=dout.device)
+    check(_abi.load().hd_roi_align_bwd(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(dfeat), R, N, H, W, C_, PH, PW,
+                                       spatial_scale, sampling_ratio, _stream()), "hd_roi_align_bwd")
+    return dfeat
+
+
+def box_iou(gt, boxes):
+    G, A = gt.shape[0], boxes.shape[0]
+    iou = torch.empty((G, A), dtype=torch.float32, device=boxes.device)
+    check(_abi.load().hd_box_iou(ptr(gt.contiguous()), G, ptr(boxes.contiguous()), A, ptr(iou), _stream()), "hd_box_iou")
+    return iou
+
+
+def adam_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, clip_value, inv_scale, step, found_inf=None):
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    check(_abi.load().hd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                   clip_value, inv_scale, bc1, bc2, ptr(found_inf), _stream()), "hd_adam_step")
+
+
+def check_finite(g, found_inf):
+    check(_abi.load().hd_check_finite(ptr(g), g.numel(), ptr(found_inf), _stream()), "hd_check_finite")

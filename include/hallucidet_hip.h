@@ -1,0 +1,212 @@
+/*
+ * hallucidet_hip.h -- C ABI of libhallucidet_hip.so (gfx950 / MI355X only).
+ *
+ * Drop-in boundary for the HalluciDet data-parallel hot path.  Every entry
+ * point takes borrowed DEVICE pointers, explicit shapes and a hipStream_t
+ * (passed as void*), allocates nothing persistent and returns an int status
+ * (0 = ok, <0 = HD_E_*).  No exception and no torch type crosses this line.
+ *
+ * The reference (heitorrapela/HalluciDet) has no native code of its own: the
+ * arithmetic it runs is ATen/cuDNN/torchvision kernels reached from Python.
+ * Each entry point therefore cites the *Python call site* whose kernel it
+ * replaces (paths relative to the reference tree) and, where that call lands
+ * in un-vendored torchvision 0.12, says so with [EXT].
+ *
+ * Tensor conventions
+ *   activations : NHWC, IEEE fp16 ("f16"), channel count a multiple of 8
+ *   weights     : [Cout][KH][KW][Cin] f16 (K-contiguous per output channel)
+ *   statistics, losses, optimizer state, box maths : fp32
+ */
+#ifndef HALLUCIDET_HIP_H
+#define HALLUCIDET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HD_OK 0
+#define HD_E_ARG (-1)     /* bad argument (shape / alignment / null)            */
+#define HD_E_LAUNCH (-2)  /* hipLaunch / runtime error, see hd_last_error()      */
+#define HD_E_UNSUPPORTED (-3)
+
+#define HD_ACT_NONE 0
+#define HD_ACT_RELU 1
+#define HD_ACT_SIGMOID 2
+
+#define HD_OUT_NHWC_F16 0
+#define HD_OUT_NCHW_F32 1
+
+/* library identity / diagnostics */
+int hd_abi_version(void);
+const char* hd_last_error(void);
+const char* hd_arch(void); /* "gfx950" */
+
+/* ------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA (v_mfma_f32_32x32x16_f16).
+ * Replaces: nn.Conv2d forward inside
+ *   src/segmentation_models/base/modules.py:28-35   (Conv2dReLU conv)
+ *   src/segmentation_models/decoders/unet/decoder.py:38-46 (upsample+cat+conv)
+ *   src/segmentation_models/base/heads.py:23-27      (head conv + activation)
+ *   src/segmentation_models/encoders/resnet.py:47-65 (ResNet stages [EXT])
+ *   src/utils/eval_forward_fasterrcnn.py:55,76       (detector backbone / RPN head [EXT])
+ * and, with flipped/transposed weights, the data-gradient of the same convs.
+ *
+ * Logical input = concat_c( up1 ? nearest2x(x) : x , x2 ) of size [N,Hin,Win,C1+C2].
+ * If in_dil > 1 the logical input is x zero-dilated by in_dil (used for the
+ * data-gradient of stride-in_dil convolutions): element (h,w) is x[h/in_dil,w/in_dil]
+ * when both are divisible and in range, else 0; Hin/Win are then ignored and the
+ * extent is taken from Hsrc/Wsrc.
+ * Epilogue: v = acc + bias[co] + res[pix,co]; stats on fp16(v); y = act(v).
+ * -------------------------------------------------------------------- */
+typedef struct hd_conv_args {
+  const void* x;      /* f16 NHWC [N,Hsrc,Wsrc,C1]                       */
+  const void* x2;     /* f16 NHWC [N,Hin,Win,C2] or NULL                  */
+  const void* w;      /* f16 [Cout][KH*KW*(C1+C2)]                        */
+  const float* bias;  /* [Cout] or NULL                                   */
+  const void* res;    /* f16 NHWC [N,Ho,Wo,Cout] or NULL                  */
+  void* y;            /* out: f16 NHWC [N,Ho,Wo,Cout] or f32 NCHW         */
+  float* stats;       /* out: [gridM][2][Cout] per-tile (sum,sumsq) or NULL */
+  int32_t N, Hsrc, Wsrc; /* stored extent of x                           */
+  int32_t Hin, Win;      /* logical extent (== Hsrc*2 when up1)            */
+  int32_t C1, C2;
+  int32_t Ho, Wo, Cout;
+  int32_t KH, KW, stride, pad;
+  int32_t up1, in_dil;
+  int32_t act, out_mode;
+} hd_conv_args;
+
+int hd_conv2d(const hd_conv_args* a, void* stream);
+/* number of M tiles (rows of `stats`) hd_conv2d will use for this problem */
+int hd_conv2d_stats_rows(const hd_conv_args* a);
+
+/* ------------------------------------------------------------------------
+ * Weight-gradient implicit GEMM: dW[co][kh][kw][ci] = sum_pix dY[pix,co] * X[pix@(kh,kw),ci]
+ * Replaces the autograd weight-gradient of every trainable Conv2d of the
+ * hallucination net (train_hallucidet.py:431-435 holds only those params).
+ * Split over `nsplit` pixel ranges; partials go to `slab` [nsplit][Cout][K]
+ * fp32 and are reduced by hd_wgrad_reduce into the OIHW fp32 gradient.
+ * -------------------------------------------------------------------- */
+typedef struct hd_wgrad_args {
+  const void* x;   /* f16 NHWC [N,Hsrc,Wsrc,C1]                          */
+  const void* x2;  /* f16 NHWC [N,Hin,Win,C2] or NULL                     */
+  const void* dy;  /* f16 NHWC [N,Ho,Wo,Cout]                             */
+  float* slab;     /* [nsplit][Cout][KH*KW*(C1+C2)] fp32                 */
+  int32_t N, Hsrc, Wsrc, Hin, Win, C1, C2, Ho, Wo, Cout;
+  int32_t KH, KW, stride, pad, up1;
+  int32_t nsplit;
+} hd_wgrad_args;
+int hd_wgrad(const hd_wgrad_args* a, void* stream);
+/* dw_oihw[co][ci][kh][kw] (=|+=) scale * sum_s slab[s][co][(kh,kw,ci)] ; Cin_real <= Cin, Cout <= Cout_slab
+ * (slab rows/channels beyond the real extents are layout padding and are dropped) */
+int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW,
+                    int Cin, int Cin_real, float scale, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Weight preparation: fp32 OIHW master -> f16 OHWI forward layout (+ optional
+ * per-output-channel scale fold and channel padding) and the flipped/transposed
+ * layout the data-gradient conv consumes.
+ * -------------------------------------------------------------------- */
+int hd_weight_prep(const float* w_oihw, const float* out_scale /*[Cout] or NULL*/, void* w_fwd /*f16 [Cout][KH][KW][Cin_pad] or NULL*/,
+                   void* w_dgrad /*f16 [Cin_pad][KH][KW][Cout_pad] flipped, or NULL*/, int Cout, int Cin, int KH, int KW,
+                   int Cin_pad, int Cout_pad, void* stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm2d, training mode (batch statistics), split in the three steps the
+ * fused pipeline needs.  Replaces nn.BatchNorm2d inside Conv2dReLU
+ * (src/segmentation_models/base/modules.py:41-42) and torchvision BasicBlock [EXT].
+ * -------------------------------------------------------------------- */
+/* deterministic column sum of a [rows][W] fp32 slab -> out[W]; ws: >= 128*W floats (needed when rows > 32) */
+int hd_colsum(const float* in, int rows, int W, float* out, float* ws, void* stream);
+/* sums[2][C] = (sum x, sum x^2) -> mean/invstd/scale/shift (+ running stats update when running_mean != NULL;
+ * unbiased variance for the running estimate, momentum as nn.BatchNorm2d) */
+int hd_bn_finalize(const float* sums, int C, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                   float* scale, float* shift, void* stream);
+/* eval mode: scale/shift from running statistics */
+int hd_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                           float eps, int C, float* scale, float* shift, void* stream);
+/* z = act(y*scale[c] + shift[c] (+ res)) , all f16 NHWC, n = number of elements (multiple of 8) */
+int hd_bn_apply(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C,
+                int relu, void* stream);
+/* backward of z = relu(bn(y) (+ res)):  part[rows][2][C] <- (sum g, sum g*xhat) with g = dz*(z>0) */
+int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, float* part,
+                     int rows, int64_t npix, int C, int relu, void* stream);
+/* dy = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g (optional); also emits dgamma/dbeta (fp32, scaled by gscale) */
+int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                    const float* gamma, const float* sums /*[2][C] column sums of part*/, void* dy, void* dres,
+                    float* dgamma, float* dbeta, float gscale, int accumulate, int64_t npix, int C, int relu, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Pooling / resampling / layout
+ * -------------------------------------------------------------------- */
+/* MaxPool2d(3, stride 2, pad 1) NHWC f16 (encoders/resnet.py:51 via torchvision ResNet.maxpool [EXT]) */
+int hd_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* generic strided-subsample (LastLevelMaxPool k=1,s=2 [EXT]) */
+int hd_subsample2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_subsample2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream);
+/* NCHW f32 [N,Cr,H,W] -> NHWC f16 [N,Ho,Wo,Cp] with nearest resize src=floor(dst*in/out)
+ * (custom_generalized_transform.py:80-87: F.interpolate default mode) ; channels >= Cr zero-filled.
+ * in_scale multiplies the value (normalize (x-0)/1 is identity: custom_generalized_transform.py:177-186). */
+int hd_nchw_to_nhwc_resize(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream);
+/* backward of the above: dx NCHW f32 (zero where no destination pixel selects the source) */
+int hd_nchw_to_nhwc_resize_bwd(const void* dy, float* dx, int N, int Cr, int H, int W, int Ho, int Wo, int Cp,
+                               float gscale, void* stream);
+/* NHWC f16 [N,H,W,Cp] -> NCHW f32 [N,Cr,H,W] */
+int hd_nhwc_to_nchw(const void* x, float* y, int N, int Cr, int H, int W, int Cp, void* stream);
+/* y = a + nearest_resize(b -> a's size)  (FPN top-down path, torchvision FeaturePyramidNetwork [EXT]) */
+int hd_upsample_add(const void* a, const void* b, void* y, int N, int H, int W, int C, int Hb, int Wb, void* stream);
+/* db[n,hb,wb,c] (+)= sum over (h,w) mapping to (hb,wb) of dy */
+int hd_upsample_add_bwd(const void* dy, void* db, int N, int H, int W, int C, int Hb, int Wb, int accumulate, void* stream);
+/* 2x2 sum-pool of the gradient of a nearest-2x upsample: dx_low[n,h,w,c] (+)= sum dy_up[n,2h+i,2w+j, c_off + c] */
+int hd_upsample2_bwd(const void* dy_up, void* dx_low, int N, int Hl, int Wl, int C, int Ctot, int c_off, int accumulate,
+                     void* stream);
+/* out = a + b ; out = copy channel slice ; all f16, vectors of 8 */
+int hd_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream);
+int hd_slice_channels(const void* x, void* y, int64_t npix, int Ctot, int c_off, int C, int accumulate, void* stream);
+/* elementwise: dlogit = dy * s * (1-s) where s = sigmoid output (NCHW f32 both) -> NHWC f16 [N,H,W,Cp] scaled */
+int hd_sigmoid_bwd_nchw_to_nhwc(const float* dy, const float* s, void* dlogit, int N, int Cr, int H, int W, int Cp,
+                                float gscale, void* stream);
+/* relu mask: dx = dy * (z > 0) */
+int hd_relu_bwd(const void* dy, const void* z, void* dx, int64_t n, void* stream);
+int hd_f32_to_f16(const float* x, void* y, int64_t n, float scale, void* stream);
+int hd_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream);
+/* per-channel sums of an NHWC f16 tensor -> part[rows][C] (bias gradients); reduce with hd_colsum */
+int hd_channel_sum_f16(const void* x, int64_t npix, int C, float* part, int rows, void* stream);
+/* out[i] (=|+=) in[i]*scale, small fp32 vectors */
+int hd_scale_store(const float* in, float* out, int n, float scale, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Detection kernels (torchvision.ops [EXT], reached from
+ * src/utils/eval_forward_fasterrcnn.py:88,122,136 and eval_forward_retinanet.py:157)
+ * -------------------------------------------------------------------- */
+/* batched greedy NMS; boxes [B][nmax][4] already sorted by descending score per image, counts[B] (device int32)
+ * valid boxes each.  mask workspace: [B][nmax][ceil(nmax/64)] u64.  keep[b][i] = 1/0 in sorted order.
+ * IoU test: inter/(a_i+a_j-inter) > thr, fp32, no FMA contraction (torchvision nms [EXT]). */
+int hd_nms_sorted_batched(const float* boxes, const int* counts, int B, int nmax, float iou_thr, uint64_t* mask_ws,
+                          uint8_t* keep, void* stream);
+/* RoIAlign (aligned=False), NHWC f16 features -> [R][PH][PW][C] f16. rois: [R][5] (batch, x1,y1,x2,y2) fp32 */
+int hd_roi_align(const void* feat, const float* rois, void* out, int R, int N, int H, int W, int C, int PH, int PW,
+                 float spatial_scale, int sampling_ratio, void* stream);
+/* backward: dfeat must be zeroed by caller; fp32 atomics into dfeat_f32 [N,H,W,C] */
+int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int R, int N, int H, int W, int C, int PH,
+                     int PW, float spatial_scale, int sampling_ratio, void* stream);
+/* pairwise IoU [G][A] fp32 (torchvision.ops.box_iou [EXT]) */
+int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Optimizer: unscale + clip_grad_value_ + Adam in one pass over a flat buffer
+ * (train_hallucidet.py:431-435,498-499; config.py:204-245)
+ * -------------------------------------------------------------------- */
+int hd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, float clip_value, float inv_scale, float bias_corr1, float bias_corr2,
+                 const float* found_inf /* device flag, step skipped when != 0 */, void* stream);
+/* found_inf[0] = 1 if any element of g is inf/nan */
+int hd_check_finite(const float* g, int64_t n, float* found_inf, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HALLUCIDET_HIP_H */
