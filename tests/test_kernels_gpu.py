@@ -24,7 +24,7 @@ def close(got, want, rtol=4e-3, atol=2e-3):
     err = (got - want).abs()
     tol = atol + rtol * want.abs()
     bad = (err > tol)
-    assert not bad.any(), "max err %.5g (tol %.5g) at %d/%d elements" % (err.max(), tol[err.argmax()] if err.numel() else 0, int(bad.sum()), err.numel())
+    assert not bad.any(), "max err %.5g (tol %.5g) at %d/%d elements" % (err.max(), tol.flatten()[err.argmax()] if err.numel() else 0, int(bad.sum()), err.numel())
 
 
 CONV_CASES = [
@@ -183,11 +183,11 @@ def test_bn_train_forward_backward(dev):
     rv_ = res.float().clone().requires_grad_(True)
     gv = gamma.clone().requires_grad_(True)
     bv = beta.clone().requires_grad_(True)
-    zz, _, _ = ok.bn_train_nhwc(yv, gv, bv, eps, res=rv_, relu=True)
+    zz, _, _ = ok.bn_train_nhwc(yv, gv, bv, eps, res=rv_, relu=False)
     dz = rnd(N, H, W, C, seed=23)
     # use the HIP z for the mask on both sides to avoid ulp-level mask flips
     mask = (z.cpu().float() > 0).float()
-    (zz * 0 + ((yv - mw) * iw * gv + bv + rv_) * mask).backward(dz.float())
+    (zz * mask).backward(dz.float())
     dy, dres, dgamma, dbeta = ops.bn_backward(dz.to(dev), z, y.to(dev), mean, invstd, gamma.to(dev), relu=True, want_dres=True, gscale=1.0)
     close(dy, yv.grad.half(), rtol=1e-2, atol=3e-3)
     close(dres, rv_.grad.half())
