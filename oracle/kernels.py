@@ -99,7 +99,7 @@ def nms_sorted(boxes, thr):
     """Greedy NMS over boxes already sorted by descending score (torchvision nms CPU kernel [EXT], restated
     with scalar fp32 arithmetic).  Returns bool keep mask in the same order."""
     n = boxes.shape[0]
-    b = boxes.float().numpy().astype("float32")
+    b = boxes.detach().float().numpy().astype("float32")
     import numpy as np
 
     areas = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])

@@ -1,0 +1,247 @@
+"""Pin the CPU oracle (oracle/) against fixtures produced by importing the reference's own files
+(tests/golden/make_golden.py) and against hand-worked known answers for the torchvision-side pieces that cannot be
+imported anywhere in this environment."""
+import importlib.util
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detection as od
+from oracle import kernels as ok
+from oracle import unet as ou
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _mg():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def npz(name):
+    return {k: torch.from_numpy(v) if v.dtype.kind in "fiub" else v for k, v in np.load(os.path.join(G, name), allow_pickle=False).items()}
+
+
+# ---------------------------------------------------------------------------------- U-Net decoder / head
+def test_decoder_head_forward_backward_matches_reference():
+    mg = _mg()
+    z = npz("decoder_small.npz")
+    dec = ou.UnetDecoder(mg.ENC_SMALL, mg.DEC_SMALL)
+    head = torch.nn.Sequential(torch.nn.Conv2d(mg.DEC_SMALL[-1], 3, 3, padding=1), torch.nn.Identity(), torch.nn.Sigmoid())
+    dec.load_state_dict({k[len("sd.decoder."):]: v for k, v in z.items() if k.startswith("sd.decoder.")})
+    head.load_state_dict({k[len("sd.segmentation_head."):]: v for k, v in z.items() if k.startswith("sd.segmentation_head.")})
+    dec.train()
+    feats = [z["feat%d" % i].clone().requires_grad_(True) for i in range(6)]
+    out = head(dec(*feats))
+    assert torch.allclose(out, z["out"], atol=1e-6, rtol=1e-5)
+    out.backward(z["gout"])
+    for i in range(1, 6):
+        assert torch.allclose(feats[i].grad, z["gfeat%d" % i], atol=1e-6, rtol=1e-4), i
+    for n, p in dec.named_parameters():
+        assert torch.allclose(p.grad, z["grad.decoder." + n], atol=1e-5, rtol=1e-4), n
+    for n, p in head.named_parameters():
+        assert torch.allclose(p.grad, z["grad.segmentation_head." + n], atol=1e-5, rtol=1e-4), n
+
+
+def test_upsample_matches_reference():
+    z = npz("upsample.npz")
+    assert torch.equal(ou.upsample2(z["x"]), z["y"])
+    assert torch.equal(ok.upsample_deterministic(z["x"], 2), z["y"])
+
+
+def test_initialisation_matches_reference_checksums():
+    rec = json.load(open(os.path.join(G, "init_checksums.json")))
+    torch.manual_seed(123)
+    dec = ou.UnetDecoder()
+    head = torch.nn.Sequential(torch.nn.Conv2d(16, 3, 3, padding=1), torch.nn.Identity(), torch.nn.Identity())
+    ou.initialize_decoder(dec)
+    ou.initialize_head(head)
+    assert sum(p.numel() for p in dec.parameters()) == rec["_n_params"]["decoder"] == 3151552
+    assert sum(p.numel() for p in head.parameters()) == rec["_n_params"]["head"] == 435
+    for prefix, m in (("decoder.", dec), ("segmentation_head.", head)):
+        for k, v in m.state_dict().items():
+            r = rec[prefix + k]
+            assert list(v.shape) == r["shape"], k
+            assert math.isclose(float(v.double().sum()), r["sum"], rel_tol=1e-9, abs_tol=1e-9), k
+            assert math.isclose(float(v.double().abs().sum()), r["abssum"], rel_tol=1e-9, abs_tol=1e-9), k
+
+
+def test_shape_check_message_matches_reference():
+    rec = json.load(open(os.path.join(G, "shape_error.json")))
+    net = ou.Unet()
+    with pytest.raises(RuntimeError) as e:
+        net(torch.zeros(1, 3, *rec["shape"]))
+    assert str(e.value) == rec["message"]
+
+
+def test_unet_parameter_count_and_keys():
+    net = ou.Unet()
+    n = sum(p.numel() for p in net.parameters())
+    assert n == 24436659  # SURVEY/BASELINE: 21 284 672 enc + 3 151 552 dec + 435 head
+    keys = set(net.state_dict().keys())
+    for k in ("encoder.conv1.weight", "encoder.bn1.running_mean", "encoder.layer2.0.downsample.0.weight",
+              "encoder.layer4.2.bn2.weight", "decoder.blocks.0.conv1.0.weight", "decoder.blocks.4.conv2.1.running_var",
+              "segmentation_head.0.weight", "segmentation_head.0.bias"):
+        assert k in keys, k
+    y = net.eval()(torch.rand(1, 3, 64, 96))
+    assert y.shape == (1, 3, 64, 96) and float(y.detach().min()) > 0 and float(y.detach().max()) < 1
+
+
+# ---------------------------------------------------------------------------------- detector transform
+def test_transform_matches_reference():
+    z = npz("transform.npz")
+    t = od.FixedSizeTransform(300).eval()
+    idx = torch.arange(512 * 640, dtype=torch.float32).view(1, 512, 640).repeat(3, 1, 1)
+    boxes = z["boxes_in"]
+    il, tg = t([idx, idx.flip(-1)], [{"boxes": boxes, "labels": torch.ones(3, dtype=torch.int64)},
+                                     {"boxes": boxes[:1], "labels": torch.ones(1, dtype=torch.int64)}])
+    assert torch.equal(il.tensors[0, 0].to(torch.int32), z["src_index"])
+    assert torch.equal(il.tensors[1, 0].to(torch.int32), z["src_index_flipped"])
+    assert [list(s) for s in il.image_sizes] == z["image_sizes"].tolist()
+    assert torch.equal(tg[0]["boxes"], z["boxes_out0"]) and torch.equal(tg[1]["boxes"], z["boxes_out1"])
+    post = t.postprocess([{"boxes": tg[0]["boxes"].clone()}, {"boxes": tg[1]["boxes"].clone()}], il.image_sizes, [(512, 640)] * 2)
+    assert torch.equal(post[0]["boxes"], z["post0"]) and torch.equal(post[1]["boxes"], z["post1"])
+    # SURVEY 0.6 known answer
+    assert torch.allclose(tg[0]["boxes"][0], torch.tensor([4.6875, 11.71875, 51.5625, 128.90625]))
+    # exactly 90 000 source pixels are selected (App. A.14b)
+    assert z["src_index"].unique().numel() == 90000
+    # other fixed size + float64 boxes stay float64
+    t2 = od.FixedSizeTransform(24).eval()
+    il2, tg2 = t2([z["small_img"]], [{"boxes": z["small_boxes_in"], "labels": torch.ones(1, dtype=torch.int64)}])
+    assert torch.equal(il2.tensors, z["small_out"])
+    assert str(tg2[0]["boxes"].dtype) == str(z["small_boxes_out_dtype"]) == "torch.float64"
+    assert torch.equal(tg2[0]["boxes"], z["small_boxes_out"])
+
+
+def test_config_defaults_recorded():
+    rec = json.load(open(os.path.join(G, "config_defaults.json")))
+    assert rec["loss_weights"]["det_regression"] == 0.1 and rec["loss_weights"]["pixel_rgb"] == 0.0
+    assert rec["optimizer_name"] == "adam" and rec["n_gpus"] == 1 and rec["decoder_head"] == "sigmoid"
+    assert rec["args"]["seed"] == 123 and rec["args"]["precision"] == 32
+
+
+# ---------------------------------------------------------------------------------- orchestration
+def test_oracle_orchestration_equals_reference_glue():
+    """The fixture was produced by the REFERENCE's eval_forward_fasterrcnn.py driving the oracle detector object; the
+    oracle's own orchestration must reproduce it exactly (same weights by seed, same injected sampler permutations)."""
+    mg = _mg()
+    z = npz("glue_fasterrcnn.npz")
+    model, images, targets, perm_log, _ = mg.make_detector_case()
+    assert torch.equal(images, z["images"])
+    losses, dets = od.eval_forward_fasterrcnn(model, images, targets, train_det=False)
+    assert len(perm_log) == int(z["n_perm"]) == 8  # 2 images x (RPN pos/neg + RoI pos/neg)
+    for k in ("loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"):
+        assert torch.allclose(losses[k], z["loss." + k], rtol=1e-6, atol=1e-7), k
+    for i, d in enumerate(dets):
+        assert torch.equal(d["labels"], z["det%d.labels" % i])
+        assert torch.allclose(d["boxes"], z["det%d.boxes" % i], rtol=1e-6, atol=1e-5)
+        assert torch.allclose(d["scores"], z["det%d.scores" % i], rtol=1e-6, atol=1e-7)
+        assert d["boxes"].shape[0] <= 100 and d["labels"].dtype == torch.int64
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference tree only exists in the build container")
+def test_reference_glue_live():
+    mg = _mg()
+    ref = mg.load_reference()
+    model, images, targets, _, _ = mg.make_detector_case(seed=11)
+    l_ref, d_ref = ref.glue.eval_forward_fasterrcnn(model, images, targets, train_det=False)
+    model2, images2, targets2, _, _ = mg.make_detector_case(seed=11)
+    l_or, d_or = od.eval_forward_fasterrcnn(model2, images2, targets2, train_det=False)
+    for k in l_ref:
+        assert torch.allclose(l_ref[k], l_or[k], rtol=1e-6, atol=1e-7), k
+    for a, b in zip(d_ref, d_or):
+        assert torch.equal(a["labels"], b["labels"]) and torch.allclose(a["boxes"], b["boxes"], atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------- known answers (torchvision side)
+def test_anchor_generator_known_answers():
+    ag = od.AnchorGenerator()
+    base = ag.base_anchors((32,), (0.5, 1.0, 2.0))
+    assert torch.equal(base, torch.tensor([[-23., -11., 23., 11.], [-16., -16., 16., 16.], [-11., -23., 11., 23.]]))
+    il = od.ImageList(torch.zeros(2, 3, 300, 300), [(300, 300)] * 2)
+    feats = [torch.zeros(2, 256, s, s) for s in (75, 38, 19, 10, 5)]
+    a = ag(il, feats)
+    assert len(a) == 2 and a[0].shape == (22665, 4)  # 3*(75^2+38^2+19^2+10^2+5^2)
+    # strides are integer floor divisions: 4,7,15,30,60
+    assert torch.equal(a[0][3], torch.tensor([4. - 23, -11., 4. + 23, 11.]))  # second location, first anchor of level 0
+    lvl1 = a[0][3 * 75 * 75:]
+    assert torch.equal(lvl1[3], torch.tensor([7. - 45, -23., 7. + 45, 23.]))
+
+
+def test_box_coder_roundtrip_and_known_answer():
+    bc = od.BoxCoder((10.0, 10.0, 5.0, 5.0))
+    prop = torch.tensor([[10.0, 10.0, 50.0, 90.0]])
+    gt = torch.tensor([[20.0, 30.0, 60.0, 70.0]])
+    code = bc.encode_single(gt, prop)
+    want = torch.tensor([[10 * (40 - 30) / 40, 10 * (50 - 50) / 80, 5 * math.log(40 / 40), 5 * math.log(40 / 80)]])
+    assert torch.allclose(code, want, atol=1e-6)
+    assert torch.allclose(bc.decode_single(code, prop), gt, atol=1e-4)
+    big = torch.tensor([[0.0, 0.0, 100.0, 100.0]])
+    d = bc.decode_single(big, prop)
+    assert torch.isfinite(d).all() and float(d[0, 2] - d[0, 0]) <= 40 * 1000 / 16 + 1e-3  # clamp at log(1000/16)
+
+
+def test_matcher_known_answers():
+    iou = torch.tensor([[0.9, 0.1, 0.45, 0.2, 0.0], [0.2, 0.35, 0.45, 0.6, 0.0]])
+    m = od.Matcher(0.7, 0.3, allow_low_quality_matches=True)(iou.clone())
+    # col0 -> gt0 (>=0.7); col1 0.35 between -> -2 ; col2 0.45 between; col3 0.6 between but is gt1's best -> restored to 1; col4 below -> -1
+    assert m.tolist() == [0, -2, -2, 1, -1]
+    m2 = od.Matcher(0.5, 0.5, allow_low_quality_matches=False)(iou.clone())
+    assert m2.tolist() == [0, -1, -1, 1, -1]
+
+
+def test_sampler_counts_and_injection():
+    perms = []
+    s = od.BalancedPositiveNegativeSampler(8, 0.25, randperm_fn=lambda n: (perms.append(n), torch.arange(n))[1])
+    lab = torch.tensor([1, 0, 0, 1, 1, -1, 0, 0, 0, 0, 0, 0])
+    pos, neg = s([lab])
+    assert perms == [3, 8] and int(pos[0].sum()) == 2 and int(neg[0].sum()) == 6
+    assert pos[0].tolist()[:5] == [1, 0, 0, 1, 0]
+
+
+def test_nms_known_answers():
+    b = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [20., 20., 30., 30.], [0., 0., 10., 10.]])
+    s = torch.tensor([0.9, 0.8, 0.7, 0.6])
+    assert od.nms(b, s, 0.5).tolist() == [0, 2]
+    assert od.nms(b, s, 0.7).tolist() == [0, 1, 2]      # IoU(0,1)=81/119=0.68
+    assert od.batched_nms(b, s, torch.tensor([0, 1, 0, 1]), 0.5).tolist() == [0, 1, 2]  # 3 falls to 1 (same class, IoU .68); 0 never suppresses 1
+    assert od.batched_nms(b, s, torch.tensor([0, 1, 2, 3]), 0.5).tolist() == [0, 1, 2, 3]  # different classes never suppress
+    assert od.batched_nms(b, s, torch.tensor([0, 0, 0, 0]), 0.5).tolist() == [0, 2]
+    assert od.nms(torch.zeros(0, 4), torch.zeros(0), 0.5).numel() == 0
+
+
+def test_roi_align_vectorised_equals_scalar():
+    torch.manual_seed(0)
+    feat = torch.randn(2, 4, 19, 19)
+    rois = torch.tensor([[0, 10.0, 20.0, 110.0, 220.0], [1, 0.0, 0.0, 299.0, 299.0], [1, 150.3, 40.2, 160.9, 47.7],
+                         [0, 280.0, 280.0, 330.0, 310.0], [0, -20.0, -5.0, 30.0, 60.0]])
+    a = od.roi_align_autograd(feat, rois, 7, 1 / 16, 2)
+    b = ok.roi_align_nchw(feat, rois, 7, 7, 1 / 16, 2)
+    assert torch.allclose(a, b, atol=1e-5)
+    # constant feature map -> constant output wherever samples are inside
+    c = od.roi_align_autograd(torch.ones(1, 1, 10, 10), torch.tensor([[0, 16.0, 16.0, 80.0, 80.0]]), 7, 1 / 16, 2)
+    assert torch.allclose(c, torch.ones_like(c))
+
+
+def test_level_mapper_and_scales():
+    p = od.MultiScaleRoIAlign()
+    feats = [torch.zeros(1, 1, s, s) for s in (75, 38, 19, 10)]
+    assert [p.infer_scale(f, (300, 300)) for f in feats] == [0.25, 0.125, 0.0625, 0.03125]
+    boxes = [torch.tensor([[0., 0., 32., 32.], [0., 0., 112., 112.], [0., 0., 224., 224.], [0., 0., 300., 300.], [0., 0., 111.9, 111.9]])]
+    assert p.level_map(boxes, 2, 5).tolist() == [0, 1, 2, 2, 0]
+
+
+def test_fastrcnn_and_rpn_loss_shapes():
+    logits = torch.tensor([[2.0, 0.0], [0.0, 3.0], [1.0, 1.0]])
+    reg = torch.zeros(3, 8)
+    cls, box = od.fastrcnn_loss(logits, reg, [torch.tensor([0, 1, 0])], [torch.tensor([[0.0] * 4, [0.5, 0.0, 0.0, 0.0], [0.0] * 4])])
+    want_cls = torch.nn.functional.cross_entropy(logits, torch.tensor([0, 1, 0]))
+    assert torch.isclose(cls, want_cls)
+    # smooth-l1 beta=1/9 on |0.5| = 0.5 - 0.5/9 ; / numel(labels)=3
+    assert torch.isclose(box, torch.tensor((0.5 - 0.5 / 9) / 3))
