@@ -1,0 +1,72 @@
+"""Optimizer and loss scaling for the hallucination network.
+
+`FusedAdam` = torch.optim.Adam semantics (reference: config.py:204-245 builds Adam(lr); train_hallucidet.py:431-435)
+with Lightning's `gradient_clip_val=0.5, gradient_clip_algorithm="value"` (train_hallucidet.py:498-499) folded in, run
+as ONE kernel over the flat fp32 parameter arena (hd_adam_step).  `LossScaler` mirrors torch.cuda.amp.GradScaler's
+policy (init 2**16, growth x2 every 2000 clean steps, backoff x0.5), which Lightning installs for `--precision 16`.
+"""
+import torch
+
+from . import ops
+
+
+class FusedAdam(torch.optim.Optimizer):
+    def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0):
+        self.runner = unet.runner
+        self.runner.flatten_parameters()
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_value=clip_value)
+        super().__init__(list(unet.parameters()), defaults)
+        flat = self.runner.flat_params
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count = 0
+        self.found_inf = torch.zeros(1, dtype=torch.float32, device=flat.device)
+
+    def zero_grad(self, set_to_none=False):
+        # gradients are overwritten (not accumulated) by every backward pass; nothing to do, and the views must stay
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None, inv_scale=1.0, check_inf=False):
+        r = self.runner
+        r.flatten_parameters()
+        g = self.param_groups[0]
+        if check_inf:
+            self.found_inf.zero_()
+            ops.check_finite(r.flat_grads, self.found_inf)
+        self.step_count += 1
+        ops.adam_step(r.flat_params, r.flat_grads, self.exp_avg, self.exp_avg_sq, lr=g["lr"], beta1=g["betas"][0],
+                      beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], clip_value=g["clip_value"],
+                      inv_scale=inv_scale, step=self.step_count, found_inf=self.found_inf if check_inf else None)
+
+
+class LossScaler:
+    def __init__(self, unet, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
+        self.runner = unet.runner
+        self.scale_value = float(init_scale) if enabled else 1.0
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+        self.enabled = enabled
+        self._good = 0
+
+    def scale(self, loss):
+        self.runner.grad_scale = self.scale_value
+        return loss * self.scale_value
+
+    def step(self, optimizer):
+        """Parameter gradients were already divided by the scale in-kernel; only inf/nan detection remains."""
+        optimizer.step(check_inf=self.enabled)
+        return optimizer.found_inf
+
+    def update(self, found_inf_host=None):
+        """`found_inf_host`: python bool if the caller already synchronised, else the device flag is read (one sync)."""
+        if not self.enabled:
+            return
+        bad = bool(found_inf_host) if found_inf_host is not None else False
+        if bad:
+            self.scale_value *= self.backoff_factor
+            self._good = 0
+        else:
+            self._good += 1
+            if self._good >= self.growth_interval:
+                self.scale_value *= self.growth_factor
+                self._good = 0

@@ -1,0 +1,447 @@
+"""Hallucination network: U-Net with a ResNet encoder, executed by hand-written HIP kernels.
+
+Host-side mirror of the reference's `smp.Unet` for the one configuration the hot path uses
+(src/models/encoder_decoder.py:22-30; src/segmentation_models/decoders/unet/model.py:56-100,
+decoders/unet/decoder.py:11-46,68-124; base/modules.py:10-47; base/heads.py:21-27; encoders/resnet.py:37-65).
+Sub-module names and parameter shapes equal the reference's checkpoint layout:
+  encoder.{conv1,bn1,layer1..4.{i}.{conv1,bn1,conv2,bn2,downsample.{0,1}}},
+  decoder.blocks.{i}.conv{1,2}.{0,1}, segmentation_head.{0,1,2}.
+
+torch.nn.Conv2d / BatchNorm2d objects are used ONLY as parameter containers (names, shapes, state_dict,
+initialisation); their forward() is never called.  `Unet.forward` runs an explicit schedule of C-ABI launches
+(`UnetRunner`) and the whole forward/backward is exposed to autograd as ONE Function, so PyTorch owns memory and the
+graph edge while every FLOP runs in libhallucidet_hip.so.  There is no ATen fallback.
+
+Data layout in HBM: activations NHWC fp16; per conv a raw output `y` and a post-BN/ReLU tensor `z` are kept for the
+backward pass; weights are re-packed each step from the fp32 masters into [Cout][KH][KW][Cin] fp16 (+ the flipped
+[Cin][KH][KW][Cout] copy the data-gradient consumes); BatchNorm statistics, parameter gradients and the optimizer run
+in fp32 on one flat arena (one all-reduce buffer for data parallelism).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..ops import ACT_NONE, ACT_SIGMOID
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# parameter containers (structure only)
+# ----------------------------------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, cin, cout, stride):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        self.stride = stride
+
+
+class ResNetEncoder(nn.Module):
+    """torchvision ResNet(BasicBlock, layers) minus avgpool/fc, as the reference's ResNetEncoder exposes it."""
+
+    def __init__(self, layers=(3, 4, 6, 3), out_channels=(3, 64, 64, 128, 256, 512), depth=5):
+        super().__init__()
+        self._depth, self._out_channels, self._in_channels = depth, out_channels, 3
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for i, (n, c) in enumerate(zip(layers, (64, 128, 256, 512))):
+            blocks = []
+            for b in range(n):
+                blocks.append(BasicBlock(cin, c, 2 if (b == 0 and i > 0) else 1))
+                cin = c
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    @property
+    def out_channels(self):
+        return self._out_channels[: self._depth + 1]
+
+    @property
+    def output_stride(self):
+        return min(32, 2 ** self._depth)
+
+
+class Conv2dReLU(nn.Sequential):
+    def __init__(self, cin, cout, kernel_size=3, padding=1, stride=1, use_batchnorm=True):
+        if not use_batchnorm or use_batchnorm == "inplace":
+            raise NotImplementedError("hallucidet_amd: only use_batchnorm=True is on the hot path")
+        super().__init__(nn.Conv2d(cin, cout, kernel_size, stride=stride, padding=padding, bias=False),
+                         nn.BatchNorm2d(cout), nn.ReLU(inplace=True))
+
+
+class DecoderBlock(nn.Module):
+    def __init__(self, in_channels, skip_channels, out_channels, use_batchnorm=True, attention_type=None):
+        super().__init__()
+        if attention_type is not None:
+            raise NotImplementedError("hallucidet_amd: decoder_attention_type must be None (reference default)")
+        self.conv1 = Conv2dReLU(in_channels + skip_channels, out_channels, use_batchnorm=use_batchnorm)
+        self.attention1 = nn.Identity()
+        self.conv2 = Conv2dReLU(out_channels, out_channels, use_batchnorm=use_batchnorm)
+        self.attention2 = nn.Identity()
+        self.in_channels, self.skip_channels = in_channels, skip_channels
+
+
+class UnetDecoder(nn.Module):
+    def __init__(self, encoder_channels, decoder_channels, n_blocks=5, use_batchnorm=True, attention_type=None, center=False):
+        super().__init__()
+        if n_blocks != len(decoder_channels):
+            raise ValueError("Model depth is {}, but you provide `decoder_channels` for {} blocks.".format(n_blocks, len(decoder_channels)))
+        if center:
+            raise NotImplementedError("hallucidet_amd: center block is only used by vgg encoders (out of scope)")
+        enc = list(encoder_channels[1:])[::-1]
+        cins = [enc[0]] + list(decoder_channels[:-1])
+        cskips = enc[1:] + [0]
+        self.center = nn.Identity()
+        self.blocks = nn.ModuleList(DecoderBlock(a, b, c, use_batchnorm, attention_type) for a, b, c in zip(cins, cskips, decoder_channels))
+
+
+class SegmentationHead(nn.Sequential):
+    def __init__(self, in_channels, out_channels, kernel_size=3, activation=None, upsampling=1):
+        if upsampling != 1:
+            raise NotImplementedError("hallucidet_amd: head upsampling is not on the hot path")
+        act = nn.Identity() if activation is None else activation
+        super().__init__(nn.Conv2d(in_channels, out_channels, kernel_size, padding=kernel_size // 2), nn.Identity(), act)
+
+
+def initialize_decoder(module):
+    """base/initialization.py:4-19"""
+    for m in module.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.BatchNorm2d):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+def initialize_head(module):
+    """base/initialization.py:22-27"""
+    for m in module.modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+
+
+_ENCODERS = {
+    "resnet18": dict(layers=(2, 2, 2, 2), out_channels=(3, 64, 64, 128, 256, 512)),
+    "resnet34": dict(layers=(3, 4, 6, 3), out_channels=(3, 64, 64, 128, 256, 512)),
+}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# execution
+# ----------------------------------------------------------------------------------------------------------------
+class _Unit:
+    """One conv (+BatchNorm) node of the schedule."""
+
+    def __init__(self, name, conv, bn, *, relu=True):
+        self.name, self.conv, self.bn, self.relu = name, conv, bn, relu
+        self.k = conv.kernel_size[0]
+        self.stride, self.pad = conv.stride[0], conv.padding[0]
+        self.cin, self.cout = conv.in_channels, conv.out_channels
+        self.cin_p = (self.cin + 7) // 8 * 8
+        self.cout_p = (self.cout + 7) // 8 * 8
+
+
+class _UnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, hook, runner):
+        out = runner.forward(x, training=True, save=True)
+        ctx.runner = runner
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dx = ctx.runner.backward(dout.contiguous(), need_dx=ctx.needs_input_grad[0])
+        return dx, None, None
+
+
+class UnetRunner:
+    """Explicit forward/backward schedule over the C ABI for one Unet module."""
+
+    def __init__(self, module):
+        self.module = module
+        self.grad_scale = 1.0          # loss scale S applied upstream; parameter gradients are emitted as g/S
+        self.saved = None
+        enc, dec = module.encoder, module.decoder
+        self.stem = _Unit("encoder.conv1", enc.conv1, enc.bn1)
+        self.stages = []
+        for li in range(1, 5):
+            blocks = []
+            for bi, blk in enumerate(getattr(enc, "layer%d" % li)):
+                pre = "encoder.layer%d.%d." % (li, bi)
+                u1 = _Unit(pre + "conv1", blk.conv1, blk.bn1)
+                u2 = _Unit(pre + "conv2", blk.conv2, blk.bn2)
+                ud = _Unit(pre + "downsample", blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else None
+                blocks.append((u1, u2, ud))
+            self.stages.append(blocks)
+        self.dec = []
+        for i, b in enumerate(dec.blocks):
+            pre = "decoder.blocks.%d." % i
+            self.dec.append((_Unit(pre + "conv1", b.conv1[0], b.conv1[1]), _Unit(pre + "conv2", b.conv2[0], b.conv2[1]), b.in_channels, b.skip_channels))
+        self.head_conv = module.segmentation_head[0]
+        self.units = [self.stem] + [u for st in self.stages for blk in st for u in blk if u is not None] + [u for d in self.dec for u in d[:2]]
+
+    # ------------------------------------------------------------------ parameters
+    def flatten_parameters(self):
+        """Make every parameter (and gradient) a view of one fp32 arena; BN running stats likewise."""
+        params = [p for p in self.module.parameters()]
+        dev = params[0].device
+        if getattr(self, "_flat", None) is not None and self._flat.device == dev and all(
+                p.data_ptr() == self._flat.data_ptr() + o * 4 and p.grad is not None
+                and p.grad.data_ptr() == self._gflat.data_ptr() + o * 4 for p, o in zip(params, self._offsets)):
+            return
+        offs, total = [], 0
+        for p in params:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4     # keep every view 16-byte aligned
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(params, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            p.grad = gflat[o:o + p.numel()].view(p.shape)
+        self._flat, self._gflat, self._offsets = flat, gflat, offs
+        self._params = params
+
+    @property
+    def flat_params(self):
+        self.flatten_parameters()
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        self.flatten_parameters()
+        return self._gflat
+
+    def _prep_weights(self, need_dgrad):
+        """fp32 OIHW masters -> fp16 GEMM layouts (every step in training: the masters move)."""
+        W = {}
+        for u in self.units:
+            wf, wd = ops.weight_prep(u.conv.weight, cin_pad=u.cin_p, cout_pad=u.cout_p, want_fwd=True,
+                                     want_dgrad=need_dgrad and u is not self.stem)
+            W[u.name] = (wf, wd)
+        hc = self.head_conv
+        W["head"] = ops.weight_prep(hc.weight, cin_pad=hc.in_channels, cout_pad=8, want_fwd=True, want_dgrad=need_dgrad)
+        return W
+
+    # ------------------------------------------------------------------ forward pieces
+    def _conv_bn(self, u, x, W, training, rec, *, x2=None, up1=False, res=None):
+        """conv -> BatchNorm(train: batch statistics / eval: running statistics) (+res) (+ReLU).  Returns z."""
+        wf = W[u.name][0]
+        if training:
+            y, stats = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1, want_stats=True)
+            sums = ops.colsum(stats.view(stats.shape[0], -1))
+            npix = y.numel() // u.cout
+            mean, invstd, scale, shift = ops.bn_finalize(sums, npix, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
+                                                         u.bn.momentum, u.bn.eps)
+        else:
+            y = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1)
+            scale, shift = ops.bn_eval_scale_shift(u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.bn.eps)
+            mean = invstd = None
+        z = ops.bn_apply(y, scale, shift, res=res, relu=u.relu)
+        if rec is not None:
+            rec[u.name] = dict(x=x, x2=x2, up1=up1, y=y, z=z, mean=mean, invstd=invstd, has_res=res is not None)
+        return z
+
+    def forward(self, x, training, save):
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("Unet expects [N,3,H,W], got %s" % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise RuntimeError("hallucidet_amd Unet runs on the GPU only (input is on %s); there is no CPU path" % x.device)
+        self.flatten_parameters()
+        N, _, H, Wd = x.shape
+        save = save and training
+        rec = {} if save else None
+        Wt = self._prep_weights(need_dgrad=save)
+        x = x.contiguous().float()
+        a0 = ops.nchw_to_nhwc_resize(x, H, Wd, 8)
+        f1 = self._conv_bn(self.stem, a0, Wt, training, rec)
+        cur = ops.maxpool3x3s2(f1)
+        feats = [f1]
+        pooled = cur
+        for blocks in self.stages:
+            for (u1, u2, ud) in blocks:
+                z1 = self._conv_bn(u1, cur, Wt, training, rec)
+                idt = cur if ud is None else self._conv_bn(ud, cur, Wt, training, rec)
+                cur = self._conv_bn(u2, z1, Wt, training, rec, res=idt)
+            feats.append(cur)
+        # feats = [f1, f2, f3, f4, f5]
+        skips = [feats[3], feats[2], feats[1], feats[0], None]
+        d = feats[4]
+        for (u1, u2, cin, cskip), skip in zip(self.dec, skips):
+            z1 = self._conv_bn(u1, d, Wt, training, rec, x2=skip, up1=True)
+            d = self._conv_bn(u2, z1, Wt, training, rec)
+        hc = self.head_conv
+        out = ops.conv2d(d, Wt["head"][0], 3, 3, bias=hc.bias, pad=1, act=ACT_SIGMOID, out_nchw_f32=True, cout=hc.out_channels)
+        if training:
+            self._bump_batches_tracked()
+        if save:
+            self.saved = dict(rec=rec, W=Wt, f1=f1, pooled=pooled, feats=feats, head_in=d, out=out, shape=(N, H, Wd))
+        return out
+
+    def _bump_batches_tracked(self):
+        for u in self.units:
+            if u.bn.num_batches_tracked is not None:
+                u.bn.num_batches_tracked += 1
+
+    # ------------------------------------------------------------------ backward pieces
+    def _unit_bwd(self, u, dz, S, *, want_dres=False, need_dx=True, dx_res=None):
+        """Backward through z = relu(bn(conv(x)) (+res)).  Writes dW/dgamma/dbeta into the flat gradient arena.
+        Returns (dx over the logical conv input or None, dres or None)."""
+        r = self.saved["rec"][u.name]
+        inv = 1.0 / S
+        dy, dres, _, _ = ops.bn_backward(dz, r["z"], r["y"], r["mean"], r["invstd"], u.bn.weight, relu=u.relu, want_dres=want_dres,
+                                         gscale=inv, dgamma=u.bn.weight.grad, dbeta=u.bn.bias.grad)
+        slab = ops.wgrad(r["x"], dy, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"])
+        ops.wgrad_reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
+        dx = None
+        if need_dx:
+            wd = self.saved["W"][u.name][1]
+            x = r["x"]
+            if r["up1"]:
+                hw = (x.shape[1] * 2, x.shape[2] * 2)
+            else:
+                hw = (x.shape[1], x.shape[2])
+            dx = ops.conv2d(dy, wd, u.k, u.k, stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res)
+        return dx, dres
+
+    def backward(self, dout, need_dx=False):
+        sv = self.saved
+        if sv is None:
+            raise RuntimeError("Unet.backward called without a saved training forward")
+        S = float(self.grad_scale)
+        inv = 1.0 / S
+        N, H, Wd = sv["shape"]
+        hc = self.head_conv
+        # head: sigmoid' then conv backward
+        dl = ops.sigmoid_bwd_nchw_to_nhwc(dout.float(), sv["out"], 8, 1.0)
+        db = ops.channel_sum(dl)
+        ops.scale_store(db, hc.bias.grad, inv, accumulate=False)
+        slab = ops.wgrad(sv["head_in"], dl, 3, 3, pad=1)
+        ops.wgrad_reduce(slab, hc.weight.grad, 3, 3, hc.in_channels, Cout=hc.out_channels, scale=inv)
+        dz = ops.conv2d(dl, sv["W"]["head"][1], 3, 3, pad=1, cout=hc.in_channels)
+        # decoder, last block first
+        feats = sv["feats"]
+        skips = [feats[3], feats[2], feats[1], feats[0], None]
+        dskip = [None] * 5
+        for i in range(len(self.dec) - 1, -1, -1):
+            u1, u2, cin, cskip = self.dec[i]
+            dz1, _ = self._unit_bwd(u2, dz, S)
+            dcat, _ = self._unit_bwd(u1, dz1, S)
+            xin = sv["rec"][u1.name]["x"]
+            dz = torch.empty_like(xin)
+            ops.upsample2_bwd(dcat, dz, 0, accumulate=False)
+            if cskip:
+                dskip[i] = torch.empty_like(skips[i])
+                ops.slice_channels(dcat, dskip[i], cin, accumulate=False)
+        # dz is now the gradient of f5; dskip[0..3] belong to f4, f3, f2, f1
+        dfeat = {4: dz, 3: dskip[0], 2: dskip[1], 1: dskip[2], 0: dskip[3]}
+        d_out = dfeat[4]
+        for si in range(3, -1, -1):
+            blocks = self.stages[si]
+            for bi in range(len(blocks) - 1, -1, -1):
+                u1, u2, ud = blocks[bi]
+                # gradient that the block INPUT also receives from elsewhere (decoder skip) when it is a stage output
+                extra = dfeat[si] if bi == 0 and si > 0 else None
+                dz1, dres = self._unit_bwd(u2, d_out, S, want_dres=True)
+                first_block = (si == 0 and bi == 0)
+                if ud is None:
+                    acc = dres if extra is None else ops.add_f16(dres, extra)
+                    d_in, _ = self._unit_bwd(u1, dz1, S, dx_res=acc)
+                else:
+                    d_in, _ = self._unit_bwd(u1, dz1, S, dx_res=extra)
+                    d_in, _ = self._unit_bwd(ud, dres, S, dx_res=d_in)
+                d_out = d_in
+                _ = first_block
+        # d_out = gradient of the max-pooled stem output
+        df1 = ops.maxpool3x3s2_bwd(sv["f1"], d_out)
+        df1 = ops.add_f16(df1, dfeat[0], out=df1)
+        dx = None
+        if need_dx:
+            raise NotImplementedError("gradient w.r.t. the Unet input is not on the hot path (IR images are data)")
+        self._unit_bwd(self.stem, df1, S, need_dx=False)
+        self.saved = None
+        return dx
+
+
+class SegmentationModel(nn.Module):
+    def check_input_shape(self, x):
+        """base/model.py:12-22 (same message)."""
+        h, w = x.shape[-2:]
+        s = self.encoder.output_stride
+        if h % s != 0 or w % s != 0:
+            new_h = (h // s + 1) * s if h % s != 0 else h
+            new_w = (w // s + 1) * s if w % s != 0 else w
+            raise RuntimeError(
+                f"Wrong input shape height={h}, width={w}. Expected image height and width "
+                f"divisible by {s}. Consider pad your images to shape ({new_h}, {new_w})."
+            )
+
+
+class Unet(SegmentationModel):
+    """`smp.Unet(encoder_name, encoder_depth, encoder_weights, ..., in_channels, classes)` for resnet18/34 encoders."""
+
+    def __init__(self, encoder_name="resnet34", encoder_depth=5, encoder_weights=None, decoder_use_batchnorm=True,
+                 decoder_channels=(256, 128, 64, 32, 16), decoder_attention_type=None, in_channels=3, classes=1,
+                 activation=None, aux_params=None):
+        super().__init__()
+        if encoder_name not in _ENCODERS:
+            raise KeyError("Wrong encoder name `{}`, supported encoders: {}".format(encoder_name, list(_ENCODERS)))
+        if encoder_depth != 5 or in_channels != 3 or aux_params is not None:
+            raise NotImplementedError("hallucidet_amd Unet: encoder_depth=5, in_channels=3, aux_params=None (reference hot path)")
+        if isinstance(encoder_weights, str) and encoder_weights not in ("imagenet",):
+            # a local state_dict path
+            sd = torch.load(encoder_weights, map_location="cpu")
+        else:
+            sd = None   # 'imagenet' cannot be downloaded offline: random initialisation (SURVEY App. D.8 deviation)
+        self.encoder = ResNetEncoder(**_ENCODERS[encoder_name])
+        if sd is not None:
+            sd.pop("fc.bias", None)
+            sd.pop("fc.weight", None)
+            self.encoder.load_state_dict(sd)
+        self.decoder = UnetDecoder(self.encoder.out_channels, decoder_channels, n_blocks=encoder_depth,
+                                   use_batchnorm=decoder_use_batchnorm, center=False, attention_type=decoder_attention_type)
+        self.segmentation_head = SegmentationHead(decoder_channels[-1], classes, kernel_size=3, activation=activation)
+        self.classification_head = None
+        self.name = "u-{}".format(encoder_name)
+        initialize_decoder(self.decoder)
+        initialize_head(self.segmentation_head)
+        self._runner = None
+        self._hook = None
+
+    @property
+    def runner(self):
+        if self._runner is None:
+            self._runner = UnetRunner(self)
+        return self._runner
+
+    def forward(self, x):
+        self.check_input_shape(x)
+        if not isinstance(self.segmentation_head[-1], nn.Sigmoid):
+            raise NotImplementedError("hallucidet_amd Unet: the fused head kernel implements the 'sigmoid' head "
+                                      "(Config.EncoderDecoder.decoder_head, config.py:78)")
+        r = self.runner
+        if not (self.training and torch.is_grad_enabled()):
+            return r.forward(x, training=self.training, save=False)
+        if self._hook is None or self._hook.device != x.device:
+            self._hook = torch.zeros(1, device=x.device, requires_grad=True)
+        return _UnetFn.apply(x, self._hook, r)

@@ -1,0 +1,68 @@
+"""Per-layer diagnostics: HIP U-Net vs quantised CPU oracle (run on the GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import unet as ou
+from hallucidet_amd.models.encoder_decoder import EncoderDecoder
+
+dev = torch.device("cuda:0")
+torch.manual_seed(2)
+net = EncoderDecoder(name="resnet34", encoder_weights=None).encoder_decoder
+with torch.no_grad():
+    for m in net.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            m.weight.copy_(m.weight.half().float())
+ref = ou.Unet(classes=3)
+ref.load_state_dict(net.state_dict())
+net = net.to(dev).train(); ref.train()
+N, H, W = 2, 64, 96
+x = torch.rand(N, 3, H, W)
+gout = torch.randn(N, 3, H, W) * 1e-2
+S = 1024.0
+net.runner.grad_scale = S
+
+# capture oracle intermediates: conv outputs (raw y) by hooking Conv2d modules
+acts = {}
+def hook(name):
+    def f(mod, inp, out):
+        acts[name] = out.detach()
+    return f
+for n, m in ref.named_modules():
+    if isinstance(m, torch.nn.Conv2d):
+        m.register_forward_hook(hook(n))
+# run HIP forward keeping the records
+r = net.runner
+out = net(x.to(dev))
+rec = dict(r.saved["rec"])
+masks = {k: (v["z"].permute(0, 3, 1, 2) > 0).float().cpu() for k, v in rec.items() if not k.endswith("downsample")}
+wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
+(wq * gout).sum().backward()
+(out * (gout.to(dev) * S)).sum().backward()
+torch.cuda.synchronize()
+
+def stat(a, b):
+    a = a.float().cpu(); b = b.float()
+    e = (a - b).abs()
+    return "max %.3e mean %.3e | ref absmean %.3e" % (e.max(), e.mean(), b.abs().mean())
+
+name_map = {}
+for n, m in ref.named_modules():
+    if isinstance(m, torch.nn.Conv2d):
+        name_map[n] = n
+for uname, rc in rec.items():
+    key = uname
+    if key.endswith("downsample"):
+        key = key + ".0"
+    if key.startswith("decoder.blocks"):
+        key = key + ".0"
+    if key in acts:
+        y = rc["y"].permute(0, 3, 1, 2)
+        print("%-34s y: %s" % (uname, stat(y, ou.fp16_round(acts[key]))))
+    else:
+        print("missing", uname, key)
+print("out:", stat(out.detach(), wq.detach()))
+for (n, p), (_, pw) in zip(net.named_parameters(), ref.named_parameters()):
+    g, w = p.grad.cpu(), pw.grad
+    rel = float((g - w).norm() / (w.norm() + 1e-12))
+    cos = float(torch.nn.functional.cosine_similarity(g.flatten(), w.flatten(), dim=0))
+    print("%-44s rel %.4f cos %.5f |g| %.3e |w| %.3e" % (n, rel, cos, g.norm(), w.norm()))
