@@ -30,7 +30,7 @@ class HipCallError(RuntimeError):
 
 class ConvArgs(C.Structure):
     _fields_ = [
-        ("x", vp), ("x2", vp), ("w", vp), ("bias", vp), ("res", vp), ("y", vp), ("stats", vp),
+        ("x", vp), ("x2", vp), ("w", vp), ("bias", vp), ("res", vp), ("mask", vp), ("y", vp), ("stats", vp),
         ("N", c_i32), ("Hsrc", c_i32), ("Wsrc", c_i32), ("Hin", c_i32), ("Win", c_i32),
         ("C1", c_i32), ("C2", c_i32), ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
         ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32),
@@ -85,6 +85,8 @@ PROTOTYPES = {
     "hd_scale_store": (C.c_int, [vp, vp, C.c_int, c_f, C.c_int, vp]),
     "hd_nms_sorted_batched": (C.c_int, [vp, vp, C.c_int, C.c_int, c_f, vp, vp, vp]),
     "hd_roi_align": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
+    "hd_roi_align_ml": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),
+    "hd_roi_align_ml_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_roi_align_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_box_iou": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "hd_adam_step": (C.c_int, [vp, vp, vp, vp, c_i64] + [c_f] * 9 + [vp, vp]),

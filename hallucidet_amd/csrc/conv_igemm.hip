@@ -24,6 +24,7 @@ struct ConvP {
   const f16* w;
   const float* bias;
   const f16* res;
+  const f16* mask;
   void* y;
   float* stats;
   int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1, in_dil, act, out_mode;
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
         if (pix < p.M && cvalid) {
           float v = acc[a][b][r] + bias;
           if (p.res) v += (float)p.res[(size_t)pix * p.Cout + co];
+          if (p.mask && !((float)p.mask[(size_t)pix * p.Cout + co] > 0.f)) v = 0.f;
           if (p.stats) {
             float vr = (float)(f16)v;
             ssum[b] += vr;
@@ -267,6 +269,7 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.w = (const f16*)a->w;
   p.bias = a->bias;
   p.res = (const f16*)a->res;
+  p.mask = (const f16*)a->mask;
   p.y = a->y;
   p.stats = a->stats;
   p.N = a->N; p.Hsrc = a->Hsrc; p.Wsrc = a->Wsrc; p.Hin = a->Hin; p.Win = a->Win;

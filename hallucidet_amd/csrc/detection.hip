@@ -202,6 +202,97 @@ __global__ void roi_align_bwd_kernel(const f16* __restrict__ dout, const float* 
   }
 }
 
+struct MLFeat {
+  const f16* f[4];
+  float* df[4];
+  int H[4], W[4];
+  float scale[4];
+};
+
+__global__ void roi_align_ml_kernel(MLFeat ml, const float* __restrict__ rois, const int* __restrict__ level, f16* __restrict__ out,
+                                    int R, int C, int PH, int PW, int sr) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)R * PH * PW * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t q = i / vecs;
+    int pw = (int)(q % PW);
+    int ph = (int)((q / PW) % PH);
+    int r = (int)(q / ((int64_t)PW * PH));
+    int l = level[r];
+    const int H = ml.H[l], W = ml.W[l];
+    const float scale = ml.scale[l];
+    const float* roi = rois + (size_t)r * 5;
+    int n = (int)roi[0];
+    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+    float bh = rh / (float)PH, bw = rw / (float)PW;
+    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
+    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
+    float count = fmaxf((float)(gh * gw), 1.f);
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    const f16* fb = ml.f[l] + (size_t)n * H * W * C + v * 8;
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
+        Bilin b = bilin_setup(y, x, H, W);
+        if (!b.valid) continue;
+        f16x8 v1 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xl) * C);
+        f16x8 v2 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xh) * C);
+        f16x8 v3 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xl) * C);
+        f16x8 v4 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xh) * C);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] += b.w1 * (float)v1[k] + b.w2 * (float)v2[k] + b.w3 * (float)v3[k] + b.w4 * (float)v4[k];
+      }
+    }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] / count);
+    *reinterpret_cast<f16x8*>(out + (size_t)q * C + v * 8) = o;
+  }
+}
+
+__global__ void roi_align_ml_bwd_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
+                                        const int* __restrict__ level, int R, int C, int PH, int PW, int sr) {
+  const int64_t total = (int64_t)R * PH * PW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    int64_t q = i / C;
+    int pw = (int)(q % PW);
+    int ph = (int)((q / PW) % PH);
+    int r = (int)(q / ((int64_t)PW * PH));
+    int l = level[r];
+    const int H = ml.H[l], W = ml.W[l];
+    const float scale = ml.scale[l];
+    const float* roi = rois + (size_t)r * 5;
+    int n = (int)roi[0];
+    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+    float bh = rh / (float)PH, bw = rw / (float)PW;
+    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
+    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
+    float count = fmaxf((float)(gh * gw), 1.f);
+    float g = (float)dout[i] / count;
+    if (g == 0.f) continue;
+    float* fb = ml.df[l] + (size_t)n * H * W * C + c;
+    for (int iy = 0; iy < gh; ++iy) {
+      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
+      for (int ix = 0; ix < gw; ++ix) {
+        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
+        Bilin b = bilin_setup(y, x, H, W);
+        if (!b.valid) continue;
+        atomicAdd(fb + ((size_t)b.yl * W + b.xl) * C, g * b.w1);
+        atomicAdd(fb + ((size_t)b.yl * W + b.xh) * C, g * b.w2);
+        atomicAdd(fb + ((size_t)b.yh * W + b.xl) * C, g * b.w3);
+        atomicAdd(fb + ((size_t)b.yh * W + b.xh) * C, g * b.w4);
+      }
+    }
+  }
+}
+
 __global__ void box_iou_kernel(const float* __restrict__ gt, int G, const float* __restrict__ boxes, int A, float* __restrict__ iou) {
   const int64_t total = (int64_t)G * A;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -256,6 +347,45 @@ extern "C" int hd_box_iou(const float* gt, int G, const float* boxes, int A, flo
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(box_iou_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, gt, G, boxes, A, iou);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_align_ml(const void* const* feats, const int* H, const int* W, const float* scale, int L, const float* rois,
+                               const int* level, void* out, int R, int C, int PH, int PW, int sampling_ratio, void* stream) {
+  HD_CHECK_ARG(feats && H && W && scale && rois && level && out && L >= 1 && L <= 4 && C % 8 == 0 && R >= 0, "hd_roi_align_ml: bad args");
+  if (R == 0) return HD_OK;
+  MLFeat ml = {};
+  for (int l = 0; l < L; ++l) {
+    ml.f[l] = (const f16*)feats[l];
+    ml.H[l] = H[l];
+    ml.W[l] = W[l];
+    ml.scale[l] = scale[l];
+  }
+  int64_t total = (int64_t)R * PH * PW * C / 8;
+  int g = (int)((total + 255) / 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(roi_align_ml_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ml, rois, level, (f16*)out, R, C, PH, PW, sampling_ratio);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_align_ml_bwd(const void* dout, const float* rois, const int* level, float* const* dfeat_f32, const int* H,
+                                   const int* W, const float* scale, int L, int R, int C, int PH, int PW, int sampling_ratio,
+                                   void* stream) {
+  HD_CHECK_ARG(dout && rois && level && dfeat_f32 && H && W && scale && L >= 1 && L <= 4 && R >= 0, "hd_roi_align_ml_bwd: bad args");
+  if (R == 0) return HD_OK;
+  MLFeat ml = {};
+  for (int l = 0; l < L; ++l) {
+    ml.df[l] = dfeat_f32[l];
+    ml.H[l] = H[l];
+    ml.W[l] = W[l];
+    ml.scale[l] = scale[l];
+  }
+  int64_t total = (int64_t)R * PH * PW * C;
+  int g = (int)((total + 255) / 256);
+  if (g > 16384) g = 16384;
+  hipLaunchKernelGGL(roi_align_ml_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ml, (const f16*)dout, rois, level, R, C, PH, PW, sampling_ratio);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

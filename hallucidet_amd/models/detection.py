@@ -1,0 +1,930 @@
+"""Faster R-CNN ResNet-50-FPN on hand-written HIP kernels, with torchvision 0.12's attribute tree.
+
+The reference takes this model from the un-vendored torchvision (src/models/detector.py:130) and reaches into it from
+src/utils/eval_forward_fasterrcnn.py:38-136: `.transform`, `.backbone(x) -> OrderedDict('0','1','2','3','pool')`,
+`.rpn.{head, anchor_generator, box_coder, filter_proposals, assign_targets_to_anchors, compute_loss}`,
+`.roi_heads.{select_training_samples, box_roi_pool, box_head, box_predictor, postprocess_detections, has_keypoint,
+keypoint_*}`.  This module provides exactly that surface and the same state_dict keys (`backbone.body.layer1.0.conv1
+.weight`, `backbone.fpn.inner_blocks.0.weight`, `rpn.head.conv.weight`, `roi_heads.box_head.fc6.weight`, ...), so
+torchvision-0.12 checkpoints load unchanged (0.13+ FPN/RPN key renames are mapped in `load_state_dict`).
+
+Execution: the detector is FROZEN on the hot path (train_hallucidet.py:100-105).  FrozenBatchNorm is folded
+into the fp16 GEMM-layout weights once; forward = implicit-GEMM convs with bias/residual/ReLU epilogues; backward = data
+gradients only (the same kernel on flipped weights, ReLU masks fused in the epilogue).  Box arithmetic, matching,
+sampling and the four losses are small fp32 tensor ops on the GPU; NMS, RoIAlign and IoU are HIP kernels.
+Sampling uses `torch.randperm` in the reference's call order (injectable for parity tests).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import ACT_NONE, ACT_RELU
+from .custom_generalized_transform import CustomGeneralizedRCNNTransform
+
+
+# ======================================================================================================================
+# parameter containers
+# ======================================================================================================================
+class FrozenBatchNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, cin, width, stride):
+        super().__init__()
+        cout = width * 4
+        self.conv1 = nn.Conv2d(cin, width, 1, bias=False)
+        self.bn1 = FrozenBatchNorm2d(width)
+        self.conv2 = nn.Conv2d(width, width, 3, stride, 1, bias=False)
+        self.bn2 = FrozenBatchNorm2d(width)
+        self.conv3 = nn.Conv2d(width, cout, 1, bias=False)
+        self.bn3 = FrozenBatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), FrozenBatchNorm2d(cout))
+        self.stride = stride
+
+
+class ResNet50Body(nn.Module):
+    """IntermediateLayerGetter(resnet50, layer1..4 -> '0'..'3')"""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
+        self.bn1 = FrozenBatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin = 64
+        for i, (n, wdt) in enumerate(zip((3, 4, 6, 3), (64, 128, 256, 512))):
+            blocks = []
+            for b in range(n):
+                blocks.append(Bottleneck(cin, wdt, 2 if (b == 0 and i > 0) else 1))
+                cin = wdt * 4
+            setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+
+class LastLevelMaxPool(nn.Module):
+    pass
+
+
+class FeaturePyramidNetwork(nn.Module):
+    def __init__(self, in_channels_list=(256, 512, 1024, 2048), out_channels=256):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList(nn.Conv2d(c, out_channels, 1) for c in in_channels_list)
+        self.layer_blocks = nn.ModuleList(nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels_list)
+        self.extra_blocks = LastLevelMaxPool()
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, a=1)
+                nn.init.constant_(m.bias, 0)
+
+
+def _conv_entry(conv, bn=None, cin_pad=None):
+    """Fold FrozenBN into the conv and build the fp16 GEMM layouts (+ data-gradient layout)."""
+    w = conv.weight.detach().float()
+    cout, cin = w.shape[:2]
+    cin_p = cin_pad or (cin + 7) // 8 * 8
+    cout_p = (cout + 7) // 8 * 8
+    if bn is not None:
+        scale, shift = bn.scale_shift()
+        scale, bias = scale.float().contiguous(), shift.float().contiguous()
+    else:
+        scale = None
+        bias = conv.bias.detach().float().contiguous() if conv.bias is not None else None
+    wf, wd = ops.weight_prep(w, out_scale=scale, cin_pad=cin_p, cout_pad=cout_p, want_fwd=True, want_dgrad=True)
+    return dict(wf=wf, wd=wd, bias=bias, k=conv.kernel_size[0], stride=conv.stride[0], pad=conv.padding[0], cin=cin, cout=cout,
+                cin_p=cin_p, cout_p=cout_p)
+
+
+def _fwd(e, x, *, act=ACT_NONE, res=None, f32=False):
+    return ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
+                      out_nchw_f32=f32, cout=e["cout"])
+
+
+def _dgrad(e, dy, in_hw, *, res=None, mask=None):
+    return ops.conv2d(dy, e["wd"], e["k"], e["k"], stride=1, pad=e["k"] - 1 - e["pad"], in_dil=e["stride"], out_hw=in_hw,
+                      cout=e["cin_p"], res=res, mask=mask)
+
+
+class _BackboneFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, hook, bb):
+        outs, saved = bb._forward(x, save=True)
+        ctx.bb, ctx.saved = bb, saved
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        dx = ctx.bb._backward(ctx.saved, grads)
+        ctx.saved = None
+        return dx, None, None
+
+
+class BackboneWithFPN(nn.Module):
+    out_channels = 256
+
+    def __init__(self):
+        super().__init__()
+        self.body = ResNet50Body()
+        self.fpn = FeaturePyramidNetwork()
+        self._pack = None
+        self._hook = None
+
+    # -------------------------------------------------------------- frozen weight pack
+    def invalidate(self):
+        self._pack = None
+
+    def pack(self):
+        if self._pack is not None:
+            return self._pack
+        b = self.body
+        P = {"stem": _conv_entry(b.conv1, b.bn1, cin_pad=8), "blocks": [], "inner": [], "layer": []}
+        for li in range(1, 5):
+            stage = []
+            for blk in getattr(b, "layer%d" % li):
+                stage.append(dict(c1=_conv_entry(blk.conv1, blk.bn1), c2=_conv_entry(blk.conv2, blk.bn2), c3=_conv_entry(blk.conv3, blk.bn3),
+                                  ds=_conv_entry(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+            P["blocks"].append(stage)
+        for c in self.fpn.inner_blocks:
+            P["inner"].append(_conv_entry(c))
+        for c in self.fpn.layer_blocks:
+            P["layer"].append(_conv_entry(c))
+        self._pack = P
+        return P
+
+    # -------------------------------------------------------------- execution
+    def _forward(self, x, save):
+        P = self.pack()
+        rec = {"x": x, "blocks": []} if save else None
+        s = _fwd(P["stem"], x, act=ACT_RELU)
+        p = ops.maxpool3x3s2(s)
+        cur = p
+        C = []
+        for stage in P["blocks"]:
+            srec = []
+            for e in stage:
+                o1 = _fwd(e["c1"], cur, act=ACT_RELU)
+                o2 = _fwd(e["c2"], o1, act=ACT_RELU)
+                idt = cur if e["ds"] is None else _fwd(e["ds"], cur)
+                out = _fwd(e["c3"], o2, act=ACT_RELU, res=idt)
+                if save:
+                    srec.append((cur, o1, o2, out))
+                cur = out
+            C.append(cur)
+            if save:
+                rec["blocks"].append(srec)
+        inner = [None] * 4
+        inner[3] = _fwd(P["inner"][3], C[3])
+        outs = [None] * 4
+        outs[3] = _fwd(P["layer"][3], inner[3])
+        for i in (2, 1, 0):
+            lat = _fwd(P["inner"][i], C[i])
+            inner[i] = ops.upsample_add(lat, inner[i + 1])
+            outs[i] = _fwd(P["layer"][i], inner[i])
+        pool = ops.subsample2(outs[3])
+        if save:
+            rec.update(stem=s, pooled=p, C=C, inner_shapes=[t.shape for t in inner], out_shapes=[t.shape for t in outs])
+        return outs + [pool], rec
+
+    def _backward(self, rec, grads):
+        P = self.pack()
+        shapes = rec["out_shapes"]
+        dP = []
+        for i in range(4):
+            g = grads[i]
+            dP.append(torch.zeros(shapes[i], dtype=torch.float16, device=rec["x"].device) if g is None else g.contiguous())
+        if grads[4] is not None:
+            ops.subsample2_bwd(grads[4].contiguous(), dP[3], accumulate=True)
+        C = rec["C"]
+        d_li = [None] * 4
+        for i in range(4):
+            hw = (shapes[i][1], shapes[i][2])
+            d_li[i] = _dgrad(P["layer"][i], dP[i], hw)
+            if i > 0:
+                ops.upsample_add_bwd(d_li[i - 1], d_li[i], accumulate=True)
+        # lateral 1x1 convs -> gradients w.r.t. C2..C5 (C5's carries the ReLU mask of layer4's output)
+        dC = [None] * 4
+        for i in range(4):
+            hw = (C[i].shape[1], C[i].shape[2])
+            dC[i] = _dgrad(P["inner"][i], d_li[i], hw, mask=C[i] if i == 3 else None)
+        gm = dC[3]
+        for si in (3, 2, 1, 0):
+            stage, srec = P["blocks"][si], rec["blocks"][si]
+            for bi in range(len(stage) - 1, -1, -1):
+                e = stage[bi]
+                x, o1, o2, out = srec[bi]
+                extra = dC[si - 1] if (bi == 0 and si > 0) else None
+                hw_o = (o2.shape[1], o2.shape[2])
+                d2 = _dgrad(e["c3"], gm, hw_o, mask=o2)
+                d1 = _dgrad(e["c2"], d2, (o1.shape[1], o1.shape[2]), mask=o1)
+                hw_x = (x.shape[1], x.shape[2])
+                # the block input is a post-ReLU tensor except for layer1.0 (max-pooled stem)
+                xmask = None if (si == 0 and bi == 0) else x
+                if e["ds"] is not None:
+                    t = _dgrad(e["ds"], gm, hw_x, res=extra)
+                else:
+                    t = gm if extra is None else ops.add_f16(gm, extra)
+                gm = _dgrad(e["c1"], d1, hw_x, res=t, mask=xmask)
+        ds_ = ops.maxpool3x3s2_bwd(rec["stem"], gm)
+        ds_ = ops.relu_bwd(ds_, rec["stem"])
+        x = rec["x"]
+        return _dgrad(P["stem"], ds_, (x.shape[1], x.shape[2]))
+
+    def forward(self, x):
+        if not (isinstance(x, torch.Tensor) and x.dim() == 4 and x.dtype == torch.float16 and x.shape[-1] == 8):
+            raise TypeError("hallucidet_amd backbone expects ImageList.tensors from CustomGeneralizedRCNNTransform "
+                            "(NHWC float16, 8 channels)")
+        if not x.is_cuda:
+            raise RuntimeError("hallucidet_amd backbone runs on the GPU only; there is no CPU path")
+        if torch.is_grad_enabled() and x.requires_grad:
+            if self._hook is None or self._hook.device != x.device:
+                self._hook = torch.zeros(1, device=x.device, requires_grad=True)
+            outs = _BackboneFn.apply(x, self._hook, self)
+        else:
+            outs, _ = self._forward(x, save=False)
+        return OrderedDict(zip(("0", "1", "2", "3", "pool"), outs))
+
+    @torch.no_grad()
+    def calibrate_(self, x_nhwc8):
+        """Synthetic-weights helper: set every FrozenBN's running statistics to the batch statistics observed on
+        `x_nhwc8` (what a trained checkpoint looks like), layer by layer, using the conv kernel's statistics epilogue.
+        Without it a randomly initialised, un-normalised 50-layer residual stack overflows fp16."""
+        b = self.body
+
+        def fit(conv, bn, x, res=None, act=ACT_RELU, gamma=1.0):
+            bn.running_mean.zero_(); bn.running_var.fill_(1.0); bn.weight.fill_(1.0); bn.bias.zero_()
+            e = _conv_entry(conv, None, cin_pad=8 if conv.in_channels == 3 else None)
+            y, st = ops.conv2d(x, e["wf"], e["k"], e["k"], stride=e["stride"], pad=e["pad"], want_stats=True, cout=e["cout"])
+            sums = ops.colsum(st.view(st.shape[0], -1))
+            n = y.numel() // e["cout"]
+            mean = sums[: e["cout"]] / n
+            var = (sums[e["cout"]:] / n - mean * mean).clamp_(min=1e-6)
+            bn.running_mean.copy_(mean)
+            bn.running_var.copy_(var)
+            bn.weight.fill_(gamma)
+            e2 = _conv_entry(conv, bn, cin_pad=8 if conv.in_channels == 3 else None)
+            return _fwd(e2, x, act=act, res=res)
+
+        cur = ops.maxpool3x3s2(fit(b.conv1, b.bn1, x_nhwc8))
+        for li in range(1, 5):
+            for blk in getattr(b, "layer%d" % li):
+                o1 = fit(blk.conv1, blk.bn1, cur)
+                o2 = fit(blk.conv2, blk.bn2, o1)
+                idt = cur if blk.downsample is None else fit(blk.downsample[0], blk.downsample[1], cur, act=ACT_NONE)
+                cur = fit(blk.conv3, blk.bn3, o2, res=idt, gamma=0.5)   # 0.5: keep the residual sum from growing
+        self.invalidate()
+
+
+# ======================================================================================================================
+# box utilities (fp32 tensor arithmetic on the GPU)
+# ======================================================================================================================
+def box_area(b):
+    return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+
+
+def box_iou(a, b):
+    return ops.box_iou(a.float().contiguous(), b.float().contiguous())
+
+
+def clip_boxes_to_image(boxes, size):
+    h, w = size
+    bx = boxes[..., 0::2].clamp(min=0, max=w)
+    by = boxes[..., 1::2].clamp(min=0, max=h)
+    return torch.stack((bx, by), dim=boxes.dim()).reshape(boxes.shape)
+
+
+class BoxCoder:
+    def __init__(self, weights, bbox_xform_clip=math.log(1000.0 / 16)):
+        self.weights, self.bbox_xform_clip = weights, bbox_xform_clip
+
+    def encode_single(self, ref, prop):
+        wx, wy, ww, wh = self.weights
+        px1, py1, px2, py2 = [prop[:, i].unsqueeze(1) for i in range(4)]
+        rx1, ry1, rx2, ry2 = [ref[:, i].unsqueeze(1) for i in range(4)]
+        ew, eh = px2 - px1, py2 - py1
+        ecx, ecy = px1 + 0.5 * ew, py1 + 0.5 * eh
+        gw, gh = rx2 - rx1, ry2 - ry1
+        gcx, gcy = rx1 + 0.5 * gw, ry1 + 0.5 * gh
+        return torch.cat((wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * torch.log(gw / ew), wh * torch.log(gh / eh)), dim=1)
+
+    def encode(self, reference_boxes, proposals):
+        n = [len(b) for b in reference_boxes]
+        return self.encode_single(torch.cat(reference_boxes, 0), torch.cat(proposals, 0)).split(n, 0)
+
+    def decode_single(self, codes, boxes):
+        boxes = boxes.to(codes.dtype)
+        w, h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+        cx, cy = boxes[:, 0] + 0.5 * w, boxes[:, 1] + 0.5 * h
+        wx, wy, ww, wh = self.weights
+        dx, dy = codes[:, 0::4] / wx, codes[:, 1::4] / wy
+        dw = torch.clamp(codes[:, 2::4] / ww, max=self.bbox_xform_clip)
+        dh = torch.clamp(codes[:, 3::4] / wh, max=self.bbox_xform_clip)
+        pcx, pcy = dx * w[:, None] + cx[:, None], dy * h[:, None] + cy[:, None]
+        pw, ph = torch.exp(dw) * w[:, None], torch.exp(dh) * h[:, None]
+        return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=2).flatten(1)
+
+    def decode(self, rel_codes, boxes):
+        cat = torch.cat(list(boxes), dim=0)
+        total = cat.shape[0]
+        if total > 0:
+            rel_codes = rel_codes.reshape(total, -1)
+        pred = self.decode_single(rel_codes, cat)
+        if total > 0:
+            pred = pred.reshape(total, -1, 4)
+        return pred
+
+
+class Matcher:
+    BELOW_LOW_THRESHOLD = -1
+    BETWEEN_THRESHOLDS = -2
+
+    def __init__(self, high_threshold, low_threshold, allow_low_quality_matches=False):
+        self.high_threshold, self.low_threshold = high_threshold, low_threshold
+        self.allow_low_quality_matches = allow_low_quality_matches
+
+    def __call__(self, mq):
+        vals, matches = mq.max(dim=0)
+        all_matches = matches.clone() if self.allow_low_quality_matches else None
+        below = vals < self.low_threshold
+        between = (vals >= self.low_threshold) & (vals < self.high_threshold)
+        matches = torch.where(below, torch.full_like(matches, self.BELOW_LOW_THRESHOLD), matches)
+        matches = torch.where(between, torch.full_like(matches, self.BETWEEN_THRESHOLDS), matches)
+        if self.allow_low_quality_matches:
+            best_per_gt, _ = mq.max(dim=1)
+            is_best = (mq == best_per_gt[:, None]).any(dim=0)
+            matches = torch.where(is_best, all_matches, matches)
+        return matches
+
+
+class BalancedPositiveNegativeSampler:
+    """torchvision semantics [EXT]: per image two `randperm` draws (positives, negatives).  `randperm_fn(n, device)`
+    is injectable; the default draws `torch.randperm(n, device=device)` in the reference's call order."""
+
+    def __init__(self, batch_size_per_image, positive_fraction, randperm_fn=None):
+        self.batch_size_per_image, self.positive_fraction = batch_size_per_image, positive_fraction
+        self.randperm_fn = randperm_fn
+
+    def _perm(self, n, device):
+        if self.randperm_fn is not None:
+            return self.randperm_fn(n).to(device)
+        return torch.randperm(n, device=device)
+
+    def __call__(self, matched_idxs):
+        # one host sync for all images' class counts instead of several per image
+        pos_l = [torch.where(m >= 1)[0] for m in matched_idxs]
+        neg_l = [torch.where(m == 0)[0] for m in matched_idxs]
+        pos_idx, neg_idx = [], []
+        for m, positive, negative in zip(matched_idxs, pos_l, neg_l):
+            num_pos = min(positive.numel(), int(self.batch_size_per_image * self.positive_fraction))
+            num_neg = min(negative.numel(), self.batch_size_per_image - num_pos)
+            p = positive[self._perm(positive.numel(), m.device)[:num_pos]]
+            n = negative[self._perm(negative.numel(), m.device)[:num_neg]]
+            pm = torch.zeros_like(m, dtype=torch.uint8)
+            nm = torch.zeros_like(m, dtype=torch.uint8)
+            pm[p] = 1
+            nm[n] = 1
+            pos_idx.append(pm)
+            neg_idx.append(nm)
+        return pos_idx, neg_idx
+
+
+def _batched_nms_padded(boxes, scores, idxs, valid, iou_thr, top_n):
+    """Batched, padded form of torchvision.ops.batched_nms (coordinate-offset trick [EXT]).
+
+    boxes [B,n,4], scores [B,n], idxs [B,n] (level / class), valid [B,n] bool.  Returns (order [B,n] = candidate index
+    sorted by descending score, sel [B,n] bool in sorted order = kept and within the first `top_n` kept, counts [B]).
+    """
+    B, n = scores.shape
+    neg = torch.full_like(scores, float("-inf"))
+    key = torch.where(valid, scores, neg)
+    order = torch.sort(key, dim=1, descending=True, stable=True)[1]
+    counts = valid.sum(dim=1).to(torch.int32)
+    bmax = torch.where(valid[..., None], boxes, torch.full_like(boxes, float("-inf"))).amax(dim=(1, 2))
+    bmax = torch.where(counts > 0, bmax, torch.zeros_like(bmax))
+    offsets = idxs.to(boxes) * (bmax[:, None] + torch.tensor(1).to(boxes))
+    shifted = boxes + offsets[:, :, None]
+    sorted_boxes = torch.gather(shifted, 1, order[:, :, None].expand(-1, -1, 4)).contiguous()
+    keep = ops.nms_sorted_batched(sorted_boxes, counts, iou_thr)
+    rank = torch.cumsum(keep.to(torch.int32), dim=1)
+    sel = keep & (rank <= top_n)
+    return order, sel, sel.sum(dim=1)
+
+
+# ======================================================================================================================
+# RPN
+# ======================================================================================================================
+class AnchorGenerator(nn.Module):
+    def __init__(self, sizes=((32,), (64,), (128,), (256,), (512,)), aspect_ratios=((0.5, 1.0, 2.0),) * 5):
+        super().__init__()
+        self.sizes, self.aspect_ratios = sizes, aspect_ratios
+        self._cache = {}
+
+    def num_anchors_per_location(self):
+        return [len(s) * len(a) for s, a in zip(self.sizes, self.aspect_ratios)]
+
+    @staticmethod
+    def generate_anchors(scales, aspect_ratios, device):
+        scales = torch.as_tensor(scales, dtype=torch.float32, device=device)
+        ratios = torch.as_tensor(aspect_ratios, dtype=torch.float32, device=device)
+        h_r = torch.sqrt(ratios)
+        w_r = 1 / h_r
+        ws = (w_r[:, None] * scales[None, :]).view(-1)
+        hs = (h_r[:, None] * scales[None, :]).view(-1)
+        return (torch.stack([-ws, -hs, ws, hs], dim=1) / 2).round()
+
+    def forward(self, image_list, feature_maps):
+        grid_sizes = [tuple(fm.shape[-2:]) if fm.dim() == 4 and fm.dtype != torch.float16 else (fm.shape[1], fm.shape[2]) for fm in feature_maps]
+        ih, iw = image_list.image_sizes[0] if getattr(image_list, "layout", None) else image_list.tensors.shape[-2:]
+        device = feature_maps[0].device
+        key = (tuple(grid_sizes), ih, iw, str(device))
+        if key not in self._cache:
+            per_level = []
+            for (gh, gw), s, a in zip(grid_sizes, self.sizes, self.aspect_ratios):
+                sh, sw = ih // gh, iw // gw
+                sx = torch.arange(0, gw, dtype=torch.int32, device=device) * sw
+                sy = torch.arange(0, gh, dtype=torch.int32, device=device) * sh
+                yy, xx = torch.meshgrid(sy, sx, indexing="ij")
+                xx, yy = xx.reshape(-1), yy.reshape(-1)
+                shifts = torch.stack((xx, yy, xx, yy), dim=1)
+                per_level.append((shifts.view(-1, 1, 4) + self.generate_anchors(s, a, device).view(1, -1, 4)).reshape(-1, 4))
+            self._cache = {key: torch.cat(per_level)}
+        allv = self._cache[key]
+        return [allv for _ in range(len(image_list.image_sizes))]
+
+
+class _RPNHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hook, head, *feats):
+        P = head.pack()
+        ts, outs = [], []
+        for f in feats:
+            t = _fwd(P["conv"], f, act=ACT_RELU)
+            ts.append(t)
+            outs.append(_fwd(P["cls"], t, f32=True))
+            outs.append(_fwd(P["box"], t, f32=True))
+        ctx.head, ctx.ts = head, ts
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        P = ctx.head.pack()
+        dfeats = []
+        for i, t in enumerate(ctx.ts):
+            N, H, W, _ = t.shape
+            dl, dr = grads[2 * i], grads[2 * i + 1]
+            hw = (H, W)
+            dt = None
+            if dl is not None:
+                dt = _dgrad(P["cls"], ops.nchw_to_nhwc_resize(dl.contiguous().float(), H, W, P["cls"]["cout_p"]), hw)
+            if dr is not None:
+                dt = _dgrad(P["box"], ops.nchw_to_nhwc_resize(dr.contiguous().float(), H, W, P["box"]["cout_p"]), hw, res=dt, mask=t)
+            elif dt is not None:
+                dt = ops.relu_bwd(dt, t)
+            dfeats.append(None if dt is None else _dgrad(P["conv"], dt, hw))
+        ctx.ts = None
+        return (None, None) + tuple(dfeats)
+
+
+class RPNHead(nn.Module):
+    def __init__(self, in_channels=256, num_anchors=3):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, in_channels, 3, padding=1)
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors, 1)
+        self.bbox_pred = nn.Conv2d(in_channels, num_anchors * 4, 1)
+        for layer in self.children():
+            nn.init.normal_(layer.weight, std=0.01)
+            nn.init.constant_(layer.bias, 0)
+        self._pack, self._hook = None, None
+
+    def invalidate(self):
+        self._pack = None
+
+    def pack(self):
+        if self._pack is None:
+            self._pack = dict(conv=_conv_entry(self.conv), cls=_conv_entry(self.cls_logits), box=_conv_entry(self.bbox_pred))
+        return self._pack
+
+    def forward(self, x):
+        """x: list of NHWC fp16 feature maps.  Returns (logits, bbox_reg): lists of NCHW fp32 tensors per level."""
+        feats = list(x)
+        if self._hook is None or self._hook.device != feats[0].device:
+            self._hook = torch.zeros(1, device=feats[0].device, requires_grad=True)
+        outs = _RPNHeadFn.apply(self._hook, self, *feats)
+        return list(outs[0::2]), list(outs[1::2])
+
+
+def permute_and_flatten(layer, N, A, C, H, W):
+    return layer.view(N, -1, C, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, C)
+
+
+def concat_box_prediction_layers(box_cls, box_regression):
+    cls_f, reg_f = [], []
+    for c, r in zip(box_cls, box_regression):
+        N, AxC, H, W = c.shape
+        A = r.shape[1] // 4
+        C = AxC // A
+        cls_f.append(permute_and_flatten(c, N, A, C, H, W))
+        reg_f.append(permute_and_flatten(r, N, A, 4, H, W))
+    return torch.cat(cls_f, dim=1).flatten(0, -2), torch.cat(reg_f, dim=1).reshape(-1, 4)
+
+
+class RegionProposalNetwork(nn.Module):
+    def __init__(self, anchor_generator=None, head=None, fg_iou_thresh=0.7, bg_iou_thresh=0.3, batch_size_per_image=256,
+                 positive_fraction=0.5, pre_nms_top_n=None, post_nms_top_n=None, nms_thresh=0.7, score_thresh=0.0):
+        super().__init__()
+        self.anchor_generator = anchor_generator or AnchorGenerator()
+        self.head = head or RPNHead()
+        self.box_coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.proposal_matcher = Matcher(fg_iou_thresh, bg_iou_thresh, allow_low_quality_matches=True)
+        self.fg_bg_sampler = BalancedPositiveNegativeSampler(batch_size_per_image, positive_fraction)
+        self._pre_nms_top_n = pre_nms_top_n or dict(training=2000, testing=1000)
+        self._post_nms_top_n = post_nms_top_n or dict(training=2000, testing=1000)
+        self.nms_thresh, self.score_thresh, self.min_size = nms_thresh, score_thresh, 1e-3
+
+    def pre_nms_top_n(self):
+        return self._pre_nms_top_n["training" if self.training else "testing"]
+
+    def post_nms_top_n(self):
+        return self._post_nms_top_n["training" if self.training else "testing"]
+
+    def assign_targets_to_anchors(self, anchors, targets):
+        labels, matched = [], []
+        for a, t in zip(anchors, targets):
+            gt = t["boxes"]
+            if gt.numel() == 0:
+                matched.append(torch.zeros(a.shape, dtype=torch.float32, device=a.device))
+                labels.append(torch.zeros((a.shape[0],), dtype=torch.float32, device=a.device))
+                continue
+            mi = self.proposal_matcher(box_iou(gt, a))
+            matched.append(gt[mi.clamp(min=0)])
+            lab = (mi >= 0).to(torch.float32)
+            lab = torch.where(mi == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(lab), lab)
+            lab = torch.where(mi == Matcher.BETWEEN_THRESHOLDS, torch.full_like(lab, -1.0), lab)
+            labels.append(lab)
+        return labels, matched
+
+    def _get_top_n_idx(self, objectness, num_anchors_per_level):
+        r, offset = [], 0
+        for ob in objectness.split(num_anchors_per_level, 1):
+            n = ob.shape[1]
+            idx = torch.sort(ob, dim=1, descending=True, stable=True)[1][:, : min(self.pre_nms_top_n(), n)]
+            r.append(idx + offset)
+            offset += n
+        return torch.cat(r, dim=1)
+
+    def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
+        n_img = proposals.shape[0]
+        device = proposals.device
+        objectness = objectness.detach().reshape(n_img, -1)
+        levels = torch.cat([torch.full((n,), i, dtype=torch.int64, device=device) for i, n in enumerate(num_anchors_per_level)], 0)
+        levels = levels.reshape(1, -1).expand_as(objectness)
+        top = self._get_top_n_idx(objectness, num_anchors_per_level)
+        bidx = torch.arange(n_img, device=device)[:, None]
+        objectness, levels, proposals = objectness[bidx, top], levels[bidx, top], proposals[bidx, top]
+        prob = torch.sigmoid(objectness)
+        if len(set(tuple(s) for s in image_shapes)) != 1:
+            raise NotImplementedError("hallucidet_amd: batched filter_proposals needs one image size per batch (fixed_size transform)")
+        boxes = clip_boxes_to_image(proposals, image_shapes[0])
+        ws, hs = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
+        valid = (ws >= self.min_size) & (hs >= self.min_size) & (prob >= self.score_thresh)
+        order, sel, counts = _batched_nms_padded(boxes, prob, levels, valid, self.nms_thresh, self.post_nms_top_n())
+        sboxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4))
+        sscores = torch.gather(prob, 1, order)
+        fb, fs = [], []
+        for i in range(n_img):       # boolean selection = one sync per image; sizes are data dependent by contract
+            fb.append(sboxes[i][sel[i]])
+            fs.append(sscores[i][sel[i]])
+        return fb, fs
+
+    def compute_loss(self, objectness, pred_bbox_deltas, labels, regression_targets):
+        pos, neg = self.fg_bg_sampler(labels)
+        pos = torch.where(torch.cat(pos, dim=0))[0]
+        neg = torch.where(torch.cat(neg, dim=0))[0]
+        sampled = torch.cat([pos, neg], dim=0)
+        objectness = objectness.flatten()
+        labels = torch.cat(labels, dim=0)
+        regression_targets = torch.cat(regression_targets, dim=0)
+        box_loss = F.smooth_l1_loss(pred_bbox_deltas[pos], regression_targets[pos], beta=1 / 9, reduction="sum") / sampled.numel()
+        obj_loss = F.binary_cross_entropy_with_logits(objectness[sampled], labels[sampled])
+        return obj_loss, box_loss
+
+
+# ======================================================================================================================
+# RoI heads
+# ======================================================================================================================
+class _RoIAlignFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, levels, cfg, *feats):
+        scales, P, sr = cfg
+        ctx.save_for_backward(rois, levels)
+        ctx.cfg = cfg
+        ctx.shapes = [tuple(f.shape) for f in feats]
+        return ops.roi_align_ml(list(feats), scales, rois, levels, P, P, sr)
+
+    @staticmethod
+    def backward(ctx, dout):
+        rois, levels = ctx.saved_tensors
+        scales, P, sr = ctx.cfg
+        dfs = ops.roi_align_ml_bwd(dout, rois, levels, ctx.shapes, scales, sr)
+        return (None, None, None) + tuple(ops.f32_to_f16(d) for d in dfs)
+
+
+class MultiScaleRoIAlign(nn.Module):
+    def __init__(self, featmap_names=("0", "1", "2", "3"), output_size=7, sampling_ratio=2, canonical_scale=224, canonical_level=4):
+        super().__init__()
+        self.featmap_names = list(featmap_names)
+        self.output_size = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+        self.sampling_ratio = sampling_ratio
+        self.canonical_scale, self.canonical_level, self.eps = canonical_scale, canonical_level, 1e-6
+
+    @staticmethod
+    def infer_scale(feat_hw, original_size):
+        s = [2 ** float(torch.tensor(float(a) / float(b)).log2().round()) for a, b in zip(feat_hw, original_size)]
+        return s[0]
+
+    def forward(self, x, boxes, image_shapes):
+        feats = [v for k, v in x.items() if k in self.featmap_names]
+        device = feats[0].device
+        rois = torch.cat([torch.cat([torch.full_like(b[:, :1], i), b], dim=1) for i, b in enumerate(boxes)], dim=0).float()
+        mh = max(s[0] for s in image_shapes)
+        mw = max(s[1] for s in image_shapes)
+        scales = [self.infer_scale((f.shape[1], f.shape[2]), (mh, mw)) for f in feats]
+        k_min = int(-math.log2(scales[0]))
+        k_max = int(-math.log2(scales[-1]))
+        s = torch.sqrt(torch.cat([box_area(b) for b in boxes]).float())
+        t = torch.floor(self.canonical_level + torch.log2(s / self.canonical_scale) + torch.tensor(self.eps, dtype=s.dtype, device=device))
+        levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
+        return _RoIAlignFn.apply(rois, levels, (scales, self.output_size[0], self.sampling_ratio), *feats)
+
+
+class _MLPFn(torch.autograd.Function):
+    """fc6 (as a 7x7 'valid' convolution over the pooled RoI) -> ReLU -> fc7 -> ReLU, fp16 in / fp16 out."""
+
+    @staticmethod
+    def forward(ctx, x, head):
+        P = head.pack()
+        h6 = _fwd(P["fc6"], x, act=ACT_RELU)
+        h7 = _fwd(P["fc7"], h6, act=ACT_RELU)
+        ctx.head, ctx.h6, ctx.h7, ctx.xshape = head, h6, h7, tuple(x.shape)
+        return h7
+
+    @staticmethod
+    def backward(ctx, d7):
+        P = ctx.head.pack()
+        d7 = ops.relu_bwd(d7.contiguous(), ctx.h7)
+        d6 = _dgrad(P["fc7"], d7, (1, 1), mask=ctx.h6)
+        R = d6.shape[0]
+        dx = ops.conv2d(d6, P["fc6_t"], 1, 1, cout=P["fc6_t"].shape[0])      # plain GEMM with the transposed fc6 matrix
+        ctx.h6 = ctx.h7 = None
+        return dx.view(ctx.xshape), None
+
+
+class TwoMLPHead(nn.Module):
+    def __init__(self, in_channels=256 * 7 * 7, representation_size=1024):
+        super().__init__()
+        self.fc6 = nn.Linear(in_channels, representation_size)
+        self.fc7 = nn.Linear(representation_size, representation_size)
+        self._pack = None
+
+    def invalidate(self):
+        self._pack = None
+
+    def pack(self):
+        if self._pack is None:
+            rep, K = self.fc6.weight.shape
+            c = K // 49
+            w6 = self.fc6.weight.detach().float().view(rep, c, 7, 7)
+            e6 = dict(k=7, stride=1, pad=0, cin=c, cout=rep, cin_p=c, cout_p=rep, bias=self.fc6.bias.detach().float().contiguous())
+            e6["wf"], _ = ops.weight_prep(w6, cin_pad=c, cout_pad=rep, want_fwd=True, want_dgrad=False)
+            e6["wd"] = None
+            fc6_t = w6.permute(2, 3, 1, 0).reshape(49 * c, rep).half().contiguous()
+            w7 = self.fc7.weight.detach().float().view(rep, rep, 1, 1)
+            e7 = dict(k=1, stride=1, pad=0, cin=rep, cout=rep, cin_p=rep, cout_p=rep, bias=self.fc7.bias.detach().float().contiguous())
+            e7["wf"], e7["wd"] = ops.weight_prep(w7, want_fwd=True, want_dgrad=True)
+            self._pack = dict(fc6=e6, fc7=e7, fc6_t=fc6_t)
+        return self._pack
+
+    def forward(self, x):
+        """x: [R,7,7,C] fp16 (RoIAlign output).  Returns [R,1,1,rep] fp16."""
+        if x.shape[0] == 0:
+            return x.new_zeros((0, 1, 1, self.fc7.out_features))
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _MLPFn.apply(x, self)
+        P = self.pack()
+        return _fwd(P["fc7"], _fwd(P["fc6"], x, act=ACT_RELU), act=ACT_RELU)
+
+
+class _PredictorFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, pred):
+        P = pred.pack()
+        ctx.pred = pred
+        R = x.shape[0]
+        return _fwd(P["cls"], x, f32=True).view(R, -1), _fwd(P["box"], x, f32=True).view(R, -1)
+
+    @staticmethod
+    def backward(ctx, dc, db):
+        P = ctx.pred.pack()
+        R = dc.shape[0] if dc is not None else db.shape[0]
+        dx = None
+        if dc is not None:
+            g = ops.nchw_to_nhwc_resize(dc.contiguous().float().view(R, -1, 1, 1), 1, 1, P["cls"]["cout_p"])
+            dx = _dgrad(P["cls"], g, (1, 1))
+        if db is not None:
+            g = ops.nchw_to_nhwc_resize(db.contiguous().float().view(R, -1, 1, 1), 1, 1, P["box"]["cout_p"])
+            dx = _dgrad(P["box"], g, (1, 1), res=dx)
+        return dx, None
+
+
+class FastRCNNPredictor(nn.Module):
+    def __init__(self, in_channels, num_classes):
+        super().__init__()
+        self.cls_score = nn.Linear(in_channels, num_classes)
+        self.bbox_pred = nn.Linear(in_channels, num_classes * 4)
+        self._pack = None
+
+    def invalidate(self):
+        self._pack = None
+
+    def pack(self):
+        if self._pack is None:
+            def ent(lin):
+                o, i = lin.weight.shape
+                e = dict(k=1, stride=1, pad=0, cin=i, cout=o, cin_p=i, cout_p=(o + 7) // 8 * 8, bias=lin.bias.detach().float().contiguous())
+                e["wf"], e["wd"] = ops.weight_prep(lin.weight.detach().float().view(o, i, 1, 1), cout_pad=e["cout_p"], want_fwd=True, want_dgrad=True)
+                return e
+            self._pack = dict(cls=ent(self.cls_score), box=ent(self.bbox_pred))
+        return self._pack
+
+    def forward(self, x):
+        """x: [R,1,1,1024] fp16.  Returns fp32 (scores [R,K], bbox_deltas [R,4K])."""
+        if x.shape[0] == 0:
+            z = torch.zeros((0, self.cls_score.out_features), device=x.device)
+            return z, torch.zeros((0, self.bbox_pred.out_features), device=x.device)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _PredictorFn.apply(x, self)
+        P = self.pack()
+        R = x.shape[0]
+        return _fwd(P["cls"], x, f32=True).view(R, -1), _fwd(P["box"], x, f32=True).view(R, -1)
+
+
+def fastrcnn_loss(class_logits, box_regression, labels, regression_targets):
+    labels = torch.cat(labels, dim=0)
+    regression_targets = torch.cat(regression_targets, dim=0)
+    cls_loss = F.cross_entropy(class_logits, labels)
+    pos = torch.where(labels > 0)[0]
+    N = class_logits.shape[0]
+    box_regression = box_regression.reshape(N, box_regression.size(-1) // 4, 4)
+    box_loss = F.smooth_l1_loss(box_regression[pos, labels[pos]], regression_targets[pos], beta=1 / 9, reduction="sum")
+    return cls_loss, box_loss / labels.numel()
+
+
+class RoIHeads(nn.Module):
+    def __init__(self, box_roi_pool=None, box_head=None, box_predictor=None, fg_iou_thresh=0.5, bg_iou_thresh=0.5,
+                 batch_size_per_image=512, positive_fraction=0.25, bbox_reg_weights=None, score_thresh=0.05, nms_thresh=0.5,
+                 detections_per_img=100, num_classes=91):
+        super().__init__()
+        self.box_roi_pool = box_roi_pool or MultiScaleRoIAlign()
+        self.box_head = box_head or TwoMLPHead()
+        self.box_predictor = box_predictor or FastRCNNPredictor(1024, num_classes)
+        self.box_coder = BoxCoder(bbox_reg_weights or (10.0, 10.0, 5.0, 5.0))
+        self.proposal_matcher = Matcher(fg_iou_thresh, bg_iou_thresh, allow_low_quality_matches=False)
+        self.fg_bg_sampler = BalancedPositiveNegativeSampler(batch_size_per_image, positive_fraction)
+        self.score_thresh, self.nms_thresh, self.detections_per_img = score_thresh, nms_thresh, detections_per_img
+        self.keypoint_roi_pool = self.keypoint_head = self.keypoint_predictor = None
+        self.mask_roi_pool = self.mask_head = self.mask_predictor = None
+
+    def has_keypoint(self):
+        return False
+
+    def has_mask(self):
+        return False
+
+    def select_training_samples(self, proposals, targets):
+        if targets is None:
+            raise ValueError("targets should not be None")
+        dtype = proposals[0].dtype
+        gt_boxes = [t["boxes"].to(dtype) for t in targets]
+        gt_labels = [t["labels"] for t in targets]
+        proposals = [torch.cat((p, g)) for p, g in zip(proposals, gt_boxes)]
+        matched_idxs, labels = [], []
+        for p, g, gl in zip(proposals, gt_boxes, gt_labels):
+            if g.numel() == 0:
+                matched_idxs.append(torch.zeros((p.shape[0],), dtype=torch.int64, device=p.device))
+                labels.append(torch.zeros((p.shape[0],), dtype=torch.int64, device=p.device))
+                continue
+            mi = self.proposal_matcher(box_iou(g, p))
+            lab = gl[mi.clamp(min=0)].to(torch.int64)
+            lab = torch.where(mi == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(lab), lab)
+            lab = torch.where(mi == Matcher.BETWEEN_THRESHOLDS, torch.full_like(lab, -1), lab)
+            matched_idxs.append(mi.clamp(min=0))
+            labels.append(lab)
+        pos, neg = self.fg_bg_sampler(labels)
+        matched_gt = []
+        for i in range(len(proposals)):
+            s = torch.where(pos[i] | neg[i])[0]
+            proposals[i], labels[i], matched_idxs[i] = proposals[i][s], labels[i][s], matched_idxs[i][s]
+            g = gt_boxes[i] if gt_boxes[i].numel() else torch.zeros((1, 4), dtype=dtype, device=proposals[i].device)
+            matched_gt.append(g[matched_idxs[i]])
+        return proposals, matched_idxs, labels, self.box_coder.encode(matched_gt, proposals)
+
+    def postprocess_detections(self, class_logits, box_regression, proposals, image_shapes):
+        num_classes = class_logits.shape[-1]
+        device = class_logits.device
+        per = [b.shape[0] for b in proposals]
+        pred_boxes = self.box_coder.decode(box_regression.detach(), proposals)
+        pred_scores = F.softmax(class_logits.detach(), -1)
+        n_img, nmax = len(per), max(per) if per else 0
+        ncand = nmax * (num_classes - 1)
+        B = torch.zeros((n_img, ncand, 4), device=device)
+        S = torch.zeros((n_img, ncand), device=device)
+        Lb = torch.zeros((n_img, ncand), dtype=torch.int64, device=device)
+        V = torch.zeros((n_img, ncand), dtype=torch.bool, device=device)
+        off = 0
+        for i, (n, shp) in enumerate(zip(per, image_shapes)):
+            b = clip_boxes_to_image(pred_boxes[off:off + n], shp)[:, 1:].reshape(-1, 4)
+            s = pred_scores[off:off + n][:, 1:].reshape(-1)
+            l = torch.arange(1, num_classes, device=device).view(1, -1).expand(n, -1).reshape(-1)
+            k = b.shape[0]
+            B[i, :k], S[i, :k], Lb[i, :k] = b, s, l
+            ws, hs = b[:, 2] - b[:, 0], b[:, 3] - b[:, 1]
+            V[i, :k] = (s > self.score_thresh) & (ws >= 1e-2) & (hs >= 1e-2)
+            off += n
+        order, sel, counts = _batched_nms_padded(B, S, Lb, V, self.nms_thresh, self.detections_per_img)
+        sb = torch.gather(B, 1, order[:, :, None].expand(-1, -1, 4))
+        ss = torch.gather(S, 1, order)
+        sl = torch.gather(Lb, 1, order)
+        ab, as_, al = [], [], []
+        for i in range(n_img):
+            ab.append(sb[i][sel[i]])
+            as_.append(ss[i][sel[i]])
+            al.append(sl[i][sel[i]])
+        return ab, as_, al
+
+
+# ======================================================================================================================
+# model
+# ======================================================================================================================
+class FasterRCNN(nn.Module):
+    def __init__(self, num_classes=91, min_size=800, max_size=1333):
+        super().__init__()
+        # torchvision's GeneralizedRCNNTransform is always replaced by the reference (detector.py:43-48); build that one.
+        self.transform = CustomGeneralizedRCNNTransform(min_size=300, max_size=300, image_mean=[0.0], image_std=[1.0],
+                                                        size_divisible=1, fixed_size=(300, 300))
+        self.backbone = BackboneWithFPN()
+        self.rpn = RegionProposalNetwork()
+        self.roi_heads = RoIHeads(num_classes=num_classes)
+
+    def invalidate_packs(self):
+        self.backbone.invalidate()
+        self.rpn.head.invalidate()
+        self.roi_heads.box_head.invalidate()
+        self.roi_heads.box_predictor.invalidate()
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = OrderedDict()
+        for k, v in state_dict.items():
+            # torchvision >= 0.13 renames
+            for i in range(4):
+                k = k.replace("fpn.inner_blocks.%d.0." % i, "fpn.inner_blocks.%d." % i).replace("fpn.layer_blocks.%d.0." % i, "fpn.layer_blocks.%d." % i)
+            k = k.replace("rpn.head.conv.0.0.", "rpn.head.conv.")
+            if k.endswith("num_batches_tracked"):
+                continue
+            sd[k] = v
+        out = super().load_state_dict(sd, strict=strict)
+        self.invalidate_packs()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        self.invalidate_packs()
+        return super()._apply(fn, *a, **k)
+
+
+def fasterrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pretrained_backbone=False, weights_path=None, **kwargs):
+    """torchvision.models.detection.fasterrcnn_resnet50_fpn [EXT].  COCO weights cannot be downloaded offline
+    (SURVEY App. D.8): `pretrained=True` is accepted for signature compatibility and ignored unless `weights_path`
+    points at a local torchvision state_dict."""
+    model = FasterRCNN(num_classes=num_classes)
+    if weights_path is not None:
+        model.load_state_dict(torch.load(weights_path, map_location="cpu"))
+    return model

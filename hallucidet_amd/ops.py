@@ -28,14 +28,14 @@ def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
+def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
            out_nchw_f32=False, want_stats=False, out_hw=None, cout=None, out=None):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
     Returns y or (y, stats_slab[rows,2,Cout]).
     """
-    _need_cuda(x, w, x2, bias, res)
+    _need_cuda(x, w, x2, bias, res, mask)
     lib = _abi.load()
     N, Hs, Ws, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
@@ -60,7 +60,7 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, stride=1, pad=0, up1=F
         y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
     else:
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
-    a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(y), None,
+    a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(mask), ptr(y), None,
                  N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
                  1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else 0)
     stats = None
@@ -356,6 +356,36 @@ def roi_align_bwd(dout, rois, feat_shape, spatial_scale, sampling_ratio):
     check(_abi.load().hd_roi_align_bwd(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(dfeat), R, N, H, W, C_, PH, PW,
                                        spatial_scale, sampling_ratio, _stream()), "hd_roi_align_bwd")
     return dfeat
+
+
+def roi_align_ml(feats, scales, rois, levels, PH, PW, sampling_ratio):
+    """Multi-level RoIAlign.  feats: list of [N,H,W,C] f16; rois [R,5] fp32 (batch,x1,y1,x2,y2); levels [R] int32."""
+    L = len(feats)
+    _need_cuda(rois, levels, *feats)
+    R = rois.shape[0]
+    C_ = feats[0].shape[3]
+    out = torch.empty((R, PH, PW, C_), dtype=torch.float16, device=rois.device)
+    fp = (C.c_void_p * L)(*[f.data_ptr() for f in feats])
+    Hs = (C.c_int * L)(*[f.shape[1] for f in feats])
+    Ws = (C.c_int * L)(*[f.shape[2] for f in feats])
+    sc = (C.c_float * L)(*scales)
+    check(_abi.load().hd_roi_align_ml(fp, Hs, Ws, sc, L, ptr(rois.contiguous()), ptr(levels), ptr(out), R, C_, PH, PW,
+                                      sampling_ratio, _stream()), "hd_roi_align_ml")
+    return out
+
+
+def roi_align_ml_bwd(dout, rois, levels, feat_shapes, scales, sampling_ratio):
+    """Returns list of fp32 gradient maps (zero-initialised, atomically accumulated)."""
+    L = len(feat_shapes)
+    R, PH, PW, C_ = dout.shape
+    dfs = [torch.zeros(s, dtype=torch.float32, device=dout.device) for s in feat_shapes]
+    fp = (C.c_void_p * L)(*[f.data_ptr() for f in dfs])
+    Hs = (C.c_int * L)(*[s[1] for s in feat_shapes])
+    Ws = (C.c_int * L)(*[s[2] for s in feat_shapes])
+    sc = (C.c_float * L)(*scales)
+    check(_abi.load().hd_roi_align_ml_bwd(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(levels), fp, Hs, Ws, sc, L, R, C_,
+                                          PH, PW, sampling_ratio, _stream()), "hd_roi_align_ml_bwd")
+    return dfs
 
 
 def box_iou(gt, boxes):

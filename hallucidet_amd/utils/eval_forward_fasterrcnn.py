@@ -1,0 +1,112 @@
+"""Loss AND detections in one detector pass (reference src/utils/eval_forward_fasterrcnn.py:13-68, rpn_eval :72-102,
+roi_heads_eval :105-185): same function names, argument order, assertions/messages, returned keys and the same
+torchvision call sequence (including `select_training_samples` at evaluation time)."""
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import torch
+
+from ..models.detection import concat_box_prediction_layers, fastrcnn_loss
+
+
+def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name='fasterrcnn'):
+    if train_det:
+        raise NotImplementedError("hallucidet_amd: detector fine-tuning (train_det=True, train_detector.py) needs the "
+                                  "weight-gradient path through the detector; round-1 scope is the frozen detector")
+    model.eval()
+
+    for target in targets:
+        boxes = target["boxes"]
+        if isinstance(boxes, torch.Tensor):
+            torch._assert(len(boxes.shape) == 2 and boxes.shape[-1] == 4,
+                          f"Expected target boxes to be a tensor of shape [N, 4], got {boxes.shape}.")
+        else:
+            torch._assert(False, f"Expected target boxes to be of type Tensor, got {type(boxes)}.")
+
+    original_image_sizes: List[Tuple[int, int]] = []
+    for img in images:
+        val = img.shape[-2:]
+        torch._assert(len(val) == 2, f"expecting the last two dimensions of the Tensor to be H and W instead got {img.shape[-2:]}")
+        original_image_sizes.append((val[0], val[1]))
+
+    images, targets = model.transform(images, targets)
+
+    if targets is not None:
+        # one fused check (single host sync) instead of one `.any()` per image (:41-53)
+        allb = torch.cat([t["boxes"] for t in targets], dim=0)
+        if allb.numel() and bool((allb[:, 2:] <= allb[:, :2]).any()):
+            for target_idx, target in enumerate(targets):
+                boxes = target["boxes"]
+                degenerate_boxes = boxes[:, 2:] <= boxes[:, :2]
+                if degenerate_boxes.any():
+                    bb_idx = torch.where(degenerate_boxes.any(dim=1))[0][0]
+                    degen_bb: List[float] = boxes[bb_idx].tolist()
+                    torch._assert(False, "All bounding boxes should have positive height and width."
+                                  f" Found invalid box {degen_bb} for target at index {target_idx}.")
+
+    features = model.backbone(images.tensors)
+    if isinstance(features, torch.Tensor):
+        features = OrderedDict([("0", features)])
+
+    proposals, proposal_losses = rpn_eval(model, images, features, targets)
+    detections, detector_losses = roi_heads_eval(model, features, proposals, images.image_sizes, targets)
+    detections = model.transform.postprocess(detections, images.image_sizes, original_image_sizes)
+
+    losses = {}
+    losses.update(detector_losses)
+    losses.update(proposal_losses)
+    return losses, detections
+
+
+def rpn_eval(model, images, features, targets):
+    features = list(features.values())
+    objectness, pred_bbox_deltas = model.rpn.head(features)
+    anchors = model.rpn.anchor_generator(images, features)
+
+    num_images = len(anchors)
+    num_anchors_per_level_shape_tensors = [o[0].shape for o in objectness]
+    num_anchors_per_level = [s[0] * s[1] * s[2] for s in num_anchors_per_level_shape_tensors]
+    objectness, pred_bbox_deltas = concat_box_prediction_layers(objectness, pred_bbox_deltas)
+    proposals = model.rpn.box_coder.decode(pred_bbox_deltas.detach(), anchors)
+    proposals = proposals.view(num_images, -1, 4)
+    boxes, scores = model.rpn.filter_proposals(proposals, objectness, images.image_sizes, num_anchors_per_level)
+
+    if targets is None:
+        raise ValueError("targets should not be None")
+    labels, matched_gt_boxes = model.rpn.assign_targets_to_anchors(anchors, targets)
+    regression_targets = model.rpn.box_coder.encode(matched_gt_boxes, anchors)
+    loss_objectness, loss_rpn_box_reg = model.rpn.compute_loss(objectness, pred_bbox_deltas, labels, regression_targets)
+    losses = {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
+    return boxes, losses
+
+
+def roi_heads_eval(model, features, proposals, image_shapes, targets=None, train_det=False):
+    if targets is not None:
+        for t in targets:
+            floating_point_types = (torch.float, torch.double, torch.half)
+            if not t["boxes"].dtype in floating_point_types:
+                raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
+            if not t["labels"].dtype == torch.int64:
+                raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
+
+    proposals, matched_idxs, labels, regression_targets = model.roi_heads.select_training_samples(proposals, targets)
+
+    box_features = model.roi_heads.box_roi_pool(features, proposals, image_shapes)
+    box_features = model.roi_heads.box_head(box_features)
+    class_logits, box_regression = model.roi_heads.box_predictor(box_features)
+
+    result: List[Dict[str, torch.Tensor]] = []
+    if labels is None:
+        raise ValueError("labels cannot be None")
+    if regression_targets is None:
+        raise ValueError("regression_targets cannot be None")
+    loss_classifier, loss_box_reg = fastrcnn_loss(class_logits, box_regression, labels, regression_targets)
+    losses = {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg}
+
+    boxes, scores, labels = model.roi_heads.postprocess_detections(class_logits, box_regression, proposals, image_shapes)
+    for i in range(len(boxes)):
+        result.append({"boxes": boxes[i], "labels": labels[i], "scores": scores[i]})
+
+    if model.roi_heads.has_keypoint():
+        raise NotImplementedError("keypoint branch is dead code for fasterrcnn_resnet50_fpn (SURVEY #7)")
+    return result, losses

@@ -58,7 +58,8 @@ const char* hd_arch(void); /* "gfx950" */
  * data-gradient of stride-in_dil convolutions): element (h,w) is x[h/in_dil,w/in_dil]
  * when both are divisible and in range, else 0; Hin/Win are then ignored and the
  * extent is taken from Hsrc/Wsrc.
- * Epilogue: v = acc + bias[co] + res[pix,co]; stats on fp16(v); y = act(v).
+ * Epilogue: v = acc + bias[co] + res[pix,co]; v = 0 where mask[pix,co] <= 0 (fused ReLU backward);
+ * stats on fp16(v); y = act(v).
  * -------------------------------------------------------------------- */
 typedef struct hd_conv_args {
   const void* x;      /* f16 NHWC [N,Hsrc,Wsrc,C1]                       */
@@ -66,6 +67,7 @@ typedef struct hd_conv_args {
   const void* w;      /* f16 [Cout][KH*KW*(C1+C2)]                        */
   const float* bias;  /* [Cout] or NULL                                   */
   const void* res;    /* f16 NHWC [N,Ho,Wo,Cout] or NULL                  */
+  const void* mask;   /* f16 NHWC [N,Ho,Wo,Cout] or NULL                  */
   void* y;            /* out: f16 NHWC [N,Ho,Wo,Cout] or f32 NCHW         */
   float* stats;       /* out: [gridM][2][Cout] per-tile (sum,sumsq) or NULL */
   int32_t N, Hsrc, Wsrc; /* stored extent of x                           */
@@ -190,6 +192,13 @@ int hd_nms_sorted_batched(const float* boxes, const int* counts, int B, int nmax
 /* RoIAlign (aligned=False), NHWC f16 features -> [R][PH][PW][C] f16. rois: [R][5] (batch, x1,y1,x2,y2) fp32 */
 int hd_roi_align(const void* feat, const float* rois, void* out, int R, int N, int H, int W, int C, int PH, int PW,
                  float spatial_scale, int sampling_ratio, void* stream);
+/* multi-level form (torchvision MultiScaleRoIAlign [EXT]): level[r] in [0,L) selects feats[l] ([N,H[l],W[l],C] f16)
+ * and scale[l].  All arrays are HOST arrays of length L <= 4. */
+int hd_roi_align_ml(const void* const* feats, const int* H, const int* W, const float* scale, int L, const float* rois,
+                    const int* level, void* out, int R, int C, int PH, int PW, int sampling_ratio, void* stream);
+int hd_roi_align_ml_bwd(const void* dout, const float* rois, const int* level, float* const* dfeat_f32, const int* H,
+                        const int* W, const float* scale, int L, int R, int C, int PH, int PW, int sampling_ratio,
+                        void* stream);
 /* backward: dfeat must be zeroed by caller; fp32 atomics into dfeat_f32 [N,H,W,C] */
 int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int R, int N, int H, int W, int C, int PH,
                      int PW, float spatial_scale, int sampling_ratio, void* stream);

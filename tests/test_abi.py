@@ -47,8 +47,8 @@ def test_identity(lib):
 def test_struct_layout_matches_c():
     """sizeof/offsetof of the ctypes mirrors equal what the C compiler lays out (natural alignment, LP64)."""
     from hallucidet_amd._abi import ConvArgs, WgradArgs
-    assert ctypes.sizeof(ConvArgs) == 7 * 8 + 18 * 4
-    assert ConvArgs.N.offset == 56 and ConvArgs.out_mode.offset == 56 + 17 * 4
+    assert ctypes.sizeof(ConvArgs) == 8 * 8 + 18 * 4
+    assert ConvArgs.N.offset == 64 and ConvArgs.out_mode.offset == 64 + 17 * 4
     assert ctypes.sizeof(WgradArgs) == 4 * 8 + 16 * 4
     assert WgradArgs.nsplit.offset == 32 + 15 * 4
 
