@@ -7,16 +7,27 @@
 // The A gather also implements, for free:
 //   * nearest-2x upsample + channel concat of two sources (U-Net decoder,
 //     reference src/segmentation_models/decoders/unet/decoder.py:38-41),
-//   * zero-dilated input (data-gradient of a strided convolution).
-// Block = 256 threads = 4 waves; tile 128 x BN x 32; LDS rows padded to 80 B so
-// every ds_read_b128 lane group hits 16 distinct 16-B slots (conflict free).
+//   * zero-dilated input (data-gradient of a stride-2 convolution).
+//
+// Structure (v3):
+//   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write (the
+//     VGPR->LDS write path, ~80 B/clk/CU, was the LDS bottleneck of the register-staged v2), four LDS stages so
+//     three K tiles are in flight behind the MFMAs, counted s_waitcnt vmcnt(N) + one raw s_barrier per K tile;
+//   * every read is a raw BUFFER access: im2col padding, ragged M/N/K tails are an out-of-range offset, which
+//     the hardware turns into zeros written to LDS -- the load path has no branch;
+//   * the DMA writes LDS lane-linearly (wave base + lane*16 B), so tiles are unpadded [row][64 B] and the bank
+//     swizzle is applied on the SOURCE side: the lane that fills 16-B slot s of row r fetches logical chunk
+//     s ^ ((r>>2)&3); fragment reads apply the same XOR -> every ds_read_b128 lane group hits 16 distinct slots;
+//   * block = 256 threads = 4 waves; tile BM x BN x 32 with BM in {128,64}, BN in {128,64,32};
+//   * blockIdx is remapped so that the M tiles an XCD works on are contiguous (neighbouring pixel tiles share
+//     their 3x3 halo and all N tiles of one M tile share the gathered pixels in that XCD's L2).
 #include "hd_common.h"
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDS_ROW = 40;  // halves per LDS row: 32 data + 8 pad  (80 bytes)
+constexpr int LDS_ROW = 32;  // halves per LDS row (64 bytes, unpadded: LDS-DMA writes lane-linearly)
+constexpr unsigned OOB = 0xFFFFFFF0u;
 
 struct ConvP {
   const f16* x;
@@ -27,88 +38,78 @@ struct ConvP {
   const f16* mask;
   void* y;
   float* stats;
+  unsigned xbytes, x2bytes, wbytes;
   int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1, in_dil, act, out_mode;
   int M, cin8, nchunks, nk, Ktot;
+  int gm, gn;          // grid extent in M / N tiles
+  float inv_cin8, inv_kw;
 };
 
-struct RowState {
-  int n, hb, wb;
-  bool valid;
-};
+typedef __attribute__((address_space(3))) void lds_void;
 
-__device__ __forceinline__ u32x4 load_a_chunk(const ConvP& p, const RowState& r, int kh, int kw, int c8, bool kvalid) {
-  u32x4 v = {0u, 0u, 0u, 0u};
-  if (!(r.valid && kvalid)) return v;
-  int hi = r.hb + kh, wi = r.wb + kw;
-  if (p.in_dil > 1) {
-    if (hi < 0 || wi < 0) return v;
-    int d = p.in_dil;
-    int hq = hi / d, wq = wi / d;
-    if (hq * d != hi || wq * d != wi || hq >= p.Hsrc || wq >= p.Wsrc) return v;
-    size_t off = ((size_t)(r.n * p.Hsrc + hq) * p.Wsrc + wq) * p.C1 + c8 * 8;
-    return *reinterpret_cast<const u32x4*>(p.x + off);
-  }
-  if ((unsigned)hi >= (unsigned)p.Hin || (unsigned)wi >= (unsigned)p.Win) return v;
-  int c = c8 * 8;
-  if (c < p.C1) {
-    if (p.up1) {
-      hi >>= 1;
-      wi >>= 1;
-    }
-    size_t off = ((size_t)(r.n * p.Hsrc + hi) * p.Wsrc + wi) * p.C1 + c;
-    return *reinterpret_cast<const u32x4*>(p.x + off);
-  } else {
-    size_t off = ((size_t)(r.n * p.Hin + hi) * p.Win + wi) * p.C2 + (c - p.C1);
-    return *reinterpret_cast<const u32x4*>(p.x2 + off);
-  }
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_dst, 16, voff, 0, 0, 0);
 }
 
-template <int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DUAL, bool KGEN, int NSTAGE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int MT = BM / (WM * 32);
   constexpr int NT = BN / (WN * 32);
-  constexpr int A_LOADS = BM * 4 / 256;                 // 2
-  constexpr int B_LOADS = (BN * 4 + 255) / 256;          // 2,1,1
-  constexpr int STAGE = (BM + BN) * LDS_ROW;             // halves per stage
-  __shared__ __attribute__((aligned(16))) f16 lds[2 * STAGE];
+  constexpr int A_LOADS = BM * 4 / 256;                 // 2 or 1
+  constexpr int BROWS = BN < 64 ? 64 : BN;               // B region rows (every wave issues the same number of DMAs)
+  constexpr int B_LOADS = BROWS * 4 / 256;               // 2,1,1
+  constexpr int STAGE = (BM + BROWS) * LDS_ROW;          // halves per stage
+  constexpr int L_TILE = A_LOADS + B_LOADS;              // DMA instructions per wave per K tile
+  __shared__ __attribute__((aligned(1024))) f16 lds[NSTAGE * STAGE];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const int j = tid & 3;
+
+  // ---- XCD-aware tile mapping: blocks are dealt round-robin over the 8 XCDs, so give XCD x the x-th contiguous
+  //      eighth of the (n-tile fastest) tile list.  Bijective for any grid size.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  }
+  const int tile_m = bid / p.gn, tile_n = bid - tile_m * p.gn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int j = (tid & 3) ^ ((tid >> 4) & 3);   // logical chunk this lane fetches into slot tid&3 of row tid>>2
   const int HoWo = p.Ho * p.Wo;
 
-  RowState rows[A_LOADS];
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.x), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(DUAL ? p.x2 : p.x), 0, DUAL ? p.x2bytes : p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.w), 0, p.wbytes, 0x00020000);
+
+  // ---- per-thread A rows
+  int hb[A_LOADS], wb[A_LOADS];
+  unsigned nb1[A_LOADS], nb2[A_LOADS];  // image base offsets (bytes) in x / x2
+  bool rvalid[A_LOADS];
 #pragma unroll
   for (int i = 0; i < A_LOADS; ++i) {
     int pix = m0 + (tid >> 2) + i * 64;
-    rows[i].valid = pix < p.M;
-    int pp = rows[i].valid ? pix : 0;
+    rvalid[i] = pix < p.M;
+    int pp = rvalid[i] ? pix : 0;
     int n = pp / HoWo;
     int rem = pp - n * HoWo;
     int ho = rem / p.Wo;
     int wo = rem - ho * p.Wo;
-    rows[i].n = n;
-    rows[i].hb = ho * p.stride - p.pad;
-    rows[i].wb = wo * p.stride - p.pad;
+    hb[i] = ho * p.stride - p.pad;
+    wb[i] = wo * p.stride - p.pad;
+    nb1[i] = (unsigned)n * (unsigned)(p.Hsrc * p.Wsrc) * (unsigned)p.C1 * 2u;
+    nb2[i] = DUAL ? (unsigned)n * (unsigned)(p.Hin * p.Win) * (unsigned)p.C2 * 2u : 0u;
   }
-  // B rows
-  const f16* wrow[B_LOADS];
+  // ---- per-thread B rows
+  unsigned wbase[B_LOADS];
   bool wvalid[B_LOADS];
 #pragma unroll
   for (int i = 0; i < B_LOADS; ++i) {
     int brow = (tid >> 2) + i * 64;
     int co = n0 + brow;
-    wvalid[i] = (brow < BN) && (co < p.Cout);
-    wrow[i] = p.w + (size_t)(wvalid[i] ? co : 0) * p.Ktot;
+    wvalid[i] = (brow < BN) && (co < p.Cout);   // rows >= BN (BN=32) fetch zeros
+    wbase[i] = (unsigned)(wvalid[i] ? co : 0) * (unsigned)p.Ktot * 2u;
   }
-
-  // K walk state for this thread's chunk column j
-  int q = j;
-  int tap = q / p.cin8;
-  int c8 = q - tap * p.cin8;
-  int kh = tap / p.KW;
-  int kw = tap - kh * p.KW;
 
   f32x16 acc[MT][NT];
 #pragma unroll
@@ -118,71 +119,120 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  u32x4 ra[A_LOADS], rb[B_LOADS];
+  const bool dil2 = p.in_dil == 2;
+  const bool up1 = p.up1 != 0;
 
-  auto gload = [&]() {
-    bool kvalid = q < p.nchunks;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) ra[i] = load_a_chunk(p, rows[i], kh, kw, c8, kvalid);
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (wvalid[i] && kvalid) v = *reinterpret_cast<const u32x4*>(wrow[i] + (size_t)q * 8);
-      rb[i] = v;
+  // K walk: chunk q = kt*4 + j.  Fast path (Cin % 32 == 0): the tap is uniform over the block, so the per-row pixel
+  // offset / validity is recomputed only when the tap changes (every Cin/32 tiles); between changes a load address is
+  // one add.  Generic path (Cin in {8,16,24,...}: stem, last decoder block, head): per-lane tap, full recompute.
+  int kt_issue = 0;
+  int kh_u = 0, kw_u = 0, c8_u = 0;
+  unsigned po1[A_LOADS], po2[A_LOADS];   // byte offset of (pixel at the current tap, channel 0) in x / x2
+  bool pv[A_LOADS];
+
+  auto pixel_state = [&](int kh, int kw, int i, unsigned& o1, unsigned& o2, bool& v) {
+    int hi = hb[i] + kh, wi = wb[i] + kw;
+    v = rvalid[i];
+    int hs, ws;
+    if (dil2) {
+      v = v && (hi >= 0) && (wi >= 0) && (((hi | wi) & 1) == 0);
+      hs = hi >> 1;
+      ws = wi >> 1;
+      v = v && (hs < p.Hsrc) && (ws < p.Wsrc);
+    } else {
+      v = v && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+      hs = up1 ? (hi >> 1) : hi;
+      ws = up1 ? (wi >> 1) : wi;
     }
-    // advance to next K tile
-    q += 4;
-    c8 += 4;
-    while (c8 >= p.cin8) {
-      c8 -= p.cin8;
-      if (++kw == p.KW) {
-        kw = 0;
-        ++kh;
+    o1 = nb1[i] + (unsigned)((hs * p.Wsrc + ws) * p.C1) * 2u;
+    o2 = DUAL ? nb2[i] + (unsigned)((hi * p.Win + wi) * p.C2) * 2u : 0u;
+  };
+  if (!KGEN) {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) pixel_state(0, 0, i, po1[i], po2[i], pv[i]);
+  }
+
+  auto gload = [&](int stage) {
+    f16* sa = lds + stage * STAGE + wave * (16 * LDS_ROW);
+    f16* sb = sa + BM * LDS_ROW;
+    const int q = kt_issue * 4 + j;
+    const bool kvalid = q < p.nchunks;
+    int c;
+    if (KGEN) {
+      const int tap = (int)(((float)q + 0.5f) * p.inv_cin8);
+      c = (q - tap * p.cin8) * 8;
+      const int kh = (int)(((float)tap + 0.5f) * p.inv_kw);
+      const int kw = tap - kh * p.KW;
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i) pixel_state(kh, kw, i, po1[i], po2[i], pv[i]);
+    } else {
+      c = (c8_u + j) * 8;
+    }
+    if (DUAL && c8_u * 8 >= p.C1) {   // uniform: a K tile never straddles the concat boundary (C1 % 32 == 0)
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+        dma16(rx2, sa + i * (64 * LDS_ROW), (pv[i] && kvalid) ? po2[i] + (unsigned)(c - p.C1) * 2u : OOB);
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_LOADS; ++i)
+        dma16(rx, sa + i * (64 * LDS_ROW), (pv[i] && kvalid) ? po1[i] + (unsigned)c * 2u : OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) dma16(rw, sb + i * (64 * LDS_ROW), (wvalid[i] && kvalid) ? wbase[i] + (unsigned)q * 16u : OOB);
+    // advance
+    ++kt_issue;
+    if (!KGEN) {
+      c8_u += 4;
+      if (c8_u >= p.cin8) {      // uniform branch, no loads inside
+        c8_u = 0;
+        if (++kw_u == p.KW) {
+          kw_u = 0;
+          ++kh_u;
+        }
+#pragma unroll
+        for (int i = 0; i < A_LOADS; ++i) pixel_state(kh_u, kw_u, i, po1[i], po2[i], pv[i]);
       }
     }
   };
-  auto lstore = [&](int buf) {
-    f16* sa = lds + buf * STAGE;
-    f16* sb = sa + BM * LDS_ROW;
-#pragma unroll
-    for (int i = 0; i < A_LOADS; ++i)
-      *reinterpret_cast<u32x4*>(sa + ((tid >> 2) + i * 64) * LDS_ROW + j * 8) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) {
-      int brow = (tid >> 2) + i * 64;
-      if (brow < BN) *reinterpret_cast<u32x4*>(sb + brow * LDS_ROW + j * 8) = rb[i];
-    }
-  };
-
-  gload();
-  lstore(0);
-  __syncthreads();
-
   const int frow = lane & 31;
-  const int fk = (lane >> 5) * 8;
-  for (int kt = 0; kt < p.nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = (kt + 1) < p.nk;
-    if (more) gload();
-    const f16* sa = lds + buf * STAGE;
+  const int fh = lane >> 5;
+  const int swz = (frow >> 2) & 3;
+  auto compute = [&](int stage) {
+    const f16* sa = lds + stage * STAGE;
     const f16* sb = sa + BM * LDS_ROW;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      const int slot = ((ks * 2 + fh) ^ swz) * 8;
       f16x8 af[MT], bf[NT];
 #pragma unroll
       for (int a = 0; a < MT; ++a)
-        af[a] = *reinterpret_cast<const f16x8*>(sa + (wm * MT * 32 + a * 32 + frow) * LDS_ROW + ks * 16 + fk);
+        af[a] = *reinterpret_cast<const f16x8*>(sa + (wm * MT * 32 + a * 32 + frow) * LDS_ROW + slot);
 #pragma unroll
       for (int b = 0; b < NT; ++b)
-        bf[b] = *reinterpret_cast<const f16x8*>(sb + (wn * NT * 32 + b * 32 + frow) * LDS_ROW + ks * 16 + fk);
+        bf[b] = *reinterpret_cast<const f16x8*>(sb + (wn * NT * 32 + b * 32 + frow) * LDS_ROW + slot);
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
+  };
+
+  // prologue: NSTAGE-1 tiles in flight
+#pragma unroll
+  for (int t = 0; t < NSTAGE - 1; ++t) gload(t);
+  int rd = 0, wr = NSTAGE - 1;
+  for (int kt = 0; kt < p.nk; ++kt) {
+    // this wave's DMAs of tile kt have landed once at most (NSTAGE-2) tiles' worth remain outstanding
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * L_TILE) : "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's part of tile kt is in LDS; stage `wr` (read at kt-1) is free
+    __builtin_amdgcn_sched_barrier(0);
+    gload(wr);                      // tile kt+NSTAGE-1 (zeros beyond the last tile: out-of-range offsets)
+    compute(rd);
+    rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;
+    wr = (wr + 1 == NSTAGE) ? 0 : wr + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   // ---------------- epilogue ----------------
   float ssum[NT], ssq[NT];
@@ -247,14 +297,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
           s += red[(m * BN + tid) * 2 + 0];
           s2 += red[(m * BN + tid) * 2 + 1];
         }
-        p.stats[((size_t)blockIdx.x * 2 + 0) * p.Cout + co] = s;
-        p.stats[((size_t)blockIdx.x * 2 + 1) * p.Cout + co] = s2;
+        p.stats[((size_t)tile_m * 2 + 0) * p.Cout + co] = s;
+        p.stats[((size_t)tile_m * 2 + 1) * p.Cout + co] = s2;
       }
     }
   }
 }
 
 int pick_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+// small problems: halve the M tile so that more of the 256 CUs get a block
+int pick_bm(int M, int Cout) {
+  int bn = pick_bn(Cout);
+  int64_t blocks128 = (int64_t)hd_cdiv(M, 128) * hd_cdiv(Cout, bn);
+  return (bn > 32 && blocks128 < 512) ? 64 : 128;
+}
 
 int fill_params(const hd_conv_args* a, ConvP& p) {
   HD_CHECK_ARG(a && a->x && a->w && a->y, "hd_conv2d: null pointer");
@@ -262,6 +318,8 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   HD_CHECK_ARG((a->C2 == 0) == (a->x2 == nullptr), "hd_conv2d: x2/C2 mismatch");
   HD_CHECK_ARG(a->N > 0 && a->Ho > 0 && a->Wo > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0 && a->stride > 0, "hd_conv2d: bad extent");
   HD_CHECK_ARG(!(a->in_dil > 1 && (a->up1 || a->C2)), "hd_conv2d: in_dil excludes up1/x2");
+  HD_CHECK_ARG(a->in_dil <= 2, "hd_conv2d: in_dil must be 1 or 2 (strides on the hot path)");
+  HD_CHECK_ARG(a->C2 == 0 || (a->C1 % 32 == 0 && a->C2 % 32 == 0), "hd_conv2d: dual-source gather needs C1, C2 multiples of 32");
   HD_CHECK_ARG(!a->up1 || (a->Hin == 2 * a->Hsrc && a->Win == 2 * a->Wsrc), "hd_conv2d: up1 needs Hin=2*Hsrc");
   HD_CHECK_ARG((int64_t)a->N * a->Ho * a->Wo < (1ll << 31), "hd_conv2d: too many pixels");
   p.x = (const f16*)a->x;
@@ -282,14 +340,41 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.nchunks = a->KH * a->KW * p.cin8;
   p.nk = (p.nchunks + 3) / 4;
   p.Ktot = a->KH * a->KW * p.Cin;
+  p.inv_cin8 = 1.0f / (float)p.cin8;
+  p.inv_kw = 1.0f / (float)a->KW;
+  int64_t xb = (int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2;
+  int64_t x2b = a->x2 ? (int64_t)a->N * a->Hin * a->Win * a->C2 * 2 : 0;
+  int64_t wb = (int64_t)a->Cout * p.Ktot * 2;
+  HD_CHECK_ARG(xb < 0xFFFFFFF0ll && x2b < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "hd_conv2d: tensor larger than 4 GiB (buffer addressing)");
+  p.xbytes = (unsigned)xb; p.x2bytes = (unsigned)x2b; p.wbytes = (unsigned)wb;
   return HD_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+void launch_variant(ConvP& p, hipStream_t s) {
+  p.gm = hd_cdiv(p.M, BM);
+  p.gn = hd_cdiv(p.Cout, BN);
+  dim3 grid(p.gm * p.gn);
+  const bool dual = p.x2 != nullptr;
+  const bool kgen = (p.cin8 % 4) != 0;
+  // thin layers (BN = 32) are bandwidth / epilogue bound with a handful of K tiles: 2 stages (24 KB LDS, 6 blocks per CU)
+  // beat a deep pipeline; everything else keeps three K tiles in flight
+  constexpr int NS = BN == 32 ? 2 : 4;
+  if (dual) {
+    if (kgen) return;  // rejected in fill_params (C1, C2 multiples of 32 => uniform taps)
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, NS>), grid, dim3(256), 0, s, p);
+  } else {
+    if (kgen) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, NS>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, false, NS>), grid, dim3(256), 0, s, p);
+  }
 }
 
 }  // namespace
 
 extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (!a) return HD_E_ARG;
-  return hd_cdiv((int64_t)a->N * a->Ho * a->Wo, BM);
+  int M = a->N * a->Ho * a->Wo;
+  return hd_cdiv(M, pick_bm(M, a->Cout));
 }
 
 extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
@@ -298,10 +383,15 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   const int bn = pick_bn(p.Cout);
-  dim3 grid(hd_cdiv(p.M, BM), hd_cdiv(p.Cout, bn));
-  if (bn == 128) hipLaunchKernelGGL((conv_igemm_kernel<128, 2, 2>), grid, dim3(256), 0, s, p);
-  else if (bn == 64) hipLaunchKernelGGL((conv_igemm_kernel<64, 2, 2>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((conv_igemm_kernel<32, 4, 1>), grid, dim3(256), 0, s, p);
+  const int bm = pick_bm(p.M, p.Cout);
+  if (bm == 128) {
+    if (bn == 128) launch_variant<128, 128, 2, 2>(p, s);
+    else if (bn == 64) launch_variant<128, 64, 2, 2>(p, s);
+    else launch_variant<128, 32, 4, 1>(p, s);
+  } else {
+    if (bn == 128) launch_variant<64, 128, 2, 2>(p, s);
+    else launch_variant<64, 64, 2, 2>(p, s);
+  }
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

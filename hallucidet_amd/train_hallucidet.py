@@ -1,0 +1,132 @@
+"""`EncoderDecoderLit` -- the training/eval module of the reference's train_hallucidet.py / eval_hallucidet.py
+(train_hallucidet.py:59-445), without the Lightning / wandb hard dependencies (absent from the toolchain).
+
+Kept: constructor keywords, `forward_step` (one U-Net pass, three detector passes, the 11-key loss dict and the 3 output
+batches, :161-240), `training_step / validation_step / test_step`, `configure_optimizers`.  The RGB and IR detector passes
+run without autograd (their losses are discarded by the reference, App. D.2 -- same results).
+"""
+import torch
+import torch.nn as nn
+
+from .config import Config
+from .distributed import GradientAverager, broadcast_parameters
+from .models.detector import Detector
+from .models.encoder_decoder import EncoderDecoder
+from .optim import LossScaler
+from .utils.utils import Utils
+
+
+class EncoderDecoderLit(nn.Module):
+    def __init__(self, batch_size=4, wandb_logger=None, model_name='resnet34', in_channels=3, output_channels=3, lr=0.0001,
+                 loss_pixel=None, loss_perceptual=None, detector_name='fasterrcnn', train_det=False, fuse_data='none',
+                 scheduler_on=False, detector=None, precision=16, device='cuda'):
+        super().__init__()
+        self.model_name, self.wandb_logger = model_name, wandb_logger
+        self.in_channels, self.output_channels = in_channels, output_channels
+        self.lr, self.batch_size, self.train_det, self.fuse_data = lr, batch_size, train_det, fuse_data
+        self.optimizer_name = Config.Optimizer.name
+        self.segmentation_head = Config.EncoderDecoder.decoder_head
+        self.scheduler_on = scheduler_on
+        self.detector_name = detector_name
+        self.dev = torch.device(device)
+        if loss_pixel is not None or loss_perceptual is not None:
+            raise NotImplementedError("pixel / LPIPS losses have weight 0.0 and selectors returning None in every BASELINE "
+                                      "config (SURVEY #17); their four keys are reported as 0.0")
+        self.encoder_decoder = EncoderDecoder(name=self.model_name, encoder_depth=5, encoder_weights=None,
+                                              decoder_attention_type=None, in_channels=self.in_channels,
+                                              output_channels=self.output_channels,
+                                              segmentation_head=Config.EncoderDecoder.decoder_head).encoder_decoder
+        self.detector = detector if detector is not None else Detector(name=detector_name, pretrained=False, n_classes=2,
+                                                                       size=Config.Detector.input_size).detector
+        self.detector.eval()
+        for p in self.detector.parameters():
+            p.requires_grad = False
+        self.precision = precision
+        self.scaler = None
+        self.optimizer = None
+        self.averager = GradientAverager()
+
+    # ------------------------------------------------------------------------------------------------------------
+    def forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train'):
+        device = self.dev
+        imgs_ir = Utils.batch_images_for_encoder_decoder(imgs=imgs_ir, device=device)
+        imgs_rgb = Utils.batch_images_for_encoder_decoder(imgs=imgs_rgb, device=device)
+        targets_rgb = Utils.batch_targets_for_detector(targets=targets_rgb, device=device, detector_name=self.detector_name)
+        targets_ir = Utils.batch_targets_for_detector(targets=targets_ir, device=device, detector_name=self.detector_name)
+
+        imgs_ir_three_channel = Utils.expand_one_channel_to_output_channels(imgs_ir, self.output_channels) if imgs_ir.shape[1] == 1 else imgs_ir
+        imgs_hallucinated = self.encoder_decoder(imgs_ir_three_channel)
+
+        loss_pixel_rgb = loss_perceptual_rgb = loss_pixel_ir = loss_perceptual_ir = 0.0
+
+        train_det = True if (self.train_det is True and step == 'train') else False
+        losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=train_det, model_name=self.detector_name)
+        with torch.no_grad():
+            _, detections_rgb = Detector.calculate_loss(self.detector, imgs_rgb, targets_rgb, train_det=False, model_name=self.detector_name)
+            _, detections_ir = Detector.calculate_loss(self.detector, imgs_ir_three_channel, targets_ir, train_det=False, model_name=self.detector_name)
+
+        w = Config.Losses.hparams_losses_weights
+        if 'fasterrcnn' in self.detector_name:
+            losses_det['classification'] = losses_det['loss_classifier']
+            losses_det['bbox_regression'] = losses_det['loss_box_reg']
+        losses_det['bbox_regression'] = losses_det['bbox_regression'] * w['det_regression']
+        losses_det['classification'] = losses_det['classification'] * w['det_classification']
+        losses_det['loss_objectness'] = (losses_det['loss_objectness'] * w['det_objectness'] if 'fasterrcnn' in self.detector_name else 0.0)
+        losses_det['loss_rpn_box_reg'] = (losses_det['loss_rpn_box_reg'] * w['det_rpn_box_reg'] if 'fasterrcnn' in self.detector_name else 0.0)
+        losses_det['bbox_ctrness'] = (losses_det['bbox_ctrness'] * w['det_bbox_ctrness'] if 'fcos' in self.detector_name else 0.0)
+        loss_det_total = losses_det['bbox_regression'] + losses_det['classification'] + losses_det['loss_objectness'] + \
+            losses_det['loss_rpn_box_reg'] + losses_det['bbox_ctrness']
+        total_loss = loss_det_total + loss_pixel_rgb + loss_perceptual_rgb + loss_pixel_ir + loss_perceptual_ir
+
+        self._last_detections = dict(hall=detections_hall, rgb=detections_rgb, ir=detections_ir)
+        return {
+            'loss': {'total': total_loss, 'pixel_rgb': loss_pixel_rgb, 'perceptual_rgb': loss_perceptual_rgb,
+                     'pixel_ir': loss_pixel_ir, 'perceptual_ir': loss_perceptual_ir,
+                     'det_regression': losses_det['bbox_regression'], 'det_classification': losses_det['classification'],
+                     'det_objectness': losses_det['loss_objectness'], 'det_rpn_box_reg': losses_det['loss_rpn_box_reg'],
+                     'det_bbox_ctrness': losses_det['bbox_ctrness'], 'det_total': loss_det_total},
+            # train_hallucidet.py:218 min-max normalises a detached clone for plotting only; kept lazy
+            'output': {'imgs_rgb': imgs_rgb, 'imgs_ir': imgs_ir, 'imgs_hallucinated': imgs_hallucinated.detach()},
+        }
+
+    def training_step(self, train_batch, batch_idx):
+        imgs_rgb, targets_rgb, imgs_ir, targets_ir = train_batch
+        out = self.forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train')
+        return out['loss']['total']
+
+    def validation_step(self, val_batch, batch_idx):
+        imgs_rgb, targets_rgb, imgs_ir, targets_ir = val_batch
+        with torch.no_grad():
+            out = self.forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='val')
+        return out['loss']['total'], self._last_detections
+
+    def test_step(self, test_batch, batch_idx):
+        return self.validation_step(test_batch, batch_idx)
+
+    def configure_optimizers(self):
+        self.encoder_decoder.to(self.dev)
+        self.optimizer = Config.config_optimizer(self.encoder_decoder, learning_rate=self.lr, name=self.optimizer_name)
+        self.scaler = LossScaler(self.encoder_decoder, enabled=(self.precision == 16))
+        return self.optimizer
+
+    # ------------------------------------------------------------------------------------------------------------
+    def prepare(self):
+        """Move to the device, build the optimizer, and (data parallel) start every rank from rank 0's weights."""
+        self.to(self.dev)
+        self.configure_optimizers()
+        r = self.encoder_decoder.runner
+        bufs = [b for b in self.encoder_decoder.buffers() if b.dtype.is_floating_point]
+        broadcast_parameters(r.flat_params, bufs)
+        return self
+
+    def fit_step(self, batch, batch_idx=0):
+        """What Lightning does around training_step: scale -> backward -> all-reduce -> (unscale+clip+Adam fused)."""
+        self.encoder_decoder.train()
+        loss = self.training_step(batch, batch_idx)
+        self.scaler.scale(loss).backward()
+        g = self.encoder_decoder.runner.flat_grads
+        self.averager.start(g)
+        self.averager.finish(g)
+        self.scaler.step(self.optimizer)
+        self.scaler.update()
+        return loss.detach()

@@ -1,0 +1,69 @@
+"""Hot-path helpers of the reference's `Utils` (src/utils/utils.py:13-53,237-254,333-338): same names and semantics.
+Plotting / VOC-XML helpers of that class are outside the hot path (SURVEY #8)."""
+import torch
+
+
+class Utils():
+
+    @staticmethod
+    def stack_images(imgs, device='cpu', ablation_flag=False):
+        if isinstance(imgs, torch.Tensor) and imgs.dim() == 4:        # already batched (synthetic / pre-staged input)
+            return imgs.to(device, dtype=torch.float) if ablation_flag else imgs.to(device)
+        if ablation_flag:
+            return torch.stack(list(image.to(device, dtype=torch.float) for image in imgs))
+        return torch.stack(list(image.to(device) for image in imgs))
+
+    @staticmethod
+    def batch_images_for_encoder_decoder(imgs, device='cpu', ablation_flag=False):
+        return Utils.stack_images(imgs=imgs, device=device, ablation_flag=ablation_flag)
+
+    @staticmethod
+    def list_targets(targets, device='cpu', detach=False, detector_name='fasterrcnn'):
+        if 'fcos' in detector_name:
+            if detach:
+                return [{k: (v.float().detach().to(device) if not isinstance(v, str) else v) if k == 'boxes' else
+                         (v.detach().to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
+            return [{k: (v.float().to(device) if not isinstance(v, str) else v) if k == 'boxes' else
+                     (v.to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
+        if detach:
+            return [{k: (v.detach().to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
+        return [{k: (v.to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
+
+    @staticmethod
+    def batch_targets_for_detector(targets, device='cpu', detach=False, detector_name='fasterrcnn'):
+        return Utils.list_targets(targets=targets, device=device, detach=detach, detector_name=detector_name)
+
+    @staticmethod
+    def expand_one_channel_to_output_channels(imgs, output_channels=3):
+        return imgs.repeat(1, output_channels, 1, 1)
+
+    @staticmethod
+    def concat_modalities(img_rgb, img_ir):
+        return torch.cat([img_rgb, img_ir], dim=0)
+
+    @staticmethod
+    def collate_fn(batch):
+        return tuple(zip(*batch))
+
+    @staticmethod
+    def normalize_image(image):
+        """Per-channel min-max to [0,1] (constant channels -> 0), in place, as utils.py:237-248 -- vectorised: no host
+        round trip per channel (the reference's `if` on a device scalar syncs 3x per image)."""
+        mins = image.amin(dim=(1, 2), keepdim=True)
+        maxs = image.amax(dim=(1, 2), keepdim=True)
+        rng = maxs - mins
+        out = torch.where(rng != 0, (image - mins) / torch.where(rng != 0, rng, torch.ones_like(rng)), torch.zeros_like(image))
+        image.copy_(out)
+        return image
+
+    @staticmethod
+    def normalize_batch_images(images):
+        mins = images.amin(dim=(2, 3), keepdim=True)
+        maxs = images.amax(dim=(2, 3), keepdim=True)
+        rng = maxs - mins
+        images.copy_(torch.where(rng != 0, (images - mins) / torch.where(rng != 0, rng, torch.ones_like(rng)), torch.zeros_like(images)))
+        return images
+
+    @staticmethod
+    def filter_dictionary(input_dict, filter_keys):
+        return {key: value for key, value in input_dict.items() if key in filter_keys}
