@@ -127,17 +127,26 @@ def _dgrad(e, dy, in_hw, *, res=None, mask=None):
 
 
 class _BackboneFn(torch.autograd.Function):
+    """`n_active`: only the first n_active images of the batch need a data gradient (the hallucinated images when the
+    RGB / IR detector passes of a training step are batched with them); the rest is forward-only."""
+
     @staticmethod
-    def forward(ctx, x, hook, bb):
-        outs, saved = bb._forward(x, save=True)
-        ctx.bb, ctx.saved = bb, saved
+    def forward(ctx, x, hook, bb, n_active):
+        outs, saved = bb._forward(x, save=True, n_active=n_active)
+        ctx.bb, ctx.saved, ctx.n_active, ctx.n = bb, saved, n_active, x.shape[0]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
+        na = ctx.n_active
+        grads = [None if g is None else g[:na] for g in grads]
         dx = ctx.bb._backward(ctx.saved, grads)
         ctx.saved = None
-        return dx, None, None
+        if na < ctx.n:
+            full = torch.zeros((ctx.n,) + tuple(dx.shape[1:]), dtype=dx.dtype, device=dx.device)
+            full[:na] = dx
+            dx = full
+        return dx, None, None, None
 
 
 class BackboneWithFPN(nn.Module):
@@ -173,9 +182,10 @@ class BackboneWithFPN(nn.Module):
         return P
 
     # -------------------------------------------------------------- execution
-    def _forward(self, x, save):
+    def _forward(self, x, save, n_active=None):
         P = self.pack()
-        rec = {"x": x, "blocks": []} if save else None
+        na = x.shape[0] if n_active is None else n_active
+        rec = {"x": x[:na], "blocks": []} if save else None
         s = _fwd(P["stem"], x, act=ACT_RELU)
         p = ops.maxpool3x3s2(s)
         cur = p
@@ -188,7 +198,7 @@ class BackboneWithFPN(nn.Module):
                 idt = cur if e["ds"] is None else _fwd(e["ds"], cur)
                 out = _fwd(e["c3"], o2, act=ACT_RELU, res=idt)
                 if save:
-                    srec.append((cur, o1, o2, out))
+                    srec.append((cur[:na], o1[:na], o2[:na], out[:na]))
                 cur = out
             C.append(cur)
             if save:
@@ -203,7 +213,7 @@ class BackboneWithFPN(nn.Module):
             outs[i] = _fwd(P["layer"][i], inner[i])
         pool = ops.subsample2(outs[3])
         if save:
-            rec.update(stem=s, pooled=p, C=C, inner_shapes=[t.shape for t in inner], out_shapes=[t.shape for t in outs])
+            rec.update(stem=s[:na], pooled=p[:na], C=[c[:na] for c in C], out_shapes=[(na,) + tuple(t.shape[1:]) for t in outs])
         return outs + [pool], rec
 
     def _backward(self, rec, grads):
@@ -250,7 +260,7 @@ class BackboneWithFPN(nn.Module):
         x = rec["x"]
         return _dgrad(P["stem"], ds_, (x.shape[1], x.shape[2]))
 
-    def forward(self, x):
+    def forward(self, x, n_active=None):
         if not (isinstance(x, torch.Tensor) and x.dim() == 4 and x.dtype == torch.float16 and x.shape[-1] == 8):
             raise TypeError("hallucidet_amd backbone expects ImageList.tensors from CustomGeneralizedRCNNTransform "
                             "(NHWC float16, 8 channels)")
@@ -259,7 +269,7 @@ class BackboneWithFPN(nn.Module):
         if torch.is_grad_enabled() and x.requires_grad:
             if self._hook is None or self._hook.device != x.device:
                 self._hook = torch.zeros(1, device=x.device, requires_grad=True)
-            outs = _BackboneFn.apply(x, self._hook, self)
+            outs = _BackboneFn.apply(x, self._hook, self, x.shape[0] if n_active is None else n_active)
         else:
             outs, _ = self._forward(x, save=False)
         return OrderedDict(zip(("0", "1", "2", "3", "pool"), outs))
@@ -474,24 +484,27 @@ class AnchorGenerator(nn.Module):
 
 class _RPNHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hook, head, *feats):
+    def forward(ctx, hook, head, n_active, *feats):
         P = head.pack()
         ts, outs = [], []
         for f in feats:
             t = _fwd(P["conv"], f, act=ACT_RELU)
-            ts.append(t)
+            ts.append(t[:n_active])
             outs.append(_fwd(P["cls"], t, f32=True))
             outs.append(_fwd(P["box"], t, f32=True))
-        ctx.head, ctx.ts = head, ts
+        ctx.head, ctx.ts, ctx.na, ctx.n = head, ts, n_active, feats[0].shape[0]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         P = ctx.head.pack()
         dfeats = []
+        na = ctx.na
         for i, t in enumerate(ctx.ts):
             N, H, W, _ = t.shape
             dl, dr = grads[2 * i], grads[2 * i + 1]
+            dl = None if dl is None else dl[:na]
+            dr = None if dr is None else dr[:na]
             hw = (H, W)
             dt = None
             if dl is not None:
@@ -500,9 +513,14 @@ class _RPNHeadFn(torch.autograd.Function):
                 dt = _dgrad(P["box"], ops.nchw_to_nhwc_resize(dr.contiguous().float(), H, W, P["box"]["cout_p"]), hw, res=dt, mask=t)
             elif dt is not None:
                 dt = ops.relu_bwd(dt, t)
-            dfeats.append(None if dt is None else _dgrad(P["conv"], dt, hw))
+            df = None if dt is None else _dgrad(P["conv"], dt, hw)
+            if df is not None and na < ctx.n:
+                full = torch.zeros((ctx.n,) + tuple(df.shape[1:]), dtype=df.dtype, device=df.device)
+                full[:na] = df
+                df = full
+            dfeats.append(df)
         ctx.ts = None
-        return (None, None) + tuple(dfeats)
+        return (None, None, None) + tuple(dfeats)
 
 
 class RPNHead(nn.Module):
@@ -524,12 +542,12 @@ class RPNHead(nn.Module):
             self._pack = dict(conv=_conv_entry(self.conv), cls=_conv_entry(self.cls_logits), box=_conv_entry(self.bbox_pred))
         return self._pack
 
-    def forward(self, x):
+    def forward(self, x, n_active=None):
         """x: list of NHWC fp16 feature maps.  Returns (logits, bbox_reg): lists of NCHW fp32 tensors per level."""
         feats = list(x)
         if self._hook is None or self._hook.device != feats[0].device:
             self._hook = torch.zeros(1, device=feats[0].device, requires_grad=True)
-        outs = _RPNHeadFn.apply(self._hook, self, *feats)
+        outs = _RPNHeadFn.apply(self._hook, self, feats[0].shape[0] if n_active is None else n_active, *feats)
         return list(outs[0::2]), list(outs[1::2])
 
 

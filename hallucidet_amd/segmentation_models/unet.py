@@ -164,14 +164,16 @@ class _Unit:
 class _UnetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, hook, runner):
-        out = runner.forward(x, training=True, save=True)
+        out = runner.run_forward_train(x)
         ctx.runner = runner
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        dx = ctx.runner.backward(dout.contiguous(), need_dx=ctx.needs_input_grad[0])
-        return dx, None, None
+        if ctx.needs_input_grad[0]:
+            raise NotImplementedError("gradient w.r.t. the Unet input is not on the hot path (IR images are data)")
+        ctx.runner.run_backward(dout)
+        return None, None, None
 
 
 class UnetRunner:
@@ -181,6 +183,8 @@ class UnetRunner:
         self.module = module
         self.grad_scale = 1.0          # loss scale S applied upstream; parameter gradients are emitted as g/S
         self.saved = None
+        self.use_graphs = False        # replay the (static-shape) schedule as two hipGraphs: see enable_graphs()
+        self._g = None
         enc, dec = module.encoder, module.decoder
         self.stem = _Unit("encoder.conv1", enc.conv1, enc.bn1)
         self.stages = []
@@ -199,6 +203,59 @@ class UnetRunner:
             self.dec.append((_Unit(pre + "conv1", b.conv1[0], b.conv1[1]), _Unit(pre + "conv2", b.conv2[0], b.conv2[1]), b.in_channels, b.skip_channels))
         self.head_conv = module.segmentation_head[0]
         self.units = [self.stem] + [u for st in self.stages for blk in st for u in blk if u is not None] + [u for d in self.dec for u in d[:2]]
+
+    # ------------------------------------------------------------------ hipGraph replay
+    def enable_graphs(self, on=True):
+        """The training forward and backward are fixed launch sequences over fixed buffers (~650 + ~700 launches at
+        3-30 us of GPU time each): capture each once per input shape / loss scale and replay it, which removes the
+        per-launch host cost (the step is host-bound otherwise).  Eager execution stays the default."""
+        self.use_graphs = on
+        self._g = None
+
+    def run_forward_train(self, x):
+        if not self.use_graphs:
+            return self.forward(x, training=True, save=True)
+        g = self._g
+        if g is None or g["xshape"] != tuple(x.shape) or g["dev"] != x.device:
+            self.flatten_parameters()
+            g = self._g = dict(xshape=tuple(x.shape), dev=x.device, x=torch.empty_like(x, dtype=torch.float32), bwd=None, scale=None)
+            g["x"].copy_(x)
+            snap = [b.clone() for b in self.module.buffers()]   # the warm-up run must not count as a training step
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):          # warm-up outside capture (lazy module loading, allocator)
+                self.forward(g["x"], training=True, save=True)
+            torch.cuda.current_stream().wait_stream(side)
+            g["pool"] = torch.cuda.graph_pool_handle()
+            g["fwd"] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g["fwd"], pool=g["pool"]):
+                g["out"] = self.forward(g["x"], training=True, save=True)
+            g["saved"] = self.saved
+            # the capture itself did not execute: restore the BatchNorm buffers the warm-up touched, then replay
+            for b, s0 in zip(self.module.buffers(), snap):
+                b.copy_(s0)
+        g["x"].copy_(x)
+        g["fwd"].replay()
+        self.saved = g["saved"]
+        return g["out"]
+
+    def run_backward(self, dout):
+        if not self.use_graphs:
+            return self.backward(dout.contiguous())
+        g = self._g
+        S = float(self.grad_scale)
+        if g["bwd"] is None or g["scale"] != S:
+            g["dout"] = torch.empty(g["out"].shape, dtype=torch.float32, device=g["dev"])
+            g["dout"].copy_(dout)
+            self.saved = g["saved"]
+            g["bwd"] = torch.cuda.CUDAGraph()
+            g["scale"] = S
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g["bwd"], pool=g["pool"]):
+                self.backward(g["dout"], keep_saved=True)
+        g["dout"].copy_(dout)
+        g["bwd"].replay()
+        return None
 
     # ------------------------------------------------------------------ parameters
     def flatten_parameters(self):
@@ -324,7 +381,7 @@ class UnetRunner:
             dx = ops.conv2d(dy, wd, u.k, u.k, stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res)
         return dx, dres
 
-    def backward(self, dout, need_dx=False):
+    def backward(self, dout, need_dx=False, keep_saved=False):
         sv = self.saved
         if sv is None:
             raise RuntimeError("Unet.backward called without a saved training forward")
@@ -379,7 +436,8 @@ class UnetRunner:
         if need_dx:
             raise NotImplementedError("gradient w.r.t. the Unet input is not on the hot path (IR images are data)")
         self._unit_bwd(self.stem, df1, S, need_dx=False)
-        self.saved = None
+        if not keep_saved:
+            self.saved = None
         return dx
 
 

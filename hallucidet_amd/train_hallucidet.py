@@ -14,12 +14,13 @@ from .models.detector import Detector
 from .models.encoder_decoder import EncoderDecoder
 from .optim import LossScaler
 from .utils.utils import Utils
+from .utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn_multi
 
 
 class EncoderDecoderLit(nn.Module):
     def __init__(self, batch_size=4, wandb_logger=None, model_name='resnet34', in_channels=3, output_channels=3, lr=0.0001,
                  loss_pixel=None, loss_perceptual=None, detector_name='fasterrcnn', train_det=False, fuse_data='none',
-                 scheduler_on=False, detector=None, precision=16, device='cuda'):
+                 scheduler_on=False, detector=None, precision=16, device='cuda', use_graphs=True):
         super().__init__()
         self.model_name, self.wandb_logger = model_name, wandb_logger
         self.in_channels, self.output_channels = in_channels, output_channels
@@ -42,6 +43,8 @@ class EncoderDecoderLit(nn.Module):
         for p in self.detector.parameters():
             p.requires_grad = False
         self.precision = precision
+        self.use_graphs = use_graphs
+        self.batch_detector_passes = True
         self.scaler = None
         self.optimizer = None
         self.averager = GradientAverager()
@@ -60,10 +63,16 @@ class EncoderDecoderLit(nn.Module):
         loss_pixel_rgb = loss_perceptual_rgb = loss_pixel_ir = loss_perceptual_ir = 0.0
 
         train_det = True if (self.train_det is True and step == 'train') else False
-        losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=train_det, model_name=self.detector_name)
-        with torch.no_grad():
-            _, detections_rgb = Detector.calculate_loss(self.detector, imgs_rgb, targets_rgb, train_det=False, model_name=self.detector_name)
-            _, detections_ir = Detector.calculate_loss(self.detector, imgs_ir_three_channel, targets_ir, train_det=False, model_name=self.detector_name)
+        if self.batch_detector_passes and not train_det and 'fasterrcnn' in self.detector_name:
+            # one trunk evaluation for the three passes (frozen, eval-mode detector: images are independent); the RGB / IR
+            # losses are discarded by the reference (train_hallucidet.py:183,186) and carry no gradient
+            (losses_det, detections_hall), (_, detections_rgb), (_, detections_ir) = eval_forward_fasterrcnn_multi(
+                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, targets_ir])
+        else:
+            losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=train_det, model_name=self.detector_name)
+            with torch.no_grad():
+                _, detections_rgb = Detector.calculate_loss(self.detector, imgs_rgb, targets_rgb, train_det=False, model_name=self.detector_name)
+                _, detections_ir = Detector.calculate_loss(self.detector, imgs_ir_three_channel, targets_ir, train_det=False, model_name=self.detector_name)
 
         w = Config.Losses.hparams_losses_weights
         if 'fasterrcnn' in self.detector_name:
@@ -115,6 +124,7 @@ class EncoderDecoderLit(nn.Module):
         self.to(self.dev)
         self.configure_optimizers()
         r = self.encoder_decoder.runner
+        r.enable_graphs(self.use_graphs)
         bufs = [b for b in self.encoder_decoder.buffers() if b.dtype.is_floating_point]
         broadcast_parameters(r.flat_params, bufs)
         return self

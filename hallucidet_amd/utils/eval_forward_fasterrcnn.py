@@ -9,6 +9,83 @@ import torch
 from ..models.detection import concat_box_prediction_layers, fastrcnn_loss
 
 
+def _check_targets(targets):
+    for target in targets:
+        boxes = target["boxes"]
+        if isinstance(boxes, torch.Tensor):
+            torch._assert(len(boxes.shape) == 2 and boxes.shape[-1] == 4,
+                          f"Expected target boxes to be a tensor of shape [N, 4], got {boxes.shape}.")
+        else:
+            torch._assert(False, f"Expected target boxes to be of type Tensor, got {type(boxes)}.")
+
+
+def _check_degenerate(targets):
+    # one fused check (single host sync) instead of one `.any()` per image (reference :41-53)
+    allb = torch.cat([t["boxes"] for t in targets], dim=0)
+    if allb.numel() and bool((allb[:, 2:] <= allb[:, :2]).any()):
+        for target_idx, target in enumerate(targets):
+            boxes = target["boxes"]
+            degenerate_boxes = boxes[:, 2:] <= boxes[:, :2]
+            if degenerate_boxes.any():
+                bb_idx = torch.where(degenerate_boxes.any(dim=1))[0][0]
+                degen_bb: List[float] = boxes[bb_idx].tolist()
+                torch._assert(False, "All bounding boxes should have positive height and width."
+                              f" Found invalid box {degen_bb} for target at index {target_idx}.")
+
+
+class _ImageSlice:
+    """ImageList view of a sub-batch (what the RPN / anchor code needs: image_sizes and the layout tag)."""
+
+    def __init__(self, il, lo, hi):
+        self.tensors = il.tensors[lo:hi]
+        self.image_sizes = il.image_sizes[lo:hi]
+        self.layout = il.layout
+
+
+def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name='fasterrcnn'):
+    """The hallucinated / RGB / IR detector passes of one training step (train_hallucidet.py:180,183,186) with ONE
+    transform + ResNet-50-FPN + RPN-head evaluation over the concatenated batch (the detector is frozen and in eval
+    mode, so every image is independent), followed by the reference's per-pass logic -- proposals, target assignment,
+    sampling (same `randperm` call order as three separate passes), RoI heads, losses, detections -- on the slices.
+    Only the first batch carries a gradient.  Returns [(losses, detections)] per pass."""
+    model.eval()
+    for t in target_lists:
+        _check_targets(t)
+    sizes = [[(img.shape[-2], img.shape[-1]) for img in b] for b in image_batches]
+    nb = [len(s) for s in sizes]
+    x = torch.cat([b if isinstance(b, torch.Tensor) else torch.stack(list(b)) for b in image_batches], dim=0)
+    flat_targets = [t for tl in target_lists for t in tl]
+    il, flat_targets = model.transform(x, flat_targets)
+    _check_degenerate(flat_targets)
+    n_active = nb[0] if image_batches[0].requires_grad else 0
+    if n_active:
+        features = model.backbone(il.tensors, n_active=n_active)
+        objectness, deltas = model.rpn.head(list(features.values()), n_active=n_active)
+    else:
+        with torch.no_grad():
+            features = model.backbone(il.tensors)
+            objectness, deltas = model.rpn.head(list(features.values()))
+    out, lo = [], 0
+    for k, n in enumerate(nb):
+        hi = lo + n
+        ctx = torch.enable_grad() if (k == 0 and n_active) else torch.no_grad()
+        with ctx:
+            f_k = OrderedDict((name, v[lo:hi]) for name, v in features.items())
+            o_k = [o[lo:hi] for o in objectness]
+            d_k = [d[lo:hi] for d in deltas]
+            il_k = _ImageSlice(il, lo, hi)
+            t_k = flat_targets[lo:hi]
+            proposals, proposal_losses = rpn_eval(model, il_k, f_k, t_k, head_out=(o_k, d_k))
+            detections, detector_losses = roi_heads_eval(model, f_k, proposals, il_k.image_sizes, t_k)
+            detections = model.transform.postprocess(detections, il_k.image_sizes, sizes[k])
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        out.append((losses, detections))
+        lo = hi
+    return out
+
+
 def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name='fasterrcnn'):
     if train_det:
         raise NotImplementedError("hallucidet_amd: detector fine-tuning (train_det=True, train_detector.py) needs the "
@@ -58,9 +135,9 @@ def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name=
     return losses, detections
 
 
-def rpn_eval(model, images, features, targets):
+def rpn_eval(model, images, features, targets, head_out=None):
     features = list(features.values())
-    objectness, pred_bbox_deltas = model.rpn.head(features)
+    objectness, pred_bbox_deltas = model.rpn.head(features) if head_out is None else head_out
     anchors = model.rpn.anchor_generator(images, features)
 
     num_images = len(anchors)

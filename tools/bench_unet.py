@@ -11,6 +11,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(123)
 net = EncoderDecoder(name="resnet34").encoder_decoder.to(dev).train()
 opt = FusedAdam(net, lr=1e-4, clip_value=0.5)
+net.runner.enable_graphs(bool(int(os.environ.get('HD_GRAPHS', '0'))))
 x = torch.rand(N, 3, H, W, device=dev)
 g = torch.randn(N, 3, H, W, device=dev) * 1e-3
 net.runner.grad_scale = 1024.0
