@@ -1,0 +1,162 @@
+"""bench.py -- images/sec of one `train_hallucidet` step (Faster R-CNN, LLVIP geometry 512x640, batch 8 / GPU, fp16) on
+N MI355X of one node, one process per GPU (RCCL all-reduce of the hallucination-net gradients), synthetic inputs already
+resident in HBM.  Prints ONE JSON line (rank 0).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+`roofline`: the dominant kernel is the implicit-GEMM convolution (conv_igemm_kernel: every conv / data-gradient / FC of
+the U-Net and the detector).  Its launches of one step are recorded and re-issued back to back between HIP events on
+the launch stream; achieved = algorithmic FLOPs of those launches / their summed duration (DESIGN.md "Measurement").
+`cpu_baseline`: the CPU oracle (oracle/step.py, "port") timed on this host's cores on a bounded sample of the same
+workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+BATCH_PER_GPU = 8
+H, W = 512, 640
+
+
+def conv_roofline(lit, batch, reps=5):
+    """Record every hd_conv2d launch of one (eager) training step, then time the recorded launches back to back."""
+    import ctypes as C
+    from hallucidet_amd import _abi, ops
+    lib = _abi.load()
+    rec = []
+    orig = ops.conv2d
+
+    def spy(x, w, KH, KW, **kw):
+        out = orig(x, w, KH, KW, **kw)
+        y = out[0] if isinstance(out, tuple) else out
+        C1 = x.shape[3]
+        C2 = 0 if kw.get("x2") is None else kw["x2"].shape[3]
+        if kw.get("out_nchw_f32"):
+            n, co, ho, wo = y.shape
+        else:
+            n, ho, wo, co = y.shape
+        dil = kw.get("in_dil", 1)
+        # algorithmic FLOPs: a data-gradient over a zero-dilated input only multiplies the non-zero taps
+        flops = 2.0 * n * ho * wo * co * KH * KW * (C1 + C2) / (dil * dil)
+        rec.append((dict(kw), (x, w, KH, KW), flops))
+        return out
+
+    ops.conv2d = spy
+    import hallucidet_amd.models.detection as det_mod
+    import hallucidet_amd.segmentation_models.unet as unet_mod
+    r = lit.encoder_decoder.runner
+    was = r.use_graphs
+    r.enable_graphs(False)
+    try:
+        lit.fit_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        ops.conv2d = orig
+        r.enable_graphs(was)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    tot_ms, tot_fl = 0.0, 0.0
+    for kw, (x, w, KH, KW), fl in rec:
+        kw = dict(kw)
+        kw["want_stats"] = False
+        orig(x, w, KH, KW, **kw)                      # warm
+        e0.record()
+        for _ in range(reps):
+            orig(x, w, KH, KW, **kw)
+        e1.record()
+        e1.synchronize()
+        tot_ms += e0.elapsed_time(e1) / reps
+        tot_fl += fl
+    n = len(rec)
+    achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+            "kernel": "conv_igemm_kernel (implicit-GEMM conv / dgrad / FC)", "launches_per_step": n,
+            "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2), "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    from hallucidet_amd import synthetic
+    dev = "cuda:%d" % local
+    lit = synthetic.make_module(seed=123, device=dev, precision=16)
+    batch = synthetic.make_batch(BATCH_PER_GPU, H, W, seed=123 + rank, device=dev)   # per-rank shard, resident in HBM
+
+    for _ in range(args.warmup):
+        lit.fit_step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = lit.fit_step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if not torch.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+
+    if rank == 0:
+        value = BATCH_PER_GPU * world * args.steps / elapsed
+        out = {
+            "metric": "images/sec train_hallucidet (640x512, batch 8/GPU)",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
+                                   "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300, loss scaling, "
+                                   "value clip 0.5, Adam", "global_batch": BATCH_PER_GPU * world, "image": "1x512x640 IR + 3x512x640 RGB",
+                       "parallelism": "dp%d" % world, "alg_gflop_per_image": 428.5,
+                       "step_alg_tflops": round(428.5e9 * value / 1e12, 1)},
+            "final_loss": round(float(loss), 5),
+        }
+        if not args.no_roofline:
+            out["roofline"] = conv_roofline(lit, batch)
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.step import time_cpu_step
+            cb = synthetic.make_batch(2, H, W, seed=123, device="cpu")
+            v, steps, cores = time_cpu_step(cb, budget_s=25.0, max_steps=2)
+            out["cpu_baseline"] = {"value": round(v, 4), "unit": "images/s", "cores": cores, "kind": "port",
+                                   "sample": "%d full training step(s) of the CPU oracle (oracle/step.py, fp32 torch) on a batch of 2 "
+                                             "synthetic 512x640 images" % steps}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

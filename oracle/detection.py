@@ -526,11 +526,12 @@ def roi_align_autograd(feat, rois, P, scale, sr):
 
     yl, yh, ly, hy, vy = prep(y, H)
     xl, xh, lx, hx, vx = prep(x, W)
-    f = feat[n]  # [R,C,H,W]
+    flat = feat.permute(0, 2, 3, 1).reshape(N * H * W, C)          # gather rows instead of materialising feat[n]
+    base = (n * (H * W))[:, None, None]
 
     def gather(yi, xi):
-        idx = (yi[:, :, None] * W + xi[:, None, :]).reshape(R, 1, -1).expand(-1, C, -1)
-        return f.reshape(R, C, H * W).gather(2, idx).reshape(R, C, P * sr, P * sr)
+        idx = base + yi[:, :, None] * W + xi[:, None, :]              # [R, P*sr, P*sr]
+        return flat[idx.reshape(-1)].reshape(R, P * sr, P * sr, C).permute(0, 3, 1, 2)
 
     w1 = (hy[:, :, None] * hx[:, None, :])[:, None]
     w2 = (hy[:, :, None] * lx[:, None, :])[:, None]

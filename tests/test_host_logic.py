@@ -1,0 +1,124 @@
+"""CPU tests of host-side logic that needs no GPU: module surface / checkpoint keys, Utils helpers, Config defaults pinned to
+the reference fixture, synthetic workload, error behaviour of the operator API."""
+import json
+import os
+
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_encoder_decoder_factory_surface():
+    from hallucidet_amd.models.encoder_decoder import EncoderDecoder
+    from oracle import unet as ou
+    m = EncoderDecoder(name="resnet34", encoder_weights=None, in_channels=3, output_channels=3).encoder_decoder
+    assert isinstance(m.segmentation_head[-1], torch.nn.Sigmoid)
+    assert list(m.state_dict().keys()) == list(ou.Unet().state_dict().keys())
+    assert sum(p.numel() for p in m.parameters()) == 24436659
+    with pytest.raises(RuntimeError, match="Wrong input shape height=500, width=640"):
+        m(torch.zeros(1, 3, 500, 640))
+    with pytest.raises(NotImplementedError):
+        EncoderDecoder(segmentation_head="relu_bn")
+
+
+def test_decoder_init_matches_reference_checksums():
+    """Product module initialisation follows the reference rules (same RNG consumption order as smp.Unet's decoder/head)."""
+    rec = json.load(open(os.path.join(G, "init_checksums.json")))
+    from hallucidet_amd.segmentation_models import unet as pu
+    torch.manual_seed(123)
+    dec = pu.UnetDecoder((3, 64, 64, 128, 256, 512), (256, 128, 64, 32, 16))
+    head = pu.SegmentationHead(16, 3)
+    pu.initialize_decoder(dec)
+    pu.initialize_head(head)
+    for prefix, m in (("decoder.", dec), ("segmentation_head.", head)):
+        for k, v in m.state_dict().items():
+            r = rec[prefix + k]
+            assert abs(float(v.double().sum()) - r["sum"]) < 1e-9 and abs(float(v.double().abs().sum()) - r["abssum"]) < 1e-9, k
+
+
+def test_detector_factory_surface_and_keys():
+    from hallucidet_amd.models.detector import Detector
+    from oracle import detection as od
+    d = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector
+    assert list(d.state_dict().keys()) == list(od.FasterRCNN(2).state_dict().keys())
+    assert sum(p.numel() for p in d.parameters()) == 41299161
+    assert d.roi_heads.box_predictor.cls_score.out_features == 2 and d.roi_heads.box_predictor.bbox_pred.out_features == 8
+    assert d.transform.fixed_size == (300, 300) and not d.roi_heads.has_keypoint() and d.roi_heads.keypoint_roi_pool is None
+    for attr in ("filter_proposals", "assign_targets_to_anchors", "compute_loss", "anchor_generator", "box_coder", "head"):
+        assert hasattr(d.rpn, attr)
+    for attr in ("select_training_samples", "box_roi_pool", "box_head", "box_predictor", "postprocess_detections"):
+        assert hasattr(d.roi_heads, attr)
+    with pytest.raises(NotImplementedError):
+        Detector(name="retinanet", pretrained=False)
+    # torchvision >= 0.13 key names are accepted
+    sd = d.state_dict()
+    sd2 = {k.replace("fpn.inner_blocks.0.", "fpn.inner_blocks.0.0.").replace("rpn.head.conv.", "rpn.head.conv.0.0."): v for k, v in sd.items()}
+    d.load_state_dict(sd2)
+
+
+def test_calculate_loss_rejects_cpu_and_bad_targets():
+    from hallucidet_amd.models.detector import Detector
+    d = Detector(name="fasterrcnn", pretrained=False).detector
+    imgs = torch.rand(1, 3, 64, 64)
+    with pytest.raises(AssertionError, match="Expected target boxes to be a tensor of shape"):
+        Detector.calculate_loss(d, imgs, [{"boxes": torch.zeros(3), "labels": torch.ones(1, dtype=torch.int64)}])
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        Detector.calculate_loss(d, imgs, [{"boxes": torch.tensor([[1.0, 1.0, 9.0, 9.0]]), "labels": torch.ones(1, dtype=torch.int64)}])
+    with pytest.raises(NotImplementedError):
+        Detector.calculate_loss(d, imgs, [], train_det=True)
+    with pytest.raises(ValueError):
+        Detector.calculate_loss(d, imgs, [], model_name="yolo")
+
+
+def test_config_defaults_match_reference_fixture():
+    from hallucidet_amd.config import Config
+    rec = json.load(open(os.path.join(G, "config_defaults.json")))
+    assert Config.Losses.hparams_losses_weights == rec["loss_weights"]
+    assert Config.Optimizer.name == rec["optimizer_name"] and Config.Environment.N_GPUS == rec["n_gpus"]
+    assert Config.EncoderDecoder.decoder_head == rec["decoder_head"] and Config.Optimizer.gradient_clip_val == 0.5
+
+
+def test_utils_helpers():
+    from hallucidet_amd.utils.utils import Utils
+    imgs = tuple(torch.rand(1, 4, 6) for _ in range(3))
+    b = Utils.batch_images_for_encoder_decoder(imgs)
+    assert b.shape == (3, 1, 4, 6)
+    assert Utils.expand_one_channel_to_output_channels(b, 3).shape == (3, 3, 4, 6)
+    t = Utils.batch_targets_for_detector([{"boxes": torch.zeros(2, 4, dtype=torch.float64), "labels": torch.ones(2, dtype=torch.int64), "name": "x"}])
+    assert t[0]["boxes"].dtype == torch.float64 and t[0]["name"] == "x"
+    tf = Utils.list_targets([{"boxes": torch.zeros(2, 4, dtype=torch.float64)}], detector_name="fcos")
+    assert tf[0]["boxes"].dtype == torch.float32
+    x = torch.rand(2, 3, 5, 5) * 7 + 1
+    x[0, 1] = 2.0
+    y = Utils.normalize_batch_images(x.clone())
+    assert float(y[0, 0].min()) == 0.0 and abs(float(y[0, 0].max()) - 1.0) < 1e-6 and float(y[0, 1].abs().max()) == 0.0
+    ref = x.clone()
+    for i in range(2):      # the reference's per-image/per-channel loop (utils.py:237-254)
+        for c in range(3):
+            lo, hi = ref[i, c].min(), ref[i, c].max()
+            ref[i, c] = (ref[i, c] - lo) / (hi - lo) if hi - lo != 0 else 0.0
+    assert torch.allclose(y, ref)
+    assert Utils.filter_dictionary({"map": 1, "map_50": 2, "x": 3}, ["map", "map_50"]) == {"map": 1, "map_50": 2}
+
+
+def test_synthetic_batch_is_deterministic_and_valid():
+    from hallucidet_amd import synthetic
+    a = synthetic.make_batch(3, 64, 96, seed=5)
+    b = synthetic.make_batch(3, 64, 96, seed=5)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[2], b[2])
+    assert a[2].shape == (3, 1, 64, 96) and a[0].shape == (3, 3, 64, 96)
+    for t in a[1]:
+        bx = t["boxes"]
+        assert 1 <= bx.shape[0] <= 8 and (bx[:, 2] > bx[:, 0]).all() and (bx[:, 3] > bx[:, 1]).all() and t["labels"].dtype == torch.int64
+
+
+def test_oracle_train_step_runs_and_learns_direction():
+    """Tiny CPU step of the oracle trainer (the cpu_baseline leg of bench.py): losses finite, parameters move."""
+    from hallucidet_amd import synthetic
+    from oracle.step import OracleTrainer
+    tr = OracleTrainer(seed=1)
+    before = tr.unet.segmentation_head[0].weight.clone()
+    total, losses = tr.train_step(synthetic.make_batch(1, 64, 96, seed=2))
+    assert torch.isfinite(total) and set(losses) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"}
+    assert not torch.equal(before, tr.unet.segmentation_head[0].weight)
