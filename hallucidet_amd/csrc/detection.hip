@@ -301,7 +301,32 @@ __global__ void box_iou_kernel(const float* __restrict__ gt, int G, const float*
   }
 }
 
+// batched: iou[n][g][a] = IoU(gt[n][g], boxes[n][a]); boxes_stride = 0 shares one box set (anchors) between images
+__global__ void box_iou_batched_kernel(const float* __restrict__ gt, int G, const float* __restrict__ boxes, int A, int N,
+                                       long boxes_stride, float* __restrict__ iou) {
+  const int64_t total = (int64_t)N * G * A;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int a = (int)(i % A);
+    int64_t q = i / A;
+    int g = (int)(q % G);
+    int n = (int)(q / G);
+    iou[i] = box_iou_dev(gt + ((size_t)n * G + g) * 4, boxes + (size_t)n * boxes_stride + (size_t)a * 4);
+  }
+}
+
 }  // namespace
+
+extern "C" int hd_box_iou_batched(const float* gt, int G, const float* boxes, int A, int N, int shared_boxes, float* iou, void* stream) {
+  HD_CHECK_ARG(gt && boxes && iou && G >= 0 && A >= 0 && N >= 0, "hd_box_iou_batched: bad args");
+  if (G == 0 || A == 0 || N == 0) return HD_OK;
+  int64_t total = (int64_t)N * G * A;
+  int g = (int)((total + 255) / 256);
+  if (g > 8192) g = 8192;
+  hipLaunchKernelGGL(box_iou_batched_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, gt, G, boxes, A, N,
+                     shared_boxes ? 0l : (long)A * 4, iou);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
 
 extern "C" int hd_nms_sorted_batched(const float* boxes, const int* counts, int B, int nmax, float iou_thr, uint64_t* mask_ws,
                                      uint8_t* keep, void* stream) {

@@ -395,6 +395,17 @@ def box_iou(gt, boxes):
     return iou
 
 
+def box_iou_batched(gt, boxes):
+    """gt [N,G,4]; boxes [A,4] (shared) or [N,A,4].  Returns [N,G,A] fp32."""
+    N, G, _ = gt.shape
+    shared = boxes.dim() == 2
+    A = boxes.shape[-2]
+    iou = torch.empty((N, G, A), dtype=torch.float32, device=gt.device)
+    check(_abi.load().hd_box_iou_batched(ptr(gt.contiguous()), G, ptr(boxes.contiguous()), A, N, 1 if shared else 0, ptr(iou),
+                                         _stream()), "hd_box_iou_batched")
+    return iou
+
+
 def adam_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, clip_value, inv_scale, step, found_inf=None):
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step

@@ -75,8 +75,11 @@ def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name
             d_k = [d[lo:hi] for d in deltas]
             il_k = _ImageSlice(il, lo, hi)
             t_k = flat_targets[lo:hi]
-            proposals, proposal_losses = rpn_eval(model, il_k, f_k, t_k, head_out=(o_k, d_k))
-            detections, detector_losses = roi_heads_eval(model, f_k, proposals, il_k.image_sizes, t_k)
+            if getattr(model, "batched_heads", False):
+                proposal_losses, detector_losses, detections = _heads_batched(model, il_k, f_k, o_k, d_k, t_k)
+            else:
+                proposals, proposal_losses = rpn_eval(model, il_k, f_k, t_k, head_out=(o_k, d_k))
+                detections, detector_losses = roi_heads_eval(model, f_k, proposals, il_k.image_sizes, t_k)
             detections = model.transform.postprocess(detections, il_k.image_sizes, sizes[k])
         losses = {}
         losses.update(detector_losses)
@@ -125,14 +128,50 @@ def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name=
     if isinstance(features, torch.Tensor):
         features = OrderedDict([("0", features)])
 
-    proposals, proposal_losses = rpn_eval(model, images, features, targets)
-    detections, detector_losses = roi_heads_eval(model, features, proposals, images.image_sizes, targets)
+    if getattr(model, "batched_heads", False):
+        objectness, deltas = model.rpn.head(list(features.values()))
+        proposal_losses, detector_losses, detections = _heads_batched(model, images, features, objectness, deltas, targets)
+    else:
+        proposals, proposal_losses = rpn_eval(model, images, features, targets)
+        detections, detector_losses = roi_heads_eval(model, features, proposals, images.image_sizes, targets)
     detections = model.transform.postprocess(detections, images.image_sizes, original_image_sizes)
 
     losses = {}
     losses.update(detector_losses)
     losses.update(proposal_losses)
     return losses, detections
+
+
+def _heads_batched(model, images, features, objectness, deltas, targets):
+    """rpn_eval + roi_heads_eval with the per-image torchvision loops in padded, batched form
+    (hallucidet_amd.models.detection: same arithmetic, same sampler call order -- asserted equal by the tests)."""
+    from ..models import detection as D
+    feats = list(features.values())
+    anchors = model.rpn.anchor_generator(images, feats)
+    n_img = len(anchors)
+    napl = [o[0].shape[0] * o[0].shape[1] * o[0].shape[2] for o in objectness]
+    obj, dl = concat_box_prediction_layers(objectness, deltas)
+    proposals = model.rpn.box_coder.decode(dl.detach(), anchors).view(n_img, -1, 4)
+    shape = images.image_sizes[0]
+    pb, _, pc = D.filter_proposals_padded(model.rpn, proposals, obj, shape, napl)
+    if targets is None:
+        raise ValueError("targets should not be None")
+    for t in targets:
+        if not t["boxes"].dtype in (torch.float, torch.double, torch.half):
+            raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
+        if not t["labels"].dtype == torch.int64:
+            raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
+    gt, glab, gvalid = D.pad_targets(targets, obj.device)
+    loss_objectness, loss_rpn_box_reg = D.rpn_targets_loss_batched(model.rpn, anchors[0], gt, gvalid, obj, dl)
+    rois, labels, reg_t, per = D.select_training_samples_batched(model.roi_heads, pb, pc, gt, glab, gvalid)
+    box_features = D.roi_pool_rois(model.roi_heads.box_roi_pool, features, rois, shape)
+    box_features = model.roi_heads.box_head(box_features)
+    class_logits, box_regression = model.roi_heads.box_predictor(box_features)
+    loss_classifier, loss_box_reg = D.fastrcnn_loss_flat(class_logits, box_regression, labels, reg_t)
+    b, s, l = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
+    dets = [{"boxes": b[i], "labels": l[i], "scores": s[i]} for i in range(len(b))]
+    return ({"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg},
+            {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg}, dets)
 
 
 def rpn_eval(model, images, features, targets, head_out=None):

@@ -204,6 +204,8 @@ int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int 
                      int PW, float spatial_scale, int sampling_ratio, void* stream);
 /* pairwise IoU [G][A] fp32 (torchvision.ops.box_iou [EXT]) */
 int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream);
+/* iou[n][g][a] for N images; shared_boxes != 0: one [A][4] box set (anchors) for every image, else boxes is [N][A][4] */
+int hd_box_iou_batched(const float* gt, int G, const float* boxes, int A, int N, int shared_boxes, float* iou, void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer: unscale + clip_grad_value_ + Adam in one pass over a flat buffer

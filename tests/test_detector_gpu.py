@@ -348,3 +348,33 @@ def test_batched_three_pass_equals_three_single_passes(dev, case):
     # RoIAlign backward accumulates with fp32 atomics (order varies run to run) before the fp16 trunk gradient
     cos = float(torch.nn.functional.cosine_similarity(x0.grad.flatten(), x1.grad.flatten(), dim=0))
     assert cos > 0.9999 and float((x0.grad - x1.grad).norm() / x0.grad.norm()) < 1e-2
+
+
+def test_batched_heads_equal_list_heads(dev, case):
+    """The padded/batched forms of filter_proposals / target assignment / sampling / losses / post-processing give the
+    same proposals, samples, detections (bit-identical) and losses (fp32 summation order only) as the torchvision-style
+    per-image list code, with the sampler permutations replayed."""
+    from hallucidet_amd.models.detector import Detector
+    det, oracle, images, targets = case
+    tg = _t2d(targets, dev)
+    # a third image without any box exercises the GT-less branches
+    imgs3 = torch.cat([images, images[:1] * 0.7], 0).to(dev)
+    tg3 = tg + [{"boxes": torch.zeros((0, 4), device=dev), "labels": torch.zeros((0,), dtype=torch.int64, device=dev)}]
+    perms = Perms(55)
+    det.rpn.fg_bg_sampler.randperm_fn = perms
+    det.roi_heads.fg_bg_sampler.randperm_fn = perms
+    try:
+        det.batched_heads = False
+        l0, d0 = Detector.calculate_loss(det, imgs3, tg3, model_name="fasterrcnn")
+        perms.replay, perms.i = perms.log, 0
+        det.batched_heads = True
+        l1, d1 = Detector.calculate_loss(det, imgs3, tg3, model_name="fasterrcnn")
+    finally:
+        det.batched_heads = True
+        det.rpn.fg_bg_sampler.randperm_fn = None
+        det.roi_heads.fg_bg_sampler.randperm_fn = None
+    assert perms.i == len(perms.log) == 12
+    for k in l0:
+        assert torch.allclose(l0[k], l1[k], rtol=2e-5, atol=1e-6), (k, float(l0[k]), float(l1[k]))
+    for a, b in zip(d0, d1):
+        assert torch.equal(a["labels"], b["labels"]) and torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["scores"], b["scores"])
