@@ -81,14 +81,24 @@ __global__ void nms_reduce_kernel(const uint64_t* __restrict__ mask, const int* 
       }
     }
     if (i < n) kb[i] = (uint8_t)((keepbits >> lane) & 1ull);
-    // OR the rows of every kept box of this chunk into the removed words (beyond this chunk)
-    for (int j = 0; j < lim; ++j) {
-      if (!((keepbits >> j) & 1ull)) continue;
-      const uint64_t* row = mb + (size_t)(c * 64 + j) * cb;
+    // OR the rows of every kept box of this chunk into the removed words (beyond this chunk).  Rows are fetched 16 at
+    // a time, unconditionally (a row of a suppressed box is simply not OR-ed): 16 independent loads in flight instead of
+    // one dependent load per kept box.
+    for (int jb = 0; jb < lim; jb += 16) {
 #pragma unroll
       for (int k = 0; k < MAXW; ++k) {
-        int w = k * 64 + lane;
-        if (w > c && w < nchunks) remv[k] |= row[w];
+        const int w = k * 64 + lane;
+        if (k * 64 >= nchunks) break;            // uniform
+        const bool act = (w > c && w < nchunks);
+        uint64_t rws[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int j = min(jb + u, lim - 1);
+          rws[u] = act ? mb[(size_t)(c * 64 + j) * cb + w] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (jb + u < lim && ((keepbits >> (jb + u)) & 1ull)) remv[k] |= rws[u];
       }
     }
   }

@@ -185,19 +185,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab, int Cout,
                                     int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
-  // one thread per OIHW element
+  // one thread per slab element (co, kk = t*Cin + ci): coalesced slab reads (the bulk of the traffic: nsplit x |W|),
+  // strided OIHW writes (|W| once)
   const int taps = KH * KW;
-  const int64_t total = (int64_t)Cout * Cin_real * taps;
   const int64_t Ktot = (int64_t)taps * Cin;
+  const int64_t total = (int64_t)Cout * Ktot;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int t = (int)(i % taps);
-    int ci = (int)((i / taps) % Cin_real);
-    int co = (int)(i / ((int64_t)taps * Cin_real));
-    const float* s = slab + (size_t)co * Ktot + (size_t)t * Cin + ci;
+    const int co = (int)(i / Ktot);
+    const int kk = (int)(i - (int64_t)co * Ktot);
+    const int t = kk / Cin;
+    const int ci = kk - t * Cin;
+    if (ci >= Cin_real) continue;
+    const float* s = slab + i;
     float acc = 0.f;
     for (int k = 0; k < nsplit; ++k) acc += s[(size_t)k * Cout_slab * Ktot];
     acc *= scale;
-    dw[i] = accumulate ? dw[i] + acc : acc;
+    const size_t o = ((size_t)co * Cin_real + ci) * taps + t;
+    dw[o] = accumulate ? dw[o] + acc : acc;
   }
 }
 
@@ -268,9 +272,9 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
 extern "C" int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW, int Cin,
                                int Cin_real, float scale, int accumulate, void* stream) {
   HD_CHECK_ARG(slab && dw_oihw && nsplit >= 1 && Cout <= Cout_slab && Cin_real <= Cin, "hd_wgrad_reduce: bad args");
-  int64_t total = (int64_t)Cout * Cin_real * KH * KW;
+  int64_t total = (int64_t)Cout * Cin * KH * KW;
   int g = (int)((total + 255) / 256);
-  if (g > 4096) g = 4096;
+  if (g > 8192) g = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin,
                      Cin_real, scale, accumulate);
   HD_CHECK_LAUNCH();

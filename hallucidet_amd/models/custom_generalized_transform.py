@@ -38,15 +38,39 @@ class _ResizeFn(torch.autograd.Function):
         return ops.nchw_to_nhwc_resize_bwd(dy.contiguous(), N, C, H, W, 1.0), None, None
 
 
+_RATIO_CACHE = {}
+
+
+def _ratios(original_size, new_size):
+    """(ratio_height, ratio_width) exactly as the reference computes them -- fp32(new) / fp32(orig) (:326-330) -- but as
+    cached python floats: the reference builds two 0-dim device tensors per image per call (a blocking host->device copy
+    each; 15 ms of host time per training step at batch 8)."""
+    key = (int(original_size[0]), int(original_size[1]), int(new_size[0]), int(new_size[1]))
+    r = _RATIO_CACHE.get(key)
+    if r is None:
+        r = tuple(float(torch.tensor(s, dtype=torch.float32) / torch.tensor(o, dtype=torch.float32))
+                  for s, o in zip(key[2:], key[:2]))
+        _RATIO_CACHE[key] = r
+    return r
+
+
 def resize_boxes(boxes: Tensor, original_size: List[int], new_size: List[int]) -> Tensor:
-    """:325-338 -- ratios are fp32 0-dim tensors, so float64 boxes stay float64."""
-    ratios = [
-        torch.tensor(s, dtype=torch.float32, device=boxes.device) / torch.tensor(s_orig, dtype=torch.float32, device=boxes.device)
-        for s, s_orig in zip(new_size, original_size)
-    ]
-    ratio_height, ratio_width = ratios
+    """:325-338.  A python scalar holding the fp32 ratio multiplies fp32 boxes in fp32 and float64 boxes in float64 --
+    the same values the reference's 0-dim fp32 tensor gives (float64 boxes stay float64)."""
+    ratio_height, ratio_width = _ratios(original_size, new_size)
     xmin, ymin, xmax, ymax = boxes.unbind(1)
     return torch.stack((xmin * ratio_width, ymin * ratio_height, xmax * ratio_width, ymax * ratio_height), dim=1)
+
+
+def resize_boxes_many(box_list, original_size, new_size):
+    """resize_boxes over a list of per-image tensors that share sizes: one scaling, then views."""
+    if len(box_list) == 0:
+        return []
+    if len({b.dtype for b in box_list}) != 1:
+        return [resize_boxes(b, original_size, new_size) for b in box_list]
+    n = [int(b.shape[0]) for b in box_list]
+    out = resize_boxes(torch.cat([b.reshape(-1, 4) for b in box_list], dim=0), original_size, new_size)
+    return list(out.split(n, 0))
 
 
 class CustomGeneralizedRCNNTransform(nn.Module):
@@ -85,13 +109,17 @@ class CustomGeneralizedRCNNTransform(nn.Module):
         Wo, Ho = self.fixed_size[0], self.fixed_size[1]           # size = [fixed_size[1], fixed_size[0]] (:65-66)
         y = _ResizeFn.apply(x, Ho, Wo)
         if targets is not None:
-            for i in range(len(imgs)):
-                targets[i]["boxes"] = resize_boxes(targets[i]["boxes"], (h, w), (Ho, Wo))
+            for t, b in zip(targets, resize_boxes_many([t["boxes"] for t in targets], (h, w), (Ho, Wo))):
+                t["boxes"] = b
         image_sizes = [(Ho, Wo) for _ in imgs]
         return ImageList(y, image_sizes), targets
 
     def postprocess(self, result, image_shapes, original_image_sizes):
         if self.training:
+            return result
+        if len(set(map(tuple, image_shapes))) == 1 and len(set(map(tuple, original_image_sizes))) == 1 and len(result):
+            for r, b in zip(result, resize_boxes_many([p["boxes"] for p in result], image_shapes[0], original_image_sizes[0])):
+                r["boxes"] = b
             return result
         for i, (pred, im_s, o_im_s) in enumerate(zip(result, image_shapes, original_image_sizes)):
             result[i]["boxes"] = resize_boxes(pred["boxes"], im_s, o_im_s)

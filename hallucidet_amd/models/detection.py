@@ -964,7 +964,8 @@ def pad_targets(targets, device):
     if gt.shape[1] < G:
         gt = F.pad(gt, (0, 0, 0, G - gt.shape[1]))
         lb = F.pad(lb, (0, G - lb.shape[1]))
-    valid = torch.arange(G, device=device)[None, :] < torch.tensor(lens, device=device)[:, None]
+    # real boxes are non-degenerate (checked upstream: x2 > x1), padding rows are all-zero: no host->device traffic
+    valid = gt[:, :, 2] > gt[:, :, 0]
     return gt, lb, valid
 
 
@@ -1013,8 +1014,9 @@ def _compact(mask_flat, total):
     return torch.sort((~mask_flat).to(torch.uint8), stable=True)[1][:total]
 
 
-def rpn_targets_loss_batched(rpn, anchors0, gt, gvalid, objectness, deltas):
-    """assign_targets_to_anchors + box_coder.encode + compute_loss for N images sharing one anchor set."""
+def rpn_targets_loss_batched(rpn, anchors0, gt, gvalid, objectness, deltas, n_loss=None):
+    """assign_targets_to_anchors + box_coder.encode + compute_loss for N images sharing one anchor set.
+    `n_loss`: the losses are taken over the first n_loss images only (the sampler still draws for all N, in order)."""
     N, A = gvalid.shape[0], anchors0.shape[0]
     iou = ops.box_iou_batched(gt, anchors0)
     m = _match_batched(iou, gvalid, rpn.proposal_matcher.high_threshold, rpn.proposal_matcher.low_threshold, True)
@@ -1025,6 +1027,10 @@ def rpn_targets_loss_batched(rpn, anchors0, gt, gvalid, objectness, deltas):
     labels = torch.where(has_gt[:, None], labels, torch.zeros_like(labels))
     matched = torch.gather(gt, 1, m.clamp(min=0)[:, :, None].expand(-1, -1, 4))
     pos_sel, neg_sel, picked = _sample_batched(rpn.fg_bg_sampler, labels)
+    if n_loss is not None and n_loss < N:
+        keep_img = (torch.arange(N, device=labels.device) < n_loss)[:, None]
+        pos_sel, neg_sel = pos_sel & keep_img, neg_sel & keep_img
+        picked = picked[:n_loss]
     n_sampled = sum(a + b for a, b in picked)
     pos_f = pos_sel.reshape(-1)
     samp_f = pos_f | neg_sel.reshape(-1)
@@ -1127,8 +1133,9 @@ def postprocess_detections_flat(rh, class_logits, box_regression, rois, per, ima
     pred_boxes = rh.box_coder.decode_single(box_regression.detach(), rois[:, 1:]).reshape(rois.shape[0], -1, 4)
     pred_scores = F.softmax(class_logits.detach(), -1)
     img = rois[:, 0].to(torch.int64)
-    offs = torch.tensor([0] + list(torch.tensor(per).cumsum(0)[:-1].tolist()), device=device)
-    slot = img * cap + (torch.arange(rois.shape[0], device=device) - offs[img])
+    # position of every RoI inside its image (RoIs are grouped by image, in order): index minus first index of the image
+    first = torch.cumsum(torch.bincount(img, minlength=n_img), 0) - torch.bincount(img, minlength=n_img)
+    slot = img * cap + (torch.arange(rois.shape[0], device=device) - first[img])
     K = num_classes - 1
     b = clip_boxes_to_image(pred_boxes, image_shape)[:, 1:]              # [R,K,4]
     s = pred_scores[:, 1:]
@@ -1148,5 +1155,46 @@ def postprocess_detections_flat(rh, class_logits, box_regression, rois, per, ima
     sb = torch.gather(sb, 1, front[:, :, None].expand(-1, -1, 4))
     ss = torch.gather(ss, 1, front)
     sl = torch.gather(sl, 1, front)
-    cl = counts.tolist()
-    return [sb[i, :c] for i, c in enumerate(cl)], [ss[i, :c] for i, c in enumerate(cl)], [sl[i, :c] for i, c in enumerate(cl)]
+    return sb, ss, sl, counts
+
+
+class LazyDetections(list):
+    """list[dict(boxes, labels, scores)] whose per-image slicing (one host sync for the detection counts) happens on
+    first access: a training step never reads its detections (train_hallucidet.py:211-215 uses them in validation only),
+    so the step stays free of that synchronisation."""
+
+    def __init__(self, boxes, scores, labels, counts, box_fn=None):
+        super().__init__()
+        self._pad = (boxes, scores, labels, counts, box_fn)
+
+    def _materialize(self):
+        if self._pad is not None:
+            b, s, l, counts, fn = self._pad
+            self._pad = None
+            if fn is not None:
+                b = fn(b)
+            super().extend({"boxes": b[i, :c], "labels": l[i, :c], "scores": s[i, :c]} for i, c in enumerate(counts.tolist()))
+
+    def __getitem__(self, i):
+        self._materialize()
+        return super().__getitem__(i)
+
+    def __iter__(self):
+        self._materialize()
+        return super().__iter__()
+
+    def __len__(self):
+        return int(self._pad[3].shape[0]) if self._pad is not None else super().__len__()
+
+    def __add__(self, other):
+        self._materialize()
+        return list(self) + list(other)
+
+    def split(self, sizes):
+        """Per-pass views of a fused multi-pass result."""
+        b, s, l, counts, fn = self._pad
+        out, lo = [], 0
+        for n in sizes:
+            out.append(LazyDetections(b[lo:lo + n], s[lo:lo + n], l[lo:lo + n], counts[lo:lo + n], fn))
+            lo += n
+        return out

@@ -260,6 +260,12 @@ class UnetRunner:
     # ------------------------------------------------------------------ parameters
     def flatten_parameters(self):
         """Make every parameter (and gradient) a view of one fp32 arena; BN running stats likewise."""
+        if getattr(self, "_flat", None) is not None:
+            # cheap aliasing probe (first / last parameter and gradient still views of the arenas)
+            ps, o = self._params, self._offsets
+            if all(p.data_ptr() == self._flat.data_ptr() + k * 4 and p.grad is not None and p.grad.data_ptr() == self._gflat.data_ptr() + k * 4
+                   for p, k in ((ps[0], o[0]), (ps[-1], o[-1]))):
+                return
         params = [p for p in self.module.parameters()]
         dev = params[0].device
         if getattr(self, "_flat", None) is not None and self._flat.device == dev and all(

@@ -45,6 +45,7 @@ class EncoderDecoderLit(nn.Module):
         self.precision = precision
         self.use_graphs = use_graphs
         self.batch_detector_passes = True
+        self.detector.fused_passes = True    # one head evaluation for the three passes (see eval_forward_fasterrcnn._multi_fused)
         self.scaler = None
         self.optimizer = None
         self.averager = GradientAverager()

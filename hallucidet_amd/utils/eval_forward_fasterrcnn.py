@@ -19,6 +19,17 @@ def _check_targets(targets):
             torch._assert(False, f"Expected target boxes to be of type Tensor, got {type(boxes)}.")
 
 
+def _degenerate_flag(targets):
+    """Device-side flag of the reference's degenerate-box check (:41-53); read at the step's first natural sync."""
+    allb = torch.cat([t["boxes"] for t in targets], dim=0)
+    return (allb[:, 2:] <= allb[:, :2]).any() if allb.numel() else None
+
+
+def _raise_if_degenerate(flag, targets):
+    if flag is not None and bool(flag):
+        _check_degenerate(targets)
+
+
 def _check_degenerate(targets):
     # one fused check (single host sync) instead of one `.any()` per image (reference :41-53)
     allb = torch.cat([t["boxes"] for t in targets], dim=0)
@@ -42,7 +53,7 @@ class _ImageSlice:
         self.layout = il.layout
 
 
-def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name='fasterrcnn'):
+def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name='fasterrcnn', fused=None):
     """The hallucinated / RGB / IR detector passes of one training step (train_hallucidet.py:180,183,186) with ONE
     transform + ResNet-50-FPN + RPN-head evaluation over the concatenated batch (the detector is frozen and in eval
     mode, so every image is independent), followed by the reference's per-pass logic -- proposals, target assignment,
@@ -56,6 +67,9 @@ def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name
     x = torch.cat([b if isinstance(b, torch.Tensor) else torch.stack(list(b)) for b in image_batches], dim=0)
     flat_targets = [t for tl in target_lists for t in tl]
     il, flat_targets = model.transform(x, flat_targets)
+    fused = getattr(model, "fused_passes", False) if fused is None else fused
+    if fused and getattr(model, "batched_heads", False):
+        return _multi_fused(model, il, flat_targets, nb, sizes, image_batches[0].requires_grad)
     _check_degenerate(flat_targets)
     n_active = nb[0] if image_batches[0].requires_grad else 0
     if n_active:
@@ -87,6 +101,57 @@ def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name
         out.append((losses, detections))
         lo = hi
     return out
+
+
+def _multi_fused(model, il, targets, nb, sizes, need_grad):
+    """All passes in ONE head evaluation over the concatenated batch: 2 host syncs per step instead of 9, one third of the
+    launches.  The sampler draws RPN(image 0..N-1) then RoI(image 0..N-1) -- every draw has the reference's distribution,
+    but the interleaving differs from three separate passes (RPN, RoI, RPN, RoI, ...); `fused_passes=False` keeps the
+    reference's interleaving.  Losses are taken over the first pass's images only."""
+    from ..models import detection as D
+    n0 = nb[0]
+    flag = _degenerate_flag(targets)
+    if need_grad:
+        features = model.backbone(il.tensors, n_active=n0)
+        objectness, deltas = model.rpn.head(list(features.values()), n_active=n0)
+    else:
+        with torch.no_grad():
+            features = model.backbone(il.tensors)
+            objectness, deltas = model.rpn.head(list(features.values()))
+    feats = list(features.values())
+    anchors = model.rpn.anchor_generator(il, feats)
+    n_img = len(anchors)
+    napl = [o[0].shape[0] * o[0].shape[1] * o[0].shape[2] for o in objectness]
+    obj, dl = concat_box_prediction_layers(objectness, deltas)
+    proposals = model.rpn.box_coder.decode(dl.detach(), anchors).view(n_img, -1, 4)
+    shape = il.image_sizes[0]
+    for t in targets:
+        if not t["boxes"].dtype in (torch.float, torch.double, torch.half):
+            raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
+        if not t["labels"].dtype == torch.int64:
+            raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
+    gt, glab, gvalid = D.pad_targets(targets, obj.device)
+    pb, _, pc = D.filter_proposals_padded(model.rpn, proposals, obj, shape, napl)
+    loss_objectness, loss_rpn_box_reg = D.rpn_targets_loss_batched(model.rpn, anchors[0], gt, gvalid, obj, dl, n_loss=n0)
+    _raise_if_degenerate(flag, targets)            # the sampler above was the first host sync of the step
+    rois, labels, reg_t, per = D.select_training_samples_batched(model.roi_heads, pb, pc, gt, glab, gvalid)
+    r0 = sum(per[:n0])
+    pool, head, pred = model.roi_heads.box_roi_pool, model.roi_heads.box_head, model.roi_heads.box_predictor
+    bf0 = D.roi_pool_rois(pool, features, rois[:r0], shape)
+    cl0, br0 = pred(head(bf0))
+    with torch.no_grad():                          # the other passes' RoIs: forward only
+        f_ng = OrderedDict((k, v.detach()) for k, v in features.items())
+        cl1, br1 = pred(head(D.roi_pool_rois(pool, f_ng, rois[r0:], shape)))
+    loss_classifier, loss_box_reg = D.fastrcnn_loss_flat(cl0, br0, labels[:r0], reg_t[:r0])
+    class_logits, box_regression = torch.cat([cl0.detach(), cl1]), torch.cat([br0.detach(), br1])
+    sb, ss, sl, counts = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
+    from ..models.custom_generalized_transform import _ratios
+    rh, rw = _ratios(shape, sizes[0][0])
+    scale = torch.tensor([rw, rh, rw, rh], dtype=sb.dtype).to(sb.device, non_blocking=True) if not model.transform.training else None
+    dets = D.LazyDetections(sb, ss, sl, counts, (lambda b: b * scale) if scale is not None else None).split(nb)
+    losses = {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg,
+              "loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
+    return [(losses if k == 0 else {}, d) for k, d in enumerate(dets)]
 
 
 def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name='fasterrcnn'):
@@ -168,8 +233,8 @@ def _heads_batched(model, images, features, objectness, deltas, targets):
     box_features = model.roi_heads.box_head(box_features)
     class_logits, box_regression = model.roi_heads.box_predictor(box_features)
     loss_classifier, loss_box_reg = D.fastrcnn_loss_flat(class_logits, box_regression, labels, reg_t)
-    b, s, l = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
-    dets = [{"boxes": b[i], "labels": l[i], "scores": s[i]} for i in range(len(b))]
+    sb, ss, sl, counts = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
+    dets = [{"boxes": sb[i, :c], "labels": sl[i, :c], "scores": ss[i, :c]} for i, c in enumerate(counts.tolist())]
     return ({"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg},
             {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg}, dets)
 

@@ -378,3 +378,34 @@ def test_batched_heads_equal_list_heads(dev, case):
         assert torch.allclose(l0[k], l1[k], rtol=2e-5, atol=1e-6), (k, float(l0[k]), float(l1[k]))
     for a, b in zip(d0, d1):
         assert torch.equal(a["labels"], b["labels"]) and torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["scores"], b["scores"])
+
+
+def test_fused_multi_pass_matches_sequential_on_everything_but_draw_order(dev, case):
+    """`fused_passes`: one head evaluation over hall+rgb+ir.  With the permutations supplied in the fused draw order
+    (RPN img 0..n, then RoI img 0..n) the losses and detections must equal three sequential passes fed the same
+    permutations per (stage, image)."""
+    from hallucidet_amd.utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn_multi
+    det, oracle, images, targets = case
+    imgs = [images.to(dev), (images * 0.5 + 0.2).to(dev), images.flip(-1).contiguous().to(dev)]
+    tg = _t2d(targets, dev)
+    perms = Perms(77)
+    det.rpn.fg_bg_sampler.randperm_fn = perms
+    det.roi_heads.fg_bg_sampler.randperm_fn = perms
+    try:
+        seq = eval_forward_fasterrcnn_multi(det, imgs, [tg, tg, tg], fused=False)
+        log = perms.log          # order: [RPN p0 (2 imgs x2), RoI p0 (2x2), RPN p1, RoI p1, RPN p2, RoI p2]
+        assert len(log) == 24
+        rpn = log[0:4] + log[8:12] + log[16:20]
+        roi = log[4:8] + log[12:16] + log[20:24]
+        perms.replay, perms.i = rpn + roi, 0
+        fus = eval_forward_fasterrcnn_multi(det, imgs, [tg, tg, tg], fused=True)
+    finally:
+        det.rpn.fg_bg_sampler.randperm_fn = None
+        det.roi_heads.fg_bg_sampler.randperm_fn = None
+    for k in seq[0][0]:
+        assert torch.allclose(seq[0][0][k], fus[0][0][k], rtol=2e-5, atol=1e-6), k
+    for p in range(3):
+        assert len(fus[p][1]) == 2
+        for a, b in zip(seq[p][1], fus[p][1]):
+            assert torch.equal(a["labels"], b["labels"]) and torch.allclose(a["boxes"], b["boxes"], rtol=1e-6, atol=1e-4)
+            assert torch.allclose(a["scores"], b["scores"], rtol=1e-6, atol=1e-7)
