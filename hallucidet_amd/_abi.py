@@ -60,11 +60,12 @@ PROTOTYPES = {
     "hd_wgrad_reduce": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_weight_prep": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_colsum": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
-    "hd_bn_finalize": (C.c_int, [vp, C.c_int, c_d, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),
+    "hd_rowsum": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
+    "hd_bn_finalize": (C.c_int, [vp, C.c_int, C.c_int, c_d, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),
     "hd_bn_eval_scale_shift": (C.c_int, [vp, vp, vp, vp, c_f, C.c_int, vp, vp, vp]),
     "hd_bn_apply": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, C.c_int, vp]),
-    "hd_bn_bwd_reduce": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, c_i64, C.c_int, C.c_int, vp]),
-    "hd_bn_bwd_apply": (C.c_int, [vp] * 11 + [c_f, C.c_int, c_i64, C.c_int, C.c_int, vp]),
+    "hd_bn_bwd_reduce": (C.c_int, [vp] * 8 + [C.c_int, c_i64, C.c_int, C.c_int, vp]),
+    "hd_bn_bwd_apply": (C.c_int, [vp] * 8 + [C.c_int] + [vp] * 4 + [c_f, C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "hd_maxpool3x3s2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_maxpool3x3s2_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_subsample2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),

@@ -33,13 +33,19 @@ __global__ void colsum_stage(const float* __restrict__ in, int rows, int W, floa
 }
 
 // ---------------------------------------------------------------- BN finalize
-__global__ void bn_finalize_kernel(const float* __restrict__ sums, int C, double count, const float* __restrict__ gamma,
+// part [rows][2][C] partial (sum, sumsq) rows are added here (rows <= 128: the conv epilogue slab after one hd_rowsum)
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
                                    float eps, float* mean, float* invstd, float* scale, float* shift) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double m = (double)sums[c] / count;
-  double var = (double)sums[C + c] / count - m * m;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s1 += (double)part[(size_t)r * 2 * C + c];
+    s2 += (double)part[(size_t)r * 2 * C + C + c];
+  }
+  double m = s1 / count;
+  double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
   float is = (float)(1.0 / sqrt(var + (double)eps));
   float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
@@ -65,17 +71,25 @@ __global__ void bn_eval_kernel(const float* gamma, const float* beta, const floa
 }
 
 // ---------------------------------------------------------------- BN apply (+res) (+relu)
+// grid stride is a multiple of C (C = 8 * 2^k <= 2048): a thread always sees the same 8 channels -> coefficients in registers
 __global__ void bn_apply_kernel(const f16* __restrict__ y, const f16* __restrict__ res, const float* __restrict__ scale,
                                 const float* __restrict__ shift, f16* __restrict__ z, int64_t nvec, int C, int relu) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    int c0 = (int)((i * 8) % C);
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)((i0 * 8) % C);
+  float sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    sc[k] = scale[c0 + k];
+    sh[k] = shift[c0 + k];
+  }
+  for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     f16x8 v = ld8(y + i * 8);
     f16x8 r;
     if (res) r = ld8(res + i * 8);
     f16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      float f = (float)v[k] * scale[c0 + k] + shift[c0 + k];
+      float f = (float)v[k] * sc[k] + sh[k];
       if (res) f += (float)r[k];
       if (relu) f = fmaxf(f, 0.f);
       o[k] = (f16)f;
@@ -85,9 +99,12 @@ __global__ void bn_apply_kernel(const f16* __restrict__ y, const f16* __restrict
 }
 
 // ---------------------------------------------------------------- BN backward
+// ReLU mask: from the saved activation z when given (residual units), else recomputed from y exactly as the forward
+// computed it ((f16)(y*scale+shift) > 0) -- one input stream less for every non-residual unit.
 // thread tid = pl*vecs + v ; v = channel vector (8 ch), pl = pixel lane
 __global__ void bn_bwd_reduce_kernel(const f16* __restrict__ dz, const f16* __restrict__ z, const f16* __restrict__ y,
                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                      float* __restrict__ part, int64_t npix, int C, int relu) {
   extern __shared__ float sm[];  // [256][16]
   const int vecs = C / 8;
@@ -95,22 +112,29 @@ __global__ void bn_bwd_reduce_kernel(const f16* __restrict__ dz, const f16* __re
   const int v = threadIdx.x % vecs, pl = threadIdx.x / vecs;
   const int64_t per = (npix + gridDim.x - 1) / gridDim.x;
   const int64_t p0 = (int64_t)blockIdx.x * per, p1 = min(npix, p0 + per);
-  float sg[8], sgx[8], mu[8], is[8];
+  float sg[8], sgx[8], mu[8], is[8], sc[8], sh[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     sg[k] = sgx[k] = 0.f;
     mu[k] = mean[v * 8 + k];
     is[k] = invstd[v * 8 + k];
+    float g = gamma ? gamma[v * 8 + k] : 1.f, b = beta ? beta[v * 8 + k] : 0.f;
+    sc[k] = g * is[k];
+    sh[k] = b - mu[k] * g * is[k];
   }
+  const bool use_z = relu && z != nullptr;
   if (pl < plan) {
     for (int64_t p = p0 + pl; p < p1; p += plan) {
       size_t off = (size_t)p * C + v * 8;
       f16x8 g = ld8(dz + off), yy = ld8(y + off), zz;
-      if (relu) zz = ld8(z + off);
+      if (use_z) zz = ld8(z + off);
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         float gk = (float)g[k];
-        if (relu && !((float)zz[k] > 0.f)) gk = 0.f;
+        if (relu) {
+          bool on = use_z ? ((float)zz[k] > 0.f) : ((float)(f16)((float)yy[k] * sc[k] + sh[k]) > 0.f);
+          if (!on) gk = 0.f;
+        }
         float xh = ((float)yy[k] - mu[k]) * is[k];
         sg[k] += gk;
         sgx[k] += gk * xh;
@@ -123,7 +147,6 @@ __global__ void bn_bwd_reduce_kernel(const f16* __restrict__ dz, const f16* __re
     sm[threadIdx.x * 16 + 8 + k] = sgx[k];
   }
   __syncthreads();
-  // 2*C outputs: index o = which*C + c
   for (int o = threadIdx.x; o < 2 * C; o += TB) {
     int which = o / C, c = o - which * C;
     int vv = c / 8, k = c & 7;
@@ -133,34 +156,59 @@ __global__ void bn_bwd_reduce_kernel(const f16* __restrict__ dz, const f16* __re
   }
 }
 
+// dy = A[c]*g + B[c]*y + D[c]  with  A = gamma*invstd, B = -A*invstd*sum_gx/M, D = -A*sum_g/M - B*mean
 __global__ void bn_bwd_apply_kernel(const f16* __restrict__ dz, const f16* __restrict__ z, const f16* __restrict__ y,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const float* __restrict__ sums, f16* __restrict__ dy,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ part, int rows, f16* __restrict__ dy,
                                     f16* __restrict__ dres, float* dgamma, float* dbeta, float gscale, int accumulate,
                                     int64_t npix, int C, int relu) {
   const float invM = 1.f / (float)npix;
   const int64_t nvec = npix * C / 8;
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      float dg = sums[C + c] * gscale, db = sums[c] * gscale;
+      float sg = 0.f, sgx = 0.f;
+      for (int r = 0; r < rows; ++r) {
+        sg += part[(size_t)r * 2 * C + c];
+        sgx += part[(size_t)r * 2 * C + C + c];
+      }
+      float dg = sgx * gscale, db = sg * gscale;
       if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
       if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
     }
   }
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    int c0 = (int)((i * 8) % C);
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)((i0 * 8) % C);
+  float A[8], B[8], D[8], sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = c0 + k;
+    float sg = 0.f, sgx = 0.f;
+    for (int r = 0; r < rows; ++r) {
+      sg += part[(size_t)r * 2 * C + c];
+      sgx += part[(size_t)r * 2 * C + C + c];
+    }
+    const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, is = invstd[c], mu = mean[c];
+    A[k] = ga * is;
+    B[k] = -A[k] * is * sgx * invM;
+    D[k] = -A[k] * sg * invM - B[k] * mu;
+    sc[k] = ga * is;
+    sh[k] = be - mu * ga * is;
+  }
+  const bool use_z = relu && z != nullptr;
+  for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     f16x8 g = ld8(dz + i * 8), yy = ld8(y + i * 8), zz;
-    if (relu) zz = ld8(z + i * 8);
+    if (use_z) zz = ld8(z + i * 8);
     f16x8 o, gr;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      int c = c0 + k;
       float gk = (float)g[k];
-      if (relu && !((float)zz[k] > 0.f)) gk = 0.f;
-      float xh = ((float)yy[k] - mean[c]) * invstd[c];
-      float ga = gamma ? gamma[c] : 1.f;
-      float d = ga * invstd[c] * (gk - sums[c] * invM - xh * sums[C + c] * invM);
-      o[k] = (f16)d;
+      const float yk = (float)yy[k];
+      if (relu) {
+        bool on = use_z ? ((float)zz[k] > 0.f) : ((float)(f16)(yk * sc[k] + sh[k]) > 0.f);
+        if (!on) gk = 0.f;
+      }
+      o[k] = (f16)(A[k] * gk + B[k] * yk + D[k]);
       gr[k] = (f16)gk;
     }
     st8(dy + i * 8, o);
@@ -570,11 +618,18 @@ extern "C" int hd_colsum(const float* in, int rows, int W, float* out, float* ws
   return HD_OK;
 }
 
-extern "C" int hd_bn_finalize(const float* sums, int C, double count, const float* gamma, const float* beta,
+extern "C" int hd_rowsum(const float* in, int rows, int W, float* out, int out_rows, void* stream) {
+  HD_CHECK_ARG(in && out && rows > 0 && W > 0 && out_rows > 0 && out_rows <= rows, "hd_rowsum: bad args");
+  hipLaunchKernelGGL(colsum_stage, dim3(hd_cdiv(W, 64), out_rows), dim3(256), 0, S_, in, rows, W, out, out_rows);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_bn_finalize(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                               float* scale, float* shift, void* stream) {
-  HD_CHECK_ARG(sums && scale && shift && C > 0 && count > 0, "hd_bn_finalize: bad args");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 64)), dim3(64), 0, S_, sums, C, count, gamma, beta, running_mean,
+  HD_CHECK_ARG(part && rows > 0 && rows <= 128 && scale && shift && C > 0 && count > 0, "hd_bn_finalize: bad args (rows <= 128)");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 64)), dim3(64), 0, S_, part, rows, C, count, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift);
   HD_CHECK_LAUNCH();
   return HD_OK;
@@ -591,29 +646,32 @@ extern "C" int hd_bn_eval_scale_shift(const float* gamma, const float* beta, con
 extern "C" int hd_bn_apply(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C,
                            int relu, void* stream) {
   HD_CHECK_ARG(y && z && scale && shift && n > 0 && C % 8 == 0 && n % 8 == 0, "hd_bn_apply: bad args");
+  HD_CHECK_ARG(pow2(C / 8) && C <= 2048, "hd_bn_apply: C/8 must be a power of two (C=%d)", C);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(n / 8)), dim3(TB), 0, S_, (const f16*)y, (const f16*)res, scale, shift, (f16*)z, n / 8, C, relu);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, float* part,
-                                int rows, int64_t npix, int C, int relu, void* stream) {
+extern "C" int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                                const float* gamma, const float* beta, float* part, int rows, int64_t npix, int C, int relu,
+                                void* stream) {
   HD_CHECK_ARG(dz && y && mean && invstd && part && rows > 0 && npix > 0, "hd_bn_bwd_reduce: bad args");
   HD_CHECK_ARG(C % 8 == 0 && pow2(C / 8) && C / 8 <= TB, "hd_bn_bwd_reduce: C/8 must be a power of two <= 256 (C=%d)", C);
-  HD_CHECK_ARG(!relu || z, "hd_bn_bwd_reduce: relu needs z");
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rows), dim3(TB), TB * 16 * sizeof(float), S_, (const f16*)dz, (const f16*)z,
-                     (const f16*)y, mean, invstd, part, npix, C, relu);
+                     (const f16*)y, mean, invstd, gamma, beta, part, npix, C, relu);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
 extern "C" int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
-                               const float* gamma, const float* sums, void* dy, void* dres, float* dgamma, float* dbeta,
-                               float gscale, int accumulate, int64_t npix, int C, int relu, void* stream) {
-  HD_CHECK_ARG(dz && y && mean && invstd && sums && dy && npix > 0 && C % 8 == 0, "hd_bn_bwd_apply: bad args");
-  HD_CHECK_ARG(!relu || z, "hd_bn_bwd_apply: relu needs z");
+                               const float* gamma, const float* beta, const float* part, int rows, void* dy, void* dres,
+                               float* dgamma, float* dbeta, float gscale, int accumulate, int64_t npix, int C, int relu,
+                               void* stream) {
+  HD_CHECK_ARG(dz && y && mean && invstd && part && rows > 0 && rows <= 64 && dy && npix > 0, "hd_bn_bwd_apply: bad args (rows <= 64)");
+  HD_CHECK_ARG(C % 8 == 0 && pow2(C / 8) && C <= 2048, "hd_bn_bwd_apply: C/8 must be a power of two (C=%d)", C);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C / 8)), dim3(TB), 0, S_, (const f16*)dz, (const f16*)z,
-                     (const f16*)y, mean, invstd, gamma, sums, (f16*)dy, (f16*)dres, dgamma, dbeta, gscale, accumulate, npix, C, relu);
+                     (const f16*)y, mean, invstd, gamma, beta, part, rows, (f16*)dy, (f16*)dres, dgamma, dbeta, gscale, accumulate,
+                     npix, C, relu);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

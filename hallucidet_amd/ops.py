@@ -135,14 +135,30 @@ def colsum(slab2d):
     return out
 
 
-def bn_finalize(sums, count, gamma, beta, running_mean, running_var, momentum, eps):
-    C_ = sums.numel() // 2
-    dev = sums.device
+def rowsum(slab2d, out_rows):
+    """[rows, W] fp32 -> [out_rows, W]: one deterministic reduction stage."""
+    rows, W = slab2d.shape
+    out = torch.empty((out_rows, W), dtype=torch.float32, device=slab2d.device)
+    check(_abi.load().hd_rowsum(ptr(slab2d), rows, W, ptr(out), out_rows, _stream()), "hd_rowsum")
+    return out
+
+
+def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """part: [rows, 2, C] (or [2C]) partial sums from the conv epilogue."""
+    if part.dim() == 3:
+        part = part.reshape(part.shape[0], -1)
+    elif part.dim() == 1:
+        part = part.reshape(1, -1)
+    if part.shape[0] > 4:          # every thread of the finalize kernel re-reads the rows: keep them few
+        part = colsum(part).reshape(1, -1)
+    rows, W = part.shape
+    C_ = W // 2
+    dev = part.device
     mean = torch.empty(C_, dtype=torch.float32, device=dev)
     invstd = torch.empty_like(mean)
     scale = torch.empty_like(mean)
     shift = torch.empty_like(mean)
-    check(_abi.load().hd_bn_finalize(ptr(sums), C_, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+    check(_abi.load().hd_bn_finalize(ptr(part), rows, C_, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
                                      ptr(running_var), momentum, eps, ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                      _stream()), "hd_bn_finalize")
     return mean, invstd, scale, shift
@@ -165,9 +181,10 @@ def bn_apply(y, scale, shift, *, res=None, relu=True, out=None):
     return z
 
 
-def bn_backward(dz, z, y, mean, invstd, gamma, *, relu=True, want_dres=False, gscale=1.0, dgamma=None, dbeta=None,
+def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dres=False, gscale=1.0, dgamma=None, dbeta=None,
                 accumulate=False, rows=None):
-    """Backward of z = relu(bn_train(y) (+res)).  Returns (dy, dres|None, dgamma, dbeta)."""
+    """Backward of z = relu(bn_train(y) (+res)).  `z=None` (no residual): the ReLU mask is recomputed from y.
+    Returns (dy, dres|None, dgamma, dbeta)."""
     _need_cuda(dz, y)
     C_ = y.shape[-1]
     npix = y.numel() // C_
@@ -175,17 +192,18 @@ def bn_backward(dz, z, y, mean, invstd, gamma, *, relu=True, want_dres=False, gs
         rows = int(max(1, min(1024, npix // 64)))
     lib = _abi.load()
     part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
-    check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(part), rows, npix, C_,
+    check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
                                1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
-    sums = colsum(part)
+    if rows > 2:                   # the apply kernel reads the partial rows in every thread: reduce them to one first
+        part = colsum(part).reshape(1, -1)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     if dgamma is None:
         dgamma = torch.empty(C_, dtype=torch.float32, device=y.device)
     if dbeta is None:
         dbeta = torch.empty(C_, dtype=torch.float32, device=y.device)
-    check(lib.hd_bn_bwd_apply(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(sums), ptr(dy),
-                              ptr(dres), ptr(dgamma), ptr(dbeta), gscale, 1 if accumulate else 0, npix, C_,
+    check(lib.hd_bn_bwd_apply(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), part.shape[0],
+                              ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), gscale, 1 if accumulate else 0, npix, C_,
                               1 if relu else 0, _stream()), "hd_bn_bwd_apply")
     return dy, dres, dgamma, dbeta
 

@@ -312,9 +312,8 @@ class UnetRunner:
         wf = W[u.name][0]
         if training:
             y, stats = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1, want_stats=True)
-            sums = ops.colsum(stats.view(stats.shape[0], -1))
             npix = y.numel() // u.cout
-            mean, invstd, scale, shift = ops.bn_finalize(sums, npix, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
+            mean, invstd, scale, shift = ops.bn_finalize(stats, npix, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
                                                          u.bn.momentum, u.bn.eps)
         else:
             y = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1)
@@ -372,7 +371,9 @@ class UnetRunner:
         Returns (dx over the logical conv input or None, dres or None)."""
         r = self.saved["rec"][u.name]
         inv = 1.0 / S
-        dy, dres, _, _ = ops.bn_backward(dz, r["z"], r["y"], r["mean"], r["invstd"], u.bn.weight, relu=u.relu, want_dres=want_dres,
+        # the saved activation is only needed as a ReLU mask when a residual was added; otherwise it is recomputed from y
+        dy, dres, _, _ = ops.bn_backward(dz, r["z"] if r["has_res"] else None, r["y"], r["mean"], r["invstd"], u.bn.weight, u.bn.bias,
+                                         relu=u.relu, want_dres=want_dres,
                                          gscale=inv, dgamma=u.bn.weight.grad, dbeta=u.bn.bias.grad)
         slab = ops.wgrad(r["x"], dy, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"])
         ops.wgrad_reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)

@@ -121,9 +121,12 @@ int hd_weight_prep(const float* w_oihw, const float* out_scale /*[Cout] or NULL*
  * -------------------------------------------------------------------- */
 /* deterministic column sum of a [rows][W] fp32 slab -> out[W]; ws: >= 128*W floats (needed when rows > 32) */
 int hd_colsum(const float* in, int rows, int W, float* out, float* ws, void* stream);
-/* sums[2][C] = (sum x, sum x^2) -> mean/invstd/scale/shift (+ running stats update when running_mean != NULL;
- * unbiased variance for the running estimate, momentum as nn.BatchNorm2d) */
-int hd_bn_finalize(const float* sums, int C, double count, const float* gamma, const float* beta,
+/* one deterministic reduction stage: out[r][W] = sum of the r-th slice of in's rows (out_rows <= rows) */
+int hd_rowsum(const float* in, int rows, int W, float* out, int out_rows, void* stream);
+/* part[rows][2][C] partial (sum x, sum x^2) rows (rows <= 128, summed in-kernel) -> mean/invstd/scale/shift
+ * (+ running stats update when running_mean != NULL; unbiased variance for the running estimate, momentum as
+ * nn.BatchNorm2d) */
+int hd_bn_finalize(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                    float* scale, float* shift, void* stream);
 /* eval mode: scale/shift from running statistics */
@@ -132,12 +135,15 @@ int hd_bn_eval_scale_shift(const float* gamma, const float* beta, const float* r
 /* z = act(y*scale[c] + shift[c] (+ res)) , all f16 NHWC, n = number of elements (multiple of 8) */
 int hd_bn_apply(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C,
                 int relu, void* stream);
-/* backward of z = relu(bn(y) (+ res)):  part[rows][2][C] <- (sum g, sum g*xhat) with g = dz*(z>0) */
-int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, float* part,
-                     int rows, int64_t npix, int C, int relu, void* stream);
-/* dy = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g (optional); also emits dgamma/dbeta (fp32, scaled by gscale) */
+/* backward of z = relu(bn(y) (+ res)):  part[rows][2][C] <- (sum g, sum g*xhat) with g = dz*(z>0).
+ * z == NULL (non-residual unit): the mask is recomputed as (f16)(y*gamma*invstd + beta - mean*gamma*invstd) > 0,
+ * bit-identical to the forward's activation. */
+int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+                     const float* gamma, const float* beta, float* part, int rows, int64_t npix, int C, int relu, void* stream);
+/* dy = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g (optional); also emits dgamma/dbeta (fp32, scaled by gscale).
+ * part[rows][2][C] (rows <= 64) are the partial rows of hd_bn_bwd_reduce (after hd_rowsum), summed in-kernel. */
 int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
-                    const float* gamma, const float* sums /*[2][C] column sums of part*/, void* dy, void* dres,
+                    const float* gamma, const float* beta, const float* part, int rows, void* dy, void* dres,
                     float* dgamma, float* dbeta, float gscale, int accumulate, int64_t npix, int C, int relu, void* stream);
 
 /* ------------------------------------------------------------------------

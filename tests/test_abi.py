@@ -61,6 +61,7 @@ def test_bad_arguments_return_status_codes(lib):
     assert lib.hd_bn_apply(None, None, None, None, None, 0, 8, 1, None) == -1
     assert lib.hd_adam_step(None, None, None, None, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, None, None) == -1
     assert lib.hd_colsum(None, 0, 0, None, None, None) == -1
+    assert lib.hd_rowsum(None, 0, 0, None, 0, None) == -1
 
 
 def test_product_fails_loudly_without_library(monkeypatch, tmp_path):

@@ -170,7 +170,7 @@ def test_bn_train_forward_backward(dev):
     yf = y.float()
     sums = torch.stack([yf.sum(dim=(0, 1, 2)), (yf * yf).sum(dim=(0, 1, 2))]).reshape(1, -1)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-    mean, invstd, scale, shift = ops.bn_finalize(ops.colsum(sums.to(dev)), N * H * W, gamma.to(dev), beta.to(dev), rm, rv, 0.1, eps)
+    mean, invstd, scale, shift = ops.bn_finalize(sums.to(dev).view(1, 2, C), N * H * W, gamma.to(dev), beta.to(dev), rm, rv, 0.1, eps)
     z = ops.bn_apply(y.to(dev), scale, shift, res=res.to(dev), relu=True)
     zw, mw, iw = ok.bn_train_nhwc(y, gamma, beta, eps, res=res, relu=True)
     close(z, zw.half())
@@ -189,7 +189,7 @@ def test_bn_train_forward_backward(dev):
     # use the HIP z for the mask on both sides to avoid ulp-level mask flips
     mask = (z.cpu().float() > 0).float()
     (zz * mask).backward(dz.float())
-    dy, dres, dgamma, dbeta = ops.bn_backward(dz.to(dev), z, y.to(dev), mean, invstd, gamma.to(dev), relu=True, want_dres=True, gscale=1.0)
+    dy, dres, dgamma, dbeta = ops.bn_backward(dz.to(dev), z, y.to(dev), mean, invstd, gamma.to(dev), beta.to(dev), relu=True, want_dres=True, gscale=1.0)
     close(dy, yv.grad.half(), rtol=1e-2, atol=3e-3)
     close(dres, rv_.grad.half())
     assert torch.allclose(dgamma.cpu(), gv.grad, rtol=1e-3, atol=1e-2)
