@@ -1,0 +1,92 @@
+// hd_conv2d entry point: argument checks, tile / K-depth selection, dispatch to the two kernel families
+//   conv_igemm_bk32.hip : 32-deep K tiles (half-line DMA pieces; any Cin % 8 == 0; the 16/32-channel layers)
+//   conv_igemm_bk64.hip : 64-deep K tiles (full 128-byte-line DMA pieces, one barrier per 16 MFMAs; Cin % 64 == 0)
+#include <stdlib.h>
+
+#include "conv_params.h"
+
+namespace {
+
+int pick_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
+// small problems: halve the M tile so that more of the 256 CUs get a block
+int pick_bm(int M, int Cout) {
+  int bn = pick_bn(Cout);
+  int64_t blocks128 = (int64_t)hd_cdiv(M, 128) * hd_cdiv(Cout, bn);
+  return (bn > 32 && blocks128 < 512) ? 64 : 128;
+}
+
+int fill_params(const hd_conv_args* a, ConvP& p) {
+  HD_CHECK_ARG(a && a->x && a->w && a->y, "hd_conv2d: null pointer");
+  HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 >= 0 && a->C2 % 8 == 0, "hd_conv2d: channel counts must be multiples of 8 (C1=%d C2=%d)", a->C1, a->C2);
+  HD_CHECK_ARG((a->C2 == 0) == (a->x2 == nullptr), "hd_conv2d: x2/C2 mismatch");
+  HD_CHECK_ARG(a->N > 0 && a->Ho > 0 && a->Wo > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0 && a->stride > 0, "hd_conv2d: bad extent");
+  HD_CHECK_ARG(!(a->in_dil > 1 && (a->up1 || a->C2)), "hd_conv2d: in_dil excludes up1/x2");
+  HD_CHECK_ARG(a->in_dil <= 2, "hd_conv2d: in_dil must be 1 or 2 (strides on the hot path)");
+  HD_CHECK_ARG(a->C2 == 0 || (a->C1 % 32 == 0 && a->C2 % 32 == 0), "hd_conv2d: dual-source gather needs C1, C2 multiples of 32 (a K tile holds channels of one source)");
+  HD_CHECK_ARG(!a->up1 || (a->Hin == 2 * a->Hsrc && a->Win == 2 * a->Wsrc), "hd_conv2d: up1 needs Hin=2*Hsrc");
+  HD_CHECK_ARG((int64_t)a->N * a->Ho * a->Wo < (1ll << 31), "hd_conv2d: too many pixels");
+  p.x = (const f16*)a->x;
+  p.x2 = (const f16*)a->x2;
+  p.w = (const f16*)a->w;
+  p.bias = a->bias;
+  p.res = (const f16*)a->res;
+  p.mask = (const f16*)a->mask;
+  p.y = a->y;
+  p.stats = a->stats;
+  p.N = a->N; p.Hsrc = a->Hsrc; p.Wsrc = a->Wsrc; p.Hin = a->Hin; p.Win = a->Win;
+  p.C1 = a->C1; p.C2 = a->C2; p.Cin = a->C1 + a->C2;
+  p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW;
+  p.stride = a->stride; p.pad = a->pad; p.up1 = a->up1; p.in_dil = a->in_dil < 1 ? 1 : a->in_dil;
+  p.act = a->act; p.out_mode = a->out_mode;
+  p.M = a->N * a->Ho * a->Wo;
+  p.cin8 = p.Cin / 8;
+  p.nchunks = a->KH * a->KW * p.cin8;
+  p.nk = 0;
+  p.Ktot = a->KH * a->KW * p.Cin;
+  p.inv_cin8 = 1.0f / (float)p.cin8;
+  p.inv_kw = 1.0f / (float)a->KW;
+  int64_t xb = (int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2;
+  int64_t x2b = a->x2 ? (int64_t)a->N * a->Hin * a->Win * a->C2 * 2 : 0;
+  int64_t wb = (int64_t)a->Cout * p.Ktot * 2;
+  HD_CHECK_ARG(xb < 0xFFFFFFF0ll && x2b < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "hd_conv2d: tensor larger than 4 GiB (buffer addressing)");
+  p.xbytes = (unsigned)xb; p.x2bytes = (unsigned)x2b; p.wbytes = (unsigned)wb;
+  return HD_OK;
+}
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+}  // namespace
+
+extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
+  if (!a) return HD_E_ARG;
+  int M = a->N * a->Ho * a->Wo;
+  return hd_cdiv(M, pick_bm(M, a->Cout));
+}
+
+extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
+  ConvP p;
+  int rc = fill_params(a, p);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const int bn = pick_bn(p.Cout);
+  const int bm = pick_bm(p.M, p.Cout);
+  const int64_t blocks = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
+  // experiment knobs (tools/bench_conv.py): HD_CONV_BK in {0 auto, 32, 64}; HD_CONV_DEEP in {-1 auto, 0, 1}
+  static const int force_bk = env_int("HD_CONV_BK", 0);
+  static const int force_deep = env_int("HD_CONV_DEEP", -1);
+  const bool can64 = (p.Cin % 64 == 0) && (p.C2 == 0 || (p.C1 % 64 == 0 && p.C2 % 64 == 0)) && bn > 32;
+  // Measured on the layer mix (tools/bench_conv.py sweep): 64-deep K tiles (full-line DMA pieces, half the barriers) win
+  // wherever the channel count allows them; co-resident blocks matter more than prefetch depth, so the extra LDS stage
+  // is only spent when the grid cannot give a CU a second block anyway.
+  bool use64 = can64;
+  if (force_bk == 32) use64 = false;
+  bool deep = blocks <= 256;
+  if (force_deep >= 0) deep = force_deep != 0;
+  if (use64) hd_conv_launch_bk64(p, bm, bn, deep, s);
+  else hd_conv_launch_bk32(p, bm, bn, deep, s);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}

@@ -22,6 +22,7 @@
 //   * blockIdx is remapped so that the M tiles an XCD works on are contiguous (neighbouring pixel tiles share
 //     their 3x3 halo and all N tiles of one M tile share the gathered pixels in that XCD's L2).
 #include "hd_common.h"
+#include "conv_params.h"
 
 namespace {
 
@@ -29,21 +30,6 @@ constexpr int BK = 32;
 constexpr int LDS_ROW = 32;  // halves per LDS row (64 bytes, unpadded: LDS-DMA writes lane-linearly)
 constexpr unsigned OOB = 0xFFFFFFF0u;
 
-struct ConvP {
-  const f16* x;
-  const f16* x2;
-  const f16* w;
-  const float* bias;
-  const f16* res;
-  const f16* mask;
-  void* y;
-  float* stats;
-  unsigned xbytes, x2bytes, wbytes;
-  int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1, in_dil, act, out_mode;
-  int M, cin8, nchunks, nk, Ktot;
-  int gm, gn;          // grid extent in M / N tiles
-  float inv_cin8, inv_kw;
-};
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -393,64 +379,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   }
 }
 
-int pick_bn(int Cout) { return Cout > 64 ? 128 : (Cout > 32 ? 64 : 32); }
-// small problems: halve the M tile so that more of the 256 CUs get a block
-int pick_bm(int M, int Cout) {
-  int bn = pick_bn(Cout);
-  int64_t blocks128 = (int64_t)hd_cdiv(M, 128) * hd_cdiv(Cout, bn);
-  return (bn > 32 && blocks128 < 512) ? 64 : 128;
-}
 
-int fill_params(const hd_conv_args* a, ConvP& p) {
-  HD_CHECK_ARG(a && a->x && a->w && a->y, "hd_conv2d: null pointer");
-  HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 >= 0 && a->C2 % 8 == 0, "hd_conv2d: channel counts must be multiples of 8 (C1=%d C2=%d)", a->C1, a->C2);
-  HD_CHECK_ARG((a->C2 == 0) == (a->x2 == nullptr), "hd_conv2d: x2/C2 mismatch");
-  HD_CHECK_ARG(a->N > 0 && a->Ho > 0 && a->Wo > 0 && a->Cout > 0 && a->KH > 0 && a->KW > 0 && a->stride > 0, "hd_conv2d: bad extent");
-  HD_CHECK_ARG(!(a->in_dil > 1 && (a->up1 || a->C2)), "hd_conv2d: in_dil excludes up1/x2");
-  HD_CHECK_ARG(a->in_dil <= 2, "hd_conv2d: in_dil must be 1 or 2 (strides on the hot path)");
-  HD_CHECK_ARG(a->C2 == 0 || (a->C1 % 32 == 0 && a->C2 % 32 == 0), "hd_conv2d: dual-source gather needs C1, C2 multiples of 32");
-  HD_CHECK_ARG(!a->up1 || (a->Hin == 2 * a->Hsrc && a->Win == 2 * a->Wsrc), "hd_conv2d: up1 needs Hin=2*Hsrc");
-  HD_CHECK_ARG((int64_t)a->N * a->Ho * a->Wo < (1ll << 31), "hd_conv2d: too many pixels");
-  p.x = (const f16*)a->x;
-  p.x2 = (const f16*)a->x2;
-  p.w = (const f16*)a->w;
-  p.bias = a->bias;
-  p.res = (const f16*)a->res;
-  p.mask = (const f16*)a->mask;
-  p.y = a->y;
-  p.stats = a->stats;
-  p.N = a->N; p.Hsrc = a->Hsrc; p.Wsrc = a->Wsrc; p.Hin = a->Hin; p.Win = a->Win;
-  p.C1 = a->C1; p.C2 = a->C2; p.Cin = a->C1 + a->C2;
-  p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW;
-  p.stride = a->stride; p.pad = a->pad; p.up1 = a->up1; p.in_dil = a->in_dil < 1 ? 1 : a->in_dil;
-  p.act = a->act; p.out_mode = a->out_mode;
-  p.M = a->N * a->Ho * a->Wo;
-  p.cin8 = p.Cin / 8;
-  p.nchunks = a->KH * a->KW * p.cin8;
-  p.nk = (p.nchunks + 3) / 4;
-  p.Ktot = a->KH * a->KW * p.Cin;
-  p.inv_cin8 = 1.0f / (float)p.cin8;
-  p.inv_kw = 1.0f / (float)a->KW;
-  int64_t xb = (int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2;
-  int64_t x2b = a->x2 ? (int64_t)a->N * a->Hin * a->Win * a->C2 * 2 : 0;
-  int64_t wb = (int64_t)a->Cout * p.Ktot * 2;
-  HD_CHECK_ARG(xb < 0xFFFFFFF0ll && x2b < 0xFFFFFFF0ll && wb < 0xFFFFFFF0ll, "hd_conv2d: tensor larger than 4 GiB (buffer addressing)");
-  p.xbytes = (unsigned)xb; p.x2bytes = (unsigned)x2b; p.wbytes = (unsigned)wb;
-  return HD_OK;
-}
+}  // namespace
 
-template <int BM, int BN, int WM, int WN>
-void launch_variant(ConvP& p, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int NS>
+static void launch_variant_bk32(ConvP& p, hipStream_t s) {
   p.gm = hd_cdiv(p.M, BM);
   p.gn = hd_cdiv(p.Cout, BN);
   dim3 grid(p.gm * p.gn);
   const bool dual = p.x2 != nullptr;
-  const bool kgen = (p.cin8 % 4) != 0;
-  // thin layers (BN = 32) are bandwidth / epilogue bound with a handful of K tiles: 2 stages (24 KB LDS, 6 blocks per CU)
-  // beat a deep pipeline; everything else keeps three K tiles in flight
-  constexpr int NS = BN == 32 ? 2 : 4;
+  const bool kgen = (p.cin8 % (32 / 8)) != 0;
   if (dual) {
-    if (kgen) return;  // rejected in fill_params (C1, C2 multiples of 32 => uniform taps)
+    if (kgen) return;
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true, false, NS>), grid, dim3(256), 0, s, p);
   } else {
     if (kgen) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, false, true, NS>), grid, dim3(256), 0, s, p);
@@ -458,29 +398,15 @@ void launch_variant(ConvP& p, hipStream_t s) {
   }
 }
 
-}  // namespace
-
-extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
-  if (!a) return HD_E_ARG;
-  int M = a->N * a->Ho * a->Wo;
-  return hd_cdiv(M, pick_bm(M, a->Cout));
-}
-
-extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
-  ConvP p;
-  int rc = fill_params(a, p);
-  if (rc) return rc;
-  hipStream_t s = (hipStream_t)stream;
-  const int bn = pick_bn(p.Cout);
-  const int bm = pick_bm(p.M, p.Cout);
+// deep = more LDS stages (fewer co-resident blocks, more K in flight)
+void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s) {
+  p.nk = (p.nchunks + 32 / 8 - 1) / (32 / 8);
+  if (bn == 32) { launch_variant_bk32<128, 32, 4, 1, 2>(p, s); return; }
   if (bm == 128) {
-    if (bn == 128) launch_variant<128, 128, 2, 2>(p, s);
-    else if (bn == 64) launch_variant<128, 64, 2, 2>(p, s);
-    else launch_variant<128, 32, 4, 1>(p, s);
+    if (bn == 128) { if (deep) launch_variant_bk32<128, 128, 2, 2, 4>(p, s); else launch_variant_bk32<128, 128, 2, 2, 2>(p, s); }
+    else { if (deep) launch_variant_bk32<128, 64, 2, 2, 4>(p, s); else launch_variant_bk32<128, 64, 2, 2, 2>(p, s); }
   } else {
-    if (bn == 128) launch_variant<64, 128, 2, 2>(p, s);
-    else launch_variant<64, 64, 2, 2>(p, s);
+    if (bn == 128) { if (deep) launch_variant_bk32<64, 128, 2, 2, 4>(p, s); else launch_variant_bk32<64, 128, 2, 2, 2>(p, s); }
+    else { if (deep) launch_variant_bk32<64, 64, 2, 2, 4>(p, s); else launch_variant_bk32<64, 64, 2, 2, 2>(p, s); }
   }
-  HD_CHECK_LAUNCH();
-  return HD_OK;
 }

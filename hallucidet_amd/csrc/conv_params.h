@@ -1,0 +1,22 @@
+// Shared parameter block of the implicit-GEMM convolution kernels (conv_igemm_bk32.hip / conv_igemm_bk64.hip).
+#pragma once
+#include "hd_common.h"
+
+struct ConvP {
+  const f16* x;
+  const f16* x2;
+  const f16* w;
+  const float* bias;
+  const f16* res;
+  const f16* mask;
+  void* y;
+  float* stats;
+  unsigned xbytes, x2bytes, wbytes;
+  int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1, in_dil, act, out_mode;
+  int M, cin8, nchunks, nk, Ktot;
+  int gm, gn;          // grid extent in M / N tiles
+  float inv_cin8, inv_kw;
+};
+
+void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
+void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);

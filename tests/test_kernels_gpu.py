@@ -32,8 +32,8 @@ CONV_CASES = [
     (2, 16, 20, 64, 0, 64, 3, 1, 1, False, 0, False, False),
     (2, 16, 20, 64, 0, 128, 3, 2, 1, False, 1, True, True),
     (1, 13, 11, 32, 0, 16, 3, 1, 1, False, 0, False, False),     # ragged M tail, Cout < 32
-    (2, 8, 10, 32, 32, 32, 3, 1, 1, True, 0, False, False),      # upsample + concat
-    (1, 6, 7, 64, 32, 128, 3, 1, 1, True, 1, False, False),      # upsample + concat, K tiles on both sides of the boundary
+    (2, 8, 10, 64, 64, 32, 3, 1, 1, True, 0, False, False),      # upsample + concat
+    (1, 6, 7, 128, 64, 128, 3, 1, 1, True, 1, False, False),      # upsample + concat, K tiles on both sides of the boundary
     (2, 8, 10, 64, 0, 16, 3, 1, 1, True, 1, False, False),       # upsample only
     (1, 32, 32, 8, 0, 64, 7, 2, 3, False, 0, False, False),      # stem: Cin padded to 8, K tile straddles taps
     (2, 15, 15, 64, 0, 256, 1, 1, 0, False, 1, True, False),     # 1x1
