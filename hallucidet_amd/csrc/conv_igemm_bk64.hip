@@ -50,7 +50,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   constexpr int B_LOADS = BROWS * CPT / 256;             // 4,2,2
   constexpr int STAGE = (BM + BROWS) * LDS_ROW;          // halves per stage
   constexpr int L_TILE = A_LOADS + B_LOADS;              // DMA instructions per wave per K tile
-  __shared__ __attribute__((aligned(1024))) f16 lds[NSTAGE * STAGE];
+  // the epilogue reuses the pipeline stages as an fp32 [BM][BN] tile: size the array for whichever is larger
+  constexpr int LDS_HALVES = (NSTAGE * STAGE > BM * BN * 2) ? NSTAGE * STAGE : BM * BN * 2;
+  __shared__ __attribute__((aligned(1024))) f16 lds[LDS_HALVES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -46,61 +46,68 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __re
   }
 }
 
-// one wavefront per image: lane w owns removed-word w (and w+64, ... for n > 4096)
-__global__ void nms_reduce_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ counts, int nmax,
-                                  uint8_t* __restrict__ keep) {
+// one 256-thread block per image.  Wave 0 resolves each 64-box chunk serially (ALU only); all four waves then OR the
+// mask rows of the kept boxes into the "removed" words -- 16 row loads in flight per wave, every wave a quarter of the
+// rows -- and the partial words are combined through LDS.  n <= 16384.
+__global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ counts, int nmax,
+                                                         uint8_t* __restrict__ keep) {
+  constexpr int MAXW = 4;  // 64*64*4 boxes
+  __shared__ uint64_t remv[MAXW * 64];
+  __shared__ uint64_t part[4][MAXW * 64];
+  __shared__ uint64_t s_keepbits;
   const int b = blockIdx.x;
   const int n = counts[b];
   const int cb = (nmax + 63) / 64;
-  const int lane = threadIdx.x;  // 64
-  constexpr int MAXW = 4;        // supports nmax <= 64*64*4 = 16384
-  uint64_t remv[MAXW];
-#pragma unroll
-  for (int k = 0; k < MAXW; ++k) remv[k] = 0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t* mb = mask + (size_t)b * nmax * cb;
   uint8_t* kb = keep + (size_t)b * nmax;
   const int nchunks = (n + 63) / 64;
+  for (int i = tid; i < MAXW * 64; i += 256) remv[i] = 0;
+  __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
-    // removed word for this chunk lives in lane (c & 63), slot c >> 6
-    uint64_t word = 0;
-#pragma unroll
-    for (int k = 0; k < MAXW; ++k)
-      if ((c >> 6) == k) word = __shfl(remv[k], c & 63);
-    const int i = c * 64 + lane;
-    // diagonal word of my row
-    uint64_t diag = (i < n) ? mb[(size_t)i * cb + c] : 0;
-    // serial resolve inside the chunk (ALU only)
-    uint64_t alive = ~word;
-    int lim = min(64, n - c * 64);
-    uint64_t keepbits = 0;
-    for (int j = 0; j < lim; ++j) {
-      uint64_t dj = __shfl(diag, j);
-      if ((alive >> j) & 1ull) {
-        keepbits |= (1ull << j);
-        alive &= ~dj;
-      }
-    }
-    if (i < n) kb[i] = (uint8_t)((keepbits >> lane) & 1ull);
-    // OR the rows of every kept box of this chunk into the removed words (beyond this chunk).  Rows are fetched 16 at
-    // a time, unconditionally (a row of a suppressed box is simply not OR-ed): 16 independent loads in flight instead of
-    // one dependent load per kept box.
-    for (int jb = 0; jb < lim; jb += 16) {
-#pragma unroll
-      for (int k = 0; k < MAXW; ++k) {
-        const int w = k * 64 + lane;
-        if (k * 64 >= nchunks) break;            // uniform
-        const bool act = (w > c && w < nchunks);
-        uint64_t rws[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int j = min(jb + u, lim - 1);
-          rws[u] = act ? mb[(size_t)(c * 64 + j) * cb + w] : 0ull;
+    const int lim = min(64, n - c * 64);
+    if (wave == 0) {
+      const int i = c * 64 + lane;
+      const uint64_t diag = (i < n) ? mb[(size_t)i * cb + c] : 0;
+      uint64_t alive = ~remv[c];
+      uint64_t keepbits = 0;
+      for (int j = 0; j < lim; ++j) {
+        const uint64_t dj = __shfl(diag, j);
+        if ((alive >> j) & 1ull) {
+          keepbits |= (1ull << j);
+          alive &= ~dj;
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          if (jb + u < lim && ((keepbits >> (jb + u)) & 1ull)) remv[k] |= rws[u];
       }
+      if (i < n) kb[i] = (uint8_t)((keepbits >> lane) & 1ull);
+      if (lane == 0) s_keepbits = keepbits;
     }
+    __syncthreads();
+    const uint64_t keepbits = s_keepbits;
+    // words beyond this chunk: w in (c, nchunks)
+    const int nw = nchunks - (c + 1);
+    if (nw > 0) {
+      for (int wb = 0; wb < nw; wb += 64) {
+        const int w = c + 1 + wb + lane;
+        const bool act = w < nchunks;
+        uint64_t accw = 0;
+        // this wave's quarter of the rows, 16 loads in flight
+        for (int jb = wave * 16; jb < lim; jb += 64) {
+          uint64_t rws[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int j = min(jb + u, lim - 1);
+            rws[u] = act ? mb[(size_t)(c * 64 + j) * cb + w] : 0ull;
+          }
+#pragma unroll
+          for (int u = 0; u < 16; ++u)
+            if (jb + u < lim && ((keepbits >> (jb + u)) & 1ull)) accw |= rws[u];
+        }
+        part[wave][wb + lane] = accw;
+      }
+      __syncthreads();
+      for (int i = tid; i < nw; i += 256) remv[c + 1 + i] |= part[0][i] | part[1][i] | part[2][i] | part[3][i];
+    }
+    __syncthreads();
   }
 }
 
@@ -344,7 +351,7 @@ extern "C" int hd_nms_sorted_batched(const float* boxes, const int* counts, int 
   hipStream_t s = (hipStream_t)stream;
   int cb = (nmax + 63) / 64;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(64), 0, s, boxes, counts, nmax, iou_thr, mask_ws);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, s, (const uint64_t*)mask_ws, counts, nmax, keep);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, (const uint64_t*)mask_ws, counts, nmax, keep);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

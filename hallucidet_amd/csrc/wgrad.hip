@@ -185,23 +185,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab, int Cout,
                                     int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
-  // one thread per slab element (co, kk = t*Cin + ci): coalesced slab reads (the bulk of the traffic: nsplit x |W|),
-  // strided OIHW writes (|W| once)
+  // one thread per 4 consecutive slab elements (co, kk..kk+3; kk = t*Cin + ci, Cin % 8 == 0 so the four share a tap):
+  // 16-byte coalesced slab reads (the bulk of the traffic: nsplit x |W|), four independent accumulators, strided OIHW
+  // writes (|W| once)
   const int taps = KH * KW;
   const int64_t Ktot = (int64_t)taps * Cin;
-  const int64_t total = (int64_t)Cout * Ktot;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t total4 = (int64_t)Cout * Ktot / 4;
+  const size_t sstride = (size_t)Cout_slab * Ktot;
+  for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = i4 * 4;
     const int co = (int)(i / Ktot);
     const int kk = (int)(i - (int64_t)co * Ktot);
     const int t = kk / Cin;
     const int ci = kk - t * Cin;
-    if (ci >= Cin_real) continue;
     const float* s = slab + i;
-    float acc = 0.f;
-    for (int k = 0; k < nsplit; ++k) acc += s[(size_t)k * Cout_slab * Ktot];
-    acc *= scale;
-    const size_t o = ((size_t)co * Cin_real + ci) * taps + t;
-    dw[o] = accumulate ? dw[o] + acc : acc;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= nsplit; k += 4) {
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 0) * sstride);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 1) * sstride);
+      f32x4 a2 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 2) * sstride);
+      f32x4 a3 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 3) * sstride);
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; k < nsplit; ++k) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * sstride);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ci + u >= Cin_real) continue;
+      const size_t o = ((size_t)co * Cin_real + ci + u) * taps + t;
+      const float v = acc[u] * scale;
+      dw[o] = accumulate ? dw[o] + v : v;
+    }
   }
 }
 
@@ -272,7 +286,7 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
 extern "C" int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW, int Cin,
                                int Cin_real, float scale, int accumulate, void* stream) {
   HD_CHECK_ARG(slab && dw_oihw && nsplit >= 1 && Cout <= Cout_slab && Cin_real <= Cin, "hd_wgrad_reduce: bad args");
-  int64_t total = (int64_t)Cout * Cin * KH * KW;
+  int64_t total = (int64_t)Cout * Cin * KH * KW / 4;
   int g = (int)((total + 255) / 256);
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin,

@@ -41,6 +41,12 @@ CONV_CASES = [
     (1, 9, 9, 16, 0, 3, 3, 1, 1, False, 2, True, False),         # head: Cout=3 + bias + sigmoid
     (3, 19, 19, 256, 0, 256, 3, 1, 1, False, 1, True, False),    # detector-like
     (1, 7, 7, 256, 0, 1024, 7, 1, 0, False, 1, True, False),     # fc6 as 7x7 conv over RoI features
+    # large grids: every (tile, K-depth, stage-count) variant the dispatcher can pick must be exercised
+    (6, 150, 150, 8, 0, 64, 7, 2, 3, False, 1, True, False),     # stem at detector size: 128x64 tile, 32-deep, 2 stages, per-lane taps
+    (4, 96, 96, 32, 0, 128, 3, 1, 1, False, 1, False, True),     # 128x128 tile, 32-deep, 2 stages
+    (4, 96, 96, 64, 0, 128, 3, 1, 1, False, 0, True, False),     # 128x128 tile, 64-deep, 2 stages
+    (4, 96, 96, 64, 0, 64, 3, 1, 1, False, 1, False, False),      # 128x64 tile, 64-deep, 2 stages
+    (2, 40, 40, 64, 64, 64, 3, 1, 1, True, 1, False, False),      # dual source, 64-deep, large grid
 ]
 
 
