@@ -25,6 +25,7 @@ struct WgP {
   float* slab;
   int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1;
   int M, cin8, nchunks, Ktot, per_split;
+  unsigned xbytes, x2bytes, dybytes;
 };
 
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -82,45 +83,64 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  u32x4 ra[A_LOADS], rb[B_LOADS];
   constexpr int A_ROWS_PER_LOAD = 256 / A_CH;  // 16, 32, 64
+  // every global read is a raw buffer load; ragged pixel / channel tails and im2col padding are out-of-range offsets
+  // (hardware zero fill) -- no branch around a load, so hipcc keeps counted vmcnt waits and two tiles stay in flight
+  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.dy), 0, p.dybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.x), 0, p.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.x2 ? p.x2 : p.x), 0, p.x2 ? p.x2bytes : p.xbytes, 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  const bool first_src = bc < p.C1;
 
-  auto gload = [&](int kt) {
-    const int pb = pbeg + kt * BP;
+  // incremental pixel walk for the B (gather) rows: pixel index advances by BP per tile
+  int bn_[B_LOADS], bho[B_LOADS], bwo[B_LOADS];
+#pragma unroll
+  for (int i = 0; i < B_LOADS; ++i) {
+    int pix = pbeg + bpr + i * 16;
+    int pp = pix < p.M ? pix : 0;
+    bn_[i] = pp / HoWo;
+    int rem = pp - bn_[i] * HoWo;
+    bho[i] = rem / p.Wo;
+    bwo[i] = rem - bho[i] * p.Wo;
+  }
+  int kt_issue = 0;
+
+  auto gload = [&](u32x4 (&ra)[A_LOADS], u32x4 (&rb)[B_LOADS]) {
+    const int pb = pbeg + kt_issue * BP;
 #pragma unroll
     for (int i = 0; i < A_LOADS; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
       int prow = apr + i * A_ROWS_PER_LOAD;
       int pix = pb + prow;
-      if (prow < BP && pix < pend && aco_valid) v = *reinterpret_cast<const u32x4*>(p.dy + (size_t)pix * p.Cout + co0 + acc_ * 8);
-      ra[i] = v;
+      bool v = (prow < BP) && (pix < pend) && aco_valid;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rdy, v ? (unsigned)(((size_t)pix * p.Cout + co0 + acc_ * 8) * 2) : OOB, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < B_LOADS; ++i) {
-      u32x4 v = {0u, 0u, 0u, 0u};
       int pix = pb + bpr + i * 16;
-      if (pix < pend && bq_valid) {
-        int n = pix / HoWo;
-        int rem = pix - n * HoWo;
-        int ho = rem / p.Wo;
-        int wo = rem - ho * p.Wo;
-        int hi = ho * p.stride - p.pad + bkh, wi = wo * p.stride - p.pad + bkw;
-        if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) {
-          if (bc < p.C1) {
-            if (p.up1) {
-              hi >>= 1;
-              wi >>= 1;
-            }
-            v = *reinterpret_cast<const u32x4*>(p.x + ((size_t)(n * p.Hsrc + hi) * p.Wsrc + wi) * p.C1 + bc);
-          } else {
-            v = *reinterpret_cast<const u32x4*>(p.x2 + ((size_t)(n * p.Hin + hi) * p.Win + wi) * p.C2 + (bc - p.C1));
-          }
+      int hi = bho[i] * p.stride - p.pad + bkh, wi = bwo[i] * p.stride - p.pad + bkw;
+      bool v = (pix < pend) && bq_valid && ((unsigned)hi < (unsigned)p.Hin) && ((unsigned)wi < (unsigned)p.Win);
+      int hs = p.up1 ? (hi >> 1) : hi, ws = p.up1 ? (wi >> 1) : wi;
+      unsigned o1 = (unsigned)((((size_t)bn_[i] * p.Hsrc + hs) * p.Wsrc + ws) * p.C1 + bc) * 2u;
+      unsigned o2 = (unsigned)((((size_t)bn_[i] * p.Hin + hi) * p.Win + wi) * p.C2 + (bc - p.C1)) * 2u;
+      u32x4 a1 = __builtin_amdgcn_raw_buffer_load_b128(rx, (v && first_src) ? o1 : OOB, 0, 0);
+      if (p.x2) {
+        u32x4 a2 = __builtin_amdgcn_raw_buffer_load_b128(rx2, (v && !first_src) ? o2 : OOB, 0, 0);
+        a1 = a1 | a2;
+      }
+      rb[i] = a1;
+      // advance this row's pixel by BP (BP <= Wo is not guaranteed: loop)
+      bwo[i] += BP;
+      while (bwo[i] >= p.Wo) {
+        bwo[i] -= p.Wo;
+        if (++bho[i] == p.Ho) {
+          bho[i] = 0;
+          ++bn_[i];
         }
       }
-      rb[i] = v;
     }
+    ++kt_issue;
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const u32x4 (&ra)[A_LOADS], const u32x4 (&rb)[B_LOADS]) {
     f16* sa = lds + buf * STAGE;
     f16* sb = sa + BP * RSA;
 #pragma unroll
@@ -133,12 +153,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
   };
   (void)a_active;
 
-  if (nk > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
-
   // transposed-read lane geometry (see header comment): 16-lane group g, lane-in-group li
   const int li = lane & 15, g = lane >> 4;
   const int tq = li >> 2, tp = li & 3;
@@ -146,10 +160,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
   const int krow = 8 * th + tq;                 // + ks*16 (+4 for the second read)
   const int coff = 16 * thalf + 4 * tp;         // + tile column base
 
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    const bool more = (kt + 1) < nk;
-    if (more) gload(kt + 1);
+  auto compute = [&](int buf) {
     const f16* sa = lds + buf * STAGE;
     const f16* sb = sa + BP * RSA;
 #pragma unroll
@@ -164,7 +175,22 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
-    if (more) lstore(buf ^ 1);
+  };
+  // tiles beyond nk load zeros (pix >= pend): the loop runs an even number of tiles
+  u32x4 ra0[A_LOADS], rb0[B_LOADS], ra1[A_LOADS], rb1[B_LOADS];
+  gload(ra0, rb0);
+  gload(ra1, rb1);
+  lstore(0, ra0, rb0);
+  __syncthreads();
+  const int npair = (nk + 1) >> 1;
+  for (int it = 0; it < npair; ++it) {
+    gload(ra0, rb0);
+    compute(0);
+    lstore(1, ra1, rb1);
+    __syncthreads();
+    gload(ra1, rb1);
+    compute(1);
+    lstore(0, ra0, rb0);
     __syncthreads();
   }
 
@@ -273,6 +299,12 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   int per = hd_cdiv(p.M, a->nsplit);
   per = hd_cdiv(per, BP) * BP;
   p.per_split = per;
+  {
+    int64_t xb = (int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2, x2b = a->x2 ? (int64_t)a->N * a->Hin * a->Win * a->C2 * 2 : 0;
+    int64_t db = (int64_t)p.M * a->Cout * 2;
+    HD_CHECK_ARG(xb < 0xFFFFFFF0ll && x2b < 0xFFFFFFF0ll && db < 0xFFFFFFF0ll, "hd_wgrad: tensor larger than 4 GiB (buffer addressing)");
+    p.xbytes = (unsigned)xb; p.x2bytes = (unsigned)x2b; p.dybytes = (unsigned)db;
+  }
   hipStream_t s = (hipStream_t)stream;
   const int tm = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
   dim3 grid(hd_cdiv(p.Ktot, TN), hd_cdiv(p.Cout, tm), a->nsplit);
