@@ -177,23 +177,34 @@ __global__ void bn_bwd_apply_kernel(const f16* __restrict__ dz, const f16* __res
       if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
     }
   }
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c0 = (int)((i0 * 8) % C);
-  float A[8], B[8], D[8], sc[8], sh[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int c = c0 + k;
+  // per-channel coefficients once per block (LDS), then 8 channels per thread in registers
+  extern __shared__ float cf[];   // [5][C]: A, B, D, sc, sh
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sg = 0.f, sgx = 0.f;
     for (int r = 0; r < rows; ++r) {
       sg += part[(size_t)r * 2 * C + c];
       sgx += part[(size_t)r * 2 * C + C + c];
     }
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, is = invstd[c], mu = mean[c];
-    A[k] = ga * is;
-    B[k] = -A[k] * is * sgx * invM;
-    D[k] = -A[k] * sg * invM - B[k] * mu;
-    sc[k] = ga * is;
-    sh[k] = be - mu * ga * is;
+    const float a_ = ga * is;
+    const float b_ = -a_ * is * sgx * invM;
+    cf[c] = a_;
+    cf[C + c] = b_;
+    cf[2 * C + c] = -a_ * sg * invM - b_ * mu;
+    cf[3 * C + c] = ga * is;
+    cf[4 * C + c] = be - mu * ga * is;
+  }
+  __syncthreads();
+  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c0 = (int)((i0 * 8) % C);
+  float A[8], B[8], D[8], sc[8], sh[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    A[k] = cf[c0 + k];
+    B[k] = cf[C + c0 + k];
+    D[k] = cf[2 * C + c0 + k];
+    sc[k] = cf[3 * C + c0 + k];
+    sh[k] = cf[4 * C + c0 + k];
   }
   const bool use_z = relu && z != nullptr;
   for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
@@ -669,7 +680,7 @@ extern "C" int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, con
                                void* stream) {
   HD_CHECK_ARG(dz && y && mean && invstd && part && rows > 0 && rows <= 64 && dy && npix > 0, "hd_bn_bwd_apply: bad args (rows <= 64)");
   HD_CHECK_ARG(C % 8 == 0 && pow2(C / 8) && C <= 2048, "hd_bn_bwd_apply: C/8 must be a power of two (C=%d)", C);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C / 8)), dim3(TB), 0, S_, (const f16*)dz, (const f16*)z,
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(npix * C / 8, TB, 2048)), dim3(TB), 5 * C * sizeof(float), S_, (const f16*)dz, (const f16*)z,
                      (const f16*)y, mean, invstd, gamma, beta, part, rows, (f16*)dy, (f16*)dres, dgamma, dbeta, gscale, accumulate,
                      npix, C, relu);
   HD_CHECK_LAUNCH();
