@@ -1014,10 +1014,11 @@ def _compact(mask_flat, total):
     return torch.sort((~mask_flat).to(torch.uint8), stable=True)[1][:total]
 
 
-def rpn_targets_loss_batched(rpn, anchors0, gt, gvalid, objectness, deltas, n_loss=None):
-    """assign_targets_to_anchors + box_coder.encode + compute_loss for N images sharing one anchor set.
-    `n_loss`: the losses are taken over the first n_loss images only (the sampler still draws for all N, in order)."""
-    N, A = gvalid.shape[0], anchors0.shape[0]
+def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
+    """assign_targets_to_anchors + sampler for N images sharing one anchor set.  Depends on the targets only (not on
+    the network), so a training step can run it -- and take the sampler's host sync -- before the detector trunk is
+    even launched.  Returns what `rpn_loss_from_samples` needs."""
+    N = gvalid.shape[0]
     iou = ops.box_iou_batched(gt, anchors0)
     m = _match_batched(iou, gvalid, rpn.proposal_matcher.high_threshold, rpn.proposal_matcher.low_threshold, True)
     has_gt = gvalid.any(dim=1)
@@ -1036,11 +1037,22 @@ def rpn_targets_loss_batched(rpn, anchors0, gt, gvalid, objectness, deltas, n_lo
     samp_f = pos_f | neg_sel.reshape(-1)
     # regression targets are only ever read at sampled positives (elsewhere they may be inf for GT-less images)
     reg_t = rpn.box_coder.encode_single(matched.reshape(-1, 4), anchors0.repeat(N, 1))
-    l1 = F.smooth_l1_loss(deltas, torch.where(pos_f[:, None], reg_t, deltas.detach()), beta=1 / 9, reduction="none").sum(dim=1)
+    return dict(labels=labels.reshape(-1).clamp(min=0), reg_t=reg_t, pos_f=pos_f, samp_f=samp_f, n_sampled=n_sampled)
+
+
+def rpn_loss_from_samples(st, objectness, deltas):
+    pos_f, samp_f, n_sampled = st["pos_f"], st["samp_f"], st["n_sampled"]
+    l1 = F.smooth_l1_loss(deltas, torch.where(pos_f[:, None], st["reg_t"], deltas.detach()), beta=1 / 9, reduction="none").sum(dim=1)
     box_loss = torch.where(pos_f, l1, torch.zeros_like(l1)).sum() / max(n_sampled, 1)
-    bce = F.binary_cross_entropy_with_logits(objectness.flatten(), labels.reshape(-1).clamp(min=0), reduction="none")
+    bce = F.binary_cross_entropy_with_logits(objectness.flatten(), st["labels"], reduction="none")
     obj_loss = torch.where(samp_f, bce, torch.zeros_like(bce)).sum() / max(n_sampled, 1)
     return obj_loss, box_loss
+
+
+def rpn_targets_loss_batched(rpn, anchors0, gt, gvalid, objectness, deltas, n_loss=None):
+    """assign_targets_to_anchors + box_coder.encode + compute_loss for N images sharing one anchor set.
+    `n_loss`: the losses are taken over the first n_loss images only (the sampler still draws for all N, in order)."""
+    return rpn_loss_from_samples(rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss), objectness, deltas)
 
 
 def filter_proposals_padded(rpn, proposals, objectness, image_shape, num_anchors_per_level):

@@ -111,6 +111,23 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     from ..models import detection as D
     n0 = nb[0]
     flag = _degenerate_flag(targets)
+    for t in targets:
+        if not t["boxes"].dtype in (torch.float, torch.double, torch.half):
+            raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
+        if not t["labels"].dtype == torch.int64:
+            raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
+    dev = il.tensors.device
+    gt, glab, gvalid = D.pad_targets(targets, dev)
+    shape = il.image_sizes[0]
+    # RPN target assignment + sampling depend on targets and anchors only: do them (and the sampler's host sync) BEFORE
+    # the trunk is launched whenever the anchors of this image size are already known (every step but the first)
+    cache = model.rpn.__dict__.setdefault("_anchor_by_size", {})
+    key = (tuple(shape), len(targets) > 0, str(dev))
+    rpn_state = None
+    if key in cache:
+        rpn_state = D.rpn_targets_sample_batched(model.rpn, cache[key], gt, gvalid, n_loss=n0)
+        _raise_if_degenerate(flag, targets)
+        flag = None
     if need_grad:
         features = model.backbone(il.tensors, n_active=n0)
         objectness, deltas = model.rpn.head(list(features.values()), n_active=n0)
@@ -120,20 +137,16 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
             objectness, deltas = model.rpn.head(list(features.values()))
     feats = list(features.values())
     anchors = model.rpn.anchor_generator(il, feats)
+    cache[key] = anchors[0]
     n_img = len(anchors)
     napl = [o[0].shape[0] * o[0].shape[1] * o[0].shape[2] for o in objectness]
     obj, dl = concat_box_prediction_layers(objectness, deltas)
     proposals = model.rpn.box_coder.decode(dl.detach(), anchors).view(n_img, -1, 4)
-    shape = il.image_sizes[0]
-    for t in targets:
-        if not t["boxes"].dtype in (torch.float, torch.double, torch.half):
-            raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
-        if not t["labels"].dtype == torch.int64:
-            raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
-    gt, glab, gvalid = D.pad_targets(targets, obj.device)
     pb, _, pc = D.filter_proposals_padded(model.rpn, proposals, obj, shape, napl)
-    loss_objectness, loss_rpn_box_reg = D.rpn_targets_loss_batched(model.rpn, anchors[0], gt, gvalid, obj, dl, n_loss=n0)
-    _raise_if_degenerate(flag, targets)            # the sampler above was the first host sync of the step
+    if rpn_state is None:
+        rpn_state = D.rpn_targets_sample_batched(model.rpn, anchors[0], gt, gvalid, n_loss=n0)
+    loss_objectness, loss_rpn_box_reg = D.rpn_loss_from_samples(rpn_state, obj, dl)
+    _raise_if_degenerate(flag, targets)            # (first step only) the sampler above was the first host sync
     rois, labels, reg_t, per = D.select_training_samples_batched(model.roi_heads, pb, pc, gt, glab, gvalid)
     r0 = sum(per[:n0])
     pool, head, pred = model.roi_heads.box_roi_pool, model.roi_heads.box_head, model.roi_heads.box_predictor
