@@ -272,8 +272,43 @@ __global__ void roi_align_ml_kernel(MLFeat ml, const float* __restrict__ rois, c
   }
 }
 
+struct RoiGeom {
+  int n, l, H, W, y0, x0, ph_, pw_, gh, gw;
+  float rsw, rsh, bh, bw, count;
+  bool any;
+};
+
+__device__ __forceinline__ RoiGeom roi_geom(const MLFeat& ml, const float* rois, const int* level, int r, int PH, int PW, int sr) {
+  RoiGeom g;
+  g.l = level[r];
+  g.H = ml.H[g.l];
+  g.W = ml.W[g.l];
+  const float scale = ml.scale[g.l];
+  const float* roi = rois + (size_t)r * 5;
+  g.n = (int)roi[0];
+  g.rsw = roi[1] * scale;
+  g.rsh = roi[2] * scale;
+  float rew = roi[3] * scale, reh = roi[4] * scale;
+  float rw = fmaxf(rew - g.rsw, 1.f), rh = fmaxf(reh - g.rsh, 1.f);
+  g.bh = rh / (float)PH;
+  g.bw = rw / (float)PW;
+  g.gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
+  g.gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
+  g.count = fmaxf((float)(g.gh * g.gw), 1.f);
+  // extent of the bilinear footprints (same clamping as bilin_setup)
+  float ymin = g.rsh + .5f * g.bh / (float)g.gh, ymax = g.rsh + (float)(PH - 1) * g.bh + ((float)g.gh - .5f) * g.bh / (float)g.gh;
+  float xmin = g.rsw + .5f * g.bw / (float)g.gw, xmax = g.rsw + (float)(PW - 1) * g.bw + ((float)g.gw - .5f) * g.bw / (float)g.gw;
+  g.any = !(ymax < -1.f || ymin > (float)g.H || xmax < -1.f || xmin > (float)g.W);
+  int y0 = (int)floorf(fmaxf(ymin, 0.f)), y1 = (int)floorf(fmaxf(ymax, 0.f)) + 1;
+  int x0 = (int)floorf(fmaxf(xmin, 0.f)), x1 = (int)floorf(fmaxf(xmax, 0.f)) + 1;
+  y0 = min(max(y0, 0), g.H - 1); y1 = min(max(y1, 0), g.H - 1);
+  x0 = min(max(x0, 0), g.W - 1); x1 = min(max(x1, 0), g.W - 1);
+  g.y0 = y0; g.x0 = x0; g.ph_ = y1 - y0 + 1; g.pw_ = x1 - x0 + 1;
+  return g;
+}
+
 __global__ void roi_align_ml_bwd_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
-                                        const int* __restrict__ level, int R, int C, int PH, int PW, int sr) {
+                                        const int* __restrict__ level, int R, int C, int PH, int PW, int sr, int px_lo) {
   const int64_t total = (int64_t)R * PH * PW * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int c = (int)(i % C);
@@ -281,6 +316,10 @@ __global__ void roi_align_ml_bwd_kernel(MLFeat ml, const f16* __restrict__ dout,
     int pw = (int)(q % PW);
     int ph = (int)((q / PW) % PH);
     int r = (int)(q / ((int64_t)PW * PH));
+    if (px_lo > 0) {   // RoIs whose patch fits on chip were handled by the patch kernels
+      const RoiGeom gg = roi_geom(ml, rois, level, r, PH, PW, sr);
+      if (gg.any && gg.ph_ * gg.pw_ <= px_lo) continue;
+    }
     int l = level[r];
     const int H = ml.H[l], W = ml.W[l];
     const float scale = ml.scale[l];
@@ -308,6 +347,55 @@ __global__ void roi_align_ml_bwd_kernel(MLFeat ml, const f16* __restrict__ dout,
       }
     }
   }
+}
+
+// ---- RoIAlign backward with on-chip pre-accumulation ---------------------------------------------------------------
+// Global float atomics run at one chip-wide rate (~1.3 TB/s of added bytes), and the direct kernel issues
+// 7*7*4*4 = 784 of them per RoI and channel.  A RoI only touches the (h+2)x(w+2) feature pixels under it, so a block
+// first accumulates one RoI x 64 channels into an LDS patch (ds_add_f32) and then flushes each touched pixel ONCE:
+// npx atomics instead of 784 (3-10x fewer for the RoIs this path takes).  RoIs whose patch does not fit the class
+// budget are left to the direct kernel (same arithmetic).
+// grid (R, C/64), block = ONE wave: lane = channel.  The wave walks the RoI's sample points in order and accumulates into
+// its private LDS patch with plain read-modify-write (LDS operations of one wave execute in order, so no atomics and
+// no barriers are needed).  Handles RoIs with px_lo < patch pixels <= MAXPX.
+template <int MAXPX>
+__global__ __launch_bounds__(64) void roi_align_ml_bwd_patch_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
+                                                                    const int* __restrict__ level, int R, int C, int PH, int PW,
+                                                                    int sr, int px_lo) {
+  __shared__ float patch[MAXPX * 64];
+  const int r = blockIdx.x;
+  const RoiGeom g = roi_geom(ml, rois, level, r, PH, PW, sr);
+  const int npx = g.ph_ * g.pw_;
+  if (!g.any || npx <= px_lo || npx > MAXPX) return;          // uniform
+  const int lane = threadIdx.x;
+  const int c = blockIdx.y * 64 + lane;
+  for (int i = 0; i < npx; ++i) patch[i * 64 + lane] = 0.f;
+  const f16* dr = dout + (size_t)r * PH * PW * C + c;
+  for (int ph = 0; ph < PH; ++ph) {
+    for (int pw = 0; pw < PW; ++pw) {
+      const float gv = (float)dr[(size_t)(ph * PW + pw) * C] / g.count;
+      for (int iy = 0; iy < g.gh; ++iy) {
+        const float y = g.rsh + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
+        for (int ix = 0; ix < g.gw; ++ix) {
+          const float x = g.rsw + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
+          const Bilin b = bilin_setup(y, x, g.H, g.W);
+          if (!b.valid) continue;                                 // uniform
+          float* p0 = patch + ((b.yl - g.y0) * g.pw_ + (b.xl - g.x0)) * 64 + lane;
+          const int dy = (b.yh - b.yl) * g.pw_ * 64, dx = (b.xh - b.xl) * 64;
+          p0[0] += gv * b.w1;
+          p0[dx] += gv * b.w2;
+          p0[dy] += gv * b.w3;
+          p0[dy + dx] += gv * b.w4;
+        }
+      }
+    }
+  }
+  float* fb = ml.df[g.l] + (size_t)g.n * g.H * g.W * C + c;
+  for (int py = 0; py < g.ph_; ++py)
+    for (int px = 0; px < g.pw_; ++px) {
+      const float v = patch[(py * g.pw_ + px) * 64 + lane];
+      if (v != 0.f) atomicAdd(fb + ((size_t)(g.y0 + py) * g.W + (g.x0 + px)) * C, v);
+    }
 }
 
 __global__ void box_iou_kernel(const float* __restrict__ gt, int G, const float* __restrict__ boxes, int A, float* __restrict__ iou) {
@@ -427,7 +515,15 @@ extern "C" int hd_roi_align_ml_bwd(const void* dout, const float* rois, const in
   int64_t total = (int64_t)R * PH * PW * C;
   int g = (int)((total + 255) / 256);
   if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(roi_align_ml_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ml, (const f16*)dout, rois, level, R, C, PH, PW, sampling_ratio);
+  int px_lo = 0;
+  if (C % 64 == 0) {
+    // RoIs that touch <= 64 feature pixels: one-wave LDS patch accumulation (16 KB, 10 waves per CU), one global atomic
+    // per touched pixel instead of 784 per RoI.  (A 224-pixel class was measured too: at 56 KB of LDS per wave its
+    // occupancy makes it slower than the direct atomics it replaces.)
+    hipLaunchKernelGGL((roi_align_ml_bwd_patch_kernel<64>), dim3(R, C / 64), dim3(64), 0, (hipStream_t)stream, ml, (const f16*)dout, rois, level, R, C, PH, PW, sampling_ratio, 0);
+    px_lo = 64;
+  }
+  hipLaunchKernelGGL(roi_align_ml_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ml, (const f16*)dout, rois, level, R, C, PH, PW, sampling_ratio, px_lo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

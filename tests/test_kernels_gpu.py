@@ -386,3 +386,43 @@ def test_adam_step(dev):
     before = P.clone()
     ops.adam_step(P, G, M, V, weight_decay=0.0, found_inf=found, **kw)
     assert float(found) == 1.0 and torch.equal(P, before)
+
+
+def test_roi_align_multilevel_bwd_patch_and_direct_paths(dev):
+    """Multi-level RoIAlign backward: small / medium RoIs go through the LDS-patch kernels, large ones through direct
+    atomics; all must equal the autograd of the oracle's RoIAlign."""
+    from hallucidet_amd import ops
+    from oracle import detection as od
+    g = torch.Generator().manual_seed(3)
+    C, N = 64, 2
+    shapes = [(N, 75, 75, C), (N, 38, 38, C)]
+    scales = [0.25, 0.125]
+    feats = [rnd(*s, seed=90 + i) for i, s in enumerate(shapes)]
+    sizes = [6.0, 14.0, 30.0, 70.0, 150.0, 280.0]
+    rois, levels = [], []
+    for k, sz in enumerate(sizes * 3):
+        x1, y1 = float(torch.rand(1, generator=g) * (299 - sz) * 0.9), float(torch.rand(1, generator=g) * (299 - sz) * 0.9)
+        ar = 0.5 + float(torch.rand(1, generator=g))
+        rois.append([k % N, x1, y1, min(x1 + sz * ar, 320.0), min(y1 + sz / ar, 310.0)])
+        levels.append(k % 2)
+    rois.append([0, -30.0, -10.0, 20.0, 40.0])
+    levels.append(0)
+    rois = torch.tensor(rois)
+    levels_t = torch.tensor(levels, dtype=torch.int32)
+    R = rois.shape[0]
+    dout = rnd(R, 7, 7, C, seed=95)
+    dfs = ops.roi_align_ml_bwd(dout.to(dev), rois.to(dev), levels_t.to(dev), shapes, scales, 2)
+    for l in range(2):
+        f = ok.nhwc_to_nchw(feats[l].float()).requires_grad_(True)
+        idx = [i for i in range(R) if levels[i] == l]
+        out = od.roi_align_autograd(f, rois[idx], 7, scales[l], 2)
+        out.backward(dout[idx].float().permute(0, 3, 1, 2))
+        want = ok.nchw_to_nhwc(f.grad)
+        got = dfs[l].cpu()
+        assert torch.allclose(got, want, rtol=1e-3, atol=2e-3), (l, float((got - want).abs().max()))
+    # forward of the multi-level kernel against the oracle as well
+    out = ops.roi_align_ml([f.to(dev) for f in feats], scales, rois.to(dev), levels_t.to(dev), 7, 7, 2).float().cpu()
+    for l in range(2):
+        idx = [i for i in range(R) if levels[i] == l]
+        want = od.roi_align_autograd(ok.nhwc_to_nchw(feats[l].float()), rois[idx], 7, scales[l], 2).permute(0, 2, 3, 1)
+        close(out[idx], want.half(), rtol=2e-3, atol=1e-3)
