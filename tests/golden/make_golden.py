@@ -58,9 +58,18 @@ def load_reference():
     sys.modules.update({"torchvision.models": m1, "torchvision.models.detection": m2,
                         "torchvision.models.detection.roi_heads": m3, "torchvision.models.detection.rpn": m4})
     glue = _load("ref_eval_forward_fasterrcnn", os.path.join(REF, "src", "utils", "eval_forward_fasterrcnn.py"))
+    # eval_forward_retinanet names torchvision.ops.box_iou and (as an annotation) torchvision.models.detection._utils.BoxCoder
+    from oracle import kernels as ok
+    tvm = sys.modules["torchvision"]
+    tvm.ops = ModuleType("torchvision.ops"); tvm.ops.box_iou = ok.box_iou
+    m5 = ModuleType("torchvision.models.detection._utils"); m5.BoxCoder = od.BoxCoder
+    m2._utils = m5; m1.detection = m2; tvm.models = m1
+    sys.modules.update({"torchvision.ops": tvm.ops, "torchvision.models.detection._utils": m5})
+    glue_retina = _load("ref_eval_forward_retinanet", os.path.join(REF, "src", "utils", "eval_forward_retinanet.py"))
     cfg = _load("ref_config", os.path.join(REF, "src", "config", "config.py"))
     ns = ModuleType("ref")
     ns.modules, ns.heads, ns.init, ns.model, ns.decoder, ns.transform, ns.glue, ns.config = modules, heads, init, model, dec, tr, glue, cfg
+    ns.glue_retina = glue_retina
     return ns
 
 
@@ -221,6 +230,54 @@ def gen_glue(ref):
     np.savez_compressed(os.path.join(OUT, "glue_fasterrcnn.npz"), **{k: v.numpy() for k, v in blob.items()})
 
 
+def make_retinanet_case(seed=13, n_img=2, H=96, W=128):
+    """Oracle RetinaNet (seeded) + inputs; image 1 has NO boxes (the reference's empty-target branch, :169-172)."""
+    from oracle import retinanet as orn
+    torch.manual_seed(seed)
+    model = orn.RetinaNet(num_classes=2, size=300)
+    tame_detector_(model)
+    with torch.no_grad():   # prior bias -log(99) keeps every score < 0.05: spread the logits so post-processing has work
+        model.head.classification_head.cls_logits.weight.normal_(0, 0.05)
+        model.head.classification_head.cls_logits.bias.fill_(-2.0)
+        model.head.regression_head.bbox_reg.weight.normal_(0, 0.02)
+    images = torch.rand(n_img, 3, H, W)
+    targets = []
+    for i in range(n_img):
+        k = 2 if i == 0 else 0
+        xy = torch.rand(k, 2) * torch.tensor([W * 0.5, H * 0.5])
+        wh = torch.rand(k, 2) * torch.tensor([W * 0.3, H * 0.4]) + 8.0
+        targets.append({"boxes": torch.cat([xy, xy + wh], 1).reshape(-1, 4), "labels": torch.ones(k, dtype=torch.int64)})
+    return model, images, targets
+
+
+def gen_glue_retinanet(ref):
+    """The REFERENCE's eval_forward_retinanet.py (its own focal loss / box loss / compute_retinanet_loss) driving the
+    oracle's duck-typed RetinaNet; plus direct known-answer vectors of the two loss functions."""
+    model, images, targets = make_retinanet_case()
+    losses, dets = ref.glue_retina.eval_forward_retinanet(model, images, targets, train_det=False)
+    blob = {"images": images}
+    for k, v in losses.items():
+        blob["loss." + k] = v.detach()
+    for i, d in enumerate(dets):
+        for k, v in d.items():
+            blob["det%d.%s" % (i, k)] = v.detach()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(37, 2, generator=g) * 3
+    t = (torch.rand(37, 2, generator=g) > 0.7).float()
+    blob["focal.x"], blob["focal.t"] = x, t
+    blob["focal.none"] = ref.glue_retina.sigmoid_focal_loss(x, t)
+    blob["focal.sum"] = ref.glue_retina.sigmoid_focal_loss(x, t, reduction="sum")
+    blob["focal.mean_a-1_g0"] = ref.glue_retina.sigmoid_focal_loss(x, t, alpha=-1, gamma=0, reduction="mean")
+    from oracle import detection as od
+    anchors = torch.tensor([[0., 0., 20., 30.], [5., 5., 45., 25.], [10., 2., 30., 42.]])
+    gts = torch.tensor([[1., 2., 22., 28.], [0., 9., 50., 20.], [12., 0., 27., 47.]])
+    breg = torch.randn(3, 4, generator=g)
+    blob["boxloss.anchors"], blob["boxloss.gts"], blob["boxloss.breg"] = anchors, gts, breg
+    blob["boxloss.l1"] = ref.glue_retina.box_loss("l1", od.BoxCoder((1.0,) * 4), anchors, gts, breg)
+    blob["boxloss.smooth_l1"] = ref.glue_retina.box_loss("smooth_l1", od.BoxCoder((1.0,) * 4), anchors, gts, breg)
+    np.savez_compressed(os.path.join(OUT, "glue_retinanet.npz"), **{k: v.numpy() for k, v in blob.items()})
+
+
 def main():
     ref = load_reference()
     gen_decoder(ref)
@@ -229,6 +286,7 @@ def main():
     gen_transform(ref)
     gen_config(ref)
     gen_glue(ref)
+    gen_glue_retinanet(ref)
     for f in sorted(os.listdir(OUT)):
         if f.endswith((".npz", ".json")):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))

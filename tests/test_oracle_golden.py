@@ -159,6 +159,58 @@ def test_reference_glue_live():
         assert torch.equal(a["labels"], b["labels"]) and torch.allclose(a["boxes"], b["boxes"], atol=1e-5)
 
 
+# ---------------------------------------------------------------------------------- RetinaNet (config 4)
+def test_retinanet_losses_equal_reference():
+    from oracle import retinanet as orn
+    z = npz("glue_retinanet.npz")
+    x, t = z["focal.x"], z["focal.t"]
+    assert torch.allclose(orn.sigmoid_focal_loss(x, t), z["focal.none"], rtol=1e-6, atol=1e-7)
+    assert torch.allclose(orn.sigmoid_focal_loss(x, t, reduction="sum"), z["focal.sum"], rtol=1e-6)
+    assert torch.allclose(orn.sigmoid_focal_loss(x, t, alpha=-1, gamma=0, reduction="mean"), z["focal.mean_a-1_g0"], rtol=1e-6)
+    bc = od.BoxCoder((1.0,) * 4)
+    tr = bc.encode_single(z["boxloss.gts"], z["boxloss.anchors"])
+    assert torch.allclose(torch.nn.functional.smooth_l1_loss(z["boxloss.breg"], tr, reduction="sum", beta=1.0), z["boxloss.smooth_l1"], rtol=1e-6)
+    assert torch.allclose(torch.nn.functional.l1_loss(z["boxloss.breg"], tr, reduction="sum"), z["boxloss.l1"], rtol=1e-6)
+
+
+def test_retinanet_orchestration_equals_reference_glue():
+    """Fixture = the REFERENCE's eval_forward_retinanet.py over the oracle RetinaNet (one image with boxes, one without)."""
+    from oracle import retinanet as orn
+    mg = _mg()
+    z = npz("glue_retinanet.npz")
+    model, images, targets = mg.make_retinanet_case()
+    assert torch.equal(images, z["images"])
+    losses, dets = orn.eval_forward_retinanet(model, images, targets, train_det=False)
+    assert set(losses) == {"classification", "bbox_regression"}
+    for k in losses:
+        assert torch.allclose(losses[k], z["loss." + k], rtol=1e-6, atol=1e-7), k
+    for i, d in enumerate(dets):
+        assert torch.equal(d["labels"], z["det%d.labels" % i])
+        assert torch.allclose(d["boxes"], z["det%d.boxes" % i], rtol=1e-6, atol=1e-5)
+        assert torch.allclose(d["scores"], z["det%d.scores" % i], rtol=1e-6, atol=1e-7)
+        assert d["boxes"].shape[0] <= 300
+
+
+def test_retinanet_structure_known_answers():
+    from oracle import retinanet as orn
+    m = orn.RetinaNet(num_classes=2, size=300)
+    ag = m.anchor_generator
+    assert ag.sizes == ((32, 40, 50), (64, 80, 101), (128, 161, 203), (256, 322, 406), (512, 645, 812))
+    assert ag.num_anchors_per_location() == [9] * 5
+    il = od.ImageList(torch.zeros(1, 3, 300, 300), [(300, 300)])
+    feats = [torch.zeros(1, 256, s, s) for s in (38, 19, 10, 5, 3)]
+    assert ag(il, feats)[0].shape == (9 * (38 * 38 + 19 * 19 + 100 + 25 + 9), 4)
+    cl = m.head.classification_head.cls_logits
+    assert cl.weight.shape == (18, 256, 3, 3) and torch.allclose(cl.bias, torch.full((18,), -math.log(99.0)))
+    keys = set(m.state_dict().keys())
+    for k in ("backbone.fpn.extra_blocks.p6.weight", "backbone.fpn.extra_blocks.p7.bias", "backbone.fpn.inner_blocks.2.weight",
+              "head.classification_head.conv.6.weight", "head.regression_head.bbox_reg.bias", "backbone.body.layer4.2.bn3.running_var"):
+        assert k in keys, k
+    assert not any(k.startswith("backbone.fpn.inner_blocks.3") for k in keys)
+    f = m.backbone(torch.rand(1, 3, 300, 300))
+    assert [tuple(v.shape[-2:]) for v in f.values()] == [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3)] and list(f) == ["0", "1", "2", "p6", "p7"]
+
+
 # ---------------------------------------------------------------------------------- known answers (torchvision side)
 def test_anchor_generator_known_answers():
     ag = od.AnchorGenerator()
