@@ -87,12 +87,23 @@ class LastLevelMaxPool(nn.Module):
     pass
 
 
+class LastLevelP6P7(nn.Module):
+    """RetinaNet's two extra levels [EXT torchvision 0.12 ops/feature_pyramid_network.py]: P6 = conv3x3/s2(P5) when
+    in_channels == out_channels (as retinanet_resnet50_fpn builds it), P7 = conv3x3/s2(ReLU(P6))."""
+
+    def __init__(self, in_channels=256, out_channels=256):
+        super().__init__()
+        self.p6 = nn.Conv2d(in_channels, out_channels, 3, 2, 1)
+        self.p7 = nn.Conv2d(out_channels, out_channels, 3, 2, 1)
+        self.use_P5 = in_channels == out_channels
+
+
 class FeaturePyramidNetwork(nn.Module):
-    def __init__(self, in_channels_list=(256, 512, 1024, 2048), out_channels=256):
+    def __init__(self, in_channels_list=(256, 512, 1024, 2048), out_channels=256, extra_blocks=None):
         super().__init__()
         self.inner_blocks = nn.ModuleList(nn.Conv2d(c, out_channels, 1) for c in in_channels_list)
         self.layer_blocks = nn.ModuleList(nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels_list)
-        self.extra_blocks = LastLevelMaxPool()
+        self.extra_blocks = LastLevelMaxPool() if extra_blocks is None else extra_blocks
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_uniform_(m.weight, a=1)
@@ -152,10 +163,17 @@ class _BackboneFn(torch.autograd.Function):
 class BackboneWithFPN(nn.Module):
     out_channels = 256
 
-    def __init__(self):
+    def __init__(self, returned_layers=(1, 2, 3, 4), extra_blocks=None):
+        """Faster R-CNN: layers 1-4 + LastLevelMaxPool ('0','1','2','3','pool'); RetinaNet: returned_layers=(2,3,4) +
+        LastLevelP6P7 ('0','1','2','p6','p7')."""
         super().__init__()
         self.body = ResNet50Body()
-        self.fpn = FeaturePyramidNetwork()
+        self.returned_layers = tuple(returned_layers)
+        assert self.returned_layers[-1] == 4 and list(self.returned_layers) == sorted(self.returned_layers)
+        chans = [256 * 2 ** (l - 1) for l in self.returned_layers]
+        self.fpn = FeaturePyramidNetwork(chans, 256, extra_blocks)
+        self.p6p7 = isinstance(self.fpn.extra_blocks, LastLevelP6P7)
+        self.out_names = tuple(str(i) for i in range(len(chans))) + (("p6", "p7") if self.p6p7 else ("pool",))
         self._pack = None
         self._hook = None
 
@@ -178,6 +196,8 @@ class BackboneWithFPN(nn.Module):
             P["inner"].append(_conv_entry(c))
         for c in self.fpn.layer_blocks:
             P["layer"].append(_conv_entry(c))
+        if self.p6p7:
+            P["p6"], P["p7"] = _conv_entry(self.fpn.extra_blocks.p6), _conv_entry(self.fpn.extra_blocks.p7)
         self._pack = P
         return P
 
@@ -203,40 +223,60 @@ class BackboneWithFPN(nn.Module):
             C.append(cur)
             if save:
                 rec["blocks"].append(srec)
-        inner = [None] * 4
-        inner[3] = _fwd(P["inner"][3], C[3])
-        outs = [None] * 4
-        outs[3] = _fwd(P["layer"][3], inner[3])
-        for i in (2, 1, 0):
-            lat = _fwd(P["inner"][i], C[i])
+        L = len(self.returned_layers)
+        Cr = [C[l - 1] for l in self.returned_layers]
+        inner = [None] * L
+        inner[L - 1] = _fwd(P["inner"][L - 1], Cr[L - 1])
+        outs = [None] * L
+        outs[L - 1] = _fwd(P["layer"][L - 1], inner[L - 1])
+        for i in range(L - 2, -1, -1):
+            lat = _fwd(P["inner"][i], Cr[i])
             inner[i] = ops.upsample_add(lat, inner[i + 1])
             outs[i] = _fwd(P["layer"][i], inner[i])
-        pool = ops.subsample2(outs[3])
+        if self.p6p7:
+            p6 = _fwd(P["p6"], outs[L - 1])
+            extra = [p6, _fwd(P["p7"], torch.relu(p6))]
+        else:
+            extra = [ops.subsample2(outs[L - 1])]
         if save:
-            rec.update(stem=s[:na], pooled=p[:na], C=[c[:na] for c in C], out_shapes=[(na,) + tuple(t.shape[1:]) for t in outs])
-        return outs + [pool], rec
+            rec.update(stem=s[:na], pooled=p[:na], C=[c[:na] for c in C], out_shapes=[(na,) + tuple(t.shape[1:]) for t in outs],
+                       p6=extra[0][:na] if self.p6p7 else None)
+        return outs + extra, rec
 
     def _backward(self, rec, grads):
         P = self.pack()
         shapes = rec["out_shapes"]
+        L = len(self.returned_layers)
+        dev = rec["x"].device
         dP = []
-        for i in range(4):
+        for i in range(L):
             g = grads[i]
-            dP.append(torch.zeros(shapes[i], dtype=torch.float16, device=rec["x"].device) if g is None else g.contiguous())
-        if grads[4] is not None:
-            ops.subsample2_bwd(grads[4].contiguous(), dP[3], accumulate=True)
+            dP.append(torch.zeros(shapes[i], dtype=torch.float16, device=dev) if g is None else g.contiguous())
+        top_hw = (shapes[L - 1][1], shapes[L - 1][2])
+        if self.p6p7:
+            g6, g7, p6 = grads[L], grads[L + 1], rec["p6"]
+            if g7 is not None:
+                d6 = _dgrad(P["p7"], g7.contiguous(), (p6.shape[1], p6.shape[2]), mask=p6)     # through ReLU(P6)
+                g6 = d6 if g6 is None else ops.add_f16(g6.contiguous(), d6)
+            if g6 is not None:
+                dP[L - 1] = _dgrad(P["p6"], g6.contiguous(), top_hw, res=dP[L - 1])
+        elif grads[L] is not None:
+            if grads[L - 1] is not None:
+                dP[L - 1] = dP[L - 1].clone()
+            ops.subsample2_bwd(grads[L].contiguous(), dP[L - 1], accumulate=True)
         C = rec["C"]
-        d_li = [None] * 4
-        for i in range(4):
+        Cr = [C[l - 1] for l in self.returned_layers]
+        d_li = [None] * L
+        for i in range(L):
             hw = (shapes[i][1], shapes[i][2])
             d_li[i] = _dgrad(P["layer"][i], dP[i], hw)
             if i > 0:
                 ops.upsample_add_bwd(d_li[i - 1], d_li[i], accumulate=True)
-        # lateral 1x1 convs -> gradients w.r.t. C2..C5 (C5's carries the ReLU mask of layer4's output)
+        # lateral 1x1 convs -> gradients w.r.t. the returned C levels (C5's carries the ReLU mask of layer4's output)
         dC = [None] * 4
-        for i in range(4):
-            hw = (C[i].shape[1], C[i].shape[2])
-            dC[i] = _dgrad(P["inner"][i], d_li[i], hw, mask=C[i] if i == 3 else None)
+        for i, l in enumerate(self.returned_layers):
+            hw = (Cr[i].shape[1], Cr[i].shape[2])
+            dC[l - 1] = _dgrad(P["inner"][i], d_li[i], hw, mask=Cr[i] if i == L - 1 else None)
         gm = dC[3]
         for si in (3, 2, 1, 0):
             stage, srec = P["blocks"][si], rec["blocks"][si]
@@ -272,7 +312,7 @@ class BackboneWithFPN(nn.Module):
             outs = _BackboneFn.apply(x, self._hook, self, x.shape[0] if n_active is None else n_active)
         else:
             outs, _ = self._forward(x, save=False)
-        return OrderedDict(zip(("0", "1", "2", "3", "pool"), outs))
+        return OrderedDict(zip(self.out_names, outs))
 
     @torch.no_grad()
     def calibrate_(self, x_nhwc8):

@@ -9,9 +9,10 @@ import sys
 
 import torch
 
-from . import detection
+from . import detection, retinanet
 from .custom_generalized_transform import CustomGeneralizedRCNNTransform
 from ..utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn
+from ..utils.eval_forward_retinanet import eval_forward_retinanet
 
 
 def _xavier_init(conv: torch.nn.Module):
@@ -34,8 +35,19 @@ class Detector():
                 in_features = self.detector.roi_heads.box_predictor.cls_score.in_features
                 self.detector.roi_heads.box_predictor = detection.FastRCNNPredictor(in_features, n_classes)
                 _xavier_init(self.detector.roi_heads)
-            elif 'fcos' in name or 'retinanet' in name:
-                raise NotImplementedError("hallucidet_amd: %s head is scheduled after the Faster R-CNN path (DESIGN.md, scope)" % name)
+            elif 'retinanet' in name:
+                head = self.detector.head.classification_head
+                out_channels = head.conv[0].out_channels
+                num_anchors = head.num_anchors
+                head.num_classes = n_classes
+                cls_logits = torch.nn.Conv2d(out_channels, num_anchors * n_classes, kernel_size=3, stride=1, padding=1)
+                torch.nn.init.normal_(cls_logits.weight, std=0.01)
+                torch.nn.init.constant_(cls_logits.bias, -math.log((1 - 0.01) / 0.01))
+                head.cls_logits = cls_logits
+                self.detector.head.invalidate()
+            elif 'fcos' in name:
+                raise NotImplementedError("hallucidet_amd: the FCOS head is out of round-1 scope (DESIGN.md); "
+                                          "fasterrcnn and retinanet are built")
             if eval_path is not None and '.bin' in eval_path:
                 self.detector.load_state_dict(torch.load(eval_path, map_location="cpu"))
             elif eval_path is not None and '.ckpt' in eval_path:
@@ -54,8 +66,10 @@ class Detector():
     def calculate_loss(detector, outs, targets, train_det=False, model_name='fasterrcnn'):
         if 'fasterrcnn' in model_name:
             losses_det, detections = eval_forward_fasterrcnn(detector, outs, targets, train_det=train_det, model_name=model_name)
-        elif 'retinanet' in model_name or 'fcos' in model_name:
-            raise NotImplementedError("hallucidet_amd: %s path is scheduled after the Faster R-CNN path" % model_name)
+        elif 'retinanet' in model_name:
+            losses_det, detections = eval_forward_retinanet(detector, outs, targets, train_det=train_det, model_name=model_name)
+        elif 'fcos' in model_name:
+            raise NotImplementedError("hallucidet_amd: the FCOS path is out of round-1 scope (DESIGN.md)")
         else:
             raise ValueError("unknown detector %r" % (model_name,))
         return losses_det, detections
@@ -64,7 +78,9 @@ class Detector():
     def select_detector(detector_name='fasterrcnn_resnet50_fpn', pretrained=True):
         if detector_name in ('fasterrcnn', 'fasterrcnn_resnet50_fpn'):
             return detection.fasterrcnn_resnet50_fpn(pretrained=pretrained)
-        if detector_name in ('retinanet', 'retinanet_resnet50_fpn', 'fcos', 'fcos_resnet50_fpn'):
-            raise NotImplementedError("hallucidet_amd: %s is scheduled after the Faster R-CNN path" % detector_name)
+        if detector_name in ('retinanet', 'retinanet_resnet50_fpn'):
+            return retinanet.retinanet_resnet50_fpn(pretrained=pretrained)
+        if detector_name in ('fcos', 'fcos_resnet50_fpn'):
+            raise NotImplementedError("hallucidet_amd: the FCOS detector is out of round-1 scope (DESIGN.md)")
         print("Model Name not found (Using fasterrcnn_resnet50_fpn")
         return detection.fasterrcnn_resnet50_fpn(pretrained=pretrained)

@@ -1,0 +1,291 @@
+"""RetinaNet ResNet-50-FPN (BASELINE config 4) on the HIP kernels, with torchvision 0.12's attribute tree.
+
+The reference builds `torchvision.models.detection.retinanet_resnet50_fpn` (src/models/detector.py:137-139), re-heads
+`head.classification_head.cls_logits` to `num_anchors * n_classes` outputs (N(0, 0.01) weights, bias -log(99), :57-66)
+and drives it from src/utils/eval_forward_retinanet.py:83-160 through `.transform`, `.backbone(x) -> OrderedDict('0','1',
+'2','p6','p7')`, `.head(features) -> {'cls_logits' [N, sum(HWA), K], 'bbox_regression' [N, sum(HWA), 4]}`,
+`.anchor_generator`, `.proposal_matcher`, `.box_coder`, `.head.classification_head.BETWEEN_THRESHOLDS`,
+`.postprocess_detections(split_head_outputs, split_anchors, image_sizes)`.  This module provides that surface with the
+same state_dict keys (`backbone.fpn.extra_blocks.p6.weight`, `head.classification_head.conv.0.weight`,
+`head.regression_head.bbox_reg.bias`, ...).
+
+Execution: frozen detector -- FrozenBN folded into fp16 GEMM-layout weights, implicit-GEMM convs with bias/ReLU
+epilogues forward, data gradients only backward (ReLU masks fused into the dgrad epilogue); the 4-conv towers of the
+two heads share weights across the 5 pyramid levels.  Matching, focal loss, smooth-L1 and post-processing are batched
+fp32 tensor ops on the GPU (IoU and NMS are HIP kernels); there is no CPU path.
+"""
+import math
+import re
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..ops import ACT_RELU
+from . import detection as D
+from .detection import _conv_entry, _dgrad, _fwd
+
+
+class _HeadFn(torch.autograd.Function):
+    """Both towers + output convs over every level.  Outputs: (cls, reg) NCHW fp32 per level."""
+
+    @staticmethod
+    def forward(ctx, hook, head, n_active, *feats):
+        P = head.pack()
+        outs, saved = [], []
+        for f in feats:
+            lv = []
+            for tower, last in ((P["cls_tower"], P["cls_out"]), (P["reg_tower"], P["reg_out"])):
+                t, acts = f, []
+                for e in tower:
+                    t = _fwd(e, t, act=ACT_RELU)
+                    acts.append(t[:n_active])
+                outs.append(_fwd(last, t, f32=True))
+                lv.append(acts)
+            saved.append(lv)
+        ctx.head, ctx.saved, ctx.na, ctx.n = head, saved, n_active, feats[0].shape[0]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        P = ctx.head.pack()
+        na = ctx.na
+        dfeats = []
+        for i, lv in enumerate(ctx.saved):
+            df = None
+            for j, (tower, last) in enumerate(((P["cls_tower"], P["cls_out"]), (P["reg_tower"], P["reg_out"]))):
+                g = grads[2 * i + j]
+                if g is None:
+                    continue
+                acts = lv[j]
+                H, W = acts[0].shape[1], acts[0].shape[2]
+                d = ops.nchw_to_nhwc_resize(g[:na].contiguous().float(), H, W, last["cout_p"])
+                d = _dgrad(last, d, (H, W), mask=acts[3])
+                for k in (3, 2, 1):
+                    d = _dgrad(tower[k], d, (H, W), mask=acts[k - 1])
+                df = _dgrad(tower[0], d, (H, W), res=df)
+            if df is not None and na < ctx.n:
+                full = torch.zeros((ctx.n,) + tuple(df.shape[1:]), dtype=df.dtype, device=df.device)
+                full[:na] = df
+                df = full
+            dfeats.append(df)
+        ctx.saved = None
+        return (None, None, None) + tuple(dfeats)
+
+
+class _Tower(nn.Module):
+    def __init__(self, in_channels):
+        super().__init__()
+        layers = []
+        for _ in range(4):
+            layers += [nn.Conv2d(in_channels, in_channels, 3, padding=1), nn.ReLU()]
+        self.conv = nn.Sequential(*layers)
+        for l in self.conv.children():
+            if isinstance(l, nn.Conv2d):
+                nn.init.normal_(l.weight, std=0.01)
+                nn.init.constant_(l.bias, 0)
+
+    def tower_entries(self):
+        return [_conv_entry(l) for l in self.conv if isinstance(l, nn.Conv2d)]
+
+
+class RetinaNetClassificationHead(_Tower):
+    BETWEEN_THRESHOLDS = D.Matcher.BETWEEN_THRESHOLDS
+
+    def __init__(self, in_channels, num_anchors, num_classes, prior_probability=0.01):
+        super().__init__(in_channels)
+        self.cls_logits = nn.Conv2d(in_channels, num_anchors * num_classes, 3, padding=1)
+        nn.init.normal_(self.cls_logits.weight, std=0.01)
+        nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_probability) / prior_probability))
+        self.num_classes, self.num_anchors = num_classes, num_anchors
+
+
+class RetinaNetRegressionHead(_Tower):
+    def __init__(self, in_channels, num_anchors):
+        super().__init__(in_channels)
+        self.bbox_reg = nn.Conv2d(in_channels, num_anchors * 4, 3, padding=1)
+        nn.init.normal_(self.bbox_reg.weight, std=0.01)
+        nn.init.zeros_(self.bbox_reg.bias)
+
+
+class RetinaNetHead(nn.Module):
+    def __init__(self, in_channels, num_anchors, num_classes):
+        super().__init__()
+        self.classification_head = RetinaNetClassificationHead(in_channels, num_anchors, num_classes)
+        self.regression_head = RetinaNetRegressionHead(in_channels, num_anchors)
+        self._pack, self._hook = None, None
+
+    def invalidate(self):
+        self._pack = None
+
+    def pack(self):
+        if self._pack is None:
+            c, r = self.classification_head, self.regression_head
+            self._pack = dict(cls_tower=c.tower_entries(), cls_out=_conv_entry(c.cls_logits),
+                              reg_tower=r.tower_entries(), reg_out=_conv_entry(r.bbox_reg))
+        return self._pack
+
+    def forward(self, x, n_active=None):
+        """x: list of NHWC fp16 feature maps -> {'cls_logits': [N, sum(H*W*A), K], 'bbox_regression': [N, sum(H*W*A), 4]} fp32."""
+        feats = list(x)
+        if self._hook is None or self._hook.device != feats[0].device:
+            self._hook = torch.zeros(1, device=feats[0].device, requires_grad=True)
+        outs = _HeadFn.apply(self._hook, self, feats[0].shape[0] if n_active is None else n_active, *feats)
+        K = self.classification_head.cls_logits.out_channels // self.classification_head.num_anchors
+        cls, reg = [], []
+        for c, r in zip(outs[0::2], outs[1::2]):
+            N, _, H, W = c.shape
+            cls.append(c.view(N, -1, K, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, K))
+            reg.append(r.view(N, -1, 4, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, 4))
+        return {"cls_logits": torch.cat(cls, dim=1), "bbox_regression": torch.cat(reg, dim=1)}
+
+
+def _default_anchorgen():
+    sizes = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in [32, 64, 128, 256, 512])
+    return D.AnchorGenerator(sizes, ((0.5, 1.0, 2.0),) * len(sizes))
+
+
+class RetinaNet(nn.Module):
+    def __init__(self, num_classes=91, min_size=800, max_size=1333, score_thresh=0.05, nms_thresh=0.5, detections_per_img=300,
+                 fg_iou_thresh=0.5, bg_iou_thresh=0.4, topk_candidates=1000):
+        super().__init__()
+        self.backbone = D.BackboneWithFPN(returned_layers=(2, 3, 4), extra_blocks=D.LastLevelP6P7(256, 256))
+        self.anchor_generator = _default_anchorgen()
+        self.head = RetinaNetHead(256, self.anchor_generator.num_anchors_per_location()[0], num_classes)
+        self.proposal_matcher = D.Matcher(fg_iou_thresh, bg_iou_thresh, allow_low_quality_matches=True)
+        self.box_coder = D.BoxCoder((1.0, 1.0, 1.0, 1.0))
+        # torchvision's GeneralizedRCNNTransform is always replaced by the reference (detector.py:43-48); build that one.
+        self.transform = D.CustomGeneralizedRCNNTransform(min_size=300, max_size=300, image_mean=[0.0], image_std=[1.0],
+                                                          size_divisible=1, fixed_size=(300, 300))
+        self.score_thresh, self.nms_thresh = score_thresh, nms_thresh
+        self.detections_per_img, self.topk_candidates = detections_per_img, topk_candidates
+        self.batched_heads = True
+
+    def invalidate_packs(self):
+        self.backbone.invalidate()
+        self.head.invalidate()
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = OrderedDict()
+        for k, v in state_dict.items():
+            for i in range(3):                       # torchvision >= 0.13 wraps the FPN convs in Conv2dNormActivation
+                k = k.replace("fpn.inner_blocks.%d.0." % i, "fpn.inner_blocks.%d." % i).replace("fpn.layer_blocks.%d.0." % i, "fpn.layer_blocks.%d." % i)
+            # ... and the tower convs: head.<h>.conv.<i>.0.weight -> head.<h>.conv.<2i>.weight
+            k = re.sub(r"(head\.\w+_head\.conv\.)(\d)\.0\.", lambda m: "%s%d." % (m.group(1), 2 * int(m.group(2))), k)
+            if k.endswith("num_batches_tracked"):
+                continue
+            sd[k] = v
+        out = super().load_state_dict(sd, strict=strict)
+        self.invalidate_packs()
+        return out
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_packs()
+        return out
+
+    # ------------------------------------------------------------------ reference-shaped (list based) post-processing
+    def postprocess_detections(self, head_outputs, anchors, image_shapes):
+        """torchvision 0.12 RetinaNet.postprocess_detections [EXT]: per image, per level: sigmoid, > score_thresh, top-k
+        (1000) candidates, decode + clip; then class-aware NMS (0.5) and the first detections_per_img."""
+        class_logits, box_regression = head_outputs["cls_logits"], head_outputs["bbox_regression"]
+        detections = []
+        for index in range(len(image_shapes)):
+            ib, is_, il = [], [], []
+            for breg, logits, anc in zip((b[index] for b in box_regression), (c[index] for c in class_logits), anchors[index]):
+                num_classes = logits.shape[-1]
+                scores = torch.sigmoid(logits.detach()).flatten()
+                keep = scores > self.score_thresh
+                scores, topk_idxs = scores[keep], torch.where(keep)[0]
+                num_topk = min(self.topk_candidates, topk_idxs.size(0))
+                order = torch.sort(scores, descending=True, stable=True)[1][:num_topk]
+                scores, topk_idxs = scores[order], topk_idxs[order]
+                anchor_idxs = torch.div(topk_idxs, num_classes, rounding_mode="floor")
+                boxes = self.box_coder.decode_single(breg.detach()[anchor_idxs], anc[anchor_idxs])
+                ib.append(D.clip_boxes_to_image(boxes, image_shapes[index]))
+                is_.append(scores)
+                il.append(topk_idxs % num_classes)
+            ib, is_, il = torch.cat(ib, 0), torch.cat(is_, 0), torch.cat(il, 0)
+            order, sel, _ = D._batched_nms_padded(ib[None], is_[None], il[None], torch.ones_like(is_[None], dtype=torch.bool),
+                                                  self.nms_thresh, self.detections_per_img)
+            keep = order[0][sel[0]]
+            detections.append({"boxes": ib[keep], "scores": is_[keep], "labels": il[keep]})
+        return detections
+
+    # ------------------------------------------------------------------ batched form (no per-image / per-level host syncs)
+    def postprocess_detections_padded(self, cls_logits, bbox_regression, anchors0, napl, image_shape):
+        """Same selection on padded tensors.  cls_logits [B, A, K], bbox_regression [B, A, 4], anchors0 [A, 4], napl =
+        anchors per level.  Returns boxes [B, D, 4], scores [B, D], labels [B, D], counts [B] (D = detections_per_img)."""
+        B, _, K = cls_logits.shape
+        cb, cs, cl, cv = [], [], [], []
+        lo = 0
+        for n in napl:
+            logits = cls_logits[:, lo:lo + n].detach().reshape(B, n * K)
+            scores = torch.sigmoid(logits)
+            keep = scores > self.score_thresh
+            k = min(self.topk_candidates, n * K)
+            key = torch.where(keep, scores, torch.full_like(scores, float("-inf")))
+            skey, idx = torch.sort(key, dim=1, descending=True, stable=True)
+            idx, sc = idx[:, :k], skey[:, :k]
+            valid = sc > float("-inf")
+            aidx = torch.div(idx, K, rounding_mode="floor")
+            breg = torch.gather(bbox_regression[:, lo:lo + n].detach(), 1, aidx[:, :, None].expand(-1, -1, 4))
+            anc = anchors0[lo:lo + n][aidx]
+            boxes = self.box_coder.decode_single(breg.reshape(-1, 4), anc.reshape(-1, 4)).reshape(B, k, 4)
+            cb.append(D.clip_boxes_to_image(boxes, image_shape))
+            cs.append(torch.where(valid, sc, torch.zeros_like(sc)))
+            cl.append(idx % K)
+            cv.append(valid)
+            lo += n
+        cb, cs, cl, cv = torch.cat(cb, 1), torch.cat(cs, 1), torch.cat(cl, 1), torch.cat(cv, 1)
+        order, sel, counts = D._batched_nms_padded(cb, cs, cl, cv, self.nms_thresh, self.detections_per_img)
+        top = min(self.detections_per_img, cs.shape[1])
+        front = torch.sort((~sel).to(torch.uint8), dim=1, stable=True)[1][:, :top]
+        pick = torch.gather(order, 1, front)
+        return (torch.gather(cb, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(cs, 1, pick), torch.gather(cl, 1, pick), counts)
+
+
+def retinanet_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pretrained_backbone=False, weights_path=None, **kwargs):
+    """torchvision.models.detection.retinanet_resnet50_fpn [EXT].  COCO weights cannot be downloaded offline:
+    `pretrained=True` is accepted for signature compatibility and ignored unless `weights_path` points at a local
+    torchvision state_dict (same policy as fasterrcnn_resnet50_fpn)."""
+    model = RetinaNet(num_classes=num_classes, **kwargs)
+    if weights_path is not None:
+        model.load_state_dict(torch.load(weights_path, map_location="cpu"))
+    return model
+
+
+# ======================================================================================================================
+# batched losses (eval_forward_retinanet.py:163-244 without the per-image loops)
+# ======================================================================================================================
+def retinanet_match_batched(model, anchors0, gt, gvalid):
+    """:165-175: box_iou + proposal_matcher per image; GT-less images are all -1.  -> matched idx [B, A]."""
+    iou = ops.box_iou_batched(gt, anchors0)
+    pm = model.proposal_matcher
+    return D._match_batched(iou, gvalid, pm.high_threshold, pm.low_threshold, pm.allow_low_quality_matches)
+
+
+def retinanet_loss_batched(model, anchors0, gt, glab, gvalid, cls_logits, bbox_regression, matched=None):
+    """compute_retinanet_loss for B images sharing one anchor set: focal loss over the non-ignored anchors and smooth-L1
+    (beta 1) over the foreground anchors, each / max(1, num_foreground) per image, averaged over images."""
+    from ..utils.eval_forward_retinanet import sigmoid_focal_loss
+    B = cls_logits.shape[0]
+    m = retinanet_match_batched(model, anchors0, gt, gvalid) if matched is None else matched
+    fg = m >= 0
+    num_fg = fg.sum(dim=1).clamp(min=1).to(cls_logits.dtype)
+    mi = m.clamp(min=0)
+    lab = torch.gather(glab, 1, mi)
+    tgt = torch.zeros_like(cls_logits)
+    tgt.scatter_(2, lab[:, :, None], fg[:, :, None].to(cls_logits.dtype))
+    valid = (m != D.Matcher.BETWEEN_THRESHOLDS)[:, :, None]
+    fl = sigmoid_focal_loss(cls_logits, tgt, reduction="none")
+    cls_loss = (torch.where(valid, fl, torch.zeros_like(fl)).sum(dim=(1, 2)) / num_fg).sum() / B
+    mgt = torch.gather(gt, 1, mi[:, :, None].expand(-1, -1, 4))
+    anc = anchors0[None].expand(B, -1, -1)
+    mgt = torch.where(fg[:, :, None], mgt, anc)                      # background rows: encode(anchor, anchor) = 0, finite
+    reg_t = model.box_coder.encode_single(mgt.reshape(-1, 4), anc.reshape(-1, 4)).reshape(B, -1, 4)
+    l1 = F.smooth_l1_loss(bbox_regression, torch.where(fg[:, :, None], reg_t, bbox_regression.detach()), reduction="none", beta=1.0)
+    reg_loss = (torch.where(fg[:, :, None], l1, torch.zeros_like(l1)).sum(dim=(1, 2)) / num_fg).sum() / max(1, B)
+    return {"classification": cls_loss, "bbox_regression": reg_loss}

@@ -50,7 +50,7 @@ def test_detector_factory_surface_and_keys():
     for attr in ("select_training_samples", "box_roi_pool", "box_head", "box_predictor", "postprocess_detections"):
         assert hasattr(d.roi_heads, attr)
     with pytest.raises(NotImplementedError):
-        Detector(name="retinanet", pretrained=False)
+        Detector(name="fcos", pretrained=False)
     # torchvision >= 0.13 key names are accepted
     sd = d.state_dict()
     sd2 = {k.replace("fpn.inner_blocks.0.", "fpn.inner_blocks.0.0.").replace("rpn.head.conv.", "rpn.head.conv.0.0."): v for k, v in sd.items()}
@@ -122,3 +122,30 @@ def test_oracle_train_step_runs_and_learns_direction():
     total, losses = tr.train_step(synthetic.make_batch(1, 64, 96, seed=2))
     assert torch.isfinite(total) and set(losses) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"}
     assert not torch.equal(before, tr.unet.segmentation_head[0].weight)
+
+
+def test_retinanet_state_dict_tree_equals_oracle_tree():
+    """torchvision-0.12 retinanet_resnet50_fpn attribute tree (re-headed to 2 classes by Detector, detector.py:57-66)."""
+    import math
+    from hallucidet_amd.models.detector import Detector
+    from oracle import retinanet as orn
+    det = Detector(name="retinanet", pretrained=False, n_classes=2, size=300).detector
+    want = orn.RetinaNet(num_classes=2, size=300).state_dict()
+    got = det.state_dict()
+    assert list(got.keys()) == list(want.keys())
+    assert all(got[k].shape == want[k].shape for k in got)
+    cl = det.head.classification_head
+    assert cl.num_classes == 2 and cl.cls_logits.out_channels == 18 and cl.BETWEEN_THRESHOLDS == -2
+    assert torch.allclose(cl.cls_logits.bias, torch.full((18,), -math.log(99.0)))
+    assert det.anchor_generator.sizes == ((32, 40, 50), (64, 80, 101), (128, 161, 203), (256, 322, 406), (512, 645, 812))
+    assert det.transform.fixed_size == (300, 300) and det.topk_candidates == 1000 and det.detections_per_img == 300
+    # torchvision >= 0.13 key spelling loads too
+    sd13 = {}
+    for k, v in got.items():
+        for i in range(3):
+            k = k.replace("fpn.inner_blocks.%d." % i, "fpn.inner_blocks.%d.0." % i).replace("fpn.layer_blocks.%d." % i, "fpn.layer_blocks.%d.0." % i)
+        for i in range(4):
+            k = k.replace("_head.conv.%d." % (2 * i), "_head.conv.X%d.0." % i)
+        sd13[k.replace("conv.X", "conv.")] = v
+    assert set(sd13) != set(got)
+    det.load_state_dict(sd13)
