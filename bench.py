@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--detector", default="fasterrcnn", choices=["fasterrcnn", "retinanet"],
+                    help="fasterrcnn = the configuration BASELINE.json's metric is quoted on (default); retinanet = configs[4]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -106,7 +108,7 @@ def main():
 
     from hallucidet_amd import synthetic
     dev = "cuda:%d" % local
-    lit = synthetic.make_module(seed=123, device=dev, precision=16)
+    lit = synthetic.make_module(seed=123, device=dev, precision=16, detector_name=args.detector)
     batch = synthetic.make_batch(BATCH_PER_GPU, H, W, seed=123 + rank, device=dev)   # per-rank shard, resident in HBM
 
     for _ in range(args.warmup):
@@ -137,9 +139,12 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
-                                   "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300, loss scaling, "
-                                   "value clip 0.5, Adam", "global_batch": BATCH_PER_GPU * world, "image": "1x512x640 IR + 3x512x640 RGB",
+            "config": {"workload": ("train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
+                                    "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300, loss scaling, "
+                                    "value clip 0.5, Adam") if args.detector == "fasterrcnn" else
+                                   ("train_hallucidet.py retinanet batch=8 fp16 (BASELINE configs[4], NOT the headline config); "
+                                    "U-Net resnet34 fwd+bwd, 3 frozen RetinaNet R50-FPN passes @300x300, loss scaling, clip, Adam"),
+                       "global_batch": BATCH_PER_GPU * world, "image": "1x512x640 IR + 3x512x640 RGB",
                        "parallelism": "dp%d" % world, "alg_gflop_per_image": 428.5,
                        "step_alg_tflops": round(428.5e9 * value / 1e12, 1)},
             "final_loss": round(float(loss), 5),

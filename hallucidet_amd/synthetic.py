@@ -22,12 +22,12 @@ def make_batch(n=8, h=512, w=640, seed=123, device="cpu"):
     return imgs_rgb, targets, imgs_ir, [dict(t) for t in targets]
 
 
-def make_module(seed=123, device="cuda", precision=16, calibrate_on=None):
+def make_module(seed=123, device="cuda", precision=16, calibrate_on=None, detector_name="fasterrcnn"):
     """Random-init U-Net (reference init rules) + random-init detector whose FrozenBN statistics are calibrated on a
     synthetic batch (there are no checkpoints offline)."""
     from .train_hallucidet import EncoderDecoderLit
     torch.manual_seed(seed)
-    lit = EncoderDecoderLit(batch_size=8, model_name="resnet34", detector_name="fasterrcnn", precision=precision, device=device)
+    lit = EncoderDecoderLit(batch_size=8, model_name="resnet34", detector_name=detector_name, precision=precision, device=device)
     lit.prepare()
     if calibrate_on is None:
         calibrate_on = make_batch(2, seed=seed + 1, device=device)[0]

@@ -8,9 +8,11 @@ import time
 import torch
 
 from . import detection as od
+from . import retinanet as orn
 from . import unet as ou
 
 LOSS_WEIGHTS = {"loss_box_reg": 0.1, "loss_classifier": 0.1, "loss_objectness": 0.1, "loss_rpn_box_reg": 0.1}
+LOSS_WEIGHTS_RETINANET = {"classification": 0.1, "bbox_regression": 0.1}      # train_hallucidet.py:196-197 + config.py weights
 
 
 class OracleTrainer:
@@ -23,15 +25,18 @@ class OracleTrainer:
             p.requires_grad = False
         self.opt = torch.optim.Adam(self.unet.parameters(), lr=lr)
         self.clip = clip
+        self.unet_q = None          # optional activation rounding schedule (tests: oracle.unet.fp16_round)
 
     def forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir):
         ir3 = imgs_ir.repeat(1, 3, 1, 1) if imgs_ir.shape[1] == 1 else imgs_ir
-        hall = self.unet(ir3)
-        losses, det_h = od.eval_forward_fasterrcnn(self.det, hall, targets_ir)
+        hall = self.unet(ir3) if self.unet_q is None else self.unet(ir3, q=self.unet_q)
+        retina = isinstance(self.det, orn.RetinaNet)
+        fwd = orn.eval_forward_retinanet if retina else od.eval_forward_fasterrcnn
+        losses, det_h = fwd(self.det, hall, targets_ir)
         with torch.no_grad():
-            _, det_rgb = od.eval_forward_fasterrcnn(self.det, imgs_rgb, targets_rgb)
-            _, det_ir = od.eval_forward_fasterrcnn(self.det, ir3, targets_ir)
-        total = sum(losses[k] * w for k, w in LOSS_WEIGHTS.items())
+            _, det_rgb = fwd(self.det, imgs_rgb, targets_rgb)
+            _, det_ir = fwd(self.det, ir3, targets_ir)
+        total = sum(losses[k] * w for k, w in (LOSS_WEIGHTS_RETINANET if retina else LOSS_WEIGHTS).items())
         return total, losses, (det_h, det_rgb, det_ir)
 
     def train_step(self, batch):

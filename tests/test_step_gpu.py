@@ -1,0 +1,129 @@
+"""End-to-end parity of ONE training step (BASELINE north-star path: U-Net fwd -> 3 detector passes -> weighted loss ->
+backward into the U-Net -> clip 0.5 -> Adam) against oracle/step.py (the CPU restatement of train_hallucidet.py:161-240
+plus Lightning's optimisation loop), for both detectors (config 1/2: Faster R-CNN, config 4: RetinaNet).
+
+The forward quantities (11-key loss dict) are compared directly.  The update is compared through Adam's first step, which
+is -lr * sign(g) wherever |g| >> eps: the sign agreement of the parameter deltas measures the whole backward chain
+(detector dgrad, resize bwd, U-Net dgrad/wgrad/BN bwd, loss-scale removal, clipping, fused Adam) in one number.  fp16
+activations flip ReLU masks relative to the fp32 oracle (DESIGN.md "fp16 noise"), which bounds that agreement below 1."""
+import pytest
+import torch
+
+from oracle import detection as od
+from oracle import retinanet as orn
+from oracle import unet as ou
+from oracle.step import OracleTrainer
+from test_detector_gpu import fold_oracle_
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(dev, detector_name, seed):
+    from hallucidet_amd import synthetic
+    lit = synthetic.make_module(seed=seed, device=str(dev), precision=16, detector_name=detector_name)
+    det = lit.detector
+    with torch.no_grad():
+        for mod in det.modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)) and mod.bias is not None:
+                mod.weight.copy_(mod.weight.half().float())
+        if detector_name == "retinanet":
+            det.head.classification_head.cls_logits.bias.fill_(-2.0)
+    det.invalidate_packs()
+    ounet = ou.Unet(classes=3)
+    ounet.load_state_dict({k: v.cpu() for k, v in lit.encoder_decoder.state_dict().items()})
+    odet = orn.RetinaNet(num_classes=2, size=300) if detector_name == "retinanet" else od.FasterRCNN(num_classes=2, size=300)
+    odet.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    fold_oracle_(odet)
+    odet.set_quant(ou.fp16_round)
+    tr = OracleTrainer(unet=ounet, detector=odet, lr=lit.lr, clip=0.5)
+    tr.unet_q = ou.fp16_round
+    with torch.no_grad():       # product stores conv weights in fp16 for the GEMMs
+        for m in ounet.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.copy_(m.weight.half().float())
+    # yardstick: the SAME oracle weights evaluated without any activation rounding (pure fp32)
+    import copy
+    tr32 = OracleTrainer(unet=copy.deepcopy(ounet), detector=copy.deepcopy(odet), lr=lit.lr, clip=0.5)
+    tr32.det.set_quant(lambda t: t)
+    if detector_name == "fasterrcnn":
+        for t_, sd in ((tr, 1), (tr32, 1)):       # same sampler draws on both oracle sides
+            g = torch.Generator().manual_seed(sd)
+            fn = (lambda gg: (lambda n: torch.randperm(n, generator=gg)))(g)
+            t_.det.rpn.fg_bg_sampler.randperm_fn = fn
+            t_.det.roi_heads.fg_bg_sampler.randperm_fn = fn
+    return lit, tr, tr32
+
+
+def _to_cpu(batch):
+    rgb, trgb, ir, tir = batch
+    c = lambda ts: [{k: v.cpu() for k, v in t.items()} for t in ts]
+    return rgb.cpu(), c(trgb), ir.cpu(), c(tir)
+
+
+@pytest.mark.parametrize("detector_name", ["retinanet", "fasterrcnn"])
+def test_training_step_matches_oracle(dev, detector_name):
+    from hallucidet_amd import synthetic
+    lit, tr, tr32 = _pair(dev, detector_name, seed=5)
+    batch = synthetic.make_batch(2, 128, 160, seed=6, device=str(dev))
+    names = [n for n, _ in tr.unet.named_parameters()]
+    p_before = {n: p.detach().clone() for n, p in tr.unet.named_parameters()}
+    tr32.unet.train()
+    tr32.train_step(_to_cpu(batch))              # one step from the same start, for the yardstick
+    g_before = {k: v.detach().cpu().clone() for k, v in lit.encoder_decoder.state_dict().items()}
+
+    # ---- forward quantities
+    lit.encoder_decoder.train()
+    tr.unet.train()
+    out = lit.forward_step(*batch, 0, step="train")
+    assert set(out["loss"]) == {"total", "pixel_rgb", "perceptual_rgb", "pixel_ir", "perceptual_ir", "det_regression",
+                                "det_classification", "det_objectness", "det_rpn_box_reg", "det_bbox_ctrness", "det_total"}
+    total, olosses, _ = tr.forward_step(*_to_cpu(batch))
+    keymap = ({"det_classification": "classification", "det_regression": "bbox_regression"} if detector_name == "retinanet" else
+              {"det_classification": "loss_classifier", "det_regression": "loss_box_reg", "det_objectness": "loss_objectness",
+               "det_rpn_box_reg": "loss_rpn_box_reg"})
+    # RetinaNet has no sampler: every loss is a deterministic function of the features -> tight; Faster R-CNN draws
+    # different random subsets on the two sides and proposals reorder under fp16 noise -> loose (see test_detector_gpu)
+    tol = 0.03 if detector_name == "retinanet" else 0.3
+    for pk, ok_ in keymap.items():
+        a, b = float(out["loss"][pk]), 0.1 * float(olosses[ok_])
+        assert abs(a - b) < tol * abs(b) + 2e-3, (pk, a, b)
+    if detector_name == "retinanet":
+        assert out["loss"]["det_objectness"] == 0.0 and out["loss"]["det_rpn_box_reg"] == 0.0 and out["loss"]["det_bbox_ctrness"] == 0.0
+        assert abs(float(out["loss"]["total"]) - float(total)) < tol * abs(float(total)) + 2e-3
+    hall = out["output"]["imgs_hallucinated"]
+    assert hall.shape == (2, 3, 128, 160) and float(hall.min()) >= 0.0 and float(hall.max()) <= 1.0
+
+    # ---- one optimisation step on both sides (fresh forward: BN running statistics advance once more on both)
+    loss = lit.fit_step(batch)
+    if detector_name == "fasterrcnn":                # re-seed so that train_step draws what tr32's single step drew
+        g = torch.Generator().manual_seed(1)
+        fn = lambda n: torch.randperm(n, generator=g)
+        tr.det.rpn.fg_bg_sampler.randperm_fn = tr.det.roi_heads.fg_bg_sampler.randperm_fn = fn
+    tr.train_step(_to_cpu(batch))
+    assert torch.isfinite(loss)
+    after = {k: v.detach().cpu() for k, v in lit.encoder_decoder.state_dict().items()}
+    agree = tot = yard = 0
+    moved = 0
+    p32 = dict(tr32.unet.named_parameters())
+    for n in names:
+        d_ref = dict(tr.unet.named_parameters())[n].detach() - p_before[n]
+        d_got = after[n].float() - g_before[n].float()
+        d_32 = p32[n].detach() - p_before[n]
+        assert float(d_got.abs().max()) <= lit.lr * 1.01 + 1e-9, n         # Adam's first step is bounded by lr
+        sel = d_ref.abs() > 0.5 * lit.lr                                     # |g| >> eps on the oracle side
+        if n.endswith(".bias") and ".bn" not in n and "segmentation_head" not in n:
+            continue
+        agree += int((torch.sign(d_ref[sel]) == torch.sign(d_got[sel])).sum())
+        yard += int((torch.sign(d_ref[sel]) == torch.sign(d_32[sel])).sum())
+        tot += int(sel.sum())
+        moved += int((d_got != 0).any())
+    frac, yfrac = agree / max(tot, 1), yard / max(tot, 1)
+    print("%s: Adam-step sign agreement product~oracle(fp16 schedule) %.3f ; yardstick oracle(fp16)~oracle(fp32) %.3f ; "
+          "%d coordinates, %d/%d tensors moved" % (detector_name, frac, yfrac, tot, moved, len(names)))
+    assert tot > 1e6 and moved > 0.9 * len(names)
+    # the product must be about as close to the fp16-schedule oracle as that oracle is to exact fp32 arithmetic
+    assert frac > yfrac - 0.06 and frac > 0.6, (frac, yfrac)
+    # BN running statistics advanced identically (two train-mode forwards on both sides)
+    for k in ("encoder.bn1.running_mean", "decoder.blocks.4.conv2.1.running_var"):
+        ref = tr.unet.state_dict()[k]
+        assert torch.allclose(after[k].float(), ref, rtol=5e-2, atol=5e-3), k
