@@ -145,8 +145,8 @@ def main():
                                    ("train_hallucidet.py retinanet batch=8 fp16 (BASELINE configs[4], NOT the headline config); "
                                     "U-Net resnet34 fwd+bwd, 3 frozen RetinaNet R50-FPN passes @300x300, loss scaling, clip, Adam"),
                        "global_batch": BATCH_PER_GPU * world, "image": "1x512x640 IR + 3x512x640 RGB",
-                       "parallelism": "dp%d" % world, "alg_gflop_per_image": 428.5,
-                       "step_alg_tflops": round(428.5e9 * value / 1e12, 1)},
+                       "parallelism": "dp%d" % world, "alg_gflop_per_image": 428.5 if args.detector == "fasterrcnn" else None,
+                       "step_alg_tflops": round(428.5e9 * value / 1e12, 1) if args.detector == "fasterrcnn" else None},
             "final_loss": round(float(loss), 5),
         }
         if not args.no_roofline:
