@@ -65,17 +65,28 @@ def conv_roofline(lit, batch, reps=5):
         r.enable_graphs(was)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     tot_ms, tot_fl = 0.0, 0.0
+    dump = os.environ.get("HD_BENCH_DUMP")
+    rows = []
     for kw, (x, w, KH, KW), fl in rec:
-        kw = dict(kw)
-        kw["want_stats"] = False
+        kw = dict(kw)                                 # same epilogue (bias / res / mask / BN statistics) as in the step
         orig(x, w, KH, KW, **kw)                      # warm
         e0.record()
         for _ in range(reps):
             orig(x, w, KH, KW, **kw)
         e1.record()
         e1.synchronize()
-        tot_ms += e0.elapsed_time(e1) / reps
+        ms = e0.elapsed_time(e1) / reps
+        tot_ms += ms
         tot_fl += fl
+        if dump:
+            rows.append((ms * 1e3, fl / 1e9, tuple(x.shape), 0 if kw.get("x2") is None else kw["x2"].shape[3], tuple(w.shape), KH,
+                         kw.get("stride", 1), kw.get("in_dil", 1), bool(kw.get("up1")), bool(kw.get("want_stats")),
+                         kw.get("mask") is not None, kw.get("res") is not None))
+    if dump:
+        with open(dump, "w") as f:
+            for r_ in rows:
+                f.write("%8.1f us %8.2f GF %7.1f TF  x=%s c2=%d w=%s k=%d s=%d dil=%d up=%d stats=%d mask=%d res=%d\n"
+                        % (r_[0], r_[1], r_[1] / r_[0] * 1e-3 * 1e3, *r_[2:]))
     n = len(rec)
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",

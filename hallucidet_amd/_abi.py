@@ -88,6 +88,7 @@ PROTOTYPES = {
     "hd_roi_align": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_roi_align_ml": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "hd_roi_align_ml_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_roi_align_ml_bwd_gather": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 7 + [vp]),
     "hd_roi_align_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_box_iou": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "hd_box_iou_batched": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),

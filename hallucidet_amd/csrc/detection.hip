@@ -398,6 +398,149 @@ __global__ __launch_bounds__(64) void roi_align_ml_bwd_patch_kernel(MLFeat ml, c
     }
 }
 
+// ---- RoIAlign backward, gather form -------------------------------------------------------------------------------
+// One thread owns ONE feature pixel (and CCH channels) and pulls the gradient from every RoI bin that touches it: no
+// atomics, no zero-initialised fp32 maps, every output element is written exactly once (fp32 accumulate, fp16 store)
+// and the result is bit-reproducible run to run.  The bilinear weight of a sample point is separable, and so is the sum
+// over the SRxSR sample points of a bin:  w(pixel <- bin (ph,pw)) = WY[ph] * WX[pw] / count  with
+// WY[ph] = sum over the bin's sample rows of the row weight of pixel row py (same clamping rules as the forward).
+// Block = 16x16 pixel tile of one (level, image) x CCH channels.  The block first scans the RoI list (any order) for
+// RoIs of its image / level whose touched-pixel box meets the tile (ordered compaction -> deterministic summation
+// order), then every thread walks that list.
+struct GatherRoi {
+  float rsw, rsh, bw, bh;
+  int r;
+  short y0, y1, x0, x1;
+};
+
+template <int SR>
+__device__ __forceinline__ float axis_weight(float start, float bin, int p, int pix, int size) {
+  // sum over the SR sample coordinates of bin `p` of the weight with which they hit pixel `pix` along one axis
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < SR; ++i) {
+    float y = start + (float)p * bin + ((float)i + .5f) * bin / (float)SR;
+    if (y < -1.0f || y > (float)size) continue;
+    if (y <= 0.f) y = 0.f;
+    int yl = (int)y, yh;
+    if (yl >= size - 1) {
+      yh = yl = size - 1;
+      y = (float)yl;
+    } else
+      yh = yl + 1;
+    const float ly = y - (float)yl, hy = 1.f - ly;
+    acc += (yl == pix ? hy : 0.f) + (yh == pix ? ly : 0.f);
+  }
+  return acc;
+}
+
+template <int PH, int PW, int SR, int CCH>
+__global__ __launch_bounds__(256) void roi_align_ml_bwd_gather_kernel(MLFeat ml, f16* const* __restrict__ dst_unused, const f16* __restrict__ dout,
+                                                                      const float* __restrict__ rois, const int* __restrict__ level,
+                                                                      int R, int C, int L, int4 tile_base, int n_images) {
+  constexpr int CAP = 1024;
+  __shared__ GatherRoi list[CAP];
+  __shared__ int wcnt[4];
+  // ---- which tile
+  int b = blockIdx.x, l = 0;
+  const int bases[4] = {tile_base.x, tile_base.y, tile_base.z, tile_base.w};
+  while (l + 1 < L && b >= bases[l + 1]) ++l;
+  b -= bases[l];
+  const int H = ml.H[l], W = ml.W[l];
+  const int tw = (W + 15) / 16, th = (H + 15) / 16;
+  const int n = b / (tw * th);
+  const int ty = (b / tw) % th, tx = b % tw;
+  const int c0 = blockIdx.y * CCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int py = ty * 16 + (tid >> 4), px = tx * 16 + (tid & 15);
+  const bool live = py < H && px < W;
+  const int ty0 = ty * 16, ty1 = min(ty * 16 + 15, H - 1), tx0 = tx * 16, tx1 = min(tx * 16 + 15, W - 1);
+  float acc[CCH];
+#pragma unroll
+  for (int k = 0; k < CCH; ++k) acc[k] = 0.f;
+
+  for (int base = 0; base < R; base += CAP) {
+    // ---- ordered compaction of the RoIs [base, base+CAP) that touch this tile
+    int total = 0;
+    for (int it = 0; it < CAP / 256; ++it) {
+      const int r = base + it * 256 + tid;
+      bool hit = false;
+      GatherRoi e;
+      if (r < R && level[r] == l && (int)rois[(size_t)r * 5] == n) {
+        const RoiGeom g = roi_geom(ml, rois, level, r, PH, PW, SR);
+        if (g.any) {
+          const int y1 = g.y0 + g.ph_ - 1, x1 = g.x0 + g.pw_ - 1;
+          hit = !(y1 < ty0 || g.y0 > ty1 || x1 < tx0 || g.x0 > tx1);
+          e.rsw = g.rsw; e.rsh = g.rsh; e.bw = g.bw; e.bh = g.bh; e.r = r;
+          e.y0 = (short)g.y0; e.y1 = (short)y1; e.x0 = (short)g.x0; e.x1 = (short)x1;
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = total;
+      for (int w = 0; w < wave; ++w) off += wcnt[w];
+      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      __syncthreads();
+    }
+    // ---- every pixel walks the list
+    if (live) {
+      for (int i = 0; i < total; ++i) {
+        const GatherRoi e = list[i];
+        if (py < e.y0 || py > e.y1 || px < e.x0 || px > e.x1) continue;
+        float wy[PH], wx[PW];
+        bool anyy = false, anyx = false;
+#pragma unroll
+        for (int p = 0; p < PH; ++p) {
+          // bin p's sample rows lie in [rsh + p*bh, rsh + (p+1)*bh]; they reach pixel row py only within one pixel of it
+          const float lo = e.rsh + (float)p * e.bh, hi = lo + e.bh;
+          const bool near_ = !(hi < (float)py - 1.f || lo > (float)py + 1.f) || py == 0 || py == H - 1;
+          wy[p] = near_ ? axis_weight<SR>(e.rsh, e.bh, p, py, H) : 0.f;
+          anyy |= wy[p] != 0.f;
+        }
+        if (!anyy) continue;
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+          const float lo = e.rsw + (float)p * e.bw, hi = lo + e.bw;
+          const bool near_ = !(hi < (float)px - 1.f || lo > (float)px + 1.f) || px == 0 || px == W - 1;
+          wx[p] = near_ ? axis_weight<SR>(e.rsw, e.bw, p, px, W) : 0.f;
+          anyx |= wx[p] != 0.f;
+        }
+        if (!anyx) continue;
+        const f16* dr = dout + (size_t)e.r * PH * PW * C + c0;
+#pragma unroll
+        for (int ph = 0; ph < PH; ++ph) {
+          if (wy[ph] == 0.f) continue;
+#pragma unroll
+          for (int pw = 0; pw < PW; ++pw) {
+            const float w = wy[ph] * wx[pw] * (1.f / (float)(SR * SR));
+            if (w == 0.f) continue;
+            const f16* q = dr + (size_t)(ph * PW + pw) * C;
+#pragma unroll
+            for (int v = 0; v < CCH / 8; ++v) {
+              const f16x8 d = *reinterpret_cast<const f16x8*>(q + v * 8);
+#pragma unroll
+              for (int k = 0; k < 8; ++k) acc[v * 8 + k] += w * (float)d[k];
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (live) {
+    f16* o = const_cast<f16*>(ml.f[l]) + (((size_t)n * H + py) * W + px) * C + c0;
+#pragma unroll
+    for (int v = 0; v < CCH / 8; ++v) {
+      f16x8 t;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = (f16)acc[v * 8 + k];
+      *reinterpret_cast<f16x8*>(o + v * 8) = t;
+    }
+  }
+}
+
 __global__ void box_iou_kernel(const float* __restrict__ gt, int G, const float* __restrict__ boxes, int A, float* __restrict__ iou) {
   const int64_t total = (int64_t)G * A;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -496,6 +639,29 @@ extern "C" int hd_roi_align_ml(const void* const* feats, const int* H, const int
   int g = (int)((total + 255) / 256);
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(roi_align_ml_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ml, rois, level, (f16*)out, R, C, PH, PW, sampling_ratio);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_align_ml_bwd_gather(const void* dout, const float* rois, const int* level, void* const* dfeat_f16, const int* H,
+                                          const int* W, const float* scale, int L, int R, int n_images, int C, int PH, int PW,
+                                          int sampling_ratio, void* stream) {
+  HD_CHECK_ARG(dout && rois && level && dfeat_f16 && H && W && scale && L >= 1 && L <= 4 && R >= 0 && n_images >= 0, "hd_roi_align_ml_bwd_gather: bad args");
+  HD_CHECK_ARG(PH == 7 && PW == 7 && sampling_ratio == 2 && C % 32 == 0,
+               "hd_roi_align_ml_bwd_gather: built for the 7x7 / sampling_ratio 2 pooler of the hot path (got %dx%d sr %d C %d)", PH, PW, sampling_ratio, C);
+  if (n_images == 0) return HD_OK;
+  MLFeat ml = {};
+  int base[5] = {0, 0, 0, 0, 0};
+  for (int l = 0; l < L; ++l) {
+    ml.f[l] = (const f16*)dfeat_f16[l];       // destination maps ride in the `f` slots (fp16), written once per element
+    ml.H[l] = H[l];
+    ml.W[l] = W[l];
+    ml.scale[l] = scale[l];
+    base[l + 1] = base[l] + n_images * ((H[l] + 15) / 16) * ((W[l] + 15) / 16);
+  }
+  for (int l = L; l < 4; ++l) base[l + 1] = base[L];
+  hipLaunchKernelGGL((roi_align_ml_bwd_gather_kernel<7, 7, 2, 32>), dim3(base[L], C / 32), dim3(256), 0, (hipStream_t)stream, ml,
+                     (f16* const*)nullptr, (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]), n_images);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

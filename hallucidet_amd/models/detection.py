@@ -693,7 +693,7 @@ class RegionProposalNetwork(nn.Module):
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, rois, levels, cfg, *feats):
-        scales, P, sr = cfg
+        scales, P, sr = cfg[:3]
         ctx.save_for_backward(rois, levels)
         ctx.cfg = cfg
         ctx.shapes = [tuple(f.shape) for f in feats]
@@ -702,7 +702,11 @@ class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         rois, levels = ctx.saved_tensors
-        scales, P, sr = ctx.cfg
+        scales, P, sr = ctx.cfg[:3]
+        if P == 7 and sr == 2 and dout.shape[-1] % 32 == 0:
+            # gather form: no atomics, deterministic, fp16 written once; cfg[3] = number of leading images that own RoIs
+            n_images = ctx.cfg[3] if len(ctx.cfg) > 3 else None
+            return (None, None, None) + tuple(ops.roi_align_ml_bwd_gather(dout, rois, levels, ctx.shapes, scales, sr, n_images))
         dfs = ops.roi_align_ml_bwd(dout, rois, levels, ctx.shapes, scales, sr)
         return (None, None, None) + tuple(ops.f32_to_f16(d) for d in dfs)
 
@@ -1028,6 +1032,8 @@ def _sample_batched(sampler, labels):
     N, A = labels.shape
     dev = labels.device
     pos, neg = labels >= 1, labels == 0
+    if sampler.randperm_fn is None:
+        return _sample_batched_keys(sampler, pos, neg)
     cnt = torch.stack([pos.sum(1), neg.sum(1)], dim=1).tolist()          # the one host sync of the sampler
     rows_p, cols_p, rows_n, cols_n, picked = [], [], [], [], []
     for i, (P_i, N_i) in enumerate(cnt):
@@ -1046,6 +1052,32 @@ def _sample_batched(sampler, labels):
     rn = (torch.cumsum(neg, dim=1) - 1).clamp(min=0) + torch.arange(N, device=dev)[:, None] * A
     pos_sel = pos & rank_sel_p[rp]
     neg_sel = neg & rank_sel_n[rn]
+    return pos_sel, neg_sel, picked
+
+
+def _sample_batched_keys(sampler, pos, neg):
+    """The sampler's draws for a whole batch in ONE sort: a uniformly random subset of size k of a population is the k
+    smallest of iid random keys -- which is also how `torch.randperm` is implemented -- so every image's positives get
+    keys in [0,1), negatives in [2,3), everything else 4, and one row-wise sort lines up `randperm(positives)` followed
+    by `randperm(negatives)` for each image.  Same distribution as the reference's 2 draws per image (uniform subsets of
+    sizes min(P, 0.x*B) and min(N, B - num_pos)), 1 sort instead of 2*N randperm launches.  Used when no `randperm_fn` is
+    injected (parity tests inject one and take the per-image path above)."""
+    N, A = pos.shape
+    dev = pos.device
+    B = sampler.batch_size_per_image
+    cap_p = int(B * sampler.positive_fraction)
+    keys = torch.rand((N, A), dtype=torch.float64, device=dev)
+    keys = torch.where(pos, keys, torch.where(neg, keys + 2.0, torch.full_like(keys, 4.0)))
+    order = torch.sort(keys, dim=1)[1]
+    P, Nn = pos.sum(1), neg.sum(1)
+    num_pos = P.clamp(max=cap_p)
+    num_neg = torch.minimum(Nn, B - num_pos)
+    ar = torch.arange(A, device=dev)[None, :]
+    sp = ar < num_pos[:, None]
+    sn = (ar >= P[:, None]) & (ar < (P + num_neg)[:, None])
+    pos_sel = torch.zeros_like(pos).scatter_(1, order, sp)
+    neg_sel = torch.zeros_like(neg).scatter_(1, order, sn)
+    picked = [tuple(t) for t in torch.stack([num_pos, num_neg], dim=1).tolist()]     # the one host sync of the sampler
     return pos_sel, neg_sel, picked
 
 
@@ -1154,7 +1186,7 @@ def select_training_samples_batched(rh, props, pcounts, gt, glabels, gvalid):
     return rois, labels, reg_t, per
 
 
-def roi_pool_rois(pool, feats_dict, rois, image_shape):
+def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
     feats = [v for k, v in feats_dict.items() if k in pool.featmap_names]
     device = rois.device
     scales = [pool.infer_scale((f.shape[1], f.shape[2]), image_shape) for f in feats]
@@ -1163,7 +1195,7 @@ def roi_pool_rois(pool, feats_dict, rois, image_shape):
     s = torch.sqrt(box_area(b).float())
     t = torch.floor(pool.canonical_level + torch.log2(s / pool.canonical_scale) + torch.tensor(pool.eps, dtype=s.dtype, device=device))
     levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
-    return _RoIAlignFn.apply(rois.float().contiguous(), levels, (scales, pool.output_size[0], pool.sampling_ratio), *feats)
+    return _RoIAlignFn.apply(rois.float().contiguous(), levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), *feats)
 
 
 def fastrcnn_loss_flat(class_logits, box_regression, labels, regression_targets):

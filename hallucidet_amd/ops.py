@@ -406,6 +406,24 @@ def roi_align_ml_bwd(dout, rois, levels, feat_shapes, scales, sampling_ratio):
     return dfs
 
 
+def roi_align_ml_bwd_gather(dout, rois, levels, feat_shapes, scales, sampling_ratio, n_images=None):
+    """Gather-form backward (7x7 bins, sampling_ratio 2): returns fp16 gradient maps shaped like the features; images
+    >= n_images (no RoI refers to them) stay zero.  No atomics: deterministic, every element written once."""
+    L = len(feat_shapes)
+    R, PH, PW, C_ = dout.shape
+    N = feat_shapes[0][0]
+    n_images = N if n_images is None else min(int(n_images), N)
+    alloc = torch.empty if n_images == N else torch.zeros
+    dfs = [alloc(s, dtype=torch.float16, device=dout.device) for s in feat_shapes]
+    fp = (C.c_void_p * L)(*[f.data_ptr() for f in dfs])
+    Hs = (C.c_int * L)(*[s[1] for s in feat_shapes])
+    Ws = (C.c_int * L)(*[s[2] for s in feat_shapes])
+    sc = (C.c_float * L)(*scales)
+    check(_abi.load().hd_roi_align_ml_bwd_gather(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(levels), fp, Hs, Ws, sc, L, R,
+                                                 n_images, C_, PH, PW, sampling_ratio, _stream()), "hd_roi_align_ml_bwd_gather")
+    return dfs
+
+
 def box_iou(gt, boxes):
     G, A = gt.shape[0], boxes.shape[0]
     iou = torch.empty((G, A), dtype=torch.float32, device=boxes.device)

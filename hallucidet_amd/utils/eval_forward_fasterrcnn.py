@@ -150,7 +150,7 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     rois, labels, reg_t, per = D.select_training_samples_batched(model.roi_heads, pb, pc, gt, glab, gvalid)
     r0 = sum(per[:n0])
     pool, head, pred = model.roi_heads.box_roi_pool, model.roi_heads.box_head, model.roi_heads.box_predictor
-    bf0 = D.roi_pool_rois(pool, features, rois[:r0], shape)
+    bf0 = D.roi_pool_rois(pool, features, rois[:r0], shape, n_images=n0)
     cl0, br0 = pred(head(bf0))
     with torch.no_grad():                          # the other passes' RoIs: forward only
         f_ng = OrderedDict((k, v.detach()) for k, v in features.items())

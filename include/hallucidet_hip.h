@@ -205,6 +205,13 @@ int hd_roi_align_ml(const void* const* feats, const int* H, const int* W, const 
 int hd_roi_align_ml_bwd(const void* dout, const float* rois, const int* level, float* const* dfeat_f32, const int* H,
                         const int* W, const float* scale, int L, int R, int C, int PH, int PW, int sampling_ratio,
                         void* stream);
+/* gather-form backward of hd_roi_align_ml for the 7x7 / sampling_ratio-2 pooler (MultiScaleRoIAlign as built at
+ * torchvision faster_rcnn.py [EXT]; reached from src/utils/eval_forward_fasterrcnn.py:120 `box_roi_pool`): every element of
+ * dfeat_f16[l][0:n_images] ([.,H[l],W[l],C] f16) is WRITTEN once (no atomics, no zero-fill needed, deterministic);
+ * RoIs may come in any order, their image index (rois[r][0]) must be < n_images. */
+int hd_roi_align_ml_bwd_gather(const void* dout, const float* rois, const int* level, void* const* dfeat_f16, const int* H,
+                               const int* W, const float* scale, int L, int R, int n_images, int C, int PH, int PW,
+                               int sampling_ratio, void* stream);
 /* backward: dfeat must be zeroed by caller; fp32 atomics into dfeat_f32 [N,H,W,C] */
 int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int R, int N, int H, int W, int C, int PH,
                      int PW, float spatial_scale, int sampling_ratio, void* stream);

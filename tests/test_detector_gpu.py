@@ -409,3 +409,26 @@ def test_fused_multi_pass_matches_sequential_on_everything_but_draw_order(dev, c
         for a, b in zip(seq[p][1], fus[p][1]):
             assert torch.equal(a["labels"], b["labels"]) and torch.allclose(a["boxes"], b["boxes"], rtol=1e-6, atol=1e-4)
             assert torch.allclose(a["scores"], b["scores"], rtol=1e-6, atol=1e-7)
+
+
+def test_keyed_batch_sampler_distribution_and_counts(dev):
+    """The one-sort batch sampler (used when no randperm_fn is injected): subset sizes follow torchvision's rules exactly,
+    selections stay inside their class, and every candidate is drawn with equal frequency (uniform subsets)."""
+    from hallucidet_amd.models import detection as D
+    s = D.BalancedPositiveNegativeSampler(16, 0.25)
+    lab = torch.tensor([[1] * 10 + [0] * 40 + [-1] * 14,          # plenty of both: 4 pos, 12 neg
+                        [1] * 2 + [0] * 5 + [-1] * 57,             # short of both: 2 pos, 5 neg
+                        [0] * 64,                                   # no positives: 0 pos, 16 neg
+                        [2] * 3 + [0] * 61], device=dev)           # 3 pos (label >= 1), 13 neg
+    torch.manual_seed(0)
+    hits = torch.zeros(lab.shape, device=dev)
+    for _ in range(400):
+        pos_sel, neg_sel, picked = D._sample_batched(s, lab)
+        assert picked == [(4, 12), (2, 5), (0, 16), (3, 13)]
+        assert pos_sel.sum(1).tolist() == [4, 2, 0, 3] and neg_sel.sum(1).tolist() == [12, 5, 16, 13]
+        assert not (pos_sel & ~(lab >= 1)).any() and not (neg_sel & ~(lab == 0)).any()
+        hits += pos_sel.float() + neg_sel.float()
+    f = (hits / 400).cpu()
+    # row 0: each positive drawn w.p. 4/10, each negative 12/40 ; binomial std ~0.025
+    assert (f[0, :10] - 0.4).abs().max() < 0.1 and (f[0, 10:50] - 0.3).abs().max() < 0.1 and f[0, 50:].sum() == 0
+    assert (f[2] - 0.25).abs().max() < 0.1
