@@ -68,6 +68,8 @@ PROTOTYPES = {
     "hd_bn_bwd_apply": (C.c_int, [vp] * 8 + [C.c_int] + [vp] * 4 + [c_f, C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "hd_maxpool3x3s2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_maxpool3x3s2_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_maxpool3x3s2_idx": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_maxpool3x3s2_bwd_idx": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_subsample2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_subsample2_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
     "hd_nchw_to_nhwc_resize": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),

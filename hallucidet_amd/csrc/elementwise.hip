@@ -124,20 +124,32 @@ __global__ void bn_bwd_reduce_kernel(const f16* __restrict__ dz, const f16* __re
   }
   const bool use_z = relu && z != nullptr;
   if (pl < plan) {
-    for (int64_t p = p0 + pl; p < p1; p += plan) {
-      size_t off = (size_t)p * C + v * 8;
-      f16x8 g = ld8(dz + off), yy = ld8(y + off), zz;
-      if (use_z) zz = ld8(z + off);
+    // 4 pixels per trip with all loads issued up front: the loop is otherwise one dependent HBM round trip per pixel
+    constexpr int U = 4;
+    for (int64_t p = p0 + pl; p < p1; p += (int64_t)plan * U) {
+      f16x8 g[U], yy[U], zz[U];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        float gk = (float)g[k];
-        if (relu) {
-          bool on = use_z ? ((float)zz[k] > 0.f) : ((float)(f16)((float)yy[k] * sc[k] + sh[k]) > 0.f);
-          if (!on) gk = 0.f;
+      for (int u = 0; u < U; ++u) {
+        const int64_t pu = p + (int64_t)u * plan;
+        const size_t off = (size_t)(pu < p1 ? pu : p) * C + v * 8;
+        g[u] = ld8(dz + off);
+        yy[u] = ld8(y + off);
+        if (use_z) zz[u] = ld8(z + off);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (p + (int64_t)u * plan >= p1) break;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float gk = (float)g[u][k];
+          if (relu) {
+            bool on = use_z ? ((float)zz[u][k] > 0.f) : ((float)(f16)((float)yy[u][k] * sc[k] + sh[k]) > 0.f);
+            if (!on) gk = 0.f;
+          }
+          float xh = ((float)yy[u][k] - mu[k]) * is[k];
+          sg[k] += gk;
+          sgx[k] += gk * xh;
         }
-        float xh = ((float)yy[k] - mu[k]) * is[k];
-        sg[k] += gk;
-        sgx[k] += gk * xh;
       }
     }
   }
@@ -308,6 +320,88 @@ __global__ void maxpool_bwd_kernel(const f16* __restrict__ x, const f16* __restr
 #pragma unroll
         for (int k = 0; k < 8; ++k)
           if (bidx[k] == mypos) acc[k] += (float)g[k];
+      }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+    st8(dx + (size_t)p * C + v * 8, o);
+  }
+}
+
+// forward that also records, per output element, WHICH of the 9 window positions won (first maximum in scan order): the
+// backward then reads 1 byte + the gradient per window instead of re-deriving the argmax from 9 inputs per window
+__global__ void maxpool_idx_kernel(const f16* __restrict__ x, f16* __restrict__ y, unsigned char* __restrict__ idx, int N, int H, int W,
+                                   int C, int Ho, int Wo) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * Ho * Wo * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int wo = (int)(p % Wo);
+    int ho = (int)((p / Wo) % Ho);
+    int n = (int)(p / ((int64_t)Wo * Ho));
+    float best[8];
+    int bidx[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      best[k] = -INFINITY;
+      bidx[k] = -1;
+    }
+    for (int kh = 0; kh < 3; ++kh) {
+      int h = ho * 2 - 1 + kh;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int kw = 0; kw < 3; ++kw) {
+        int w = wo * 2 - 1 + kw;
+        if ((unsigned)w >= (unsigned)W) continue;
+        f16x8 t = ld8(x + ((size_t)(n * H + h) * W + w) * C + v * 8);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float f = (float)t[k];
+          if (f > best[k] || bidx[k] < 0) {
+            best[k] = f;
+            bidx[k] = kh * 3 + kw;
+          }
+        }
+      }
+    }
+    f16x8 o;
+    unsigned long long pk = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      o[k] = (f16)best[k];
+      pk |= (unsigned long long)(bidx[k] & 0xff) << (8 * k);
+    }
+    st8(y + (size_t)p * C + v * 8, o);
+    *reinterpret_cast<unsigned long long*>(idx + (size_t)p * C + v * 8) = pk;
+  }
+}
+
+__global__ void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const f16* __restrict__ dy, f16* __restrict__ dx, int N,
+                                       int H, int W, int C, int Ho, int Wo) {
+  const int vecs = C / 8;
+  const int64_t total = (int64_t)N * H * W * vecs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int v = (int)(i % vecs);
+    int64_t p = i / vecs;
+    int w = (int)(p % W);
+    int h = (int)((p / W) % H);
+    int n = (int)(p / ((int64_t)W * H));
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    int ho0 = max(0, h / 2), ho1 = min(Ho - 1, (h + 1) / 2);
+    int wo0 = max(0, w / 2), wo1 = min(Wo - 1, (w + 1) / 2);
+    for (int ho = ho0; ho <= ho1; ++ho)
+      for (int wo = wo0; wo <= wo1; ++wo) {
+        int mykh = h - (ho * 2 - 1), mykw = w - (wo * 2 - 1);
+        if (mykh < 0 || mykh > 2 || mykw < 0 || mykw > 2) continue;
+        const unsigned long long mypos = (unsigned long long)(mykh * 3 + mykw);
+        const size_t off = ((size_t)(n * Ho + ho) * Wo + wo) * C + v * 8;
+        const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + off);
+        f16x8 g = ld8(dy + off);
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          if (((pk >> (8 * k)) & 0xffull) == mypos) acc[k] += (float)g[k];
       }
     f16x8 o;
 #pragma unroll
@@ -697,6 +791,20 @@ extern "C" int hd_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int 
 extern "C" int hd_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
   HD_CHECK_ARG(x && dy && dx && C % 8 == 0, "hd_maxpool3x3s2_bwd: bad args");
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const f16*)x, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_maxpool3x3s2_idx(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  HD_CHECK_ARG(x && y && idx_u8 && C % 8 == 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "hd_maxpool3x3s2_idx: bad args");
+  hipLaunchKernelGGL(maxpool_idx_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, (unsigned char*)idx_u8, N, H, W, C, Ho, Wo);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+  HD_CHECK_ARG(idx_u8 && dy && dx && C % 8 == 0, "hd_maxpool3x3s2_bwd_idx: bad args");
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const unsigned char*)idx_u8, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

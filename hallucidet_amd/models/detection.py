@@ -207,7 +207,7 @@ class BackboneWithFPN(nn.Module):
         na = x.shape[0] if n_active is None else n_active
         rec = {"x": x[:na], "blocks": []} if save else None
         s = _fwd(P["stem"], x, act=ACT_RELU)
-        p = ops.maxpool3x3s2(s)
+        p, pidx = ops.maxpool3x3s2_idx(s) if save else (ops.maxpool3x3s2(s), None)
         cur = p
         C = []
         for stage in P["blocks"]:
@@ -239,7 +239,7 @@ class BackboneWithFPN(nn.Module):
         else:
             extra = [ops.subsample2(outs[L - 1])]
         if save:
-            rec.update(stem=s[:na], pooled=p[:na], C=[c[:na] for c in C], out_shapes=[(na,) + tuple(t.shape[1:]) for t in outs],
+            rec.update(stem=s[:na], pool_idx=pidx[:na], pooled=p[:na], C=[c[:na] for c in C], out_shapes=[(na,) + tuple(t.shape[1:]) for t in outs],
                        p6=extra[0][:na] if self.p6p7 else None)
         return outs + extra, rec
 
@@ -295,7 +295,7 @@ class BackboneWithFPN(nn.Module):
                 else:
                     t = gm if extra is None else ops.add_f16(gm, extra)
                 gm = _dgrad(e["c1"], d1, hw_x, res=t, mask=xmask)
-        ds_ = ops.maxpool3x3s2_bwd(rec["stem"], gm)
+        ds_ = ops.maxpool3x3s2_bwd_idx(rec["pool_idx"], gm, (rec["stem"].shape[1], rec["stem"].shape[2]))
         ds_ = ops.relu_bwd(ds_, rec["stem"])
         x = rec["x"]
         return _dgrad(P["stem"], ds_, (x.shape[1], x.shape[2]))

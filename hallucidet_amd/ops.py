@@ -216,6 +216,24 @@ def maxpool3x3s2(x):
     return y
 
 
+def maxpool3x3s2_idx(x):
+    """-> (y, idx uint8 [N,Ho,Wo,C]) ; idx feeds maxpool3x3s2_bwd_idx."""
+    N, H, W, C_ = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((N, Ho, Wo, C_), dtype=torch.float16, device=x.device)
+    idx = torch.empty((N, Ho, Wo, C_), dtype=torch.uint8, device=x.device)
+    check(_abi.load().hd_maxpool3x3s2_idx(ptr(x), ptr(y), ptr(idx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_idx")
+    return y, idx
+
+
+def maxpool3x3s2_bwd_idx(idx, dy, in_hw):
+    N, Ho, Wo, C_ = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, H, W, C_), dtype=torch.float16, device=dy.device)
+    check(_abi.load().hd_maxpool3x3s2_bwd_idx(ptr(idx), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd_idx")
+    return dx
+
+
 def maxpool3x3s2_bwd(x, dy):
     N, H, W, C_ = x.shape
     _, Ho, Wo, _ = dy.shape

@@ -337,7 +337,7 @@ class UnetRunner:
         x = x.contiguous().float()
         a0 = ops.nchw_to_nhwc_resize(x, H, Wd, 8)
         f1 = self._conv_bn(self.stem, a0, Wt, training, rec)
-        cur = ops.maxpool3x3s2(f1)
+        cur, pool_idx = ops.maxpool3x3s2_idx(f1) if save else (ops.maxpool3x3s2(f1), None)
         feats = [f1]
         pooled = cur
         for blocks in self.stages:
@@ -357,7 +357,7 @@ class UnetRunner:
         if training:
             self._bump_batches_tracked()
         if save:
-            self.saved = dict(rec=rec, W=Wt, f1=f1, pooled=pooled, feats=feats, head_in=d, out=out, shape=(N, H, Wd))
+            self.saved = dict(rec=rec, W=Wt, f1=f1, pool_idx=pool_idx, pooled=pooled, feats=feats, head_in=d, out=out, shape=(N, H, Wd))
         return out
 
     def _bump_batches_tracked(self):
@@ -437,7 +437,7 @@ class UnetRunner:
                 d_out = d_in
                 _ = first_block
         # d_out = gradient of the max-pooled stem output
-        df1 = ops.maxpool3x3s2_bwd(sv["f1"], d_out)
+        df1 = ops.maxpool3x3s2_bwd_idx(sv["pool_idx"], d_out, (sv["f1"].shape[1], sv["f1"].shape[2]))
         df1 = ops.add_f16(df1, dfeat[0], out=df1)
         dx = None
         if need_dx:

@@ -152,6 +152,11 @@ int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* m
 /* MaxPool2d(3, stride 2, pad 1) NHWC f16 (encoders/resnet.py:51 via torchvision ResNet.maxpool [EXT]) */
 int hd_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int hd_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* same pooling, additionally recording the winning window position (0..8, first maximum in (kh,kw) scan order = ATen's
+ * rule) per output element in idx_u8 [N,Ho,Wo,C]; the _bwd_idx form routes dy with it (1 byte + 1 gradient read per
+ * window instead of 9 inputs) */
+int hd_maxpool3x3s2_idx(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 /* generic strided-subsample (LastLevelMaxPool k=1,s=2 [EXT]) */
 int hd_subsample2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int hd_subsample2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream);

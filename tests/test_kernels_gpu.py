@@ -225,6 +225,11 @@ def test_maxpool_fwd_bwd(dev, hw):
     out.backward(ok.nhwc_to_nchw(dy.float()))
     dx = ops.maxpool3x3s2_bwd(x.to(dev), dy.to(dev))
     close(dx, ok.nchw_to_nhwc(xv.grad).half(), rtol=2e-3, atol=1e-3)
+    # index-recording form: identical output, identical routing (ties go to the first maximum, ATen's rule)
+    y2, idx = ops.maxpool3x3s2_idx(x.to(dev))
+    assert torch.equal(y2, y) and idx.dtype == torch.uint8 and int(idx.max()) <= 8
+    dx2 = ops.maxpool3x3s2_bwd_idx(idx, dy.to(dev), (H, W))
+    assert torch.equal(dx2, dx)
 
 
 def test_resize_and_layout(dev):
