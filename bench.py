@@ -103,7 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detector", default="fasterrcnn", choices=["fasterrcnn", "retinanet"],
-                    help="fasterrcnn = the configuration BASELINE.json's metric is quoted on (default); retinanet = configs[4]")
+                    help="fasterrcnn = the configuration BASELINE.json's metric is quoted on (default); retinanet = configs[3]")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -153,7 +153,7 @@ def main():
             "config": {"workload": ("train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
                                     "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300, loss scaling, "
                                     "value clip 0.5, Adam") if args.detector == "fasterrcnn" else
-                                   ("train_hallucidet.py retinanet batch=8 fp16 (BASELINE configs[4], NOT the headline config); "
+                                   ("train_hallucidet.py retinanet batch=8 fp16 (BASELINE configs[3], NOT the headline config); "
                                     "U-Net resnet34 fwd+bwd, 3 frozen RetinaNet R50-FPN passes @300x300, loss scaling, clip, Adam"),
                        "global_batch": BATCH_PER_GPU * world, "image": "1x512x640 IR + 3x512x640 RGB",
                        "parallelism": "dp%d" % world, "alg_gflop_per_image": 428.5 if args.detector == "fasterrcnn" else None,

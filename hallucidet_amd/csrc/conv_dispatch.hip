@@ -71,9 +71,15 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   int rc = fill_params(a, p);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  const int bn = pick_bn(p.Cout);
+  int bn = pick_bn(p.Cout);
   const int bm = pick_bm(p.M, p.Cout);
-  const int64_t blocks = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
+  int64_t blocks = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
+  // grids that cannot give every CU two 64x128 blocks: 64x64 tiles double the block count (one MFMA tile per wave)
+  static const int small_n = env_int("HD_CONV_SMALLN", 512);
+  if (bn == 128 && bm == 64 && blocks < small_n) {
+    bn = 64;
+    blocks = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
+  }
   // experiment knobs (tools/bench_conv.py): HD_CONV_BK in {0 auto, 32, 64}; HD_CONV_DEEP in {-1 auto, 0, 1}
   static const int force_bk = env_int("HD_CONV_BK", 0);
   static const int force_deep = env_int("HD_CONV_DEEP", -1);

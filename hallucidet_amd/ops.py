@@ -5,6 +5,7 @@ Nothing here computes on the host and nothing falls back to ATen: a missing libr
 or a failing launch raises (``_abi.HipLibraryMissing`` / ``_abi.HipCallError``).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -91,7 +92,11 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None):
     return slab
 
 
-def pick_nsplit(M, Cout, K, target_blocks=1024):
+_WGRAD_BLOCKS = int(os.environ.get("HD_WGRAD_BLOCKS", "768"))   # measured sweep 256..2048 (tools/bench_wgrad.py): slab traffic vs occupancy
+
+
+def pick_nsplit(M, Cout, K, target_blocks=None):
+    target_blocks = target_blocks or _WGRAD_BLOCKS
     tm = 128 if Cout > 64 else (64 if Cout > 32 else 32)
     tiles = ((K + 127) // 128) * ((Cout + tm - 1) // tm)
     ns = max(1, min(target_blocks // max(tiles, 1), M // 256))
