@@ -137,6 +137,27 @@ def _dgrad(e, dy, in_hw, *, res=None, mask=None):
                       cout=e["cin_p"], res=res, mask=mask)
 
 
+# ---- parameter gradients (detector fine-tuning, train_detector.py:147-203 / `train_det=True`) ---------------------------
+# Modules carry `train_params` (bool) and `grad_scale` (loss scale to remove); parameter gradients are ACCUMULATED into
+# `param.grad`, which `ParamArena` (optim.py) makes a view of one flat fp32 arena that is zeroed once per step.
+def _wgrad_into(param, e, x, dy, inv_scale, bn_scale=None):
+    """param.grad += inv_scale * dL/dW for conv entry `e` (x: NHWC f16 input, dy: NHWC f16 gradient of the conv output
+    before bias/activation).  FrozenBN-folded convs: W_eff = W * s[cout]  =>  dL/dW = s[cout] * dL/dW_eff."""
+    k = e["k"]
+    slab = ops.wgrad(x, dy, k, k, stride=e["stride"], pad=e["pad"])
+    g = param.grad
+    if bn_scale is None:
+        ops.wgrad_reduce(slab, g, k, k, Cin=e["cin_p"], Cin_real=e["cin"], Cout=e["cout"], scale=inv_scale, accumulate=True)
+    else:
+        tmp = torch.empty_like(g)
+        ops.wgrad_reduce(slab, tmp, k, k, Cin=e["cin_p"], Cin_real=e["cin"], Cout=e["cout"], scale=inv_scale, accumulate=False)
+        g.addcmul_(tmp, bn_scale.view(-1, 1, 1, 1))
+
+
+def _bgrad_into(param, dy, inv_scale):
+    param.grad.add_(ops.channel_sum(dy)[: param.numel()], alpha=inv_scale)
+
+
 class _BackboneFn(torch.autograd.Function):
     """`n_active`: only the first n_active images of the batch need a data gradient (the hallucinated images when the
     RGB / IR detector passes of a training step are batched with them); the rest is forward-only."""
@@ -145,14 +166,17 @@ class _BackboneFn(torch.autograd.Function):
     def forward(ctx, x, hook, bb, n_active):
         outs, saved = bb._forward(x, save=True, n_active=n_active)
         ctx.bb, ctx.saved, ctx.n_active, ctx.n = bb, saved, n_active, x.shape[0]
+        ctx.need_dx = x.requires_grad
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         na = ctx.n_active
         grads = [None if g is None else g[:na] for g in grads]
-        dx = ctx.bb._backward(ctx.saved, grads)
+        dx = ctx.bb._backward(ctx.saved, grads, need_dx=ctx.need_dx)
         ctx.saved = None
+        if dx is None:
+            return None, None, None, None
         if na < ctx.n:
             full = torch.zeros((ctx.n,) + tuple(dx.shape[1:]), dtype=dx.dtype, device=dx.device)
             full[:na] = dx
@@ -176,6 +200,7 @@ class BackboneWithFPN(nn.Module):
         self.out_names = tuple(str(i) for i in range(len(chans))) + (("p6", "p7") if self.p6p7 else ("pool",))
         self._pack = None
         self._hook = None
+        self.train_params, self.grad_scale = False, 1.0     # set by FasterRCNN.set_trainable (detector fine-tuning)
 
     # -------------------------------------------------------------- frozen weight pack
     def invalidate(self):
@@ -190,7 +215,7 @@ class BackboneWithFPN(nn.Module):
             stage = []
             for blk in getattr(b, "layer%d" % li):
                 stage.append(dict(c1=_conv_entry(blk.conv1, blk.bn1), c2=_conv_entry(blk.conv2, blk.bn2), c3=_conv_entry(blk.conv3, blk.bn3),
-                                  ds=_conv_entry(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None))
+                                  ds=_conv_entry(blk.downsample[0], blk.downsample[1]) if blk.downsample is not None else None, blk=blk))
             P["blocks"].append(stage)
         for c in self.fpn.inner_blocks:
             P["inner"].append(_conv_entry(c))
@@ -239,12 +264,15 @@ class BackboneWithFPN(nn.Module):
         else:
             extra = [ops.subsample2(outs[L - 1])]
         if save:
+            rec["inner"] = [t[:na] for t in inner] if self.train_params else None
             rec.update(stem=s[:na], pool_idx=pidx[:na], pooled=p[:na], C=[c[:na] for c in C], out_shapes=[(na,) + tuple(t.shape[1:]) for t in outs],
                        p6=extra[0][:na] if self.p6p7 else None)
         return outs + extra, rec
 
-    def _backward(self, rec, grads):
+    def _backward(self, rec, grads, need_dx=True):
         P = self.pack()
+        tp = self.train_params
+        inv = 1.0 / self.grad_scale
         shapes = rec["out_shapes"]
         L = len(self.returned_layers)
         dev = rec["x"].device
@@ -272,6 +300,15 @@ class BackboneWithFPN(nn.Module):
             d_li[i] = _dgrad(P["layer"][i], dP[i], hw)
             if i > 0:
                 ops.upsample_add_bwd(d_li[i - 1], d_li[i], accumulate=True)
+        if tp:
+            if self.p6p7:
+                raise NotImplementedError("hallucidet_amd: detector fine-tuning is built for Faster R-CNN (BASELINE configs[4])")
+            for i in range(L):
+                lb, ib = self.fpn.layer_blocks[i], self.fpn.inner_blocks[i]
+                _wgrad_into(lb.weight, P["layer"][i], rec["inner"][i], dP[i], inv)
+                _bgrad_into(lb.bias, dP[i], inv)
+                _wgrad_into(ib.weight, P["inner"][i], Cr[i], d_li[i], inv)
+                _bgrad_into(ib.bias, d_li[i], inv)
         # lateral 1x1 convs -> gradients w.r.t. the returned C levels (C5's carries the ReLU mask of layer4's output)
         dC = [None] * 4
         for i, l in enumerate(self.returned_layers):
@@ -288,6 +325,15 @@ class BackboneWithFPN(nn.Module):
                 d2 = _dgrad(e["c3"], gm, hw_o, mask=o2)
                 d1 = _dgrad(e["c2"], d2, (o1.shape[1], o1.shape[2]), mask=o1)
                 hw_x = (x.shape[1], x.shape[2])
+                if tp and si >= 1:                                     # layer2..4 are trainable (trainable_backbone_layers=3)
+                    blk = e["blk"]
+                    _wgrad_into(blk.conv3.weight, e["c3"], o2, gm, inv, blk.bn3.scale_shift()[0])
+                    _wgrad_into(blk.conv2.weight, e["c2"], o1, d2, inv, blk.bn2.scale_shift()[0])
+                    _wgrad_into(blk.conv1.weight, e["c1"], x, d1, inv, blk.bn1.scale_shift()[0])
+                    if e["ds"] is not None:
+                        _wgrad_into(blk.downsample[0].weight, e["ds"], x, gm, inv, blk.downsample[1].scale_shift()[0])
+                if not need_dx and si == 1 and bi == 0:
+                    return None                                        # nothing below layer2 is trainable and the input is data
                 # the block input is a post-ReLU tensor except for layer1.0 (max-pooled stem)
                 xmask = None if (si == 0 and bi == 0) else x
                 if e["ds"] is not None:
@@ -306,7 +352,7 @@ class BackboneWithFPN(nn.Module):
                             "(NHWC float16, 8 channels)")
         if not x.is_cuda:
             raise RuntimeError("hallucidet_amd backbone runs on the GPU only; there is no CPU path")
-        if torch.is_grad_enabled() and x.requires_grad:
+        if torch.is_grad_enabled() and (x.requires_grad or self.train_params):
             if self._hook is None or self._hook.device != x.device:
                 self._hook = torch.zeros(1, device=x.device, requires_grad=True)
             outs = _BackboneFn.apply(x, self._hook, self, x.shape[0] if n_active is None else n_active)
@@ -533,6 +579,7 @@ class _RPNHeadFn(torch.autograd.Function):
             outs.append(_fwd(P["cls"], t, f32=True))
             outs.append(_fwd(P["box"], t, f32=True))
         ctx.head, ctx.ts, ctx.na, ctx.n = head, ts, n_active, feats[0].shape[0]
+        ctx.feats = [f[:n_active] for f in feats] if head.train_params else None
         return tuple(outs)
 
     @staticmethod
@@ -547,12 +594,24 @@ class _RPNHeadFn(torch.autograd.Function):
             dr = None if dr is None else dr[:na]
             hw = (H, W)
             dt = None
+            tp, inv = ctx.head.train_params, 1.0 / ctx.head.grad_scale
             if dl is not None:
-                dt = _dgrad(P["cls"], ops.nchw_to_nhwc_resize(dl.contiguous().float(), H, W, P["cls"]["cout_p"]), hw)
+                gl = ops.nchw_to_nhwc_resize(dl.contiguous().float(), H, W, P["cls"]["cout_p"])
+                dt = _dgrad(P["cls"], gl, hw)
+                if tp:
+                    _wgrad_into(ctx.head.cls_logits.weight, P["cls"], t, gl, inv)
+                    _bgrad_into(ctx.head.cls_logits.bias, gl, inv)
             if dr is not None:
-                dt = _dgrad(P["box"], ops.nchw_to_nhwc_resize(dr.contiguous().float(), H, W, P["box"]["cout_p"]), hw, res=dt, mask=t)
+                gr = ops.nchw_to_nhwc_resize(dr.contiguous().float(), H, W, P["box"]["cout_p"])
+                dt = _dgrad(P["box"], gr, hw, res=dt, mask=t)
+                if tp:
+                    _wgrad_into(ctx.head.bbox_pred.weight, P["box"], t, gr, inv)
+                    _bgrad_into(ctx.head.bbox_pred.bias, gr, inv)
             elif dt is not None:
                 dt = ops.relu_bwd(dt, t)
+            if tp and dt is not None:
+                _wgrad_into(ctx.head.conv.weight, P["conv"], ctx.feats[i], dt, inv)
+                _bgrad_into(ctx.head.conv.bias, dt, inv)
             df = None if dt is None else _dgrad(P["conv"], dt, hw)
             if df is not None and na < ctx.n:
                 full = torch.zeros((ctx.n,) + tuple(df.shape[1:]), dtype=df.dtype, device=df.device)
@@ -573,6 +632,7 @@ class RPNHead(nn.Module):
             nn.init.normal_(layer.weight, std=0.01)
             nn.init.constant_(layer.bias, 0)
         self._pack, self._hook = None, None
+        self.train_params, self.grad_scale = False, 1.0
 
     def invalidate(self):
         self._pack = None
@@ -748,17 +808,28 @@ class _MLPFn(torch.autograd.Function):
         h6 = _fwd(P["fc6"], x, act=ACT_RELU)
         h7 = _fwd(P["fc7"], h6, act=ACT_RELU)
         ctx.head, ctx.h6, ctx.h7, ctx.xshape = head, h6, h7, tuple(x.shape)
+        ctx.x = x if head.train_params else None
+        ctx.need_dx = x.requires_grad
         return h7
 
     @staticmethod
     def backward(ctx, d7):
         P = ctx.head.pack()
+        head = ctx.head
         d7 = ops.relu_bwd(d7.contiguous(), ctx.h7)
         d6 = _dgrad(P["fc7"], d7, (1, 1), mask=ctx.h6)
-        R = d6.shape[0]
-        dx = ops.conv2d(d6, P["fc6_t"], 1, 1, cout=P["fc6_t"].shape[0])      # plain GEMM with the transposed fc6 matrix
-        ctx.h6 = ctx.h7 = None
-        return dx.view(ctx.xshape), None
+        if head.train_params:
+            inv = 1.0 / head.grad_scale
+            # nn.Linear weights seen as OIHW tensors: fc7 [rep,rep,1,1]; fc6 [rep,C,7,7] (torch flattens RoI features C,H,W)
+            _wgrad_into(head.fc7.weight, P["fc7"], ctx.h6, d7, inv)
+            _bgrad_into(head.fc7.bias, d7, inv)
+            _wgrad_into(head.fc6.weight, P["fc6"], ctx.x, d6, inv)
+            _bgrad_into(head.fc6.bias, d6, inv)
+        dx = None
+        if ctx.need_dx:
+            dx = ops.conv2d(d6, P["fc6_t"], 1, 1, cout=P["fc6_t"].shape[0]).view(ctx.xshape)   # plain GEMM with the transposed fc6 matrix
+        ctx.h6 = ctx.h7 = ctx.x = None
+        return dx, None
 
 
 class TwoMLPHead(nn.Module):
@@ -767,6 +838,7 @@ class TwoMLPHead(nn.Module):
         self.fc6 = nn.Linear(in_channels, representation_size)
         self.fc7 = nn.Linear(representation_size, representation_size)
         self._pack = None
+        self.train_params, self.grad_scale = False, 1.0
 
     def invalidate(self):
         self._pack = None
@@ -790,7 +862,7 @@ class TwoMLPHead(nn.Module):
         """x: [R,7,7,C] fp16 (RoIAlign output).  Returns [R,1,1,rep] fp16."""
         if x.shape[0] == 0:
             return x.new_zeros((0, 1, 1, self.fc7.out_features))
-        if torch.is_grad_enabled() and x.requires_grad:
+        if torch.is_grad_enabled() and (x.requires_grad or self.train_params):
             return _MLPFn.apply(x, self)
         P = self.pack()
         return _fwd(P["fc7"], _fwd(P["fc6"], x, act=ACT_RELU), act=ACT_RELU)
@@ -801,20 +873,30 @@ class _PredictorFn(torch.autograd.Function):
     def forward(ctx, x, pred):
         P = pred.pack()
         ctx.pred = pred
+        ctx.x = x if pred.train_params else None
         R = x.shape[0]
         return _fwd(P["cls"], x, f32=True).view(R, -1), _fwd(P["box"], x, f32=True).view(R, -1)
 
     @staticmethod
     def backward(ctx, dc, db):
-        P = ctx.pred.pack()
+        pred = ctx.pred
+        P = pred.pack()
         R = dc.shape[0] if dc is not None else db.shape[0]
+        tp, inv = pred.train_params, 1.0 / pred.grad_scale
         dx = None
         if dc is not None:
             g = ops.nchw_to_nhwc_resize(dc.contiguous().float().view(R, -1, 1, 1), 1, 1, P["cls"]["cout_p"])
             dx = _dgrad(P["cls"], g, (1, 1))
+            if tp:
+                _wgrad_into(pred.cls_score.weight, P["cls"], ctx.x, g, inv)
+                _bgrad_into(pred.cls_score.bias, g, inv)
         if db is not None:
             g = ops.nchw_to_nhwc_resize(db.contiguous().float().view(R, -1, 1, 1), 1, 1, P["box"]["cout_p"])
             dx = _dgrad(P["box"], g, (1, 1), res=dx)
+            if tp:
+                _wgrad_into(pred.bbox_pred.weight, P["box"], ctx.x, g, inv)
+                _bgrad_into(pred.bbox_pred.bias, g, inv)
+        ctx.x = None
         return dx, None
 
 
@@ -824,6 +906,7 @@ class FastRCNNPredictor(nn.Module):
         self.cls_score = nn.Linear(in_channels, num_classes)
         self.bbox_pred = nn.Linear(in_channels, num_classes * 4)
         self._pack = None
+        self.train_params, self.grad_scale = False, 1.0
 
     def invalidate(self):
         self._pack = None
@@ -843,7 +926,7 @@ class FastRCNNPredictor(nn.Module):
         if x.shape[0] == 0:
             z = torch.zeros((0, self.cls_score.out_features), device=x.device)
             return z, torch.zeros((0, self.bbox_pred.out_features), device=x.device)
-        if torch.is_grad_enabled() and x.requires_grad:
+        if torch.is_grad_enabled() and (x.requires_grad or self.train_params):
             return _PredictorFn.apply(x, self)
         P = self.pack()
         R = x.shape[0]
@@ -964,6 +1047,22 @@ class FasterRCNN(nn.Module):
         self.rpn.head.invalidate()
         self.roi_heads.box_head.invalidate()
         self.roi_heads.box_predictor.invalidate()
+
+    def set_trainable(self, flag=True, grad_scale=1.0):
+        """Detector fine-tuning switch (train_detector.py / `train_det=True`): the hand-written backward chains also emit
+        parameter gradients (into `param.grad`), for what torchvision's fasterrcnn_resnet50_fpn leaves trainable
+        (trainable_backbone_layers=3 [EXT]: body.layer2-4 convs, FPN, RPN head, box head, predictor; FrozenBN, conv1 and
+        layer1 stay fixed)."""
+        for m in (self.backbone, self.rpn.head, self.roi_heads.box_head, self.roi_heads.box_predictor):
+            m.train_params, m.grad_scale = bool(flag), float(grad_scale)
+        for name, p in self.backbone.body.named_parameters():
+            p.requires_grad_(bool(flag) and name.split(".")[0] in ("layer2", "layer3", "layer4"))
+        for mod in (self.backbone.fpn, self.rpn, self.roi_heads):
+            for p in mod.parameters():
+                p.requires_grad_(bool(flag))
+
+    def trainable_parameters(self):
+        return [p for p in self.parameters() if p.requires_grad]
 
     def load_state_dict(self, state_dict, strict=True):
         sd = OrderedDict()

@@ -10,12 +10,54 @@ import torch
 from . import ops
 
 
+class ParamArena:
+    """Flat fp32 parameter / gradient arenas over an arbitrary parameter list (the detector's trainable parameters in
+    train_detector.py; the U-Net has its own inside UnetRunner).  Every `p.data` / `p.grad` becomes a view, so one fused
+    optimizer launch updates everything and a data-parallel exchange is a few large all-reduces over contiguous memory."""
+
+    def __init__(self, params):
+        self._params = list(params)
+        self._flat = None
+        self.grad_scale = 1.0
+        self.flatten_parameters()
+
+    def flatten_parameters(self):
+        ps = self._params
+        if self._flat is not None and all(p.data_ptr() == self._flat.data_ptr() + o * 4 and p.grad is not None
+                                          and p.grad.data_ptr() == self._gflat.data_ptr() + o * 4
+                                          for p, o in ((ps[0], self._offsets[0]), (ps[-1], self._offsets[-1]))):
+            return
+        dev = ps[0].device
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        gflat = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            p.grad = gflat[o:o + p.numel()].view(p.shape)
+        self._flat, self._gflat, self._offsets = flat, gflat, offs
+
+    @property
+    def flat_params(self):
+        self.flatten_parameters()
+        return self._flat
+
+    @property
+    def flat_grads(self):
+        self.flatten_parameters()
+        return self._gflat
+
+
 class FusedAdam(torch.optim.Optimizer):
     def __init__(self, unet, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, clip_value=0.0):
-        self.runner = unet.runner
+        """`unet`: a module with a `.runner` that owns flat arenas (Unet), or a ParamArena."""
+        self.runner = unet if isinstance(unet, ParamArena) else unet.runner
         self.runner.flatten_parameters()
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip_value=clip_value)
-        super().__init__(list(unet.parameters()), defaults)
+        super().__init__(list(self.runner._params), defaults)
         flat = self.runner.flat_params
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
@@ -42,7 +84,7 @@ class FusedAdam(torch.optim.Optimizer):
 
 class LossScaler:
     def __init__(self, unet, init_scale=2.0 ** 16, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000, enabled=True):
-        self.runner = unet.runner
+        self.runner = unet if isinstance(unet, ParamArena) else unet.runner
         self.scale_value = float(init_scale) if enabled else 1.0
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
         self.enabled = enabled

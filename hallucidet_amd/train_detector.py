@@ -1,0 +1,113 @@
+"""Detector-only training (reference train_detector.py:86-345, BASELINE configs[4]): `DetectorLit` with the reference's
+constructor keywords and hook names (`training_step`, `validation_step`, `test_step`, `configure_optimizers`), driven by
+`fit_step` instead of `pl.Trainer` (Lightning is not installable offline; its loop around training_step is: zero_grad ->
+backward -> optimizer.step, no gradient clipping in this script, train_detector.py:377-390).
+
+What runs where: the detector forward is the same HIP path as the frozen detector; `FasterRCNN.set_trainable(True)` makes
+the hand-written backward chains also emit PARAMETER gradients (hd_wgrad / hd_wgrad_reduce for every trainable conv and
+FC, hd_channel_sum_f16 for biases) for what torchvision leaves trainable (body.layer2-4, FPN, RPN, RoI heads; FrozenBN,
+conv1, layer1 fixed), accumulated into one flat fp32 arena; Adam is the fused hd_adam_step over that arena; the data-
+parallel exchange is the all-reduce of the arena (same GradientAverager as the hallucination network).
+fp16 storage needs a loss scale for the small detector gradients: a fixed power of two (default 1024) that is removed
+inside hd_wgrad_reduce; steps with non-finite gradients are skipped (hd_check_finite), as GradScaler would.
+"""
+import torch
+
+from .config import Config
+from .distributed import GradientAverager, broadcast_parameters
+from .models.detector import Detector
+from .optim import FusedAdam, LossScaler, ParamArena
+from .utils.utils import Utils
+
+
+class DetectorLit:
+    def __init__(self, batch_size=4, wandb_logger=None, lr=0.0001, detector_name='fasterrcnn', pretrained=True, optimizer_name='adam',
+                 modality=None, directly_coco=False, detector=None, device='cuda', loss_scale=1024.0):
+        if 'fasterrcnn' not in detector_name:
+            raise NotImplementedError("hallucidet_amd: detector fine-tuning is built for fasterrcnn (BASELINE configs[4])")
+        self.wandb_logger, self.lr, self.batch_size = wandb_logger, lr, batch_size
+        self.optimizer_name, self.detector_name, self.modality = optimizer_name, detector_name, modality
+        self.dev = device
+        self.detector = detector if detector is not None else Detector(name=detector_name, pretrained=pretrained,
+                                                                       n_classes=getattr(getattr(Config, 'Dataset', None), 'n_classes', 2), size=Config.Detector.input_size,
+                                                                       modality=modality, directly_coco=directly_coco).detector
+        self.detector.fused_passes = False
+        self.loss_scale = float(loss_scale)
+        self.optimizer = self.scaler = self.arena = self.averager = None
+        self._last_detections = None
+
+    # ------------------------------------------------------------------ setup
+    def configure_optimizers(self):
+        if self.optimizer_name != 'adam':
+            raise NotImplementedError("the reference runs train_detector.py with Config.Optimizer.name == 'adam'")
+        self.detector.to(self.dev)
+        self.detector.set_trainable(True, grad_scale=self.loss_scale)
+        self.arena = ParamArena(self.detector.trainable_parameters())
+        self.optimizer = FusedAdam(self.arena, lr=self.lr, clip_value=0.0)
+        self.scaler = LossScaler(self.arena, init_scale=self.loss_scale, growth_interval=1 << 30)   # fixed scale
+        return self.optimizer
+
+    def prepare(self):
+        self.configure_optimizers()
+        broadcast_parameters(self.arena.flat_params)
+        self.averager = GradientAverager()
+        return self
+
+    # ------------------------------------------------------------------ hooks (train_detector.py:147-203, 205-254)
+    def _weighted(self, losses_det):
+        w = Config.Losses.hparams_losses_weights
+        losses_det = dict(losses_det)
+        losses_det['classification'] = losses_det['loss_classifier'] * w['det_classification']
+        losses_det['bbox_regression'] = losses_det['loss_box_reg'] * w['det_regression']
+        losses_det['loss_objectness'] = losses_det['loss_objectness'] * w['det_objectness']
+        losses_det['loss_rpn_box_reg'] = losses_det['loss_rpn_box_reg'] * w['det_rpn_box_reg']
+        losses_det['bbox_ctrness'] = 0.0
+        total = losses_det['bbox_regression'] + losses_det['classification'] + losses_det['loss_objectness'] + \
+            losses_det['loss_rpn_box_reg'] + losses_det['bbox_ctrness']
+        return total, losses_det
+
+    def _unpack(self, batch):
+        if len(batch) == 2:
+            imgs, targets = batch
+            if self.modality == 'ir':
+                imgs = Utils.expand_one_channel_to_output_channels(imgs, 3) if imgs.shape[1] == 1 else imgs
+        else:
+            imgs, targets, _, _ = batch
+        return imgs, Utils.batch_targets_for_detector(targets=targets, device=self.dev, detector_name=self.detector_name)
+
+    def training_step(self, train_batch, batch_idx):
+        imgs, targets = self._unpack(train_batch)
+        losses_det, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=True, model_name=self.detector_name)
+        total_loss, self._last_losses = self._weighted(losses_det)
+        self._last_detections = detections
+        return total_loss
+
+    def validation_step(self, val_batch, batch_idx):
+        imgs, targets = self._unpack(val_batch)
+        with torch.no_grad():
+            losses_det, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=False, model_name=self.detector_name)
+        self._last_detections = detections
+        # train_detector.py:224-229: the validation total is the UNWEIGHTED sum
+        return losses_det['loss_box_reg'] + losses_det['loss_classifier'] + losses_det['loss_objectness'] + losses_det['loss_rpn_box_reg']
+
+    def test_step(self, test_batch, batch_idx):
+        imgs, targets = self._unpack(test_batch)
+        with torch.no_grad():
+            _, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=False, model_name=self.detector_name)
+        self._last_detections = detections
+        return detections
+
+    # ------------------------------------------------------------------ what Lightning does around training_step
+    def fit_step(self, batch, batch_idx=0):
+        if self.optimizer is None:
+            self.prepare()
+        self.detector.train()
+        self.detector.invalidate_packs()              # the fp32 masters moved: rebuild the fp16 GEMM layouts
+        g = self.arena.flat_grads
+        g.zero_()                                     # optimizer_zero_grad (train_detector.py:344-345); kernels accumulate
+        loss = self.training_step(batch, batch_idx)
+        (loss * self.loss_scale).backward()
+        self.averager.start(g)
+        self.averager.finish(g)
+        self.scaler.step(self.optimizer)
+        return loss.detach()

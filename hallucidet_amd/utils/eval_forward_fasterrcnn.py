@@ -169,9 +169,13 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
 
 def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name='fasterrcnn'):
     if train_det:
-        raise NotImplementedError("hallucidet_amd: detector fine-tuning (train_det=True, train_detector.py) needs the "
-                                  "weight-gradient path through the detector; round-1 scope is the frozen detector")
-    model.eval()
+        # train_detector.py:159 -- the module's mode is left as the caller set it (Lightning: train()); parameter
+        # gradients need FasterRCNN.set_trainable(True) (DetectorLit does it), otherwise nothing would be learned
+        if not getattr(model.backbone, "train_params", False):
+            raise RuntimeError("hallucidet_amd: train_det=True needs detector.set_trainable(True) first (see "
+                               "hallucidet_amd.train_detector.DetectorLit); the frozen-detector kernels emit data gradients only")
+    else:
+        model.eval()
 
     for target in targets:
         boxes = target["boxes"]

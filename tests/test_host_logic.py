@@ -65,8 +65,10 @@ def test_calculate_loss_rejects_cpu_and_bad_targets():
         Detector.calculate_loss(d, imgs, [{"boxes": torch.zeros(3), "labels": torch.ones(1, dtype=torch.int64)}])
     with pytest.raises(RuntimeError, match="no CPU path"):
         Detector.calculate_loss(d, imgs, [{"boxes": torch.tensor([[1.0, 1.0, 9.0, 9.0]]), "labels": torch.ones(1, dtype=torch.int64)}])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="set_trainable"):       # fine-tuning needs the parameter-gradient switch first
         Detector.calculate_loss(d, imgs, [], train_det=True)
+    with pytest.raises(NotImplementedError):
+        Detector.calculate_loss(d, imgs, [], train_det=True, model_name="retinanet")
     with pytest.raises(ValueError):
         Detector.calculate_loss(d, imgs, [], model_name="yolo")
 
@@ -149,3 +151,31 @@ def test_retinanet_state_dict_tree_equals_oracle_tree():
         sd13[k.replace("conv.X", "conv.")] = v
     assert set(sd13) != set(got)
     det.load_state_dict(sd13)
+
+
+def test_param_arena_views_and_detector_trainable_rule():
+    """ParamArena makes p.data / p.grad views of flat fp32 arenas (fused Adam + one all-reduce for train_detector.py);
+    FasterRCNN.set_trainable follows torchvision's trainable_backbone_layers=3 rule."""
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.optim import ParamArena
+    det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector
+    det.set_trainable(True, grad_scale=8.0)
+    ps = det.trainable_parameters()
+    names = [n for n, p in det.named_parameters() if p.requires_grad]
+    assert all(n.startswith(("backbone.body.layer2", "backbone.body.layer3", "backbone.body.layer4", "backbone.fpn", "rpn", "roi_heads")) for n in names)
+    assert not det.backbone.body.conv1.weight.requires_grad and not det.backbone.body.layer1[0].conv1.weight.requires_grad
+    assert det.backbone.train_params and det.rpn.head.grad_scale == 8.0
+    before = [p.detach().clone() for p in ps[:3]]
+    arena = ParamArena(ps)
+    assert arena.flat_params.numel() >= sum(p.numel() for p in ps) and arena.flat_params.dtype == torch.float32
+    for p, b in zip(ps[:3], before):
+        assert torch.equal(p.detach(), b)                       # values preserved
+    ps[0].grad.fill_(2.0)
+    n0 = ps[0].numel()
+    assert float(arena.flat_grads[:n0].sum()) == 2.0 * n0      # grads are views of the arena
+    arena.flat_params[:n0].zero_()
+    assert float(ps[0].detach().abs().sum()) == 0.0            # params are views of the arena
+    with pytest.raises(RuntimeError, match="set_trainable"):
+        det.set_trainable(False)
+        from hallucidet_amd.utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn
+        eval_forward_fasterrcnn(det, torch.rand(1, 3, 32, 32), [{"boxes": torch.tensor([[1., 1., 9., 9.]]), "labels": torch.ones(1, dtype=torch.int64)}], train_det=True)

@@ -1,0 +1,161 @@
+"""Detector fine-tuning path (reference train_detector.py:147-203 -> Detector.calculate_loss(..., train_det=True); SURVEY
+a20, BASELINE configs[4]): the hand-written backward chains must emit the PARAMETER gradients torch autograd gives on the
+CPU oracle, for exactly the parameters torchvision leaves trainable, and DetectorLit.fit_step must learn with them."""
+import pytest
+import torch
+
+from oracle import detection as od
+from oracle import unet as ou
+from test_detector_gpu import nchw, _t2d
+
+pytestmark = pytest.mark.gpu
+
+TRAINABLE_PREFIXES = ("backbone.body.layer2", "backbone.body.layer3", "backbone.body.layer4", "backbone.fpn", "rpn", "roi_heads")
+
+
+@pytest.fixture(scope="module")
+def case(dev):
+    from hallucidet_amd.models.detector import Detector
+    torch.manual_seed(31)
+    det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector.to(dev)
+    N, H, W = 2, 96, 128
+    images = torch.rand(N, 3, H, W)
+    targets = []
+    for i in range(N):
+        k = 1 + i
+        xy = torch.rand(k, 2) * torch.tensor([W * 0.5, H * 0.5])
+        wh = torch.rand(k, 2) * torch.tensor([W * 0.3, H * 0.4]) + 8.0
+        targets.append({"boxes": torch.cat([xy, xy + wh], 1), "labels": torch.ones(k, dtype=torch.int64)})
+    il, _ = det.transform(images.to(dev), None)
+    det.backbone.calibrate_(il.tensors)
+    oracle = od.FasterRCNN(num_classes=2, size=300)           # NOT folded: conv weights and FrozenBN stay separate tensors
+    oracle.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    oracle.set_quant(ou.fp16_round)
+    return det, oracle, images, targets
+
+
+def test_trainable_set_matches_torchvision_rule(dev, case):
+    det, _, _, _ = case
+    det.set_trainable(True)
+    names = {n for n, p in det.named_parameters() if p.requires_grad}
+    all_names = {n for n, _ in det.named_parameters()}
+    assert names == {n for n in all_names if n.startswith(TRAINABLE_PREFIXES)}
+    assert "backbone.body.conv1.weight" not in names and not any(n.startswith("backbone.body.layer1") for n in names)
+    assert len(det.trainable_parameters()) == len(names)
+    det.set_trainable(False)
+    assert not any(p.requires_grad for p in det.parameters())
+
+
+def test_parameter_gradients_match_oracle_autograd(dev, case):
+    """Linear probe loss on RPN outputs and box-head outputs over FIXED proposals (no sampler): every trainable tensor's
+    gradient against torch autograd on the oracle (fp16 activation rounding on both sides)."""
+    from hallucidet_amd.optim import ParamArena
+    det, oracle, images, targets = case
+    S = 256.0
+    det.train()
+    det.set_trainable(True, grad_scale=S)
+    arena = ParamArena(det.trainable_parameters())
+    det.invalidate_packs()
+    g = torch.Generator().manual_seed(5)
+    il, _ = det.transform(images.to(dev), None)
+    f = det.backbone(il.tensors)
+    obj, reg = det.rpn.head(list(f.values()))
+    props = []
+    for i in range(2):
+        xy = torch.rand(40, 2, generator=g) * 200
+        wh = torch.rand(40, 2, generator=g) * torch.tensor([90.0, 90.0]) + 8
+        props.append(torch.cat([xy, xy + wh], 1))
+    bf = det.roi_heads.box_roi_pool(f, [p.to(dev) for p in props], il.image_sizes)
+    logits, regs = det.roi_heads.box_predictor(det.roi_heads.box_head(bf))
+    w_obj = [torch.randn(o.shape, generator=g) for o in obj]
+    w_reg = [torch.randn(o.shape, generator=g) for o in reg]
+    w_l, w_r = torch.randn(logits.shape, generator=g), torch.randn(regs.shape, generator=g)
+    loss = sum((o * w.to(dev)).sum() for o, w in zip(obj, w_obj)) + sum((o * w.to(dev)).sum() for o, w in zip(reg, w_reg))
+    loss = loss + (logits * w_l.to(dev)).sum() + (regs * w_r.to(dev)).sum()
+    arena.flat_grads.zero_()
+    (loss * S).backward()
+    got = {n: p.grad.detach().cpu().clone() for n, p in det.named_parameters() if p.requires_grad}
+
+    oracle.train()
+    for n, p in oracle.named_parameters():
+        p.requires_grad_(n.startswith(TRAINABLE_PREFIXES))
+        p.grad = None
+    ol, _ = oracle.transform(images, None)
+    of = oracle.backbone(ol.tensors)
+    oobj, oreg = oracle.rpn.head(list(of.values()))
+    obf = oracle.roi_heads.box_roi_pool(of, props, ol.image_sizes)
+    ologits, oregs = oracle.roi_heads.box_predictor(oracle.roi_heads.box_head(obf))
+    oloss = sum((o * w).sum() for o, w in zip(oobj, w_obj)) + sum((o * w).sum() for o, w in zip(oreg, w_reg))
+    oloss = oloss + (ologits * w_l).sum() + (oregs * w_r).sum()
+    oloss.backward()
+    want = {n: p.grad for n, p in oracle.named_parameters() if p.requires_grad}
+    assert set(got) == set(want)
+
+    def agree(n, ref):
+        a, b = got[n].flatten().double(), ref.flatten().double()
+        assert torch.isfinite(a).all(), n
+        return float((a * b).sum() / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
+
+    # (A) stage-wise on IDENTICAL inputs (the product's own feature maps / pooled RoI features fed to the oracle heads):
+    # every ReLU decision is then taken on the same numbers, what remains is fp16 storage of activations and gradients
+    for p in oracle.parameters():
+        p.grad = None
+    pf = [nchw(t).detach() for t in f.values()]
+    sobj, sreg = oracle.rpn.head(pf)
+    (sum((o * w).sum() for o, w in zip(sobj, w_obj)) + sum((o * w).sum() for o, w in zip(sreg, w_reg))).backward()
+    slog, sregs = oracle.roi_heads.box_predictor(oracle.roi_heads.box_head(bf.detach().float().cpu().permute(0, 3, 1, 2)))
+    ((slog * w_l).sum() + (sregs * w_r).sum()).backward()
+    for n, p in oracle.named_parameters():
+        if n.startswith(("rpn.head", "roi_heads.box_head", "roi_heads.box_predictor")):
+            cos, rel = agree(n, p.grad)
+            print("   stage  %-42s cos %.6f rel %.4f" % (n, cos, rel))
+            assert cos > 0.9995 and rel < 0.03, (n, cos, rel)
+
+    # (B) end to end: the oracle re-takes every ReLU decision on its own (fp32-accumulated, fp16-rounded) activations, which
+    # differ from the product's by fp16 noise -> statistical agreement (same yardstick as the image-gradient test)
+    worst = {}
+    for n in sorted(want):
+        cos, rel = agree(n, want[n])
+        grp = ("heads" if n.startswith(("roi_heads", "rpn")) else "fpn" if "fpn" in n else n.split(".")[2])
+        if cos < worst.setdefault(grp, [1.0, 0.0, n])[0]:
+            worst[grp] = [cos, rel, n]
+    print({k: (round(v[0], 4), round(v[1], 3), v[2]) for k, v in worst.items()})
+    assert worst["heads"][0] > 0.97 and worst["fpn"][0] > 0.97, worst
+    for grp in ("layer4", "layer3", "layer2"):
+        assert worst[grp][0] > 0.90, (grp, worst[grp])
+    # frozen tensors received nothing
+    assert det.backbone.body.conv1.weight.grad is None and det.backbone.body.layer1[0].conv1.weight.grad is None
+    det.set_trainable(False)
+    det.eval()
+
+
+def test_fit_step_learns_and_keeps_frozen_parts_fixed(dev):
+    from hallucidet_amd import synthetic
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.train_detector import DetectorLit
+    torch.manual_seed(41)
+    det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector.to(dev)
+    rgb, trgb, _, _ = synthetic.make_batch(2, 128, 160, seed=9, device=str(dev))
+    il, _ = det.transform(rgb, None)
+    det.backbone.calibrate_(il.tensors)
+    lit = DetectorLit(batch_size=2, lr=1e-4, detector_name="fasterrcnn", pretrained=False, detector=det, device=str(dev)).prepare()
+    with pytest.raises(RuntimeError, match="set_trainable"):
+        det.set_trainable(False)
+        Detector.calculate_loss(det, rgb, trgb, train_det=True, model_name="fasterrcnn")
+    det.set_trainable(True, grad_scale=lit.loss_scale)
+    before = {n: p.detach().clone() for n, p in det.named_parameters()}
+    v0 = float(lit.validation_step((rgb, trgb), 0))
+    losses = [float(lit.fit_step((rgb, trgb))) for _ in range(12)]
+    assert all(map(lambda v: v == v and abs(v) < 1e4, losses)), losses
+    assert float(lit.optimizer.found_inf) == 0.0
+    moved = [n for n, p in det.named_parameters() if not torch.equal(p.detach(), before[n])]
+    frozen = [n for n, p in det.named_parameters() if not p.requires_grad]
+    assert frozen and not set(moved) & set(frozen)
+    assert len(moved) == len(det.trainable_parameters()), (len(moved), len(det.trainable_parameters()))
+    # Adam's first steps are bounded by lr per coordinate
+    assert max(float((p.detach() - before[n]).abs().max()) for n, p in det.named_parameters()) <= 12 * 1e-4 * 1.01
+    v1 = float(lit.validation_step((rgb, trgb), 0))
+    print("train losses", [round(v, 4) for v in losses], "val (unweighted sum)", round(v0, 4), "->", round(v1, 4))
+    assert v1 < v0, (v0, v1)             # 12 Adam steps on one batch reduce its own loss
+    dets = lit.test_step((rgb, trgb), 0)
+    assert len(dets) == 2 and set(dets[0]) == {"boxes", "labels", "scores"}
