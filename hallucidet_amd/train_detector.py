@@ -87,6 +87,7 @@ class DetectorLit:
         with torch.no_grad():
             losses_det, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=False, model_name=self.detector_name)
         self._last_detections = detections
+        self._metric('val').update(detections, targets)          # train_detector.py:220
         # train_detector.py:224-229: the validation total is the UNWEIGHTED sum
         return losses_det['loss_box_reg'] + losses_det['loss_classifier'] + losses_det['loss_objectness'] + losses_det['loss_rpn_box_reg']
 
@@ -95,7 +96,27 @@ class DetectorLit:
         with torch.no_grad():
             _, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=False, model_name=self.detector_name)
         self._last_detections = detections
+        self._metric('test').update(detections, targets)         # train_detector.py:300
         return detections
+
+    def _metric(self, split):
+        from .metrics import Detection
+        store = self.__dict__.setdefault("_map_metrics", {})
+        if split not in store:
+            store[split] = Detection(class_metrics=True).map      # train_detector.py:115-116
+        return store[split]
+
+    def _epoch_end(self, split):
+        m = self._metric(split)
+        out = Utils.filter_dictionary(m.compute(), {'map_50', 'map_75', 'map', 'map_per_class'})
+        m.reset()
+        return out
+
+    def on_validation_epoch_end(self):
+        return self._epoch_end('val')
+
+    def on_test_epoch_end(self):
+        return self._epoch_end('test')
 
     # ------------------------------------------------------------------ what Lightning does around training_step
     def fit_step(self, batch, batch_idx=0):

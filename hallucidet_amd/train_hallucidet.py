@@ -108,14 +108,44 @@ class EncoderDecoderLit(nn.Module):
         out = self.forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train')
         return out['loss']['total']
 
-    def validation_step(self, val_batch, batch_idx):
-        imgs_rgb, targets_rgb, imgs_ir, targets_ir = val_batch
+    def _metrics(self, split):
+        """train_hallucidet.py:121-131: one COCO-style mAP accumulator per (split, stream)."""
+        from .metrics import Detection
+        store = self.__dict__.setdefault("_map_metrics", {})
+        if split not in store:
+            store[split] = {k: Detection().map for k in ("hall", "rgb", "ir")}
+        return store[split]
+
+    def _eval_step(self, batch, batch_idx, split):
+        imgs_rgb, targets_rgb, imgs_ir, targets_ir = batch
         with torch.no_grad():
-            out = self.forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='val')
-        return out['loss']['total'], self._last_detections
+            out = self.forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step=split)
+        d, m = self._last_detections, self._metrics(split)
+        m["rgb"].update(d["rgb"], targets_rgb)          # :213-215 / :399-401
+        m["hall"].update(d["hall"], targets_ir)
+        m["ir"].update(d["ir"], targets_ir)
+        return out['loss']['total'], d
+
+    def validation_step(self, val_batch, batch_idx):
+        return self._eval_step(val_batch, batch_idx, 'val')
 
     def test_step(self, test_batch, batch_idx):
-        return self.validation_step(test_batch, batch_idx)
+        return self._eval_step(test_batch, batch_idx, 'test')
+
+    def _epoch_end(self, split):
+        m = self._metrics(split)
+        out = {"map_" + k: Utils.filter_dictionary(m[k].compute(), {'map_50', 'map_75', 'map'}) for k in ("rgb", "hall", "ir")}
+        for v in m.values():
+            v.reset()
+        return out
+
+    def on_validation_epoch_end(self):
+        """:328-362 without the wandb / checkpoint side effects: returns {'map_rgb','map_hall','map_ir'} -> {map, map_50, map_75}."""
+        return self._epoch_end('val')
+
+    def on_test_epoch_end(self):
+        """:412-427"""
+        return self._epoch_end('test')
 
     def configure_optimizers(self):
         self.encoder_decoder.to(self.dev)

@@ -1,0 +1,101 @@
+"""Hand-worked known answers for the COCO-style mAP evaluator (hallucidet_amd/metrics/metrics.py)."""
+import math
+
+import pytest
+import torch
+
+from hallucidet_amd.metrics import Detection, MeanAveragePrecision
+
+
+def T(*rows):
+    return torch.tensor(rows, dtype=torch.float32).reshape(-1, 4)
+
+
+def one(boxes, scores, labels=None):
+    n = len(scores)
+    return {"boxes": T(*boxes), "scores": torch.tensor(scores, dtype=torch.float32),
+            "labels": torch.tensor(labels if labels is not None else [1] * n, dtype=torch.int64)}
+
+
+def gt(boxes, labels=None):
+    return {"boxes": T(*boxes), "labels": torch.tensor(labels if labels is not None else [1] * len(boxes), dtype=torch.int64)}
+
+
+def test_perfect_detections():
+    m = MeanAveragePrecision()
+    m.update([one([[10, 10, 110, 110], [200, 200, 260, 300]], [0.9, 0.8])], [gt([[10, 10, 110, 110], [200, 200, 260, 300]])])
+    r = m.compute()
+    assert r["map"] == 1.0 and r["map_50"] == 1.0 and r["map_75"] == 1.0 and r["mar_100"] == 1.0
+    assert r["mar_1"] == 0.5                        # one detection per image can recall one of the two boxes
+    assert r["map_small"] == -1.0                   # no ground truth in that area range
+    assert r["map_large"] == 1.0 and r["map_medium"] == 1.0   # 100x100 = 1e4 > 96^2 large ; 60x100 = 6000 medium
+    assert float(r["map_per_class"]) == -1.0
+
+
+def test_false_positive_ranked_first_halves_precision():
+    m = MeanAveragePrecision()
+    m.update([one([[300, 300, 340, 340], [10, 10, 110, 110]], [0.9, 0.8])], [gt([[10, 10, 110, 110]])])
+    r = m.compute()
+    # ranked list: FP, TP -> precision at recall 1 is 1/2, and the envelope makes every recall point 1/2
+    assert abs(float(r["map"]) - 0.5) < 1e-6 and abs(float(r["map_50"]) - 0.5) < 1e-6 and r["mar_100"] == 1.0
+    assert r["mar_1"] == 0.0                        # the single allowed detection is the false positive
+
+
+def test_iou_threshold_sweep():
+    # prediction shifted so that IoU = 0.6 exactly: [0,0,100,100] vs [0,0,100,60] -> 6000/10000
+    m = MeanAveragePrecision()
+    m.update([one([[0, 0, 100, 60]], [0.7])], [gt([[0, 0, 100, 100]])])
+    r = m.compute()
+    # a hit at thresholds .50 .55 .60 (3 of 10), a miss above
+    assert abs(float(r["map"]) - 0.3) < 1e-6 and r["map_50"] == 1.0 and r["map_75"] == 0.0
+    assert abs(float(r["mar_100"]) - 0.3) < 1e-6
+
+
+def test_two_images_interleaved_scores_and_missed_gt():
+    m = MeanAveragePrecision()
+    m.update([one([[0, 0, 50, 50]], [0.9])], [gt([[0, 0, 50, 50], [100, 100, 150, 150]])])      # 1 TP, 1 missed
+    m.update([one([[0, 0, 40, 40], [200, 200, 240, 240]], [0.8, 0.95])], [gt([[0, 0, 40, 40]])])  # FP (0.95) then TP (0.8)
+    r = m.compute()
+    # ranked: FP(.95) TP(.9) TP(.8) over 3 gts: recall 0,1/3,2/3 ; precision 0,1/2,2/3 -> envelope 2/3,2/3,2/3
+    # recall thresholds <= 2/3 (67 of 101: 0.00..0.66) get 2/3, the rest 0
+    want = (2 / 3) * 67 / 101
+    assert abs(float(r["map_50"]) - want) < 1e-6
+    assert abs(float(r["mar_100"]) - 2 / 3) < 1e-6
+
+
+def test_per_class_and_area_ranges_and_reset():
+    m = Detection(class_metrics=True).map
+    m.update([one([[0, 0, 20, 20], [50, 50, 250, 250]], [0.9, 0.8], labels=[1, 2])],
+             [gt([[0, 0, 20, 20], [50, 50, 250, 250]], labels=[1, 2])])
+    r = m.compute()
+    assert r["map_per_class"].tolist() == [1.0, 1.0] and r["mar_100_per_class"].tolist() == [1.0, 1.0]
+    assert r["map_small"] == 1.0 and r["map_large"] == 1.0 and r["map_medium"] == -1.0
+    # wrong class never matches
+    m.reset()
+    m.update([one([[0, 0, 20, 20]], [0.9], labels=[2])], [gt([[0, 0, 20, 20]], labels=[1])])
+    r = m.compute()
+    assert r["map"] == 0.0 and r["mar_100"] == 0.0
+    m.reset()
+    assert float(m.compute()["map"]) == -1.0
+
+
+def test_empty_predictions_and_validation():
+    m = MeanAveragePrecision()
+    m.update([one([], [])], [gt([[0, 0, 20, 20]])])
+    r = m.compute()
+    assert r["map"] == 0.0 and r["mar_100"] == 0.0
+    with pytest.raises(ValueError):
+        m.update([{"boxes": T()}], [gt([])])
+    with pytest.raises(ValueError):
+        m.update([one([], [])], [])
+
+
+def test_filter_dictionary_contract_of_the_hooks():
+    from hallucidet_amd.utils.utils import Utils
+    m = MeanAveragePrecision()
+    m.update([one([[0, 0, 20, 20]], [0.9])], [gt([[0, 0, 20, 20]])])
+    got = Utils.filter_dictionary(m.compute(), {'map_50', 'map_75', 'map'})
+    assert set(got) == {'map_50', 'map_75', 'map'} and all(float(v) == 1.0 for v in got.values())
+    d = Detection()
+    iou = d.iou_bboxes([[0, 0.9, 0, 0, 0, 10, 10]], [[0, 0.8, 0, 0, 0, 10, 5]])
+    assert iou.shape == (1, 1) and abs(float(iou[0, 0]) - 0.5) < 1e-6

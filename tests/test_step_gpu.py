@@ -127,3 +127,23 @@ def test_training_step_matches_oracle(dev, detector_name):
     for k in ("encoder.bn1.running_mean", "decoder.blocks.4.conv2.1.running_var"):
         ref = tr.unet.state_dict()[k]
         assert torch.allclose(after[k].float(), ref, rtol=5e-2, atol=5e-3), k
+
+
+def test_validation_and_test_hooks_accumulate_map(dev):
+    """validation_step / test_step feed the three detection streams into COCO-style mAP accumulators and the epoch-end
+    hooks return {'map_rgb','map_hall','map_ir'} -> {map, map_50, map_75} (train_hallucidet.py:213-215, 328-362, 399-427)."""
+    from hallucidet_amd import synthetic
+    lit = synthetic.make_module(seed=5, device=str(dev), precision=16)
+    batch = synthetic.make_batch(2, 128, 160, seed=6, device=str(dev))
+    loss, dets = lit.validation_step(batch, 0)
+    assert torch.isfinite(loss) and set(dets) == {"hall", "rgb", "ir"} and len(dets["hall"]) == 2
+    lit.validation_step(batch, 1)
+    out = lit.on_validation_epoch_end()
+    assert set(out) == {"map_rgb", "map_hall", "map_ir"}
+    for v in out.values():
+        assert set(v) == {"map", "map_50", "map_75"} and all(-1.0 <= float(t) <= 1.0 for t in v.values())
+    lit.test_step(batch, 0)
+    out_t = lit.on_test_epoch_end()
+    assert set(out_t) == set(out)
+    # accumulators were reset by the epoch-end hook
+    assert all(float(t) == -1.0 for t in lit.on_validation_epoch_end()["map_hall"].values())

@@ -159,3 +159,7 @@ def test_fit_step_learns_and_keeps_frozen_parts_fixed(dev):
     assert v1 < v0, (v0, v1)             # 12 Adam steps on one batch reduce its own loss
     dets = lit.test_step((rgb, trgb), 0)
     assert len(dets) == 2 and set(dets[0]) == {"boxes", "labels", "scores"}
+    m = lit.on_test_epoch_end()
+    assert set(m) == {"map", "map_50", "map_75", "map_per_class"} and -1.0 <= float(m["map_50"]) <= 1.0
+    mv = lit.on_validation_epoch_end()                       # two validation_step calls above fed it
+    assert -1.0 <= float(mv["map"]) <= 1.0
