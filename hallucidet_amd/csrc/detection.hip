@@ -541,6 +541,125 @@ __global__ __launch_bounds__(256) void roi_align_ml_bwd_gather_kernel(MLFeat ml,
   }
 }
 
+// C % 256 == 0 form of the gather backward (the detector's 256-channel pyramid): 8x8 pixel tile, thread = (pixel, 64-channel
+// quarter).  The per-axis bin weights depend on (RoI, pixel ROW) and (RoI, pixel COLUMN) only, so a tile needs
+// 16 x 7 of them per RoI instead of 64 x 14: they are computed cooperatively into LDS for 32 RoIs at a time and every
+// pixel thread then reads its 14 numbers -- the weight arithmetic, which dominated the generic kernel above, drops ~8x
+// and is no longer repeated per channel chunk.
+template <int PH, int PW, int SR>
+__global__ __launch_bounds__(256) void roi_align_ml_bwd_gather256_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
+                                                                         const int* __restrict__ level, int R, int C, int L, int4 tile_base) {
+  constexpr int CAP = 1024, SB = 32, TS = 8, CQ = 64;
+  static_assert(PH == PW, "square pooler");
+  __shared__ GatherRoi list[CAP];
+  __shared__ float wtab[SB][2][TS][PH];
+  __shared__ int wcnt[4];
+  int b = blockIdx.x, l = 0;
+  const int bases[4] = {tile_base.x, tile_base.y, tile_base.z, tile_base.w};
+  while (l + 1 < L && b >= bases[l + 1]) ++l;
+  b -= bases[l];
+  const int H = ml.H[l], W = ml.W[l];
+  const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS;
+  const int n = b / (tw * th);
+  const int ty = (b / tw) % th, tx = b % tw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ly = lane >> 3, lx = lane & 7;
+  const int py = ty * TS + ly, px = tx * TS + lx;
+  const bool live = py < H && px < W;
+  const int c0 = blockIdx.y * 256 + wave * CQ;
+  const int ty0 = ty * TS, ty1 = min(ty * TS + TS - 1, H - 1), tx0 = tx * TS, tx1 = min(tx * TS + TS - 1, W - 1);
+  float acc[CQ];
+#pragma unroll
+  for (int k = 0; k < CQ; ++k) acc[k] = 0.f;
+
+  for (int base = 0; base < R; base += CAP) {
+    int total = 0;
+    for (int it = 0; it < CAP / 256; ++it) {
+      const int r = base + it * 256 + tid;
+      bool hit = false;
+      GatherRoi e;
+      if (r < R && level[r] == l && (int)rois[(size_t)r * 5] == n) {
+        const RoiGeom g = roi_geom(ml, rois, level, r, PH, PW, SR);
+        if (g.any) {
+          const int y1 = g.y0 + g.ph_ - 1, x1 = g.x0 + g.pw_ - 1;
+          hit = !(y1 < ty0 || g.y0 > ty1 || x1 < tx0 || g.x0 > tx1);
+          e.rsw = g.rsw; e.rsh = g.rsh; e.bw = g.bw; e.bh = g.bh; e.r = r;
+          e.y0 = (short)g.y0; e.y1 = (short)y1; e.x0 = (short)g.x0; e.x1 = (short)x1;
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = total;
+      for (int w = 0; w < wave; ++w) off += wcnt[w];
+      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      __syncthreads();
+    }
+    for (int sb = 0; sb < total; sb += SB) {
+      const int nsb = min(SB, total - sb);
+      // ---- phase A: bin weights of nsb RoIs for the tile's 8 rows and 8 columns
+      for (int idx = tid; idx < nsb * 2 * TS * PH; idx += 256) {
+        const int p = idx % PH;
+        const int pos = (idx / PH) % TS;
+        const int axis = (idx / (PH * TS)) & 1;
+        const int j = idx / (2 * TS * PH);
+        const GatherRoi e = list[sb + j];
+        const float start = axis ? e.rsw : e.rsh, bin = axis ? e.bw : e.bh;
+        const int pix = axis ? tx * TS + pos : ty * TS + pos, size = axis ? W : H;
+        const float lo = start + (float)p * bin, hi = lo + bin;
+        const bool near_ = pix < size && (!(hi < (float)pix - 1.f || lo > (float)pix + 1.f) || pix == 0 || pix == size - 1);
+        wtab[j][axis][pos][p] = near_ ? axis_weight<SR>(start, bin, p, pix, size) : 0.f;
+      }
+      __syncthreads();
+      // ---- phase B
+      if (live) {
+        for (int j = 0; j < nsb; ++j) {
+          const GatherRoi e = list[sb + j];
+          if (py < e.y0 || py > e.y1 || px < e.x0 || px > e.x1) continue;
+          // the bins that reach a pixel are contiguous along each axis: find the two ranges, then a small 2-D loop
+          // (kept rolled: 49 unrolled bin bodies of 64 FMAs each overflow the instruction cache)
+          const float* WY = &wtab[j][0][ly][0];
+          const float* WX = &wtab[j][1][lx][0];
+          int ya = -1, yb = -1, xa = -1, xb = -1;
+#pragma unroll
+          for (int p = 0; p < PH; ++p) {
+            if (WY[p] != 0.f) { if (ya < 0) ya = p; yb = p; }
+            if (WX[p] != 0.f) { if (xa < 0) xa = p; xb = p; }
+          }
+          if (ya < 0 || xa < 0) continue;
+          const f16* dr = dout + (size_t)e.r * PH * PW * C + c0;
+          for (int ph = ya; ph <= yb; ++ph) {
+            const float wyv = WY[ph] * (1.f / (float)(SR * SR));
+            for (int pw = xa; pw <= xb; ++pw) {
+              const float w = wyv * WX[pw];
+              if (w == 0.f) continue;
+              const f16* q = dr + (size_t)(ph * PW + pw) * C;
+#pragma unroll
+              for (int v = 0; v < CQ / 8; ++v) {
+                const f16x8 d = *reinterpret_cast<const f16x8*>(q + v * 8);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc[v * 8 + k] += w * (float)d[k];
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (live) {
+    f16* o = const_cast<f16*>(ml.f[l]) + (((size_t)n * H + py) * W + px) * C + c0;
+#pragma unroll
+    for (int v = 0; v < CQ / 8; ++v) {
+      f16x8 t;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = (f16)acc[v * 8 + k];
+      *reinterpret_cast<f16x8*>(o + v * 8) = t;
+    }
+  }
+}
+
 __global__ void box_iou_kernel(const float* __restrict__ gt, int G, const float* __restrict__ boxes, int A, float* __restrict__ iou) {
   const int64_t total = (int64_t)G * A;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -657,9 +776,16 @@ extern "C" int hd_roi_align_ml_bwd_gather(const void* dout, const float* rois, c
     ml.H[l] = H[l];
     ml.W[l] = W[l];
     ml.scale[l] = scale[l];
-    base[l + 1] = base[l] + n_images * ((H[l] + 15) / 16) * ((W[l] + 15) / 16);
+    const int ts = (C % 256 == 0) ? 8 : 16;
+    base[l + 1] = base[l] + n_images * ((H[l] + ts - 1) / ts) * ((W[l] + ts - 1) / ts);
   }
   for (int l = L; l < 4; ++l) base[l + 1] = base[L];
+  if (C % 256 == 0) {
+    hipLaunchKernelGGL((roi_align_ml_bwd_gather256_kernel<7, 7, 2>), dim3(base[L], C / 256), dim3(256), 0, (hipStream_t)stream, ml,
+                       (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]));
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
   hipLaunchKernelGGL((roi_align_ml_bwd_gather_kernel<7, 7, 2, 32>), dim3(base[L], C / 32), dim3(256), 0, (hipStream_t)stream, ml,
                      (f16* const*)nullptr, (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]), n_images);
   HD_CHECK_LAUNCH();

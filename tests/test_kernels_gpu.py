@@ -433,14 +433,15 @@ def test_roi_align_multilevel_bwd_patch_and_direct_paths(dev):
         close(out[idx], want.half(), rtol=2e-3, atol=1e-3)
 
 
-def test_roi_align_multilevel_bwd_gather_form(dev):
+@pytest.mark.parametrize("C", [64, 256])
+def test_roi_align_multilevel_bwd_gather_form(dev, C):
     """Gather-form RoIAlign backward (no atomics): equals the oracle's autograd for tiny / large / out-of-image RoIs, with
     more RoIs than one LDS list batch (1024), RoIs in arbitrary image order, trailing images without RoIs left zero, and is
     bit-reproducible."""
     from hallucidet_amd import ops
     from oracle import detection as od
     g = torch.Generator().manual_seed(4)
-    C, N = 64, 3
+    N = 3                                        # C = 64: generic kernel; C = 256: the tile-weight kernel of the detector
     shapes = [(N, 75, 75, C), (N, 38, 38, C), (N, 19, 19, C)]
     scales = [0.25, 0.125, 0.0625]
     sizes = [2.0, 6.0, 14.0, 30.0, 70.0, 150.0, 280.0]
