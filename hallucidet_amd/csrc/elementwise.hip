@@ -34,16 +34,26 @@ __global__ void colsum_stage(const float* __restrict__ in, int rows, int W, floa
 
 // ---------------------------------------------------------------- BN finalize
 // part [rows][2][C] partial (sum, sumsq) rows are added here (rows <= 128: the conv epilogue slab after one hd_rowsum)
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* running_mean, float* running_var, float momentum,
-                                   float eps, float* mean, float* invstd, float* scale, float* shift) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// block = 4 row lanes x 64 channels: the partial rows are summed with 4-way row parallelism (fixed order), then finalized
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* running_mean, float* running_var, float momentum, float eps,
+                                                          float* mean, float* invstd, float* scale, float* shift) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s1 += (double)part[(size_t)r * 2 * C + c];
-    s2 += (double)part[(size_t)r * 2 * C + C + c];
-  }
+  if (c < C)
+    for (int r = rl; r < rows; r += 4) {
+      s1 += (double)part[(size_t)r * 2 * C + c];
+      s2 += (double)part[(size_t)r * 2 * C + C + c];
+    }
+  red[0][rl][cl] = s1;
+  red[1][rl][cl] = s2;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   double m = s1 / count;
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -734,7 +744,7 @@ extern "C" int hd_bn_finalize(const float* part, int rows, int C, double count, 
                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                               float* scale, float* shift, void* stream) {
   HD_CHECK_ARG(part && rows > 0 && rows <= 128 && scale && shift && C > 0 && count > 0, "hd_bn_finalize: bad args (rows <= 128)");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 64)), dim3(64), 0, S_, part, rows, C, count, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 64)), dim3(256), 0, S_, part, rows, C, count, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift);
   HD_CHECK_LAUNCH();
   return HD_OK;

@@ -154,8 +154,8 @@ def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, e
         part = part.reshape(part.shape[0], -1)
     elif part.dim() == 1:
         part = part.reshape(1, -1)
-    if part.shape[0] > 4:          # every thread of the finalize kernel re-reads the rows: keep them few
-        part = colsum(part).reshape(1, -1)
+    if part.shape[0] > 128:        # one row-range stage; the finalize kernel sums the remaining <= 128 rows itself
+        part = rowsum(part, 128)
     rows, W = part.shape
     C_ = W // 2
     dev = part.device
@@ -199,8 +199,8 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
     part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
     check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
                                1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
-    if rows > 2:                   # the apply kernel reads the partial rows in every thread: reduce them to one first
-        part = colsum(part).reshape(1, -1)
+    if rows > 16:                  # one row-range stage; every block of the apply kernel sums the remaining 16 rows in its
+        part = rowsum(part, 16)    # coefficient prologue (16 x 2C floats per block)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     if dgamma is None:
