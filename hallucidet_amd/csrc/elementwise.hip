@@ -34,17 +34,17 @@ __global__ void colsum_stage(const float* __restrict__ in, int rows, int W, floa
 
 // ---------------------------------------------------------------- BN finalize
 // part [rows][2][C] partial (sum, sumsq) rows are added here (rows <= 128: the conv epilogue slab after one hd_rowsum)
-// block = 4 row lanes x 64 channels: the partial rows are summed with 4-way row parallelism (fixed order), then finalized
+// block = 16 row lanes x 16 channels: the partial rows are summed with 16-way row parallelism (fixed order), then finalized
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum, float eps,
                                                           float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C)
-    for (int r = rl; r < rows; r += 4) {
+    for (int r = rl; r < rows; r += 16) {
       s1 += (double)part[(size_t)r * 2 * C + c];
       s2 += (double)part[(size_t)r * 2 * C + C + c];
     }
@@ -52,8 +52,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   red[1][rl][cl] = s2;
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-  s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+  s1 = s2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    s1 += red[0][q][cl];
+    s2 += red[1][q][cl];
+  }
   double m = s1 / count;
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -178,6 +182,28 @@ __global__ void bn_bwd_reduce_kernel(const f16* __restrict__ dz, const f16* __re
   }
 }
 
+// column c of the partial rows; the common 16-row case is unrolled so that all 32 loads are in flight at once
+__device__ __forceinline__ void sum_part_rows(const float* __restrict__ part, int rows, int C, int c, float& sg, float& sgx) {
+  if (rows == 16) {
+    float a[16], b[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      a[r] = part[(size_t)r * 2 * C + c];
+      b[r] = part[(size_t)r * 2 * C + C + c];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sg += a[r];
+      sgx += b[r];
+    }
+    return;
+  }
+  for (int r = 0; r < rows; ++r) {
+    sg += part[(size_t)r * 2 * C + c];
+    sgx += part[(size_t)r * 2 * C + C + c];
+  }
+}
+
 // dy = A[c]*g + B[c]*y + D[c]  with  A = gamma*invstd, B = -A*invstd*sum_gx/M, D = -A*sum_g/M - B*mean
 __global__ void bn_bwd_apply_kernel(const f16* __restrict__ dz, const f16* __restrict__ z, const f16* __restrict__ y,
                                     const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -190,10 +216,7 @@ __global__ void bn_bwd_apply_kernel(const f16* __restrict__ dz, const f16* __res
   if (blockIdx.x == 0) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float sg = 0.f, sgx = 0.f;
-      for (int r = 0; r < rows; ++r) {
-        sg += part[(size_t)r * 2 * C + c];
-        sgx += part[(size_t)r * 2 * C + C + c];
-      }
+      sum_part_rows(part, rows, C, c, sg, sgx);
       float dg = sgx * gscale, db = sg * gscale;
       if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
       if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
@@ -203,10 +226,7 @@ __global__ void bn_bwd_apply_kernel(const f16* __restrict__ dz, const f16* __res
   extern __shared__ float cf[];   // [5][C]: A, B, D, sc, sh
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sg = 0.f, sgx = 0.f;
-    for (int r = 0; r < rows; ++r) {
-      sg += part[(size_t)r * 2 * C + c];
-      sgx += part[(size_t)r * 2 * C + C + c];
-    }
+    sum_part_rows(part, rows, C, c, sg, sgx);
     const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, is = invstd[c], mu = mean[c];
     const float a_ = ga * is;
     const float b_ = -a_ * is * sgx * invM;
@@ -744,7 +764,7 @@ extern "C" int hd_bn_finalize(const float* part, int rows, int C, double count, 
                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                               float* scale, float* shift, void* stream) {
   HD_CHECK_ARG(part && rows > 0 && rows <= 128 && scale && shift && C > 0 && count > 0, "hd_bn_finalize: bad args (rows <= 128)");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 64)), dim3(256), 0, S_, part, rows, C, count, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 16)), dim3(256), 0, S_, part, rows, C, count, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift);
   HD_CHECK_LAUNCH();
   return HD_OK;
