@@ -36,6 +36,18 @@ class DetectorLit:
         self.optimizer = self.scaler = self.arena = self.averager = None
         self._last_detections = None
 
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, strict=True, **kwargs):
+        """`detectorLit.load_from_checkpoint(checkpoint_path=args.detector_path, ...).detector` (train_hallucidet.py:107-115)."""
+        from .checkpoint import load_detector
+        lit = cls(**kwargs)
+        load_detector(lit.detector, checkpoint_path, strict=strict)
+        return lit
+
+    def save_checkpoint(self, path, epoch=0, global_step=0):
+        from .checkpoint import save_lightning_checkpoint
+        return save_lightning_checkpoint(path, {"detector": self.detector}, epoch, global_step)
+
     # ------------------------------------------------------------------ setup
     def configure_optimizers(self):
         if self.optimizer_name != 'adam':

@@ -108,6 +108,18 @@ class EncoderDecoderLit(nn.Module):
         out = self.forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train')
         return out['loss']['total']
 
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, strict=True, **kwargs):
+        """train_hallucidet.py:467-481 / eval_hallucidet.py:199 (Lightning's classmethod): construct with the given
+        keywords, then restore `encoder_decoder.*` and `detector.*` from the checkpoint's state_dict."""
+        from .checkpoint import load_encoder_decoder_lit
+        return load_encoder_decoder_lit(cls(**kwargs), checkpoint_path, strict=strict)
+
+    def save_checkpoint(self, path, epoch=0, global_step=0):
+        """trainer.save_checkpoint (:353-356, :544-545)."""
+        from .checkpoint import save_lightning_checkpoint
+        return save_lightning_checkpoint(path, {"encoder_decoder": self.encoder_decoder, "detector": self.detector}, epoch, global_step)
+
     def _metrics(self, split):
         """train_hallucidet.py:121-131: one COCO-style mAP accumulator per (split, stream)."""
         from .metrics import Detection
