@@ -60,8 +60,39 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
+// 3x3 / s1 / p1 layers with >= 64 in/out channels CAN go to the input-patch kernel (conv3x3_patch.hip: 1.7-2.3x fewer bytes
+// filled per FLOP).  Measured on the hot path's layers it is 5-20 % SLOWER than the igemm family (launches of 9-72 K steps
+// are bound by per-block fixed costs and fill latency, not by fill volume), so it is opt-in (HD_CONV_PATCH=1 or
+// hd_conv2d_patch) until it keeps weights resident across tiles.
+bool patch_eligible(const ConvP& p) {
+  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.in_dil == 1 && !p.up1 && p.C2 == 0 && p.C1 % 64 == 0 &&
+         p.out_mode == HD_OUT_NHWC_F16 && p.Cout % 8 == 0 && p.Cout >= 64 && p.Ho == p.Hin && p.Wo == p.Win;
+}
+bool use_patch(const ConvP& p) {
+  static const int on = env_int("HD_CONV_PATCH", 0);
+  return on && patch_eligible(p);
+}
+
+extern "C" int hd_conv2d_patch(const hd_conv_args* a, void* stream) {
+  ConvP p;
+  int rc = fill_params(a, p);
+  if (rc) return rc;
+  HD_CHECK_ARG(patch_eligible(p), "hd_conv2d_patch: needs 3x3 / stride 1 / pad 1, one source, Cin %% 64 == 0, Cout %% 8 == 0, Cout >= 64, NHWC f16 output");
+  hd_conv_launch_patch(p, (hipStream_t)stream);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_conv2d_patch_stats_rows(const hd_conv_args* a) {
+  ConvP p;
+  if (!a || fill_params(a, p) != HD_OK || !patch_eligible(p)) return HD_E_ARG;
+  return hd_conv_patch_tiles(p);
+}
+
 extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (!a) return HD_E_ARG;
+  ConvP p;
+  if (fill_params(a, p) == HD_OK && use_patch(p)) return hd_conv_patch_tiles(p);
   int M = a->N * a->Ho * a->Wo;
   return hd_cdiv(M, pick_bm(M, a->Cout));
 }
@@ -71,6 +102,11 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   int rc = fill_params(a, p);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  if (use_patch(p)) {
+    hd_conv_launch_patch(p, s);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
   int bn = pick_bn(p.Cout);
   const int bm = pick_bm(p.M, p.Cout);
   int64_t blocks = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);

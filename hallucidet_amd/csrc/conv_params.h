@@ -20,3 +20,6 @@ struct ConvP {
 
 void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
+// conv3x3_patch.hip: 3x3 / stride 1 / pad 1, Cin % 64 == 0, NHWC f16 output, LDS-staged input patches
+void hd_conv_launch_patch(ConvP& p, hipStream_t s);
+int hd_conv_patch_tiles(const ConvP& p);

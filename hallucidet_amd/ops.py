@@ -30,7 +30,7 @@ def conv_out_size(h, k, stride, pad):
 
 
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
-           out_nchw_f32=False, want_stats=False, out_hw=None, cout=None, out=None):
+           out_nchw_f32=False, want_stats=False, out_hw=None, cout=None, out=None, patch_kernel=False):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
@@ -66,10 +66,14 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
                  1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else 0)
     stats = None
     if want_stats:
-        rows = lib.hd_conv2d_stats_rows(C.byref(a))
+        rows = (lib.hd_conv2d_patch_stats_rows if patch_kernel else lib.hd_conv2d_stats_rows)(C.byref(a))
+        check(0 if rows > 0 else rows, "hd_conv2d_stats_rows")
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         a.stats = ptr(stats)
-    check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
+    if patch_kernel:      # explicit request for the LDS-staged-input-patch kernel (3x3 / s1 / p1, >= 64 channels)
+        check(lib.hd_conv2d_patch(C.byref(a), _stream()), "hd_conv2d_patch")
+    else:
+        check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
     return (y, stats) if want_stats else y
 
 

@@ -82,6 +82,13 @@ typedef struct hd_conv_args {
 int hd_conv2d(const hd_conv_args* a, void* stream);
 /* number of M tiles (rows of `stats`) hd_conv2d will use for this problem */
 int hd_conv2d_stats_rows(const hd_conv_args* a);
+/* Same operator for the 3x3 / stride 1 / pad 1, single-source, Cin % 64 == 0, Cout >= 64, NHWC-f16 case through the
+ * LDS-staged-input-patch kernel (each input pixel is filled into LDS once per channel chunk and read by the nine taps as
+ * shifted windows; replaces the same Conv2d call sites as hd_conv2d: src/segmentation_models/base/modules.py:21-29,
+ * torchvision Bottleneck.conv2 / FPN layer_blocks [EXT]).  Opt-in: see DESIGN.md 6.1 for the measured comparison.
+ * BN partial-sum rows are per 8x16 output tile: hd_conv2d_patch_stats_rows. */
+int hd_conv2d_patch(const hd_conv_args* a, void* stream);
+int hd_conv2d_patch_stats_rows(const hd_conv_args* a);
 
 /* ------------------------------------------------------------------------
  * Weight-gradient implicit GEMM: dW[co][kh][kw][ci] = sum_pix dY[pix,co] * X[pix@(kh,kw),ci]

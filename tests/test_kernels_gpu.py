@@ -44,8 +44,15 @@ CONV_CASES = [
     # large grids: every (tile, K-depth, stage-count) variant the dispatcher can pick must be exercised
     (6, 150, 150, 8, 0, 64, 7, 2, 3, False, 1, True, False),     # stem at detector size: 128x64 tile, 32-deep, 2 stages, per-lane taps
     (4, 96, 96, 32, 0, 128, 3, 1, 1, False, 1, False, True),     # 128x128 tile, 32-deep, 2 stages
-    (4, 96, 96, 64, 0, 128, 3, 1, 1, False, 0, True, False),     # 128x128 tile, 64-deep, 2 stages
-    (4, 96, 96, 64, 0, 64, 3, 1, 1, False, 1, False, False),      # 128x64 tile, 64-deep, 2 stages
+    (4, 96, 96, 256, 0, 128, 1, 1, 0, False, 0, True, False),    # 128x128 tile, 64-deep, 2 stages (1x1: igemm family)
+    (4, 96, 96, 256, 0, 64, 1, 1, 0, False, 1, False, False),     # 128x64 tile, 64-deep, 2 stages
+    (4, 96, 96, 64, 0, 128, 3, 2, 1, False, 0, True, False),     # 3x3 stride 2 stays on the igemm family
+    # 3x3 / s1 / p1 with >= 64 channels: also run through the input-patch kernel (conv3x3_patch.hip) by test_conv2d_patch_kernel
+    (4, 96, 96, 64, 0, 128, 3, 1, 1, False, 0, True, False),     # BN=128, one channel chunk, full tiles
+    (4, 96, 96, 64, 0, 64, 3, 1, 1, False, 1, False, False),      # BN=64
+    (2, 13, 21, 128, 0, 192, 3, 1, 1, False, 1, True, True),      # ragged tiles in both directions, 2 chunks, partial N tile, residual
+    (1, 9, 40, 256, 0, 72, 3, 1, 1, False, 0, False, False),      # 4 chunks, Cout not a multiple of 32
+    (3, 5, 5, 512, 0, 512, 3, 1, 1, False, 1, True, False),       # image smaller than a tile, 8 chunks, 4 N tiles
     (2, 40, 40, 64, 64, 64, 3, 1, 1, True, 1, False, False),      # dual source, 64-deep, large grid
 ]
 
@@ -75,6 +82,33 @@ def test_conv2d_forward(dev, case):
     assert torch.allclose(s[1], wstats[1], rtol=3e-3, atol=1e-2)
 
 
+PATCH_CASES = [c for c in CONV_CASES if c[6] == 3 and c[7] == 1 and c[8] == 1 and not c[9] and c[4] == 0 and c[3] % 64 == 0 and c[5] >= 64]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv2d_patch_kernel(dev, case):
+    """LDS-staged-input-patch kernel (opt-in): same results as the oracle / the igemm family, incl. BN partial sums per tile,
+    ragged tiles, multi-chunk K, partial N tiles, residual + ReLU epilogue."""
+    from hallucidet_amd import ops
+    N, H, W, C1, C2, Cout, K, stride, pad, up1, act, use_bias, use_res = case
+    x = rnd(N, H, W, C1, seed=1)
+    Kt = K * K * C1
+    w = rnd(Cout, Kt, scale=1.0 / math.sqrt(Kt), seed=3)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(4)) if use_bias else None
+    res = rnd(N, H, W, Cout, seed=5) if use_res else None
+    want, wstats = ok.conv2d_nhwc(x, w, K, K, bias=bias, res=res, stride=1, pad=1, act=act)
+    d = lambda t: None if t is None else t.to(dev)
+    got, stats = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), stride=1, pad=1, act=act, want_stats=True, patch_kernel=True)
+    ref = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), stride=1, pad=1, act=act)
+    assert stats.shape[0] == N * ((H + 7) // 8) * ((W + 15) // 16)
+    close(got, want.half())
+    assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
+    s = stats.sum(dim=0).cpu()
+    assert torch.allclose(s[0], wstats[0], rtol=2e-3, atol=2e-3 * (N * H * W) ** 0.5 + 1e-2) and torch.allclose(s[1], wstats[1], rtol=3e-3, atol=1e-2)
+    with pytest.raises(Exception, match="hd_conv2d_patch"):
+        ops.conv2d(d(x), d(w[:, : 9 * C1]), 3, 3, stride=2, pad=1, patch_kernel=True)
+
+
 def test_conv2d_nchw_f32_output(dev):
     from hallucidet_amd import ops
     x = rnd(2, 12, 16, 16, seed=1)
@@ -94,6 +128,7 @@ DGRAD_CASES = [
     (2, 15, 15, 64, 128, 1, 2, 0),
     (1, 30, 30, 3, 64, 7, 2, 3),     # stem, Cin=3 padded to 8
     (2, 9, 9, 16, 3, 3, 1, 1),       # head: Cout=3 padded to 8
+    (2, 21, 19, 128, 256, 3, 1, 1),  # input-patch kernel as data gradient: 4 chunks of dy, ragged tiles
 ]
 
 
