@@ -28,6 +28,27 @@ BATCH_PER_GPU = 8
 H, W = 512, 640
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in two separate
+    runs, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py) committed under profiles/ for this round.
+    bench.py itself cannot collect PMCs (they need rocprofv3 around the process): null if the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_traffic.json")
+    try:
+        return round(json.load(open(path))["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown CPU"
+
+
 def conv_roofline(lit, batch, reps=5):
     """Record every hd_conv2d launch of one (eager) training step, then time the recorded launches back to back."""
     import ctypes as C
@@ -48,7 +69,10 @@ def conv_roofline(lit, batch, reps=5):
         dil = kw.get("in_dil", 1)
         # algorithmic FLOPs: a data-gradient over a zero-dilated input only multiplies the non-zero taps
         flops = 2.0 * n * ho * wo * co * KH * KW * (C1 + C2) / (dil * dil)
-        rec.append((dict(kw), (x, w, KH, KW), flops))
+        # algorithmic bytes: every operand once (x, x2, w, y, residual, mask)
+        by = x.numel() * 2 + (0 if kw.get("x2") is None else kw["x2"].numel() * 2) + w.numel() * 2 + y.numel() * y.element_size()
+        by += sum(t.numel() * 2 for t in (kw.get("res"), kw.get("mask")) if t is not None)
+        rec.append((dict(kw), (x, w, KH, KW), flops, by))
         return out
 
     ops.conv2d = spy
@@ -64,10 +88,11 @@ def conv_roofline(lit, batch, reps=5):
         ops.conv2d = orig
         r.enable_graphs(was)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    tot_ms, tot_fl = 0.0, 0.0
+    tot_ms, tot_fl, tot_by = 0.0, 0.0, 0.0
     dump = os.environ.get("HD_BENCH_DUMP")
     rows = []
-    for kw, (x, w, KH, KW), fl in rec:
+    for kw, (x, w, KH, KW), fl, by in rec:
+        tot_by += by
         kw = dict(kw)                                 # same epilogue (bias / res / mask / BN statistics) as in the step
         orig(x, w, KH, KW, **kw)                      # warm
         e0.record()
@@ -90,7 +115,8 @@ def conv_roofline(lit, batch, reps=5):
     n = len(rec)
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": _pmc_traffic(), "traffic_unit": "HBM bytes per launch (PMC)",
+            "alg_bytes_per_launch": round(tot_by / max(n, 1)),
             "kernel": "conv_igemm_kernel (implicit-GEMM conv / dgrad / FC)", "launches_per_step": n,
             "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2), "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3)}
 
@@ -160,6 +186,16 @@ def main():
                        "step_alg_tflops": round(428.5e9 * value / 1e12, 1) if args.detector == "fasterrcnn" else None},
             "final_loss": round(float(loss), 5),
         }
+        if world == 1:
+            # PCIe-inclusive rate (never `value`): the same step with the batch copied from pinned host memory every step
+            hb = [t.cpu().pin_memory() if torch.is_tensor(t) else [{k: v.cpu().pin_memory() for k, v in d.items()} for d in t] for t in batch]
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                db = [t.to(dev, non_blocking=True) if torch.is_tensor(t) else [{k: v.to(dev, non_blocking=True) for k, v in d.items()} for d in t] for t in hb]
+                lit.fit_step(db)
+            torch.cuda.synchronize()
+            out["pcie_inclusive_images_per_s"] = round(BATCH_PER_GPU * 5 / (time.perf_counter() - t1), 2)
         if not args.no_roofline:
             out["roofline"] = conv_roofline(lit, batch)
         if world == 1 and not args.no_cpu_baseline:
@@ -168,7 +204,7 @@ def main():
             v, steps, cores = time_cpu_step(cb, budget_s=25.0, max_steps=2)
             out["cpu_baseline"] = {"value": round(v, 4), "unit": "images/s", "cores": cores, "kind": "port",
                                    "sample": "%d full training step(s) of the CPU oracle (oracle/step.py, fp32 torch) on a batch of 2 "
-                                             "synthetic 512x640 images" % steps}
+                                             "synthetic 512x640 images; host: %s" % (steps, _cpu_model())}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,26 @@
+"""Aggregate the two rocprofv3 PMC passes (--pmc FETCH_SIZE / --pmc WRITE_SIZE, each with --kernel-trace only) into the
+per-launch HBM traffic of the dominant kernel, with the guide's corrections (MI355X_MICROARCH.md, HBM section):
+counter unit = KiB; on gfx950 FETCH_SIZE tallies wide (16 B/lane) streaming reads at one half -> x2; WRITE_SIZE exact.
+
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch/run_counter_collection.csv gpurun_out/pmc_write/run_counter_collection.csv conv_igemm_kernel out.json
+"""
+import csv, json, sys
+
+
+def per_launch(path, counter, match):
+    tot, n = 0.0, 0
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and match in r["Kernel_Name"]:
+            tot += float(r["Counter_Value"])
+            n += 1
+    return tot / max(n, 1), n
+
+
+fetch_kib, nf = per_launch(sys.argv[1], "FETCH_SIZE", sys.argv[3])
+write_kib, nw = per_launch(sys.argv[2], "WRITE_SIZE", sys.argv[3])
+out = {"kernel": sys.argv[3], "launches_sampled": [nf, nw], "fetch_bytes_per_launch": fetch_kib * 1024 * 2.0, "write_bytes_per_launch": write_kib * 1024,
+       "corrections": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies 16-B/lane streaming reads at half); WRITE_SIZE [KiB] x 1024",
+       "command": "STEPS=3 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/bench_step.py (two separate passes)"}
+out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(out))
