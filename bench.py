@@ -138,9 +138,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
     torch.cuda.set_device(local)
-    if world > 1:
+    force_dist = os.environ.get("HD_FORCE_DIST") == "1"      # exercise the RCCL path on one GPU (world size 1)
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
 
     from hallucidet_amd import synthetic
@@ -151,18 +153,18 @@ def main():
     for _ in range(args.warmup):
         lit.fit_step(batch)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = lit.fit_step(batch)
     torch.cuda.synchronize()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
@@ -206,7 +208,7 @@ def main():
                                    "sample": "%d full training step(s) of the CPU oracle (oracle/step.py, fp32 torch) on a batch of 2 "
                                              "synthetic 512x640 images; host: %s" % (steps, _cpu_model())}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

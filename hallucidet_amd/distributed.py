@@ -6,12 +6,15 @@ large all-reduces over contiguous slices (default 4 buckets of ~24 MB: xGMI is p
 messages beat many small ones) issued asynchronously and waited on right before the optimizer step.  BatchNorm statistics
 stay per rank (the reference has no SyncBatchNorm).  The same code runs on the gloo backend for CPU tests.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    # HD_FORCE_DIST=1: run the collectives even at world size 1 (exercises the RCCL path on a single-GPU box)
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("HD_FORCE_DIST") == "1")
 
 
 def broadcast_parameters(flat_params, buffers=()):
