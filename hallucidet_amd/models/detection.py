@@ -155,7 +155,12 @@ def _wgrad_into(param, e, x, dy, inv_scale, bn_scale=None):
 
 
 def _bgrad_into(param, dy, inv_scale):
-    param.grad.add_(ops.channel_sum(dy)[: param.numel()], alpha=inv_scale)
+    c8 = dy.shape[-1] // 8
+    if dy.shape[-1] % 8 == 0 and c8 & (c8 - 1) == 0:
+        s = ops.channel_sum(dy)
+    else:                       # 24- / 40-channel head outputs (RetinaNet cls / box convs): hd_channel_sum_f16 wants C/8 = 2^k
+        s = dy.float().sum(dim=(0, 1, 2))
+    param.grad.add_(s[: param.numel()], alpha=inv_scale)
 
 
 class _BackboneFn(torch.autograd.Function):
@@ -265,6 +270,7 @@ class BackboneWithFPN(nn.Module):
             extra = [ops.subsample2(outs[L - 1])]
         if save:
             rec["inner"] = [t[:na] for t in inner] if self.train_params else None
+            rec["outs_top"] = outs[L - 1][:na] if (self.train_params and self.p6p7) else None
             rec.update(stem=s[:na], pool_idx=pidx[:na], pooled=p[:na], C=[c[:na] for c in C], out_shapes=[(na,) + tuple(t.shape[1:]) for t in outs],
                        p6=extra[0][:na] if self.p6p7 else None)
         return outs + extra, rec
@@ -283,11 +289,20 @@ class BackboneWithFPN(nn.Module):
         top_hw = (shapes[L - 1][1], shapes[L - 1][2])
         if self.p6p7:
             g6, g7, p6 = grads[L], grads[L + 1], rec["p6"]
+            eb = self.fpn.extra_blocks
             if g7 is not None:
-                d6 = _dgrad(P["p7"], g7.contiguous(), (p6.shape[1], p6.shape[2]), mask=p6)     # through ReLU(P6)
+                g7 = g7.contiguous()
+                if tp:
+                    _wgrad_into(eb.p7.weight, P["p7"], torch.relu(p6), g7, inv)
+                    _bgrad_into(eb.p7.bias, g7, inv)
+                d6 = _dgrad(P["p7"], g7, (p6.shape[1], p6.shape[2]), mask=p6)     # through ReLU(P6)
                 g6 = d6 if g6 is None else ops.add_f16(g6.contiguous(), d6)
             if g6 is not None:
-                dP[L - 1] = _dgrad(P["p6"], g6.contiguous(), top_hw, res=dP[L - 1])
+                g6 = g6.contiguous()
+                if tp:
+                    _wgrad_into(eb.p6.weight, P["p6"], rec["outs_top"], g6, inv)
+                    _bgrad_into(eb.p6.bias, g6, inv)
+                dP[L - 1] = _dgrad(P["p6"], g6, top_hw, res=dP[L - 1])
         elif grads[L] is not None:
             if grads[L - 1] is not None:
                 dP[L - 1] = dP[L - 1].clone()
@@ -301,8 +316,6 @@ class BackboneWithFPN(nn.Module):
             if i > 0:
                 ops.upsample_add_bwd(d_li[i - 1], d_li[i], accumulate=True)
         if tp:
-            if self.p6p7:
-                raise NotImplementedError("hallucidet_amd: detector fine-tuning is built for Faster R-CNN (BASELINE configs[4])")
             for i in range(L):
                 lb, ib = self.fpn.layer_blocks[i], self.fpn.inner_blocks[i]
                 _wgrad_into(lb.weight, P["layer"][i], rec["inner"][i], dP[i], inv)

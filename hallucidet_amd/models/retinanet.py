@@ -46,12 +46,16 @@ class _HeadFn(torch.autograd.Function):
                 lv.append(acts)
             saved.append(lv)
         ctx.head, ctx.saved, ctx.na, ctx.n = head, saved, n_active, feats[0].shape[0]
+        ctx.feats = [f[:n_active] for f in feats] if head.train_params else None
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        P = ctx.head.pack()
+        head = ctx.head
+        P = head.pack()
         na = ctx.na
+        tp, inv = head.train_params, 1.0 / head.grad_scale
+        mods = ((head.classification_head, head.classification_head.cls_logits), (head.regression_head, head.regression_head.bbox_reg))
         dfeats = []
         for i, lv in enumerate(ctx.saved):
             df = None
@@ -61,10 +65,20 @@ class _HeadFn(torch.autograd.Function):
                     continue
                 acts = lv[j]
                 H, W = acts[0].shape[1], acts[0].shape[2]
+                convs = [l for l in mods[j][0].conv if isinstance(l, nn.Conv2d)]
                 d = ops.nchw_to_nhwc_resize(g[:na].contiguous().float(), H, W, last["cout_p"])
+                if tp:                                   # the towers share their weights over the 5 levels: accumulate
+                    D._wgrad_into(mods[j][1].weight, last, acts[3], d, inv)
+                    D._bgrad_into(mods[j][1].bias, d, inv)
                 d = _dgrad(last, d, (H, W), mask=acts[3])
                 for k in (3, 2, 1):
+                    if tp:
+                        D._wgrad_into(convs[k].weight, tower[k], acts[k - 1], d, inv)
+                        D._bgrad_into(convs[k].bias, d, inv)
                     d = _dgrad(tower[k], d, (H, W), mask=acts[k - 1])
+                if tp:
+                    D._wgrad_into(convs[0].weight, tower[0], ctx.feats[i], d, inv)
+                    D._bgrad_into(convs[0].bias, d, inv)
                 df = _dgrad(tower[0], d, (H, W), res=df)
             if df is not None and na < ctx.n:
                 full = torch.zeros((ctx.n,) + tuple(df.shape[1:]), dtype=df.dtype, device=df.device)
@@ -116,6 +130,7 @@ class RetinaNetHead(nn.Module):
         self.classification_head = RetinaNetClassificationHead(in_channels, num_anchors, num_classes)
         self.regression_head = RetinaNetRegressionHead(in_channels, num_anchors)
         self._pack, self._hook = None, None
+        self.train_params, self.grad_scale = False, 1.0
 
     def invalidate(self):
         self._pack = None
@@ -166,6 +181,21 @@ class RetinaNet(nn.Module):
     def invalidate_packs(self):
         self.backbone.invalidate()
         self.head.invalidate()
+
+    def set_trainable(self, flag=True, grad_scale=1.0):
+        """Detector fine-tuning switch (train_detector.py with detector_name='retinanet'): parameter gradients for what
+        torchvision's retinanet_resnet50_fpn leaves trainable (trainable_backbone_layers=3 [EXT]: body.layer2-4, FPN incl.
+        P6/P7, both head towers and their output convs)."""
+        for m in (self.backbone, self.head):
+            m.train_params, m.grad_scale = bool(flag), float(grad_scale)
+        for name, p in self.backbone.body.named_parameters():
+            p.requires_grad_(bool(flag) and name.split(".")[0] in ("layer2", "layer3", "layer4"))
+        for mod in (self.backbone.fpn, self.head):
+            for p in mod.parameters():
+                p.requires_grad_(bool(flag))
+
+    def trainable_parameters(self):
+        return [p for p in self.parameters() if p.requires_grad]
 
     def load_state_dict(self, state_dict, strict=True):
         sd = OrderedDict()

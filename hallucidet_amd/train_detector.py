@@ -23,8 +23,8 @@ from .utils.utils import Utils
 class DetectorLit:
     def __init__(self, batch_size=4, wandb_logger=None, lr=0.0001, detector_name='fasterrcnn', pretrained=True, optimizer_name='adam',
                  modality=None, directly_coco=False, detector=None, device='cuda', loss_scale=1024.0):
-        if 'fasterrcnn' not in detector_name:
-            raise NotImplementedError("hallucidet_amd: detector fine-tuning is built for fasterrcnn (BASELINE configs[4])")
+        if 'fasterrcnn' not in detector_name and 'retinanet' not in detector_name:
+            raise NotImplementedError("hallucidet_amd: detector fine-tuning is built for fasterrcnn and retinanet")
         self.wandb_logger, self.lr, self.batch_size = wandb_logger, lr, batch_size
         self.optimizer_name, self.detector_name, self.modality = optimizer_name, detector_name, modality
         self.dev = device
@@ -69,10 +69,14 @@ class DetectorLit:
     def _weighted(self, losses_det):
         w = Config.Losses.hparams_losses_weights
         losses_det = dict(losses_det)
-        losses_det['classification'] = losses_det['loss_classifier'] * w['det_classification']
-        losses_det['bbox_regression'] = losses_det['loss_box_reg'] * w['det_regression']
-        losses_det['loss_objectness'] = losses_det['loss_objectness'] * w['det_objectness']
-        losses_det['loss_rpn_box_reg'] = losses_det['loss_rpn_box_reg'] * w['det_rpn_box_reg']
+        frcnn = 'fasterrcnn' in self.detector_name
+        if frcnn:                                                     # train_detector.py:162-164
+            losses_det['classification'] = losses_det['loss_classifier']
+            losses_det['bbox_regression'] = losses_det['loss_box_reg']
+        losses_det['classification'] = losses_det['classification'] * w['det_classification']
+        losses_det['bbox_regression'] = losses_det['bbox_regression'] * w['det_regression']
+        losses_det['loss_objectness'] = losses_det['loss_objectness'] * w['det_objectness'] if frcnn else 0.0
+        losses_det['loss_rpn_box_reg'] = losses_det['loss_rpn_box_reg'] * w['det_rpn_box_reg'] if frcnn else 0.0
         losses_det['bbox_ctrness'] = 0.0
         total = losses_det['bbox_regression'] + losses_det['classification'] + losses_det['loss_objectness'] + \
             losses_det['loss_rpn_box_reg'] + losses_det['bbox_ctrness']
@@ -101,7 +105,9 @@ class DetectorLit:
         self._last_detections = detections
         self._metric('val').update(detections, targets)          # train_detector.py:220
         # train_detector.py:224-229: the validation total is the UNWEIGHTED sum
-        return losses_det['loss_box_reg'] + losses_det['loss_classifier'] + losses_det['loss_objectness'] + losses_det['loss_rpn_box_reg']
+        if 'fasterrcnn' in self.detector_name:
+            return losses_det['loss_box_reg'] + losses_det['loss_classifier'] + losses_det['loss_objectness'] + losses_det['loss_rpn_box_reg']
+        return losses_det['bbox_regression'] + losses_det['classification']
 
     def test_step(self, test_batch, batch_idx):
         imgs, targets = self._unpack(test_batch)

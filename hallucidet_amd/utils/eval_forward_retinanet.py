@@ -61,9 +61,11 @@ def box_loss(type: str, box_coder, anchors_per_image: torch.Tensor, matched_gt_b
 
 def eval_forward_retinanet(model, images, targets, train_det=False, model_name='retinanet'):
     if train_det:
-        raise NotImplementedError("hallucidet_amd: detector fine-tuning (train_det=True, train_detector.py) needs the "
-                                  "weight-gradient path through the detector; round-1 scope is the frozen detector")
-    model.eval()
+        if not getattr(model.backbone, "train_params", False):
+            raise RuntimeError("hallucidet_amd: train_det=True needs detector.set_trainable(True) first (see "
+                               "hallucidet_amd.train_detector.DetectorLit); the frozen-detector kernels emit data gradients only")
+    else:
+        model.eval()
     _check_targets(targets)
     original_image_sizes: List[Tuple[int, int]] = []
     for img in images:

@@ -67,8 +67,13 @@ def test_calculate_loss_rejects_cpu_and_bad_targets():
         Detector.calculate_loss(d, imgs, [{"boxes": torch.tensor([[1.0, 1.0, 9.0, 9.0]]), "labels": torch.ones(1, dtype=torch.int64)}])
     with pytest.raises(RuntimeError, match="set_trainable"):       # fine-tuning needs the parameter-gradient switch first
         Detector.calculate_loss(d, imgs, [], train_det=True)
-    with pytest.raises(NotImplementedError):
-        Detector.calculate_loss(d, imgs, [], train_det=True, model_name="retinanet")
+    r = Detector(name="retinanet", pretrained=False).detector
+    with pytest.raises(RuntimeError, match="set_trainable"):
+        Detector.calculate_loss(r, imgs, [], train_det=True, model_name="retinanet")
+    r.set_trainable(True)
+    names = {n for n, p in r.named_parameters() if p.requires_grad}
+    assert "backbone.fpn.extra_blocks.p6.weight" in names and "head.regression_head.conv.0.weight" in names
+    assert not any(n.startswith(("backbone.body.conv1", "backbone.body.layer1")) for n in names)
     with pytest.raises(ValueError):
         Detector.calculate_loss(d, imgs, [], model_name="yolo")
 

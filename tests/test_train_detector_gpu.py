@@ -163,3 +163,85 @@ def test_fit_step_learns_and_keeps_frozen_parts_fixed(dev):
     assert set(m) == {"map", "map_50", "map_75", "map_per_class"} and -1.0 <= float(m["map_50"]) <= 1.0
     mv = lit.on_validation_epoch_end()                       # two validation_step calls above fed it
     assert -1.0 <= float(mv["map"]) <= 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RetinaNet fine-tuning (train_detector.py with detector_name='retinanet': towers shared over 5 levels, P6/P7 convs)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_retinanet_parameter_gradients_and_fit_step(dev):
+    from hallucidet_amd import synthetic
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.optim import ParamArena
+    from hallucidet_amd.train_detector import DetectorLit
+    from oracle import retinanet as orn
+    torch.manual_seed(51)
+    det = Detector(name="retinanet", pretrained=False, n_classes=2, size=300).detector.to(dev)
+    with torch.no_grad():
+        for t in (det.head.classification_head, det.head.regression_head):      # N(0,0.01) towers shrink the signal 5x per layer
+            for l in t.conv:
+                if isinstance(l, torch.nn.Conv2d):
+                    l.weight.normal_(0, 0.03)
+        det.head.classification_head.cls_logits.bias.fill_(-2.0)
+    rgb, trgb, _, _ = synthetic.make_batch(2, 128, 160, seed=9, device=str(dev))
+    il, _ = det.transform(rgb, None)
+    det.backbone.calibrate_(il.tensors)
+    oracle = orn.RetinaNet(num_classes=2, size=300)
+    oracle.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    oracle.set_quant(ou.fp16_round)
+
+    S = 256.0
+    det.train()
+    det.set_trainable(True, grad_scale=S)
+    arena = ParamArena(det.trainable_parameters())
+    det.invalidate_packs()
+    feats = list(det.backbone(il.tensors).values())
+    ho = det.head(feats)
+    g = torch.Generator().manual_seed(6)
+    w_c, w_r = torch.randn(ho["cls_logits"].shape, generator=g), torch.randn(ho["bbox_regression"].shape, generator=g)
+    arena.flat_grads.zero_()
+    (((ho["cls_logits"] * w_c.to(dev)).sum() + (ho["bbox_regression"] * w_r.to(dev)).sum()) * S).backward()
+    got = {n: p.grad.detach().cpu().clone() for n, p in det.named_parameters() if p.requires_grad}
+
+    prefixes = ("backbone.body.layer2", "backbone.body.layer3", "backbone.body.layer4", "backbone.fpn", "head")
+    assert set(got) == {n for n, _ in det.named_parameters() if n.startswith(prefixes)}
+    oracle.train()
+    for n, p in oracle.named_parameters():
+        p.requires_grad_(n.startswith(prefixes))
+    # stage-wise: oracle head on the product's own feature maps -> every ReLU decision on identical numbers
+    oho = oracle.head([nchw(t).detach() for t in feats])
+    ((oho["cls_logits"] * w_c).sum() + (oho["bbox_regression"] * w_r).sum()).backward()
+    for n, p in oracle.named_parameters():
+        if n.startswith("head."):
+            a, b = got[n].flatten().double(), p.grad.flatten().double()
+            cos, rel = float((a * b).sum() / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
+            assert cos > 0.999 and rel < 0.05, (n, cos, rel)
+    # end to end: trunk / FPN / P6 / P7 (ReLU decisions re-taken on fp16-noisy activations: statistical agreement)
+    for p in oracle.parameters():
+        p.grad = None
+    ol, _ = oracle.transform(rgb.cpu(), None)
+    oho = oracle.head(list(oracle.backbone(ol.tensors).values()))
+    ((oho["cls_logits"] * w_c).sum() + (oho["bbox_regression"] * w_r).sum()).backward()
+    worst = {}
+    for n, p in oracle.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = got[n].flatten().double(), p.grad.flatten().double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        grp = "head" if n.startswith("head") else ("extra" if "extra_blocks" in n else "fpn" if "fpn" in n else n.split(".")[2])
+        worst[grp] = min(worst.get(grp, 1.0), cos)
+    print({k: round(v, 4) for k, v in worst.items()})
+    assert worst["head"] > 0.95 and worst["fpn"] > 0.95 and worst["extra"] > 0.95, worst
+    assert min(worst["layer4"], worst["layer3"], worst["layer2"]) > 0.85, worst
+    det.set_trainable(False)
+
+    # ---- DetectorLit on RetinaNet: learns on its own batch, frozen parts stay fixed
+    lit = DetectorLit(batch_size=2, lr=1e-4, detector_name="retinanet", pretrained=False, detector=det, device=str(dev)).prepare()
+    before = {n: p.detach().clone() for n, p in det.named_parameters()}
+    v0 = float(lit.validation_step((rgb, trgb), 0))
+    losses = [float(lit.fit_step((rgb, trgb))) for _ in range(12)]
+    v1 = float(lit.validation_step((rgb, trgb), 0))
+    print("retinanet train losses", [round(v, 4) for v in losses], "val", round(v0, 4), "->", round(v1, 4))
+    assert all(v == v for v in losses) and float(lit.optimizer.found_inf) == 0.0 and v1 < v0
+    moved = {n for n, p in det.named_parameters() if not torch.equal(p.detach(), before[n])}
+    assert moved == {n for n, p in det.named_parameters() if p.requires_grad}
+    assert set(lit._last_losses) >= {"classification", "bbox_regression"} and lit._last_losses["loss_objectness"] == 0.0
