@@ -57,7 +57,13 @@ class DetectorLit:
         self.arena = ParamArena(self.detector.trainable_parameters())
         self.optimizer = FusedAdam(self.arena, lr=self.lr, clip_value=0.0)
         self.scaler = LossScaler(self.arena, init_scale=self.loss_scale, growth_interval=1 << 30)   # fixed scale
-        return self.optimizer
+        # train_detector.py:336-343: ReduceLROnPlateau(optimizer, mode='min') monitored on val_loss
+        self.lr_scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='min')
+        return {"optimizer": self.optimizer, "lr_scheduler": {"scheduler": self.lr_scheduler, "monitor": "val_loss"}}
+
+    def lr_scheduler_step(self, val_loss):
+        self.lr_scheduler.step(float(val_loss))
+        return self.optimizer.param_groups[0]["lr"]
 
     def prepare(self):
         self.configure_optimizers()

@@ -163,7 +163,15 @@ class EncoderDecoderLit(nn.Module):
         self.encoder_decoder.to(self.dev)
         self.optimizer = Config.config_optimizer(self.encoder_decoder, learning_rate=self.lr, name=self.optimizer_name)
         self.scaler = LossScaler(self.encoder_decoder, enabled=(self.precision == 16))
-        return self.optimizer
+        # train_hallucidet.py:436-444: ReduceLROnPlateau(optimizer, mode='min') monitored on val_loss (torch defaults:
+        # factor 0.1, patience 10); the fused optimizer reads param_groups[0]['lr'] at every step
+        self.lr_scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='min')
+        return {"optimizer": self.optimizer, "lr_scheduler": {"scheduler": self.lr_scheduler, "monitor": "val_loss"}}
+
+    def lr_scheduler_step(self, val_loss):
+        """What Lightning does with the monitored metric at the end of a validation epoch."""
+        self.lr_scheduler.step(float(val_loss))
+        return self.optimizer.param_groups[0]["lr"]
 
     # ------------------------------------------------------------------------------------------------------------
     def prepare(self):

@@ -184,3 +184,16 @@ def test_param_arena_views_and_detector_trainable_rule():
         det.set_trainable(False)
         from hallucidet_amd.utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn
         eval_forward_fasterrcnn(det, torch.rand(1, 3, 32, 32), [{"boxes": torch.tensor([[1., 1., 9., 9.]]), "labels": torch.ones(1, dtype=torch.int64)}], train_det=True)
+
+
+def test_reduce_lr_on_plateau_drives_the_fused_optimizer_lr():
+    """configure_optimizers returns Lightning's dict (optimizer + ReduceLROnPlateau monitored on val_loss,
+    train_hallucidet.py:429-445 / train_detector.py:326-343); torch defaults: factor 0.1 after 10 epochs without improvement."""
+    from hallucidet_amd.train_detector import DetectorLit
+    lit = DetectorLit(batch_size=2, pretrained=False, device="cpu", lr=1e-4)
+    cfg = lit.configure_optimizers()
+    assert set(cfg) == {"optimizer", "lr_scheduler"} and cfg["lr_scheduler"]["monitor"] == "val_loss"
+    assert cfg["optimizer"] is lit.optimizer and lit.optimizer.param_groups[0]["lr"] == 1e-4
+    lrs = [lit.lr_scheduler_step(1.0) for _ in range(12)]
+    assert lrs[0] == 1e-4 and abs(lrs[-1] - 1e-5) < 1e-12          # patience 10 exceeded -> x0.1
+    assert lit.lr_scheduler_step(0.5) == lrs[-1]
