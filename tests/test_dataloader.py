@@ -1,0 +1,97 @@
+"""Input pipeline on a synthetic LLVIP-layout tree: file discovery, VOC-xml rules, uint8 staging, collate,
+split determinism, device staging values (== the reference's float/255)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from hallucidet_amd.dataloader import (DevicePrefetcher, MultiModalDataModule, MultiModalDetectionDataset, SingleModalDetectionDataset,
+                                       get_bbox, split_dataset)
+
+XML = """<annotation><filename>{name}.jpg</filename>{objs}</annotation>"""
+OBJ = "<object><name>{cls}</name><bndbox><xmin>{a}</xmin><ymin>{b}</ymin><xmax>{c}</xmax><ymax>{d}</ymax></bndbox></object>"
+
+
+@pytest.fixture()
+def llvip(tmp_path):
+    root = tmp_path / "data" / "LLVIP"
+    rng = np.random.RandomState(0)
+    for split, n in (("train", 10), ("test", 3)):
+        for mod in ("visible", "infrared"):
+            os.makedirs(root / mod / split, exist_ok=True)
+        os.makedirs(root / "Annotations", exist_ok=True)
+        for i in range(n):
+            name = "%s%04d" % ("1" if split == "train" else "9", i)
+            Image.fromarray(rng.randint(0, 256, (32, 40, 3), dtype=np.uint8)).save(root / "visible" / split / (name + ".jpg"), quality=95)
+            Image.fromarray(rng.randint(0, 256, (32, 40), dtype=np.uint8)).save(root / "infrared" / split / (name + ".jpg"), quality=95)
+            objs = OBJ.format(cls="person", a=4 + i, b=5, c=20 + i, d=30)
+            objs += OBJ.format(cls="person", a=30, b=10, c=28, d=2)          # reversed corners -> re-ordered
+            objs += OBJ.format(cls="person", a=1, b=1, c=3, d=3)             # area 4 <= 5 -> dropped
+            objs += OBJ.format(cls="car", a=0, b=0, c=30, d=30)              # not a person -> dropped
+            (root / "Annotations" / (name + ".xml")).write_text(XML.format(name=name, objs=objs))
+    return str(root)
+
+
+def test_get_bbox_rules(llvip):
+    a = get_bbox(os.path.join(llvip, "visible", "train", "10003") + ".xml", "llvip", True)
+    assert a["bboxes"].dtype == np.float64 and a["labels"].shape == (2, 1)
+    assert a["bboxes"].tolist() == [[7.0, 5.0, 23.0, 30.0], [28.0, 2.0, 30.0, 10.0]]
+    with pytest.raises(Exception, match="Dataset not supported"):
+        get_bbox("x.xml", "coco")
+
+
+def test_multimodal_dataset_items_and_module(llvip):
+    ds = MultiModalDetectionDataset("llvip", llvip, llvip, modality="both", ext=".jpg", train=True)
+    assert len(ds) == 10 and ds.get_name(0)[0].endswith("visible/train/10000") and ds.get_name(0)[1].endswith("infrared/train/10000")
+    rgb, t_rgb, ir, t_ir = ds[2]
+    assert rgb.dtype == torch.uint8 and rgb.shape == (3, 32, 40) and ir.dtype == torch.uint8 and ir.shape == (1, 32, 40)
+    assert t_rgb["boxes"].dtype == torch.float64 and t_rgb["boxes"].shape == (2, 4) and t_rgb["labels"].tolist() == [1, 1]
+    assert torch.equal(t_rgb["boxes"], t_ir["boxes"])                       # LLVIP pairs are aligned: same annotation file
+    want = np.asarray(Image.open(os.path.join(llvip, "visible", "train", "10002.jpg")).convert("RGB")).transpose(2, 0, 1)
+    assert np.array_equal(rgb.numpy(), want)
+    dm = MultiModalDataModule("llvip", llvip, llvip, llvip, llvip, batch_size=2, num_workers=0, ext=".jpg", seed=123)
+    tr, va, te = dm.train_dataloader(), dm.val_dataloader(), dm.test_dataloader()
+    assert len(tr) == 4 and len(va) == 1 and len(te) == 1                   # 8/2 split, drop_last
+    b = next(iter(te))
+    assert len(b) == 4 and len(b[0]) == 2 and isinstance(b[1], tuple) and b[0][0].shape == (3, 32, 40)
+    a1, a2 = split_dataset(ds, 0.8, seed=123), split_dataset(ds, 0.8, seed=123)
+    assert a1[0].indices == a2[0].indices and len(a1[0]) == 8 and len(a1[1]) == 2
+
+
+def test_single_modal_and_prefetcher_values(llvip):
+    ds = SingleModalDetectionDataset("llvip", llvip, modality="ir", ext=".jpg", train=False)
+    img, t = ds[0]
+    assert len(ds) == 3 and img.shape == (1, 32, 40) and img.dtype == torch.uint8 and t["path_image"].endswith("infrared/test/90000.jpg")
+    with pytest.raises(NotImplementedError):
+        SingleModalDetectionDataset("kaist", llvip, modality="rgb")
+    dm = MultiModalDataModule("llvip", llvip, llvip, llvip, llvip, batch_size=2, num_workers=0, ext=".jpg")
+    batches = list(DevicePrefetcher(dm.test_dataloader(), device="cpu"))
+    assert len(batches) == 1
+    rgb, t_rgb, ir, t_ir = batches[0]
+    assert rgb.shape == (2, 3, 32, 40) and rgb.dtype == torch.float32 and ir.shape == (2, 1, 32, 40)
+    raw = MultiModalDetectionDataset("llvip", llvip, llvip, modality="both", ext=".jpg", train=False)[0][0]
+    # the reference's host value: uint8.astype(float) / 255.0 (float64), later cast to fp32
+    want = torch.from_numpy((raw.numpy().astype("float") / 255.0)).float()
+    assert torch.equal(rgb[0], want) and float(rgb.max()) <= 1.0
+    assert isinstance(t_rgb, list) and t_rgb[0]["labels"].dtype == torch.int64
+
+
+def test_augmentation_hook_signature_and_empty_fallback(llvip):
+    from hallucidet_amd.dataloader.dataloader import DatasetTransform
+    ds = MultiModalDetectionDataset("llvip", llvip, llvip, modality="both", ext=".jpg", train=True)
+    calls = []
+
+    def flip(image, bboxes, labels, image1, bboxes1, labels1):
+        calls.append(image.shape)
+        W = image.shape[1]
+        fb = lambda b: [[W - x2, y1, W - x1, y2] for x1, y1, x2, y2 in np.asarray(b).tolist()]
+        return {"image": image[:, ::-1].copy(), "bboxes": fb(bboxes), "labels": list(np.asarray(labels)), "image1": image1[:, ::-1].copy(),
+                "bboxes1": fb(bboxes1), "labels1": list(np.asarray(labels1))}
+    rgb, t, ir, _ = DatasetTransform(ds, flip, "multimodal")[1]
+    assert calls == [(32, 40, 3)] and rgb.shape == (3, 32, 40) and ir.shape == (1, 32, 40)
+    assert torch.equal(rgb, ds[1][0].flip(-1)) and t["boxes"][0].tolist() == [40 - 21.0, 5.0, 40 - 5.0, 30.0]
+    drop_all = lambda **k: {"image": k["image"], "bboxes": [], "labels": [], "image1": k["image1"], "bboxes1": [], "labels1": []}
+    _, t2, _, _ = DatasetTransform(ds, drop_all, "multimodal")[1]
+    assert torch.equal(t2["boxes"], ds[1][1]["boxes"])                      # fell back to the original targets
