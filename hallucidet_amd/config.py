@@ -69,5 +69,72 @@ class Config:
         return FusedAdam(unet, lr=learning_rate, clip_value=Config.Optimizer.gradient_clip_val)
 
     @staticmethod
+    def argument_parser(argv=None):
+        """config.py:96-197 -- the reference's flags and defaults (one parser for the three scripts)."""
+        import argparse
+        p = argparse.ArgumentParser(description='HalluciDet')
+        p.add_argument('--dataset', type=str, default=None, help='llvip/flir')
+        p.add_argument('--train', type=str, default=None, help='Train Dataset Path')
+        p.add_argument('--valid', type=str, default=None, help='Valid Dataset Path')
+        p.add_argument('--test', type=str, default=None, help='Test Dataset Path')
+        p.add_argument('--n-classes', '--n_classes', '--num-classes', '--nclasses', type=int, default=2)
+        p.add_argument('--detector', type=str, default='fasterrcnn', help="choices=['fasterrcnn', 'fcos', 'retinanet']")
+        p.add_argument('--pretrained', action='store_true')
+        p.add_argument('--fine-tuning', action='store_true')
+        p.add_argument('--fine-tuning-lp', action='store_true')
+        p.add_argument('--modality', type=str, default='rgb')
+        p.add_argument('--threshold', type=float, default=0.5)
+        p.add_argument('--epochs', type=int, default=10)
+        p.add_argument('--lr', type=float, default=None)
+        p.add_argument('--seed', type=int, default=123)
+        p.add_argument('--wandb-project', type=str, default="hallucidet")
+        p.add_argument('--wandb-name', type=str, default="detector")
+        p.add_argument("--batch", type=int, default=16)
+        p.add_argument("--num-workers", type=int, default=4)
+        p.add_argument("--ext", "--input-ext", type=str, default=None)
+        p.add_argument("--output-model", type=str, default="example.ckpt")
+        p.add_argument("--detector-path", type=str, default=None)
+        p.add_argument("--device", type=str, default=None)
+        p.add_argument("--fuse-data", type=str, default='none')
+        p.add_argument("--decoder-backbone", type=str, default='resnet34')
+        p.add_argument("--precision", type=int, default=32)
+        p.add_argument("--optimizer", type=str, default='adamw')
+        p.add_argument("--path", type=str, default=None)
+        p.add_argument("--segmentation-head", type=str, default='sigmoid')
+        p.add_argument("--pixel", type=str, default=None)
+        p.add_argument("--weight-pixel-rgb", type=float, default=0.0)
+        p.add_argument("--weight-pixel-ir", type=float, default=0.0)
+        p.add_argument("--perceptual", type=str, default=None)
+        p.add_argument("--weight-perceptual-rgb", type=float, default=0.0)
+        p.add_argument("--weight-perceptual-ir", type=float, default=0.0)
+        p.add_argument("--weight-det-regression", type=float, default=0.1)
+        p.add_argument("--weight-det-classification", type=float, default=0.1)
+        p.add_argument("--weight-det-masked", type=float, default=0.0)
+        p.add_argument("--weight-det-objectness", type=float, default=0.1)
+        p.add_argument("--weight-det-rpn-box-reg", type=float, default=0.1)
+        p.add_argument("--weight-det-bbox-ctrness", type=float, default=0.1)
+        p.add_argument("--image2image-model", type=str, default=None)
+        p.add_argument('--directly-coco', action='store_true')
+        p.add_argument('--limit-train-batches', type=float, default=1.0)
+        p.add_argument('--ablation-flag', action='store_true')
+        p.add_argument("--pre-train-path", type=str, default=None)
+        p.add_argument("--encoder-depth", type=int, default=5)
+        p.add_argument('--hallucidet-path', type=str)
+        return p.parse_args(argv)
+
+    @staticmethod
+    def set_loss_weights(args):
+        """config.py: `set_loss_weights(args)` copies the --weight-* flags into Losses.hparams_losses_weights."""
+        if args.pixel is not None:
+            Config.Losses.pixel = args.pixel
+        if args.perceptual is not None:
+            Config.Losses.perceptual = args.perceptual
+        w = Config.Losses.hparams_losses_weights
+        w.update(pixel_rgb=args.weight_pixel_rgb, pixel_ir=args.weight_pixel_ir, perceptual_rgb=args.weight_perceptual_rgb,
+                 perceptual_ir=args.weight_perceptual_ir, det_regression=args.weight_det_regression,
+                 det_classification=args.weight_det_classification, det_objectness=args.weight_det_objectness,
+                 det_rpn_box_reg=args.weight_det_rpn_box_reg, det_bbox_ctrness=args.weight_det_bbox_ctrness, det_masked=args.weight_det_masked)
+
+    @staticmethod
     def cuda_or_cpu():
         return 'cuda' if torch.cuda.is_available() else 'cpu'
