@@ -13,16 +13,16 @@ from oracle import unet as ou
 pytestmark = pytest.mark.gpu
 
 
-def _pair(dev, seed=0):
+def _pair(dev, seed=0, name="resnet34"):
     from hallucidet_amd.models.encoder_decoder import EncoderDecoder
     torch.manual_seed(seed)
-    net = EncoderDecoder(name="resnet34", encoder_weights=None, in_channels=3, output_channels=3).encoder_decoder
+    net = EncoderDecoder(name=name, encoder_weights=None, in_channels=3, output_channels=3).encoder_decoder
     # conv weights representable in fp16: the fp32 master -> fp16 GEMM-layout repack is then exact on both sides
     with torch.no_grad():
         for m in net.modules():
             if isinstance(m, torch.nn.Conv2d):
                 m.weight.copy_(m.weight.half().float())
-    ref = ou.Unet(classes=3)
+    ref = ou.Unet(classes=3, layers=(2, 2, 2, 2) if name == "resnet18" else (3, 4, 6, 3))
     ref.load_state_dict(net.state_dict())   # identical key layout
     return net.to(dev), ref
 
@@ -151,3 +151,27 @@ def test_graph_replay_equals_eager(dev):
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k
     assert int(s1["encoder.bn1.num_batches_tracked"]) == 3
+
+
+def test_resnet18_backbone_forward_and_gradients(dev):
+    """`--decoder-backbone resnet18` (config.py:147; encoders/resnet.py:127-135): same runner, BasicBlock [2,2,2,2]."""
+    net, ref = _pair(dev, 4, name="resnet18")
+    assert sum(p.numel() for p in net.parameters()) == sum(p.numel() for p in ref.parameters()) == 14328499
+    net.eval(); ref.eval()
+    x = torch.rand(2, 3, 64, 96)
+    with torch.no_grad():
+        e = (net(x.to(dev)).cpu() - ref(x, q=ou.fp16_round)).abs()
+    assert e.mean() < 1e-3 and e.max() < 2e-2, (float(e.mean()), float(e.max()))
+    net.train(); ref.train()
+    gout = torch.randn(2, 3, 64, 96) * 1e-2
+    net.runner.grad_scale = 256.0
+    out = net(x.to(dev))
+    rec = net.runner.saved["rec"]
+    masks = {k: (v["z"].permute(0, 3, 1, 2) > 0).float().cpu() for k, v in rec.items() if not k.endswith("downsample")}
+    (out * (gout.to(dev) * 256.0)).sum().backward()
+    wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
+    (wq * gout).sum().backward()
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        a, b = p.grad.detach().cpu().flatten().double(), q.grad.flatten().double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        assert cos > 0.995, (n, cos)
