@@ -72,10 +72,34 @@ def conv_roofline(lit, batch, reps=5):
         # algorithmic bytes: every operand once (x, x2, w, y, residual, mask)
         by = x.numel() * 2 + (0 if kw.get("x2") is None else kw["x2"].numel() * 2) + w.numel() * 2 + y.numel() * y.element_size()
         by += sum(t.numel() * 2 for t in (kw.get("res"), kw.get("mask")) if t is not None)
-        rec.append((dict(kw), (x, w, KH, KW), flops, by))
+        rec.append((dict(kw), (x, w, KH, KW), flops, by, where[0]))
         return out
 
+    # weight-gradient launches of the hallucination network (hd_wgrad): part of its "conv blocks" (BASELINE north_star)
+    wrec = []
+    orig_wg = ops.wgrad
+
+    def spy_wg(x, dy, KH, KW, **kw):
+        out = orig_wg(x, dy, KH, KW, **kw)
+        C2 = 0 if kw.get("x2") is None else kw["x2"].shape[3]
+        wrec.append(((x, dy, KH, KW), dict(kw), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * KH * KW * (x.shape[3] + C2)))
+        return out
+
+    where = ["detector"]
+    rr = lit.encoder_decoder.runner
+    o_fwd, o_bwd = rr.forward, rr.backward
+
+    def tag(fn):
+        def g(*a, **k):
+            where[0] = "unet"
+            try:
+                return fn(*a, **k)
+            finally:
+                where[0] = "detector"
+        return g
+    rr.forward, rr.backward = tag(o_fwd), tag(o_bwd)
     ops.conv2d = spy
+    ops.wgrad = spy_wg
     import hallucidet_amd.models.detection as det_mod
     import hallucidet_amd.segmentation_models.unet as unet_mod
     r = lit.encoder_decoder.runner
@@ -86,12 +110,15 @@ def conv_roofline(lit, batch, reps=5):
         torch.cuda.synchronize()
     finally:
         ops.conv2d = orig
+        ops.wgrad = orig_wg
+        rr.forward, rr.backward = o_fwd, o_bwd
         r.enable_graphs(was)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     tot_ms, tot_fl, tot_by = 0.0, 0.0, 0.0
     dump = os.environ.get("HD_BENCH_DUMP")
     rows = []
-    for kw, (x, w, KH, KW), fl, by in rec:
+    grp = {"unet": [0.0, 0.0], "detector": [0.0, 0.0]}
+    for kw, (x, w, KH, KW), fl, by, origin in rec:
         tot_by += by
         kw = dict(kw)                                 # same epilogue (bias / res / mask / BN statistics) as in the step
         orig(x, w, KH, KW, **kw)                      # warm
@@ -103,6 +130,8 @@ def conv_roofline(lit, batch, reps=5):
         ms = e0.elapsed_time(e1) / reps
         tot_ms += ms
         tot_fl += fl
+        grp[origin][0] += ms
+        grp[origin][1] += fl
         if dump:
             rows.append((ms * 1e3, fl / 1e9, tuple(x.shape), 0 if kw.get("x2") is None else kw["x2"].shape[3], tuple(w.shape), KH,
                          kw.get("stride", 1), kw.get("in_dil", 1), bool(kw.get("up1")), bool(kw.get("want_stats")),
@@ -114,7 +143,26 @@ def conv_roofline(lit, batch, reps=5):
                         % (r_[0], r_[1], r_[1] / r_[0] * 1e-3 * 1e3, *r_[2:]))
     n = len(rec)
     achieved = tot_fl / (tot_ms * 1e-3) / 1e12
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+    wg_ms = wg_fl = 0.0
+    for (x, dy, KH, KW), kw, fl in wrec:
+        orig_wg(x, dy, KH, KW, **kw)
+        e0.record()
+        for _ in range(reps):
+            orig_wg(x, dy, KH, KW, **kw)
+        e1.record()
+        e1.synchronize()
+        wg_ms += e0.elapsed_time(e1) / reps
+        wg_fl += fl
+    tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None
+    u_ms, u_fl = grp["unet"][0] + wg_ms, grp["unet"][1] + wg_fl
+    groups = {
+        "unet_conv_fwd_dgrad": {"ms": round(grp["unet"][0], 3), "tflops": tf(grp["unet"][1], grp["unet"][0])},
+        "unet_wgrad": {"ms": round(wg_ms, 3), "tflops": tf(wg_fl, wg_ms), "kernel": "wgrad_kernel"},
+        "unet_conv_blocks_total": {"ms": round(u_ms, 3), "tflops": tf(u_fl, u_ms), "frac": round(u_fl / (u_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if u_ms else None,
+                                   "gflop_per_image": round(u_fl / 1e9 / BATCH_PER_GPU, 1)},
+        "detector_conv": {"ms": round(grp["detector"][0], 3), "tflops": tf(grp["detector"][1], grp["detector"][0])},
+    }
+    return {"bound": "mfma", "groups": groups, "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": _pmc_traffic(), "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
             "kernel": "conv_igemm_kernel (implicit-GEMM conv / dgrad / FC)", "launches_per_step": n,
