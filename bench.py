@@ -220,6 +220,10 @@ def main():
         raise SystemExit("non-finite loss in the timed region")
 
     if rank == 0:
+        # everything below is rank-0-only measurement: no collective may be issued from here on (the other ranks are
+        # already waiting at the final barrier), so the gradient averager is detached for the extra steps
+        lit.averager.start = lambda g: None
+        lit.averager.finish = lambda g: None
         value = BATCH_PER_GPU * world * args.steps / elapsed
         out = {
             "metric": "images/sec train_hallucidet (640x512, batch 8/GPU)",
@@ -257,6 +261,7 @@ def main():
                                              "synthetic 512x640 images; host: %s" % (steps, _cpu_model())}
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
+        dist.barrier()                 # ranks > 0 wait here while rank 0 finishes its roofline / baseline legs
         dist.destroy_process_group()
 
 
