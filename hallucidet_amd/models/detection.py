@@ -1178,8 +1178,10 @@ def _sample_batched_keys(sampler, pos, neg):
     dev = pos.device
     B = sampler.batch_size_per_image
     cap_p = int(B * sampler.positive_fraction)
-    keys = torch.rand((N, A), dtype=torch.float64, device=dev)
-    keys = torch.where(pos, keys, torch.where(neg, keys + 2.0, torch.full_like(keys, 4.0)))
+    # 30 random bits per candidate (collision probability per row ~A^2 / 2^31: a handful of ties in a million draws, broken
+    # by position); positives in [0, 2^30), negatives in [2^30, 2^31), everything else at the top: an int32 radix sort
+    r = torch.randint(0, 1 << 30, (N, A), dtype=torch.int32, device=dev)
+    keys = torch.where(pos, r, torch.where(neg, r + (1 << 30), 0x7FFFFFFF))
     order = torch.sort(keys, dim=1)[1]
     P, Nn = pos.sum(1), neg.sum(1)
     num_pos = P.clamp(max=cap_p)
