@@ -46,6 +46,11 @@ class EncoderDecoderLit(nn.Module):
         self.precision = precision
         self.use_graphs = use_graphs
         self.batch_detector_passes = True
+        # The reference evaluates the RGB and IR detector passes in EVERY training step (train_hallucidet.py:183,186) and uses
+        # their detections only in validation: two thirds of the detector forward of a training step are dead work.  False
+        # (default) reproduces the reference's step exactly -- and is what bench.py measures; True skips the two passes when
+        # step == 'train' (their detections are then empty lists).  Opt-in: it changes the work per step, not the result.
+        self.skip_unused_train_passes = False
         self.detector.fused_passes = True    # one head evaluation for the three passes (see eval_forward_fasterrcnn._multi_fused)
         self.scaler = None
         self.optimizer = None
@@ -65,7 +70,10 @@ class EncoderDecoderLit(nn.Module):
         loss_pixel_rgb = loss_perceptual_rgb = loss_pixel_ir = loss_perceptual_ir = 0.0
 
         train_det = True if (self.train_det is True and step == 'train') else False
-        if self.batch_detector_passes and not train_det and 'fasterrcnn' in self.detector_name:
+        if step == 'train' and self.skip_unused_train_passes and not train_det:
+            losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=False, model_name=self.detector_name)
+            detections_rgb, detections_ir = [], []
+        elif self.batch_detector_passes and not train_det and 'fasterrcnn' in self.detector_name:
             # one trunk evaluation for the three passes (frozen, eval-mode detector: images are independent); the RGB / IR
             # losses are discarded by the reference (train_hallucidet.py:183,186) and carry no gradient
             (losses_det, detections_hall), (_, detections_rgb), (_, detections_ir) = eval_forward_fasterrcnn_multi(

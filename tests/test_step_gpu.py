@@ -147,3 +147,21 @@ def test_validation_and_test_hooks_accumulate_map(dev):
     assert set(out_t) == set(out)
     # accumulators were reset by the epoch-end hook
     assert all(float(t) == -1.0 for t in lit.on_validation_epoch_end()["map_hall"].values())
+
+
+def test_skip_unused_train_passes_is_opt_in_and_keeps_the_losses(dev):
+    """Opt-in flag: the training step without the RGB / IR passes whose results the reference discards (RetinaNet: no sampler,
+    so the hallucinated pass's losses are bit-identical with and without them)."""
+    from hallucidet_amd import synthetic
+    lit = synthetic.make_module(seed=5, device=str(dev), precision=16, detector_name="retinanet")
+    assert lit.skip_unused_train_passes is False
+    batch = synthetic.make_batch(2, 128, 160, seed=6, device=str(dev))
+    lit.encoder_decoder.eval()                       # fixed BN statistics: two forward_step calls see the same network
+    with torch.no_grad():
+        a = lit.forward_step(*batch, 0, step="train")
+        lit.skip_unused_train_passes = True
+        b = lit.forward_step(*batch, 0, step="train")
+        c = lit.forward_step(*batch, 0, step="val")
+    for k in ("det_classification", "det_regression", "total"):
+        assert float(a["loss"][k]) == float(b["loss"][k]) == float(c["loss"][k]), k
+    assert lit._last_detections["rgb"] is not None and len(lit._last_detections["rgb"]) == 2      # validation still runs all three
