@@ -89,12 +89,75 @@ extern "C" int hd_conv2d_patch_stats_rows(const hd_conv_args* a) {
   return hd_conv_patch_tiles(p);
 }
 
+// tuning hook (tools/tune_conv.py): force the tile / K-depth / stage choice of the igemm family; -1 = heuristic
+static int g_ov_bm = -1, g_ov_bn = -1, g_ov_bk = -1, g_ov_deep = -1;
+extern "C" int hd_conv_tune_override(int bm, int bn, int bk, int deep) {
+  HD_CHECK_ARG((bm == -1 || bm == 64 || bm == 128) && (bn == -1 || bn == 32 || bn == 64 || bn == 128) && (bk == -1 || bk == 32 || bk == 64) &&
+               deep >= -1 && deep <= 1, "hd_conv_tune_override: bm in {64,128}, bn in {32,64,128}, bk in {32,64}, deep in {0,1} or -1");
+  g_ov_bm = bm; g_ov_bn = bn; g_ov_bk = bk; g_ov_deep = deep;
+  return HD_OK;
+}
+
+struct TileChoice {
+  int bm, bn;
+  bool use64, deep;
+};
+
+// Tile / K-depth / stage choice of the igemm family.  Rules come from an exhaustive per-shape search over the 136 launch
+// shapes of one training step (tools/tune_conv.py; 7.71 ms with the previous rules, 7.37 ms with these, 7.13 ms with a
+// perfect per-shape table):
+//   * 1x1 convolutions onto > 64 channels are output-write bound (small K, wide N): 64-wide N tiles, 64 rows unless the
+//     grid is already large, 64-deep K tiles only from 256 input channels, 2 stages;
+//   * any other conv onto > 64 channels whose 64x128 grid cannot give each CU more than one block: 64x64 tiles, deep ring;
+//   * otherwise: the widest N tile that the channel count fills, 64 rows below 512 blocks, 64-deep K where the channel
+//     count allows, deep ring only at <= 1 block per CU.
+static TileChoice choose_tile(const ConvP& p) {
+  TileChoice c;
+  const bool can64_ch = (p.Cin % 64 == 0) && (p.C2 == 0 || (p.C1 % 64 == 0 && p.C2 % 64 == 0));
+  static const int small_n = env_int("HD_CONV_SMALLN", 512);
+  static const int force_bk = env_int("HD_CONV_BK", 0);
+  static const int force_deep = env_int("HD_CONV_DEEP", -1);
+  static const int old_rules = env_int("HD_CONV_OLD_RULES", 0);     // A/B knob for the rule set below
+  if (!old_rules && p.KH * p.KW == 1 && p.Cout > 64) {
+    c.bn = 64;
+    c.bm = ((int64_t)hd_cdiv(p.M, 128) * hd_cdiv(p.Cout, 64) < 1024) ? 64 : 128;
+    c.use64 = can64_ch && p.Cin >= 256;
+    c.deep = false;
+  } else if (!old_rules && p.Cout > 64 && (int64_t)hd_cdiv(p.M, 64) * hd_cdiv(p.Cout, 128) <= 256) {
+    c.bm = 64;
+    c.bn = 64;
+    c.use64 = can64_ch;
+    c.deep = true;
+  } else {
+    c.bn = pick_bn(p.Cout);
+    c.bm = pick_bm(p.M, p.Cout);
+    int64_t blocks = (int64_t)hd_cdiv(p.M, c.bm) * hd_cdiv(p.Cout, c.bn);
+    if (c.bn == 128 && c.bm == 64 && blocks < small_n) {
+      c.bn = 64;
+      blocks = (int64_t)hd_cdiv(p.M, c.bm) * hd_cdiv(p.Cout, c.bn);
+    }
+    c.use64 = can64_ch && c.bn > 32;
+    c.deep = blocks <= 256;
+  }
+  // experiment knobs: HD_CONV_BK in {0 auto, 32, 64}; HD_CONV_DEEP in {-1 auto, 0, 1}; hd_conv_tune_override
+  if (g_ov_bn > 0) c.bn = g_ov_bn;
+  if (g_ov_bm > 0) c.bm = g_ov_bm;
+  if (c.bn == 32) c.bm = 128;                     // the 32-wide tile only exists with 128 rows
+  if (g_ov_bn > 0 || g_ov_bm > 0) c.use64 = can64_ch && c.bn > 32;
+  if (force_bk == 32 || g_ov_bk == 32 || c.bn == 32) c.use64 = false;
+  if (g_ov_bk == 64) c.use64 = can64_ch && c.bn > 32;
+  if (force_deep >= 0) c.deep = force_deep != 0;
+  if (g_ov_deep >= 0) c.deep = g_ov_deep != 0;
+  return c;
+}
+
 extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (!a) return HD_E_ARG;
   ConvP p;
-  if (fill_params(a, p) == HD_OK && use_patch(p)) return hd_conv_patch_tiles(p);
-  int M = a->N * a->Ho * a->Wo;
-  return hd_cdiv(M, pick_bm(M, a->Cout));
+  int rc = fill_params(a, p);
+  if (rc) return rc;
+  if (use_patch(p)) return hd_conv_patch_tiles(p);
+  return hd_cdiv(p.M, choose_tile(p).bm);
 }
 
 extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
@@ -107,26 +170,9 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
     HD_CHECK_LAUNCH();
     return HD_OK;
   }
-  int bn = pick_bn(p.Cout);
-  const int bm = pick_bm(p.M, p.Cout);
-  int64_t blocks = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
-  // grids that cannot give every CU two 64x128 blocks: 64x64 tiles double the block count (one MFMA tile per wave)
-  static const int small_n = env_int("HD_CONV_SMALLN", 512);
-  if (bn == 128 && bm == 64 && blocks < small_n) {
-    bn = 64;
-    blocks = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
-  }
-  // experiment knobs (tools/bench_conv.py): HD_CONV_BK in {0 auto, 32, 64}; HD_CONV_DEEP in {-1 auto, 0, 1}
-  static const int force_bk = env_int("HD_CONV_BK", 0);
-  static const int force_deep = env_int("HD_CONV_DEEP", -1);
-  const bool can64 = (p.Cin % 64 == 0) && (p.C2 == 0 || (p.C1 % 64 == 0 && p.C2 % 64 == 0)) && bn > 32;
-  // Measured on the layer mix (tools/bench_conv.py sweep): 64-deep K tiles (full-line DMA pieces, half the barriers) win
-  // wherever the channel count allows them; co-resident blocks matter more than prefetch depth, so the extra LDS stage
-  // is only spent when the grid cannot give a CU a second block anyway.
-  bool use64 = can64;
-  if (force_bk == 32) use64 = false;
-  bool deep = blocks <= 256;
-  if (force_deep >= 0) deep = force_deep != 0;
+  const TileChoice c = choose_tile(p);
+  const int bm = c.bm, bn = c.bn;
+  const bool use64 = c.use64, deep = c.deep;
   if (use64) hd_conv_launch_bk64(p, bm, bn, deep, s);
   else hd_conv_launch_bk32(p, bm, bn, deep, s);
   HD_CHECK_LAUNCH();

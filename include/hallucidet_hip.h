@@ -88,6 +88,9 @@ int hd_conv2d_stats_rows(const hd_conv_args* a);
  * torchvision Bottleneck.conv2 / FPN layer_blocks [EXT]).  Opt-in: see DESIGN.md 6.1 for the measured comparison.
  * BN partial-sum rows are per 8x16 output tile: hd_conv2d_patch_stats_rows. */
 int hd_conv2d_patch(const hd_conv_args* a, void* stream);
+/* tuning hook for hd_conv2d's tile choice (tools/tune_conv.py): bm in {64,128}, bn in {32,64,128}, bk in {32,64}, deep in {0,1};
+ * -1 = the built-in heuristic.  Process-wide; not for production use. */
+int hd_conv_tune_override(int bm, int bn, int bk, int deep);
 int hd_conv2d_patch_stats_rows(const hd_conv_args* a);
 
 /* ------------------------------------------------------------------------
