@@ -96,11 +96,15 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None):
     return slab
 
 
-_WGRAD_BLOCKS = int(os.environ.get("HD_WGRAD_BLOCKS", "768"))   # measured sweep 256..2048 (tools/bench_wgrad.py): slab traffic vs occupancy
+_WGRAD_BLOCKS = int(os.environ.get("HD_WGRAD_BLOCKS", "0"))   # 0: per-class targets below
 
 
 def pick_nsplit(M, Cout, K, target_blocks=None):
-    target_blocks = target_blocks or _WGRAD_BLOCKS
+    """Split count of the pixel reduction.  Per-layer sweep (tools/tune_wgrad.py; hd_wgrad + hd_wgrad_reduce timed
+    together): the 32-row kernel of the thin decoder layers wants ~1500 blocks, the 128-row kernel ~500 (slab traffic grows
+    with the split), the 256/512-channel layers ~750."""
+    if target_blocks is None:
+        target_blocks = _WGRAD_BLOCKS or (1536 if Cout <= 32 else (768 if Cout >= 256 else 512))
     tm = 128 if Cout > 64 else (64 if Cout > 32 else 32)
     tiles = ((K + 127) // 128) * ((Cout + tm - 1) // tm)
     ns = max(1, min(target_blocks // max(tiles, 1), M // 256))
