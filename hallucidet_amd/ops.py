@@ -202,7 +202,7 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
     C_ = y.shape[-1]
     npix = y.numel() // C_
     if rows is None:
-        rows = int(max(1, min(1024, npix // 64)))
+        rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere
     lib = _abi.load()
     part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
     check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
