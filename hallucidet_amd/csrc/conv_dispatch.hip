@@ -145,7 +145,7 @@ static TileChoice choose_tile(const ConvP& p) {
   if (c.bn == 32) c.bm = 128;                     // the 32-wide tile only exists with 128 rows
   if (g_ov_bn > 0 || g_ov_bm > 0) c.use64 = can64_ch && c.bn > 32;
   if (force_bk == 32 || g_ov_bk == 32 || c.bn == 32) c.use64 = false;
-  if (g_ov_bk == 64) c.use64 = can64_ch && c.bn > 32;
+  if (g_ov_bk == 64) c.use64 = can64_ch;
   if (force_deep >= 0) c.deep = force_deep != 0;
   if (g_ov_deep >= 0) c.deep = g_ov_deep != 0;
   return c;

@@ -61,8 +61,6 @@ for s, lst in groups.items():
     for bm, bn, bk, deep in itertools.product((64, 128), (32, 64, 128), (32, 64), (0, 1)):
         if bn == 32 and bm == 64:
             continue
-        if bn == 32 and bk == 64:
-            continue
         if bn // 2 >= max(cout, 32) and bn > 32:      # tile twice as wide as the output: pointless
             continue
         lib.hd_conv_tune_override(bm, bn, bk, deep)
