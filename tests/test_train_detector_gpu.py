@@ -152,8 +152,8 @@ def test_fit_step_learns_and_keeps_frozen_parts_fixed(dev):
     frozen = [n for n, p in det.named_parameters() if not p.requires_grad]
     assert frozen and not set(moved) & set(frozen)
     assert len(moved) == len(det.trainable_parameters()), (len(moved), len(det.trainable_parameters()))
-    # Adam's first steps are bounded by lr per coordinate
-    assert max(float((p.detach() - before[n]).abs().max()) for n, p in det.named_parameters()) <= 12 * 1e-4 * 1.01
+    # Adam: |update| <= lr * (1-b1)/sqrt(1-b2) ~ 3.2 lr in the worst case (a gradient spike), ~lr typically
+    assert max(float((p.detach() - before[n]).abs().max()) for n, p in det.named_parameters()) <= 12 * 1e-4 * 3.2
     v1 = float(lit.validation_step((rgb, trgb), 0))
     print("train losses", [round(v, 4) for v in losses], "val (unweighted sum)", round(v0, 4), "->", round(v1, 4))
     assert v1 < v0, (v0, v1)             # 12 Adam steps on one batch reduce its own loss
