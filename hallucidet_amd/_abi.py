@@ -38,6 +38,11 @@ class ConvArgs(C.Structure):
     ]
 
 
+class WprepDesc(C.Structure):
+    _fields_ = [("w_oihw", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("Cout", "Cin", "KH", "KW", "Cin_pad", "Cout_pad")]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("x", vp), ("x2", vp), ("dy", vp), ("slab", vp),
@@ -62,6 +67,7 @@ PROTOTYPES = {
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "hd_wgrad_reduce": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_weight_prep": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_weight_prep_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "hd_colsum": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
     "hd_rowsum": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp]),
     "hd_bn_finalize": (C.c_int, [vp, C.c_int, C.c_int, c_d, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),

@@ -280,7 +280,46 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
   }
 }
 
+// all layers of a network in ONE launch: blockIdx.y = layer (descriptor table in device memory), blockIdx.x strides over
+// that layer's elements; blocks beyond a small layer's extent exit at once
+__global__ void weight_prep_multi_kernel(const hd_wprep_desc* __restrict__ tab) {
+  const hd_wprep_desc d = tab[blockIdx.y];
+  const float* __restrict__ w = d.w_oihw;
+  f16* __restrict__ wf = (f16*)d.w_fwd;
+  f16* __restrict__ wd = (f16*)d.w_dgrad;
+  const int taps = d.KH * d.KW;
+  if (wf) {
+    const int64_t total = (int64_t)d.Cout * taps * d.Cin_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int ci = (int)(i % d.Cin_pad);
+      int t = (int)((i / d.Cin_pad) % taps);
+      int co = (int)(i / ((int64_t)d.Cin_pad * taps));
+      float v = 0.f;
+      if (ci < d.Cin) v = w[((size_t)co * d.Cin + ci) * taps + t];
+      wf[i] = (f16)v;
+    }
+  }
+  if (wd) {
+    const int64_t total = (int64_t)d.Cin_pad * taps * d.Cout_pad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      int co = (int)(i % d.Cout_pad);
+      int t = (int)((i / d.Cout_pad) % taps);
+      int ci = (int)(i / ((int64_t)d.Cout_pad * taps));
+      float v = 0.f;
+      if (ci < d.Cin && co < d.Cout) v = w[((size_t)co * d.Cin + ci) * taps + (taps - 1 - t)];
+      wd[i] = (f16)v;
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int hd_weight_prep_multi(const hd_wprep_desc* table_dev, int n_layers, int blocks_per_layer, void* stream) {
+  HD_CHECK_ARG(table_dev && n_layers > 0 && blocks_per_layer > 0 && blocks_per_layer <= 65535, "hd_weight_prep_multi: bad args");
+  hipLaunchKernelGGL(weight_prep_multi_kernel, dim3(blocks_per_layer, n_layers), dim3(256), 0, (hipStream_t)stream, table_dev);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
 
 extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   HD_CHECK_ARG(a && a->x && a->dy && a->slab, "hd_wgrad: null pointer");

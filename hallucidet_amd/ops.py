@@ -138,6 +138,36 @@ def weight_prep(w_oihw, *, out_scale=None, cin_pad=None, cout_pad=None, want_fwd
     return wf, wd
 
 
+class WeightPrepPlan:
+    """All (fp32 master -> fp16 GEMM layouts) conversions of a network as ONE launch: persistent output buffers and a
+    device-resident descriptor table built once; `run()` re-packs every layer (hd_weight_prep_multi)."""
+
+    def __init__(self, items):
+        """items: list of (w_oihw fp32 parameter, cin_pad, cout_pad, want_dgrad)."""
+        from ._abi import WprepDesc
+        dev = items[0][0].device
+        self.outputs, descs, biggest = [], [], 1
+        for w, cin_pad, cout_pad, want_d in items:
+            Cout, Cin, KH, KW = w.shape
+            wf = torch.empty((Cout, KH * KW * cin_pad), dtype=torch.float16, device=dev)
+            wd = torch.empty((cin_pad, KH * KW * cout_pad), dtype=torch.float16, device=dev) if want_d else None
+            self.outputs.append((wf, wd))
+            descs.append(WprepDesc(w.data_ptr(), wf.data_ptr(), wd.data_ptr() if want_d else None, Cout, Cin, KH, KW, cin_pad, cout_pad))
+            biggest = max(biggest, Cout * KH * KW * cin_pad, cin_pad * KH * KW * cout_pad if want_d else 0)
+        self._ptrs = [w.data_ptr() for w, *_ in items]
+        raw = bytes(bytearray().join(bytes(d) for d in descs))
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.n = len(descs)
+        self.blocks = int(min(2048, (biggest + 4 * 256 - 1) // (4 * 256)))
+
+    def valid_for(self, params):
+        return len(params) == self.n and all(p.data_ptr() == q for p, q in zip(params, self._ptrs))
+
+    def run(self):
+        check(_abi.load().hd_weight_prep_multi(ptr(self.table), self.n, self.blocks, _stream()), "hd_weight_prep_multi")
+        return self.outputs
+
+
 def colsum(slab2d):
     """[rows, W] fp32 -> [W] (deterministic)."""
     _need_cuda(slab2d)

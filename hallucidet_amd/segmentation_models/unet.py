@@ -203,6 +203,7 @@ class UnetRunner:
             self.dec.append((_Unit(pre + "conv1", b.conv1[0], b.conv1[1]), _Unit(pre + "conv2", b.conv2[0], b.conv2[1]), b.in_channels, b.skip_channels))
         self.head_conv = module.segmentation_head[0]
         self.units = [self.stem] + [u for st in self.stages for blk in st for u in blk if u is not None] + [u for d in self.dec for u in d[:2]]
+        self._wplan = {}
 
     # ------------------------------------------------------------------ hipGraph replay
     def enable_graphs(self, on=True):
@@ -297,13 +298,17 @@ class UnetRunner:
 
     def _prep_weights(self, need_dgrad):
         """fp32 OIHW masters -> fp16 GEMM layouts (every step in training: the masters move)."""
-        W = {}
-        for u in self.units:
-            wf, wd = ops.weight_prep(u.conv.weight, cin_pad=u.cin_p, cout_pad=u.cout_p, want_fwd=True,
-                                     want_dgrad=need_dgrad and u is not self.stem)
-            W[u.name] = (wf, wd)
         hc = self.head_conv
-        W["head"] = ops.weight_prep(hc.weight, cin_pad=hc.in_channels, cout_pad=8, want_fwd=True, want_dgrad=need_dgrad)
+        params = [u.conv.weight for u in self.units] + [hc.weight]
+        plan = self._wplan.get(need_dgrad)
+        if plan is None or not plan.valid_for(params):
+            # one launch for every layer (the masters are views of the flat arena: stable pointers -> the table is built once)
+            items = [(u.conv.weight, u.cin_p, u.cout_p, need_dgrad and u is not self.stem) for u in self.units]
+            items.append((hc.weight, hc.in_channels, 8, need_dgrad))
+            plan = self._wplan[need_dgrad] = ops.WeightPrepPlan(items)
+        outs = plan.run()
+        W = {u.name: outs[i] for i, u in enumerate(self.units)}
+        W["head"] = outs[-1]
         return W
 
     # ------------------------------------------------------------------ forward pieces

@@ -115,6 +115,15 @@ int hd_wgrad(const hd_wgrad_args* a, void* stream);
 int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW,
                     int Cin, int Cin_real, float scale, int accumulate, void* stream);
 
+/* one descriptor per layer for hd_weight_prep_multi (device-resident table; same meaning as hd_weight_prep's arguments,
+ * no output scale) */
+typedef struct hd_wprep_desc {
+  const float* w_oihw;
+  void* w_fwd;    /* f16 [Cout][KH][KW][Cin_pad] or NULL */
+  void* w_dgrad;  /* f16 [Cin_pad][KH][KW][Cout_pad] flipped, or NULL */
+  int32_t Cout, Cin, KH, KW, Cin_pad, Cout_pad;
+} hd_wprep_desc;
+
 /* ------------------------------------------------------------------------
  * Weight preparation: fp32 OIHW master -> f16 OHWI forward layout (+ optional
  * per-output-channel scale fold and channel padding) and the flipped/transposed
@@ -123,6 +132,9 @@ int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab
 int hd_weight_prep(const float* w_oihw, const float* out_scale /*[Cout] or NULL*/, void* w_fwd /*f16 [Cout][KH][KW][Cin_pad] or NULL*/,
                    void* w_dgrad /*f16 [Cin_pad][KH][KW][Cout_pad] flipped, or NULL*/, int Cout, int Cin, int KH, int KW,
                    int Cin_pad, int Cout_pad, void* stream);
+/* every trainable conv of the hallucination net re-packed in ONE launch (the fp32 masters move every optimizer step:
+ * train_hallucidet.py:431-435); table_dev: n_layers descriptors in device memory; grid = (blocks_per_layer, n_layers) */
+int hd_weight_prep_multi(const hd_wprep_desc* table_dev, int n_layers, int blocks_per_layer, void* stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm2d, training mode (batch statistics), split in the three steps the
