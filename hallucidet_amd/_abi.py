@@ -96,6 +96,7 @@ PROTOTYPES = {
     "hd_channel_sum_f16": (C.c_int, [vp, c_i64, C.c_int, vp, C.c_int, vp]),
     "hd_scale_store": (C.c_int, [vp, vp, C.c_int, c_f, C.c_int, vp]),
     "hd_nms_sorted_batched": (C.c_int, [vp, vp, C.c_int, C.c_int, c_f, vp, vp, vp]),
+    "hd_nms_sorted_batched_topk": (C.c_int, [vp, vp, C.c_int, C.c_int, c_f, vp, vp, C.c_int, vp]),
     "hd_roi_align": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_roi_align_ml": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "hd_roi_align_ml_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),

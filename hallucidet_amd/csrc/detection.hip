@@ -50,11 +50,12 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __re
 // mask rows of the kept boxes into the "removed" words -- 16 row loads in flight per wave, every wave a quarter of the
 // rows -- and the partial words are combined through LDS.  n <= 16384.
 __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ counts, int nmax,
-                                                         uint8_t* __restrict__ keep) {
+                                                         uint8_t* __restrict__ keep, int max_keep) {
   constexpr int MAXW = 4;  // 64*64*4 boxes
   __shared__ uint64_t remv[MAXW * 64];
   __shared__ uint64_t part[4][MAXW * 64];
   __shared__ uint64_t s_keepbits;
+  __shared__ int s_kept;
   const int b = blockIdx.x;
   const int n = counts[b];
   const int cb = (nmax + 63) / 64;
@@ -63,8 +64,15 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
   uint8_t* kb = keep + (size_t)b * nmax;
   const int nchunks = (n + 63) / 64;
   for (int i = tid; i < MAXW * 64; i += 256) remv[i] = 0;
+  if (tid == 0) s_kept = 0;
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
+    // callers that only use the first max_keep survivors (post-NMS top-n): once that many are kept, nothing later can be
+    // selected -- mark the rest not kept and stop the serial scan
+    if (s_kept >= max_keep) {
+      for (int i = c * 64 + tid; i < n; i += 256) kb[i] = 0;
+      break;
+    }
     const int lim = min(64, n - c * 64);
     if (wave == 0) {
       const int i = c * 64 + lane;
@@ -79,7 +87,10 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
         }
       }
       if (i < n) kb[i] = (uint8_t)((keepbits >> lane) & 1ull);
-      if (lane == 0) s_keepbits = keepbits;
+      if (lane == 0) {
+        s_keepbits = keepbits;
+        s_kept += __popcll(keepbits);
+      }
     }
     __syncthreads();
     const uint64_t keepbits = s_keepbits;
@@ -697,11 +708,16 @@ extern "C" int hd_box_iou_batched(const float* gt, int G, const float* boxes, in
 
 extern "C" int hd_nms_sorted_batched(const float* boxes, const int* counts, int B, int nmax, float iou_thr, uint64_t* mask_ws,
                                      uint8_t* keep, void* stream) {
-  HD_CHECK_ARG(boxes && counts && mask_ws && keep && B > 0 && nmax > 0 && nmax <= 16384, "hd_nms_sorted_batched: bad args (nmax<=16384)");
+  return hd_nms_sorted_batched_topk(boxes, counts, B, nmax, iou_thr, mask_ws, keep, 0x7fffffff, stream);
+}
+
+extern "C" int hd_nms_sorted_batched_topk(const float* boxes, const int* counts, int B, int nmax, float iou_thr, uint64_t* mask_ws,
+                                          uint8_t* keep, int max_keep, void* stream) {
+  HD_CHECK_ARG(boxes && counts && mask_ws && keep && B > 0 && nmax > 0 && nmax <= 16384 && max_keep > 0, "hd_nms_sorted_batched: bad args (nmax<=16384)");
   hipStream_t s = (hipStream_t)stream;
   int cb = (nmax + 63) / 64;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(64), 0, s, boxes, counts, nmax, iou_thr, mask_ws);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, (const uint64_t*)mask_ws, counts, nmax, keep);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, (const uint64_t*)mask_ws, counts, nmax, keep, max_keep);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -533,7 +533,7 @@ def _batched_nms_padded(boxes, scores, idxs, valid, iou_thr, top_n):
     offsets = idxs.to(boxes) * (bmax[:, None] + torch.tensor(1).to(boxes))
     shifted = boxes + offsets[:, :, None]
     sorted_boxes = torch.gather(shifted, 1, order[:, :, None].expand(-1, -1, 4)).contiguous()
-    keep = ops.nms_sorted_batched(sorted_boxes, counts, iou_thr)
+    keep = ops.nms_sorted_batched(sorted_boxes, counts, iou_thr, max_keep=top_n)
     rank = torch.cumsum(keep.to(torch.int32), dim=1)
     sel = keep & (rank <= top_n)
     return order, sel, sel.sum(dim=1)

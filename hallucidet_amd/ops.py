@@ -407,15 +407,17 @@ def scale_store(src, dst, scale=1.0, accumulate=False):
     return dst
 
 
-def nms_sorted_batched(boxes, counts, iou_thr):
-    """boxes [B, nmax, 4] fp32 sorted by descending score per image; counts [B] int32.  Returns keep [B, nmax] bool."""
+def nms_sorted_batched(boxes, counts, iou_thr, max_keep=None):
+    """boxes [B, nmax, 4] fp32 sorted by descending score per image; counts [B] int32.  Returns keep [B, nmax] bool.
+    `max_keep`: the caller only uses the first max_keep survivors per image -> the serial scan stops once they are found
+    (entries after that 64-box chunk read False)."""
     _need_cuda(boxes, counts)
     B, nmax, _ = boxes.shape
     cb = (nmax + 63) // 64
     ws = torch.empty((B, nmax, cb), dtype=torch.int64, device=boxes.device)
     keep = torch.zeros((B, nmax), dtype=torch.uint8, device=boxes.device)
-    check(_abi.load().hd_nms_sorted_batched(ptr(boxes.contiguous()), ptr(counts), B, nmax, iou_thr, ptr(ws), ptr(keep),
-                                            _stream()), "hd_nms_sorted_batched")
+    check(_abi.load().hd_nms_sorted_batched_topk(ptr(boxes.contiguous()), ptr(counts), B, nmax, iou_thr, ptr(ws), ptr(keep),
+                                                 0x7fffffff if max_keep is None else int(max_keep), _stream()), "hd_nms_sorted_batched")
     return keep.bool()
 
 

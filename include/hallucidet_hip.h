@@ -222,6 +222,10 @@ int hd_scale_store(const float* in, float* out, int n, float scale, int accumula
  * IoU test: inter/(a_i+a_j-inter) > thr, fp32, no FMA contraction (torchvision nms [EXT]). */
 int hd_nms_sorted_batched(const float* boxes, const int* counts, int B, int nmax, float iou_thr, uint64_t* mask_ws,
                           uint8_t* keep, void* stream);
+/* same, for callers that only use the first max_keep survivors of each image (RPN post_nms_top_n, detections_per_img):
+ * keep[] equals the full result up to the 64-box chunk in which the max_keep-th survivor falls and is 0 after it. */
+int hd_nms_sorted_batched_topk(const float* boxes, const int* counts, int B, int nmax, float iou_thr, uint64_t* mask_ws,
+                               uint8_t* keep, int max_keep, void* stream);
 /* RoIAlign (aligned=False), NHWC f16 features -> [R][PH][PW][C] f16. rois: [R][5] (batch, x1,y1,x2,y2) fp32 */
 int hd_roi_align(const void* feat, const float* rois, void* out, int R, int N, int H, int W, int C, int PH, int PW,
                  float spatial_scale, int sampling_ratio, void* stream);

@@ -513,3 +513,27 @@ def test_roi_align_multilevel_bwd_gather_form(dev, C):
         assert torch.allclose(dfs[l].float(), dfa[l], rtol=2e-3, atol=1e-2)
     with pytest.raises(Exception, match="7x7"):
         ops.roi_align_ml_bwd_gather(rnd(2, 5, 5, C, seed=1).to(dev), rois[:2].to(dev), levels_t[:2].to(dev), shapes, scales, 2)
+
+
+def test_nms_topk_early_stop_equals_full_prefix(dev):
+    """hd_nms_sorted_batched_topk: same keep flags as the full scan up to (and including) the 64-box chunk where the
+    max_keep-th survivor falls, nothing kept after it; the first max_keep survivors are therefore identical."""
+    from hallucidet_amd import ops
+    g = torch.Generator().manual_seed(12)
+    B, n = 3, 1500
+    xy = torch.rand(B, n, 2, generator=g) * 200
+    wh = torch.rand(B, n, 2, generator=g) * 60 + 4
+    boxes = torch.cat([xy, xy + wh], dim=2).to(dev)
+    counts = torch.tensor([1500, 900, 0], dtype=torch.int32, device=dev)
+    full = ops.nms_sorted_batched(boxes, counts, 0.5)
+    for mk in (1, 50, 300, 10 ** 6):
+        part = ops.nms_sorted_batched(boxes, counts, 0.5, max_keep=mk)
+        for b in range(B):
+            kf, kp = full[b].cpu(), part[b].cpu()
+            surv_f = torch.nonzero(kf).flatten()[:mk]
+            surv_p = torch.nonzero(kp).flatten()[:mk]
+            assert torch.equal(surv_f, surv_p), (mk, b)
+            assert not (kp & ~kf).any()                                  # never keeps something the full scan suppresses
+            if int(kf.sum()) > mk:
+                last = int(surv_f[-1]) // 64 * 64 + 64
+                assert torch.equal(kp[:last], kf[:last]) and not kp[last:].any()
