@@ -530,7 +530,7 @@ def _batched_nms_padded(boxes, scores, idxs, valid, iou_thr, top_n):
     counts = valid.sum(dim=1).to(torch.int32)
     bmax = torch.where(valid[..., None], boxes, torch.full_like(boxes, float("-inf"))).amax(dim=(1, 2))
     bmax = torch.where(counts > 0, bmax, torch.zeros_like(bmax))
-    offsets = idxs.to(boxes) * (bmax[:, None] + torch.tensor(1).to(boxes))
+    offsets = idxs.to(boxes) * (bmax[:, None] + 1)          # python scalar: a `torch.tensor(1).to(device)` is a blocking H2D copy
     shifted = boxes + offsets[:, :, None]
     sorted_boxes = torch.gather(shifted, 1, order[:, :, None].expand(-1, -1, 4)).contiguous()
     keep = ops.nms_sorted_batched(sorted_boxes, counts, iou_thr, max_keep=top_n)
@@ -1307,7 +1307,7 @@ def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
     k_min, k_max = int(-math.log2(scales[0])), int(-math.log2(scales[-1]))
     b = rois[:, 1:]
     s = torch.sqrt(box_area(b).float())
-    t = torch.floor(pool.canonical_level + torch.log2(s / pool.canonical_scale) + torch.tensor(pool.eps, dtype=s.dtype, device=device))
+    t = torch.floor(pool.canonical_level + torch.log2(s / pool.canonical_scale) + pool.eps)   # fp32 scalar add, no H2D copy
     levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
     return _RoIAlignFn.apply(rois.float().contiguous(), levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), *feats)
 

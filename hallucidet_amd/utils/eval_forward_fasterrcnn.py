@@ -160,11 +160,24 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     sb, ss, sl, counts = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
     from ..models.custom_generalized_transform import _ratios
     rh, rw = _ratios(shape, sizes[0][0])
-    scale = torch.tensor([rw, rh, rw, rh], dtype=sb.dtype).to(sb.device, non_blocking=True) if not model.transform.training else None
+    scale = _scale_tensor(rw, rh, sb) if not model.transform.training else None
     dets = D.LazyDetections(sb, ss, sl, counts, (lambda b: b * scale) if scale is not None else None).split(nb)
     losses = {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg,
               "loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
     return [(losses if k == 0 else {}, d) for k, d in enumerate(dets)]
+
+
+_SCALE_CACHE = {}
+
+
+def _scale_tensor(rw, rh, like):
+    """[rw, rh, rw, rh] on the device, built once per (ratio, device): a fresh host->device copy every step is a
+    blocking call that drains the launch queue."""
+    key = (float(rw), float(rh), str(like.device), like.dtype)
+    t = _SCALE_CACHE.get(key)
+    if t is None:
+        t = _SCALE_CACHE[key] = torch.tensor([rw, rh, rw, rh], dtype=like.dtype).to(like.device)
+    return t
 
 
 def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name='fasterrcnn'):

@@ -113,7 +113,8 @@ def _detections_padded(model, head_outputs, anchors0, napl, image_sizes, origina
     scale = None
     if not model.transform.training:
         rh, rw = _ratios(image_sizes[0], original_image_sizes[0])
-        scale = torch.tensor([rw, rh, rw, rh], dtype=sb.dtype).to(sb.device, non_blocking=True)
+        from .eval_forward_fasterrcnn import _scale_tensor
+        scale = _scale_tensor(rw, rh, sb)
     return D.LazyDetections(sb, ss, sl, counts, (lambda b: b * scale) if scale is not None else None)
 
 
