@@ -1138,14 +1138,14 @@ def _match_batched(iou, gvalid, high, low, allow_low_quality):
     return m
 
 
-def _sample_batched(sampler, labels):
+def _sample_batched(sampler, labels, host_counts=True):
     """BalancedPositiveNegativeSampler over labels [N,A] (>=1 positive, 0 negative, <0 ignored).
     Returns (pos_sel, neg_sel) bool [N,A] and the per-image (num_pos, num_neg) python ints."""
     N, A = labels.shape
     dev = labels.device
     pos, neg = labels >= 1, labels == 0
     if sampler.randperm_fn is None:
-        return _sample_batched_keys(sampler, pos, neg)
+        return _sample_batched_keys(sampler, pos, neg, host_counts)
     cnt = torch.stack([pos.sum(1), neg.sum(1)], dim=1).tolist()          # the one host sync of the sampler
     rows_p, cols_p, rows_n, cols_n, picked = [], [], [], [], []
     for i, (P_i, N_i) in enumerate(cnt):
@@ -1167,7 +1167,7 @@ def _sample_batched(sampler, labels):
     return pos_sel, neg_sel, picked
 
 
-def _sample_batched_keys(sampler, pos, neg):
+def _sample_batched_keys(sampler, pos, neg, host_counts=True):
     """The sampler's draws for a whole batch in ONE sort: a uniformly random subset of size k of a population is the k
     smallest of iid random keys -- which is also how `torch.randperm` is implemented -- so every image's positives get
     keys in [0,1), negatives in [2,3), everything else 4, and one row-wise sort lines up `randperm(positives)` followed
@@ -1191,6 +1191,8 @@ def _sample_batched_keys(sampler, pos, neg):
     sn = (ar >= P[:, None]) & (ar < (P + num_neg)[:, None])
     pos_sel = torch.zeros_like(pos).scatter_(1, order, sp)
     neg_sel = torch.zeros_like(neg).scatter_(1, order, sn)
+    if not host_counts:          # caller only needs the totals as device scalars: no host synchronisation at all
+        return pos_sel, neg_sel, torch.stack([num_pos, num_neg], dim=1)
     picked = [tuple(t) for t in torch.stack([num_pos, num_neg], dim=1).tolist()]     # the one host sync of the sampler
     return pos_sel, neg_sel, picked
 
@@ -1213,12 +1215,14 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
     labels = torch.where(m == Matcher.BETWEEN_THRESHOLDS, torch.full_like(labels, -1.0), labels)
     labels = torch.where(has_gt[:, None], labels, torch.zeros_like(labels))
     matched = torch.gather(gt, 1, m.clamp(min=0)[:, :, None].expand(-1, -1, 4))
-    pos_sel, neg_sel, picked = _sample_batched(rpn.fg_bg_sampler, labels)
+    # the RPN losses only need the NUMBER of sampled anchors: keep it on the device (no host sync) unless a permutation
+    # function is injected (parity tests), whose per-image loop needs the counts on the host anyway
+    pos_sel, neg_sel, picked = _sample_batched(rpn.fg_bg_sampler, labels, host_counts=False)
     if n_loss is not None and n_loss < N:
         keep_img = (torch.arange(N, device=labels.device) < n_loss)[:, None]
         pos_sel, neg_sel = pos_sel & keep_img, neg_sel & keep_img
         picked = picked[:n_loss]
-    n_sampled = sum(a + b for a, b in picked)
+    n_sampled = picked.sum() if torch.is_tensor(picked) else sum(a + b for a, b in picked)
     pos_f = pos_sel.reshape(-1)
     samp_f = pos_f | neg_sel.reshape(-1)
     # regression targets are only ever read at sampled positives (elsewhere they may be inf for GT-less images)
@@ -1229,9 +1233,10 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
 def rpn_loss_from_samples(st, objectness, deltas):
     pos_f, samp_f, n_sampled = st["pos_f"], st["samp_f"], st["n_sampled"]
     l1 = F.smooth_l1_loss(deltas, torch.where(pos_f[:, None], st["reg_t"], deltas.detach()), beta=1 / 9, reduction="none").sum(dim=1)
-    box_loss = torch.where(pos_f, l1, torch.zeros_like(l1)).sum() / max(n_sampled, 1)
+    denom = n_sampled.clamp(min=1) if torch.is_tensor(n_sampled) else max(n_sampled, 1)
+    box_loss = torch.where(pos_f, l1, torch.zeros_like(l1)).sum() / denom
     bce = F.binary_cross_entropy_with_logits(objectness.flatten(), st["labels"], reduction="none")
-    obj_loss = torch.where(samp_f, bce, torch.zeros_like(bce)).sum() / max(n_sampled, 1)
+    obj_loss = torch.where(samp_f, bce, torch.zeros_like(bce)).sum() / denom
     return obj_loss, box_loss
 
 
@@ -1332,7 +1337,9 @@ def postprocess_detections_flat(rh, class_logits, box_regression, rois, per, ima
     pred_scores = F.softmax(class_logits.detach(), -1)
     img = rois[:, 0].to(torch.int64)
     # position of every RoI inside its image (RoIs are grouped by image, in order): index minus first index of the image
-    first = torch.cumsum(torch.bincount(img, minlength=n_img), 0) - torch.bincount(img, minlength=n_img)
+    # (torch.bincount synchronises with the host to size its output: count by comparison instead)
+    cnt = (img[None, :] == torch.arange(n_img, device=device)[:, None]).sum(dim=1)
+    first = torch.cumsum(cnt, 0) - cnt
     slot = img * cap + (torch.arange(rois.shape[0], device=device) - first[img])
     K = num_classes - 1
     b = clip_boxes_to_image(pred_boxes, image_shape)[:, 1:]              # [R,K,4]

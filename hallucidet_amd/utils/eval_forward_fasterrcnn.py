@@ -126,8 +126,6 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     rpn_state = None
     if key in cache:
         rpn_state = D.rpn_targets_sample_batched(model.rpn, cache[key], gt, gvalid, n_loss=n0)
-        _raise_if_degenerate(flag, targets)
-        flag = None
     if need_grad:
         features = model.backbone(il.tensors, n_active=n0)
         objectness, deltas = model.rpn.head(list(features.values()), n_active=n0)
@@ -146,8 +144,8 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     if rpn_state is None:
         rpn_state = D.rpn_targets_sample_batched(model.rpn, anchors[0], gt, gvalid, n_loss=n0)
     loss_objectness, loss_rpn_box_reg = D.rpn_loss_from_samples(rpn_state, obj, dl)
-    _raise_if_degenerate(flag, targets)            # (first step only) the sampler above was the first host sync
     rois, labels, reg_t, per = D.select_training_samples_batched(model.roi_heads, pb, pc, gt, glab, gvalid)
+    _raise_if_degenerate(flag, targets)            # read at the step's ONE host sync (the RoI sampler's counts, just above)
     r0 = sum(per[:n0])
     pool, head, pred = model.roi_heads.box_roi_pool, model.roi_heads.box_head, model.roi_heads.box_predictor
     bf0 = D.roi_pool_rois(pool, features, rois[:r0], shape, n_images=n0)
