@@ -65,6 +65,7 @@ PROTOTYPES = {
     "hd_conv_tune_override": (C.c_int, [C.c_int] * 4),
     "hd_conv2d_patch_stats_rows": (C.c_int, [C.POINTER(ConvArgs)]),
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
+    "hd_wgrad_tune_override": (C.c_int, [C.c_int]),
     "hd_wgrad_reduce": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_weight_prep": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_weight_prep_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),

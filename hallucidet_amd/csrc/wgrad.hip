@@ -321,6 +321,13 @@ extern "C" int hd_weight_prep_multi(const hd_wprep_desc* table_dev, int n_layers
   return HD_OK;
 }
 
+static int g_wg_tm = -1;   // tuning hook (tools/tune_wgrad.py): force the Cout tile of hd_wgrad; -1 = by channel count
+extern "C" int hd_wgrad_tune_override(int tm) {
+  HD_CHECK_ARG(tm == -1 || tm == 32 || tm == 64 || tm == 128, "hd_wgrad_tune_override: tm in {32, 64, 128} or -1");
+  g_wg_tm = tm;
+  return HD_OK;
+}
+
 extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   HD_CHECK_ARG(a && a->x && a->dy && a->slab, "hd_wgrad: null pointer");
   HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->Cout % 8 == 0, "hd_wgrad: channels must be multiples of 8");
@@ -345,7 +352,7 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
     p.xbytes = (unsigned)xb; p.x2bytes = (unsigned)x2b; p.dybytes = (unsigned)db;
   }
   hipStream_t s = (hipStream_t)stream;
-  const int tm = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
+  const int tm = g_wg_tm > 0 ? g_wg_tm : (p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32));
   dim3 grid(hd_cdiv(p.Ktot, TN), hd_cdiv(p.Cout, tm), a->nsplit);
   if (tm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 2, 2>), grid, dim3(256), 0, s, p);
   else if (tm == 64) hipLaunchKernelGGL((wgrad_kernel<64, 2, 2>), grid, dim3(256), 0, s, p);

@@ -110,6 +110,8 @@ typedef struct hd_wgrad_args {
   int32_t nsplit;
 } hd_wgrad_args;
 int hd_wgrad(const hd_wgrad_args* a, void* stream);
+/* tuning hook (tools/tune_wgrad.py): force hd_wgrad's Cout tile (32 / 64 / 128 rows); -1 = by channel count. Process-wide. */
+int hd_wgrad_tune_override(int tm);
 /* dw_oihw[co][ci][kh][kw] (=|+=) scale * sum_s slab[s][co][(kh,kw,ci)] ; Cin_real <= Cin, Cout <= Cout_slab
  * (slab rows/channels beyond the real extents are layout padding and are dropped) */
 int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW,

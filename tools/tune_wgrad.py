@@ -33,22 +33,31 @@ for (x, dy, KH, KW, kw, shp) in rec:
     ns0 = shp[0]
     dw = torch.empty((Cout, Cin, KH, KW), dtype=torch.float32, device=x.device)
     res = {}
-    for f in (0.125, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0):
-        ns = max(1, min(int(round(ns0 * f)), M // 64))
-        if ns in res or ns * Cout * K * 4 > (256 << 20):
+    from hallucidet_amd import _abi
+    lib = _abi.load()
+    tm0 = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+    for tm in (32, 64, 128):
+        if tm > max(Cout, 32) * 2:
             continue
-        k2 = dict(kw); k2["nsplit"] = ns
+        for f in (0.25, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0):
+            ns = max(1, min(int(round(ns0 * f * tm0 / tm)) if tm != tm0 else int(round(ns0 * f)), M // 64))
+            if (tm, ns) in res or ns * Cout * K * 4 > (256 << 20):
+                continue
+            k2 = dict(kw); k2["nsplit"] = ns
+            lib.hd_wgrad_tune_override(tm)
 
-        def run():
-            slab = o_w(x, dy, KH, KW, **k2)
-            ops.wgrad_reduce(slab, dw, KH, KW, Cin, Cout=Cout)
-        run()
-        e0.record()
-        for _ in range(6):
+            def run():
+                slab = o_w(x, dy, KH, KW, **k2)
+                ops.wgrad_reduce(slab, dw, KH, KW, Cin, Cout=Cout)
             run()
-        e1.record(); e1.synchronize()
-        res[ns] = e0.elapsed_time(e1) / 6 * 1e3
+            e0.record()
+            for _ in range(6):
+                run()
+            e1.record(); e1.synchronize()
+            res[(tm, ns)] = e0.elapsed_time(e1) / 6 * 1e3
+    lib.hd_wgrad_tune_override(-1)
     best = min(res, key=res.get)
-    tot_h += res[ns0]; tot_b += res[best]
-    print("M=%7d Cout=%4d K=%5d  heuristic ns=%3d %6.1f us | best ns=%3d %6.1f us | %s" % (M, Cout, K, ns0, res[ns0], best, res[best], " ".join("%d:%.0f" % (k, v) for k, v in sorted(res.items()))))
+    tot_h += res[(tm0, ns0)]; tot_b += res[best]
+    bytm = {t: min((v, k[1]) for k, v in res.items() if k[0] == t) for t in (32, 64, 128) if any(k[0] == t for k in res)}
+    print("M=%7d Cout=%4d K=%5d  heuristic tm=%d ns=%3d %6.1f us | best %s %6.1f us | best per tm: %s" % (M, Cout, K, tm0, ns0, res[(tm0, ns0)], best, res[best], " ".join("%d:%.0f(ns %d)" % (t, v[0], v[1]) for t, v in bytm.items())))
 print("total heuristic %.2f ms, per-layer best %.2f ms" % (tot_h / 1e3, tot_b / 1e3))
