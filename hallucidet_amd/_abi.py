@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhallucidet_hip.so")
+# HD_HIP_LIB: load another build of the same ABI (A/B runs of kernel changes, the profiling build); default = the in-tree library
+LIB_PATH = os.environ.get("HD_HIP_LIB") or os.path.join(_HERE, "lib", "libhallucidet_hip.so")
 
 HD_ACT_NONE, HD_ACT_RELU, HD_ACT_SIGMOID = 0, 1, 2
 HD_OUT_NHWC_F16, HD_OUT_NCHW_F32 = 0, 1

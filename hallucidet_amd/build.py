@@ -27,20 +27,25 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
-def build(verbose=False, force=False):
-    os.makedirs(os.path.join(LIBDIR, "obj"), exist_ok=True)
+def build(verbose=False, force=False, trace=False):
+    """trace=True builds lib/libhallucidet_hip_trace.so with -DHD_CONV_TRACE (per-block timeline stamps in the conv kernels,
+    tools/conv_trace.py); the product library never carries them."""
+    objdir = os.path.join(LIBDIR, "obj_trace" if trace else "obj")
+    lib_path = os.path.join(LIBDIR, "libhallucidet_hip_trace.so") if trace else LIB
+    flags = FLAGS + (["-DHD_CONV_TRACE"] if trace else [])
+    os.makedirs(objdir, exist_ok=True)
     hm = _headers_mtime()
     jobs = []
     objs = []
     for src in _sources():
-        obj = os.path.join(LIBDIR, "obj", os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
             jobs.append((src, obj))
 
     def cc(job):
         src, obj = job
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -53,15 +58,15 @@ def build(verbose=False, force=False):
             for warn in ex.map(cc, jobs):
                 if verbose and warn:
                     print(warn)
-    if jobs or not os.path.exists(LIB):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if jobs or not os.path.exists(lib_path):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (r.stdout, r.stderr))
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(verbose=True, force="--force" in sys.argv))
+    print(build(verbose=True, force="--force" in sys.argv, trace="--trace" in sys.argv))

@@ -98,6 +98,15 @@ extern "C" int hd_conv_tune_override(int bm, int bn, int bk, int deep) {
   return HD_OK;
 }
 
+#ifdef HD_CONV_TRACE
+// profiling build only (not part of the shipped ABI): where the 64-deep kernels write their per-block stamps
+static unsigned long long* g_trace = nullptr;
+extern "C" int hd_conv_trace_buffer(void* buf) {
+  g_trace = (unsigned long long*)buf;
+  return HD_OK;
+}
+#endif
+
 struct TileChoice {
   int bm, bn;
   bool use64, deep;
@@ -170,6 +179,9 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
     HD_CHECK_LAUNCH();
     return HD_OK;
   }
+#ifdef HD_CONV_TRACE
+  p.trace = g_trace;
+#endif
   const TileChoice c = choose_tile(p);
   const int bm = c.bm, bn = c.bn;
   const bool use64 = c.use64, deep = c.deep;

@@ -1,0 +1,217 @@
+// Epilogue shared by the implicit-GEMM convolution kernels (conv_igemm_bk32.hip / conv_igemm_bk64.hip):
+//   y = act( mask( acc (+ residual) + bias ) ),  optional per-tile BatchNorm partial sums of the f16-rounded pre-activation.
+//
+// Vector path (NHWC f16 output, Cout % 8 == 0): accumulators -> LDS fp32 tile -> each thread owns 8 consecutive output
+// channels of BM/RPI pixels: 16-byte residual / mask loads and 16-byte coalesced stores (per-lane 2-byte stores cost
+// 4-5x the HBM time on the 16/32-channel decoder layers).  Measured with per-block stamps (tools/conv_trace.py) the
+// first version of this path took 5 700 - 13 500 cycles per block, 11-33 % of a block's life: every row iteration
+// waited for its own residual / mask load and the per-element flag tests compiled to branches.  Now every residual /
+// mask row of the thread is requested BEFORE the LDS transpose (they land while the tile is written and read back),
+// the option tests are hoisted to one uniform branch per 8-vector, and the BatchNorm partial sums are reduced with
+// lane shuffles + one 4-row LDS step instead of a 16-64-row serial LDS walk.
+// Direct path (NCHW fp32 output or ragged channel counts: head / RPN / predictor outputs, all tiny): per-lane stores.
+#pragma once
+#include "conv_params.h"
+
+template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM / (WM * 32)][BN / (WN * 32)], f16* lds,
+                                              int m0, int n0, int tile_m, int HoWo) {
+  constexpr int MT = BM / (WM * 32);
+  constexpr int NT = BN / (WN * 32);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  if (p.out_mode == HD_OUT_NHWC_F16 && (p.Cout & 7) == 0) {
+    constexpr int CPR = BN / 8;            // 8-channel chunks per tile row
+    constexpr int RPI = 256 / CPR;         // rows covered per iteration
+    constexpr int ITER = BM / RPI;         // rows per thread
+    const int cch = tid % CPR, r0 = tid / CPR;
+    const int co = n0 + cch * 8;
+    const bool cvalid = co < p.Cout;       // Cout % 8 == 0 => whole chunk valid
+    const f16* __restrict__ resp = p.res;
+    const f16* __restrict__ maskp = p.mask;
+    float* __restrict__ statsp = p.stats;
+    const int act = p.act;
+    const int Cout = p.Cout;
+    const size_t off0 = (size_t)(m0 + r0) * Cout + co;
+    bool ok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) ok[it] = cvalid && (m0 + r0 + it * RPI < p.M);
+
+    // residual / mask rows: all requested up front
+    f16x8 rv[ITER], mv[ITER];
+    if (resp) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it)
+        if (ok[it]) rv[it] = *reinterpret_cast<const f16x8*>(resp + off0 + (size_t)it * RPI * Cout);
+    }
+    if (maskp) {
+#pragma unroll
+      for (int it = 0; it < ITER; ++it)
+        if (ok[it]) mv[it] = *reinterpret_cast<const f16x8*>(maskp + off0 + (size_t)it * RPI * Cout);
+    }
+    float bias8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) bias8[k] = (p.bias && cvalid) ? p.bias[co + k] : 0.f;
+
+    float* ct = reinterpret_cast<float*>(lds);   // [BM][BN] fp32
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * MT * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = wn * NT * 32 + b * 32 + (lane & 31);
+          ct[row * BN + col] = acc[a][b][r];
+        }
+    __syncthreads();
+
+    float ssum8[8], ssq8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) ssum8[k] = ssq8[k] = 0.f;
+    f16* __restrict__ yp = reinterpret_cast<f16*>(p.y);
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      if (ok[it]) {
+        const int row = r0 + it * RPI;
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(ct + row * BN + cch * 8);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(ct + row * BN + cch * 8 + 4);
+        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
+        if (resp) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += (float)rv[it][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] += bias8[k];
+        if (maskp) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = ((float)mv[it][k] > 0.f) ? v[k] : 0.f;
+        }
+        if (statsp) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const float vr = (float)(f16)v[k];
+            ssum8[k] += vr;
+            ssq8[k] += vr * vr;
+          }
+        }
+        if (act == HD_ACT_RELU) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
+        } else if (act == HD_ACT_SIGMOID) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = 1.f / (1.f + __expf(-v[k]));
+        }
+        f16x8 o;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
+        *reinterpret_cast<f16x8*>(yp + off0 + (size_t)it * RPI * Cout) = o;
+      }
+    }
+    if (statsp) {
+      // lanes that share a channel chunk sit CPR apart: fold the 64/CPR rows of this wave with shuffles, then the 4 waves
+      // through LDS (fixed order: the partial sums are deterministic)
+#pragma unroll
+      for (int d = CPR; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          ssum8[k] += __shfl_xor(ssum8[k], d);
+          ssq8[k] += __shfl_xor(ssq8[k], d);
+        }
+      }
+      __syncthreads();                     // everyone is done reading the C tile
+      float* red = reinterpret_cast<float*>(lds);   // [4 waves][BN][2]
+      if (lane < CPR) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          red[((wave * BN) + lane * 8 + k) * 2 + 0] = ssum8[k];
+          red[((wave * BN) + lane * 8 + k) * 2 + 1] = ssq8[k];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && n0 + tid < Cout) {
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          s += red[(m * BN + tid) * 2 + 0];
+          s2 += red[(m * BN + tid) * 2 + 1];
+        }
+        statsp[((size_t)tile_m * 2 + 0) * Cout + n0 + tid] = s;
+        statsp[((size_t)tile_m * 2 + 1) * Cout + n0 + tid] = s2;
+      }
+    }
+    return;
+  }
+
+  // Direct path
+  float ssum[NT], ssq[NT];
+#pragma unroll
+  for (int b = 0; b < NT; ++b) ssum[b] = ssq[b] = 0.f;
+
+#pragma unroll
+  for (int b = 0; b < NT; ++b) {
+    const int col = wn * NT * 32 + b * 32 + (lane & 31);
+    const int co = n0 + col;
+    const bool cvalid = co < p.Cout;
+    const float bias = (p.bias && cvalid) ? p.bias[co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < MT; ++a) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * MT * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int pix = m0 + row;
+        if (pix < p.M && cvalid) {
+          float v = acc[a][b][r];
+          if (p.res) v += (float)p.res[(size_t)pix * p.Cout + co];
+          v += bias;
+          if (p.mask && !((float)p.mask[(size_t)pix * p.Cout + co] > 0.f)) v = 0.f;
+          if (p.stats) {
+            float vr = (float)(f16)v;
+            ssum[b] += vr;
+            ssq[b] += vr * vr;
+          }
+          if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
+          else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+          if (p.out_mode == HD_OUT_NHWC_F16) {
+            reinterpret_cast<f16*>(p.y)[(size_t)pix * p.Cout + co] = (f16)v;
+          } else {
+            int n = pix / HoWo;
+            int rem = pix - n * HoWo;
+            reinterpret_cast<float*>(p.y)[((size_t)n * p.Cout + co) * HoWo + rem] = v;
+          }
+        }
+      }
+    }
+  }
+
+  if (p.stats) {
+    // reduce the two lane halves, then across the WM waves that share columns
+    float* red = reinterpret_cast<float*>(lds);  // [WM][BN][2]
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+      float s = ssum[b] + __shfl_xor(ssum[b], 32);
+      float s2 = ssq[b] + __shfl_xor(ssq[b], 32);
+      if (lane < 32) {
+        int col = wn * NT * 32 + b * 32 + lane;
+        red[(wm * BN + col) * 2 + 0] = s;
+        red[(wm * BN + col) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    if (tid < BN) {
+      int co = n0 + tid;
+      if (co < p.Cout) {
+        float s = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int m = 0; m < WM; ++m) {
+          s += red[(m * BN + tid) * 2 + 0];
+          s2 += red[(m * BN + tid) * 2 + 1];
+        }
+        p.stats[((size_t)tile_m * 2 + 0) * p.Cout + co] = s;
+        p.stats[((size_t)tile_m * 2 + 1) * p.Cout + co] = s2;
+      }
+    }
+  }
+}

@@ -23,6 +23,7 @@
 //     their 3x3 halo and all N tiles of one M tile share the gathered pixels in that XCD's L2).
 #include "hd_common.h"
 #include "conv_params.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -222,163 +223,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  // ---------------- epilogue ----------------
-  // Vector path (NHWC f16 output, Cout % 8 == 0): accumulators -> LDS fp32 tile -> each thread owns 8 consecutive
-  // output channels of a pixel: 16-byte residual / mask loads and 16-byte coalesced stores (the per-lane 2-byte
-  // stores of the direct path cost 4-5x the HBM time on the 16/32-channel decoder layers).
-  if (p.out_mode == HD_OUT_NHWC_F16 && (p.Cout & 7) == 0) {
-    float* ct = reinterpret_cast<float*>(lds);   // [BM][BN] fp32
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * MT * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int col = wn * NT * 32 + b * 32 + (lane & 31);
-          ct[row * BN + col] = acc[a][b][r];
-        }
-    __syncthreads();
-    constexpr int CPR = BN / 8;            // 8-channel chunks per tile row
-    constexpr int RPI = 256 / CPR;         // rows covered per iteration
-    const int cch = tid % CPR, r0 = tid / CPR;
-    const int co = n0 + cch * 8;
-    const bool cvalid = co < p.Cout;       // Cout % 8 == 0 => whole chunk valid
-    float bias8[8], ssum8[8], ssq8[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      bias8[k] = (p.bias && cvalid) ? p.bias[co + k] : 0.f;
-      ssum8[k] = ssq8[k] = 0.f;
-    }
-    if (cvalid) {
-#pragma unroll 4
-      for (int row = r0; row < BM; row += RPI) {
-        const int pix = m0 + row;
-        if (pix >= p.M) break;
-        const f32x4 c0 = *reinterpret_cast<const f32x4*>(ct + row * BN + cch * 8);
-        const f32x4 c1 = *reinterpret_cast<const f32x4*>(ct + row * BN + cch * 8 + 4);
-        float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-        const size_t off = (size_t)pix * p.Cout + co;
-        if (p.res) {
-          const f16x8 rv = *reinterpret_cast<const f16x8*>(p.res + off);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] += (float)rv[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += bias8[k];
-        if (p.mask) {
-          const f16x8 mv = *reinterpret_cast<const f16x8*>(p.mask + off);
-#pragma unroll
-          for (int k = 0; k < 8; ++k)
-            if (!((float)mv[k] > 0.f)) v[k] = 0.f;
-        }
-        f16x8 o;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          if (p.stats) {
-            float vr = (float)(f16)v[k];
-            ssum8[k] += vr;
-            ssq8[k] += vr * vr;
-          }
-          float w = v[k];
-          if (p.act == HD_ACT_RELU) w = fmaxf(w, 0.f);
-          else if (p.act == HD_ACT_SIGMOID) w = 1.f / (1.f + __expf(-w));
-          o[k] = (f16)w;
-        }
-        *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.y) + off) = o;
-      }
-    }
-    if (p.stats) {
-      __syncthreads();                     // everyone is done reading the C tile
-      float* red = reinterpret_cast<float*>(lds);   // [RPI][BN][2]
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        red[(r0 * BN + cch * 8 + k) * 2 + 0] = ssum8[k];
-        red[(r0 * BN + cch * 8 + k) * 2 + 1] = ssq8[k];
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < p.Cout) {
-        float s = 0.f, s2 = 0.f;
-        for (int m = 0; m < RPI; ++m) {
-          s += red[(m * BN + tid) * 2 + 0];
-          s2 += red[(m * BN + tid) * 2 + 1];
-        }
-        p.stats[((size_t)tile_m * 2 + 0) * p.Cout + n0 + tid] = s;
-        p.stats[((size_t)tile_m * 2 + 1) * p.Cout + n0 + tid] = s2;
-      }
-    }
-    return;
-  }
-
-  // Direct path (NCHW fp32 output or ragged channel counts: head / RPN / predictor outputs, all tiny)
-  float ssum[NT], ssq[NT];
-#pragma unroll
-  for (int b = 0; b < NT; ++b) ssum[b] = ssq[b] = 0.f;
-
-#pragma unroll
-  for (int b = 0; b < NT; ++b) {
-    const int col = wn * NT * 32 + b * 32 + (lane & 31);
-    const int co = n0 + col;
-    const bool cvalid = co < p.Cout;
-    const float bias = (p.bias && cvalid) ? p.bias[co] : 0.f;
-#pragma unroll
-    for (int a = 0; a < MT; ++a) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * MT * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int pix = m0 + row;
-        if (pix < p.M && cvalid) {
-          float v = acc[a][b][r];
-          if (p.res) v += (float)p.res[(size_t)pix * p.Cout + co];
-          v += bias;
-          if (p.mask && !((float)p.mask[(size_t)pix * p.Cout + co] > 0.f)) v = 0.f;
-          if (p.stats) {
-            float vr = (float)(f16)v;
-            ssum[b] += vr;
-            ssq[b] += vr * vr;
-          }
-          if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
-          else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-          if (p.out_mode == HD_OUT_NHWC_F16) {
-            reinterpret_cast<f16*>(p.y)[(size_t)pix * p.Cout + co] = (f16)v;
-          } else {
-            int n = pix / HoWo;
-            int rem = pix - n * HoWo;
-            reinterpret_cast<float*>(p.y)[((size_t)n * p.Cout + co) * HoWo + rem] = v;
-          }
-        }
-      }
-    }
-  }
-
-  if (p.stats) {
-    // reduce the two lane halves, then across the WM waves that share columns
-    float* red = reinterpret_cast<float*>(lds);  // [WM][BN][2]
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-      float s = ssum[b] + __shfl_xor(ssum[b], 32);
-      float s2 = ssq[b] + __shfl_xor(ssq[b], 32);
-      if (lane < 32) {
-        int col = wn * NT * 32 + b * 32 + lane;
-        red[(wm * BN + col) * 2 + 0] = s;
-        red[(wm * BN + col) * 2 + 1] = s2;
-      }
-    }
-    __syncthreads();
-    if (tid < BN) {
-      int co = n0 + tid;
-      if (co < p.Cout) {
-        float s = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int m = 0; m < WM; ++m) {
-          s += red[(m * BN + tid) * 2 + 0];
-          s2 += red[(m * BN + tid) * 2 + 1];
-        }
-        p.stats[((size_t)tile_m * 2 + 0) * p.Cout + co] = s;
-        p.stats[((size_t)tile_m * 2 + 1) * p.Cout + co] = s2;
-      }
-    }
-  }
+  // ---------------- epilogue (conv_epilogue.h) ----------------
+  conv_epilogue<BM, BN, WM, WN>(p, acc, lds, m0, n0, tile_m, HoWo);
 }
 
 

@@ -16,6 +16,9 @@ struct ConvP {
   int M, cin8, nchunks, nk, Ktot;
   int gm, gn;          // grid extent in M / N tiles
   float inv_cin8, inv_kw;
+#ifdef HD_CONV_TRACE
+  unsigned long long* trace;   // profiling builds only (tools/conv_trace.py): 8 stamps per block
+#endif
 };
 
 void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
