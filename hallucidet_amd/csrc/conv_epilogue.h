@@ -67,6 +67,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
           ct[row * BN + col] = acc[a][b][r];
         }
     __syncthreads();
+    HD_TRACE(8, clock64());
 
     float ssum8[8], ssq8[8];
 #pragma unroll
@@ -110,6 +111,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
         *reinterpret_cast<f16x8*>(yp + off0 + (size_t)it * RPI * Cout) = o;
       }
     }
+    HD_TRACE(9, clock64());
     if (statsp) {
       // lanes that share a channel chunk sit CPR apart: fold the 64/CPR rows of this wave with shuffles, then the 4 waves
       // through LDS (fixed order: the partial sums are deterministic)

@@ -38,21 +38,6 @@ constexpr unsigned OOB = 0xFFFFFFF0u;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
-// per-block timeline stamps, compiled only into the profiling build (build.py --trace, tools/conv_trace.py)
-#ifdef HD_CONV_TRACE
-__device__ __forceinline__ unsigned long long hw_ids() {
-  unsigned a, b;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(a));
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(b));
-  return ((unsigned long long)b << 32) | a;
-}
-#define HD_TRACE(slot, expr)                                                            \
-  do {                                                                                  \
-    if (threadIdx.x == 0 && p.trace) p.trace[(size_t)blockIdx.x * 8 + (slot)] = (expr); \
-  } while (0)
-#else
-#define HD_TRACE(slot, expr) do {} while (0)
-#endif
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_dst, 16, voff, 0, 0, 0);

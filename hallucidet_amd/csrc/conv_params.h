@@ -17,9 +17,25 @@ struct ConvP {
   int gm, gn;          // grid extent in M / N tiles
   float inv_cin8, inv_kw;
 #ifdef HD_CONV_TRACE
-  unsigned long long* trace;   // profiling builds only (tools/conv_trace.py): 8 stamps per block
+  unsigned long long* trace;   // profiling builds only (tools/conv_trace.py): 12 stamps per block
 #endif
 };
+
+// per-block timeline stamps, compiled only into the profiling build (build.py --trace, tools/conv_trace.py)
+#ifdef HD_CONV_TRACE
+__device__ __forceinline__ unsigned long long hw_ids() {
+  unsigned a, b;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(a));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(b));
+  return ((unsigned long long)b << 32) | a;
+}
+#define HD_TRACE(slot, expr)                                                            \
+  do {                                                                                  \
+    if (threadIdx.x == 0 && p.trace) p.trace[(size_t)blockIdx.x * 12 + (slot)] = (expr); \
+  } while (0)
+#else
+#define HD_TRACE(slot, expr) do {} while (0)
+#endif
 
 void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);

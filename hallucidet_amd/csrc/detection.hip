@@ -692,6 +692,91 @@ __global__ void box_iou_batched_kernel(const float* __restrict__ gt, int G, cons
   }
 }
 
+
+// ---- fused target assignment (box_iou + Matcher + label lookup + BoxCoder.encode), one thread per (image, box) ---------
+// Replaces ~70 elementwise launches over [N, G, A] / [N, A] tensors per call (detection.py: _match_batched and its callers).
+// Arithmetic order follows the separate torch ops (fp-contract is off for this library), so the results are the ones
+// the per-op path produces: IoU via box_iou_dev, first maximal GT on ties (torch.max), torchvision's low-quality rule
+// (an anchor whose IoU equals some GT's best IoU gets ITS OWN arg-max GT, not that GT), encode = BoxCoder.encode_single.
+
+// pass 1 (allow_low_quality only): best[n][g] = max over boxes of IoU(gt[n][g], box); -1 for invalid GT rows
+__global__ __launch_bounds__(256) void match_best_kernel(const float* __restrict__ gt, const uint8_t* __restrict__ gvalid, int G,
+                                                         const float* __restrict__ boxes, int A, long boxes_stride,
+                                                         float* __restrict__ best) {
+  const int ng = blockIdx.x;                 // n * G + g
+  const int n = ng / G;
+  __shared__ float red[4];
+  float m = -1.f;
+  if (gvalid[ng]) {
+    const float g4[4] = {gt[(size_t)ng * 4 + 0], gt[(size_t)ng * 4 + 1], gt[(size_t)ng * 4 + 2], gt[(size_t)ng * 4 + 3]};
+    const float* bb = boxes + (size_t)n * boxes_stride;
+    for (int a = threadIdx.x; a < A; a += 256) m = fmaxf(m, box_iou_dev(g4, bb + (size_t)a * 4));
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) best[ng] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void match_assign_kernel(const float* __restrict__ gt, const uint8_t* __restrict__ gvalid,
+                                                           const int64_t* __restrict__ glabels, int G, const float* __restrict__ boxes,
+                                                           int A, int N, long boxes_stride, float high, float low,
+                                                           const float* __restrict__ best, float wx, float wy, float ww, float wh,
+                                                           int want_reg, int64_t* __restrict__ matched, int64_t* __restrict__ labels,
+                                                           float* __restrict__ reg_t) {
+  extern __shared__ float s_gt[];            // [G][4] boxes, [G] best, [G] valid (as float)
+  const int n = blockIdx.y;
+  float* s_best = s_gt + G * 4;
+  float* s_valid = s_best + G;
+  for (int i = threadIdx.x; i < G * 4; i += 256) s_gt[i] = gt[(size_t)n * G * 4 + i];
+  for (int i = threadIdx.x; i < G; i += 256) {
+    s_best[i] = best ? best[n * G + i] : 0.f;
+    s_valid[i] = gvalid[n * G + i] ? 1.f : 0.f;
+  }
+  __syncthreads();
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  if (a >= A) return;
+  const float* bp = boxes + (size_t)n * boxes_stride + (size_t)a * 4;
+  const float b4[4] = {bp[0], bp[1], bp[2], bp[3]};
+  float vmax = -INFINITY;
+  int imax = 0;
+  bool is_best = false, has_gt = false;
+  for (int g = 0; g < G; ++g) {
+    const bool v = s_valid[g] != 0.f;
+    has_gt = has_gt || v;
+    const float iou = v ? box_iou_dev(s_gt + g * 4, b4) : -1.f;
+    if (iou > vmax) {                        // strict: the FIRST maximal GT wins, as torch.max(dim) does
+      vmax = iou;
+      imax = g;
+    }
+    if (best && v && iou == s_best[g]) is_best = true;
+  }
+  int64_t m = imax;
+  if (vmax < low) m = -1;                                     // Matcher.BELOW_LOW_THRESHOLD
+  else if (vmax < high) m = -2;                               // Matcher.BETWEEN_THRESHOLDS
+  if (is_best) m = imax;
+  const size_t o = (size_t)n * A + a;
+  matched[o] = m;
+  if (labels) {
+    int64_t lab = m >= 0 ? (glabels ? glabels[(size_t)n * G + m] : 1) : (m == -1 ? 0 : -1);
+    labels[o] = has_gt ? lab : 0;
+  }
+  if (want_reg) {
+    const float* r = s_gt + (m > 0 ? (int)m : 0) * 4;         // matched.clamp(min=0)
+    const float ew = b4[2] - b4[0], eh = b4[3] - b4[1];
+    const float ecx = b4[0] + 0.5f * ew, ecy = b4[1] + 0.5f * eh;
+    const float gw = r[2] - r[0], gh = r[3] - r[1];
+    const float gcx = r[0] + 0.5f * gw, gcy = r[1] + 0.5f * gh;
+    float4 t;
+    t.x = wx * (gcx - ecx) / ew;
+    t.y = wy * (gcy - ecy) / eh;
+    t.z = ww * logf(gw / ew);
+    t.w = wh * logf(gh / eh);
+    *reinterpret_cast<float4*>(reg_t + o * 4) = t;
+  }
+}
+
 }  // namespace
 
 extern "C" int hd_box_iou_batched(const float* gt, int G, const float* boxes, int A, int N, int shared_boxes, float* iou, void* stream) {
@@ -702,6 +787,26 @@ extern "C" int hd_box_iou_batched(const float* gt, int G, const float* boxes, in
   if (g > 8192) g = 8192;
   hipLaunchKernelGGL(box_iou_batched_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, gt, G, boxes, A, N,
                      shared_boxes ? 0l : (long)A * 4, iou);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+
+extern "C" int hd_match_targets(const float* gt, const uint8_t* gvalid, const int64_t* glabels, int G, const float* boxes, int A, int N,
+                                int shared_boxes, float high, float low, int allow_low_quality, const float* coder_weights,
+                                float* best_ws, int64_t* matched, int64_t* labels, float* reg_t, void* stream) {
+  HD_CHECK_ARG(gt && gvalid && boxes && matched && G >= 1 && G <= 2048 && A >= 0 && N >= 0, "hd_match_targets: bad args (1 <= G <= 2048)");
+  HD_CHECK_ARG(!allow_low_quality || best_ws, "hd_match_targets: allow_low_quality needs the [N*G] float workspace");
+  HD_CHECK_ARG((reg_t == nullptr) == (coder_weights == nullptr), "hd_match_targets: reg_t and coder_weights go together");
+  if (A == 0 || N == 0) return HD_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const long stride = shared_boxes ? 0l : (long)A * 4;
+  if (allow_low_quality)
+    hipLaunchKernelGGL(match_best_kernel, dim3(N * G), dim3(256), 0, s, gt, gvalid, G, boxes, A, stride, best_ws);
+  const float* w = coder_weights;
+  hipLaunchKernelGGL(match_assign_kernel, dim3((A + 255) / 256, N), dim3(256), (size_t)G * 6 * sizeof(float), s, gt, gvalid, glabels, G, boxes,
+                     A, N, stride, high, low, allow_low_quality ? (const float*)best_ws : (const float*)nullptr, w ? w[0] : 1.f, w ? w[1] : 1.f,
+                     w ? w[2] : 1.f, w ? w[3] : 1.f, reg_t ? 1 : 0, matched, labels, reg_t);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

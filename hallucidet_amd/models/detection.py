@@ -1111,15 +1111,35 @@ def fasterrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pre
 # list-based methods above (tests assert identical outputs); an order of magnitude fewer device launches and two host
 # synchronisations per detector pass (sampler population sizes, detection counts).
 # ======================================================================================================================
+_PAD_IDX_CACHE = {}
+
+
 def pad_targets(targets, device):
-    """-> gt [N,G,4] fp32, labels [N,G] int64, valid [N,G] bool (G >= 1)."""
-    lens = [int(t["boxes"].shape[0]) for t in targets]
+    """-> gt [N,G,4] fp32, labels [N,G] int64, valid [N,G] bool (G >= 1).
+    One concatenation + one gather through a [N,G] row-index table (pad_sequence issues two device copies per target: 48
+    launches for the 24 targets of a step).  The table depends on the box counts only: built on the host, cached per count
+    tuple, uploaded from pinned memory without a stream synchronisation."""
+    lens = tuple(int(t["boxes"].shape[0]) for t in targets)
+    N, S = len(lens), sum(lens)
     G = max(1, max(lens))
-    gt = torch.nn.utils.rnn.pad_sequence([t["boxes"].to(torch.float32).reshape(-1, 4) for t in targets], batch_first=True)
-    lb = torch.nn.utils.rnn.pad_sequence([t["labels"].reshape(-1) for t in targets], batch_first=True)
-    if gt.shape[1] < G:
-        gt = F.pad(gt, (0, 0, 0, G - gt.shape[1]))
-        lb = F.pad(lb, (0, G - lb.shape[1]))
+    key = (lens, str(device))
+    idx = _PAD_IDX_CACHE.get(key)
+    if idx is None:
+        rows, lo = [], 0
+        for n in lens:
+            rows.append(list(range(lo, lo + n)) + [S] * (G - n))      # row S of the sources = the all-zero padding row
+            lo += n
+        host = torch.tensor(rows, dtype=torch.int64).reshape(N, G)
+        if torch.device(device).type == "cuda":
+            idx = host.pin_memory().to(device, non_blocking=True)
+        else:
+            idx = host.to(device)
+        if len(_PAD_IDX_CACHE) > 256:
+            _PAD_IDX_CACHE.clear()
+        _PAD_IDX_CACHE[key] = idx
+    boxes = torch.cat([t["boxes"].to(torch.float32).reshape(-1, 4) for t in targets] + [torch.zeros((1, 4), dtype=torch.float32, device=device)], dim=0)
+    labels = torch.cat([t["labels"].reshape(-1) for t in targets] + [torch.zeros((1,), dtype=targets[0]["labels"].dtype, device=device)], dim=0)
+    gt, lb = boxes[idx], labels[idx]
     # real boxes are non-degenerate (checked upstream: x2 > x1), padding rows are all-zero: no host->device traffic
     valid = gt[:, :, 2] > gt[:, :, 0]
     return gt, lb, valid
@@ -1168,29 +1188,30 @@ def _sample_batched(sampler, labels, host_counts=True):
 
 
 def _sample_batched_keys(sampler, pos, neg, host_counts=True):
-    """The sampler's draws for a whole batch in ONE sort: a uniformly random subset of size k of a population is the k
-    smallest of iid random keys -- which is also how `torch.randperm` is implemented -- so every image's positives get
-    keys in [0,1), negatives in [2,3), everything else 4, and one row-wise sort lines up `randperm(positives)` followed
-    by `randperm(negatives)` for each image.  Same distribution as the reference's 2 draws per image (uniform subsets of
-    sizes min(P, 0.x*B) and min(N, B - num_pos)), 1 sort instead of 2*N randperm launches.  Used when no `randperm_fn` is
-    injected (parity tests inject one and take the per-image path above)."""
+    """The sampler's draws for a whole batch in ONE selection: a uniformly random subset of size k of a population is the k
+    smallest of iid random keys -- which is also how `torch.randperm` is implemented -- so every candidate gets a random
+    key and each image takes the smallest keys of its positives and of its negatives.  Same distribution as the
+    reference's 2 draws per image (uniform subsets of sizes min(P, 0.x*B) and min(N, B - num_pos)), 1 top-k instead of 2*N
+    randperm launches.  Used when no `randperm_fn` is injected (parity tests inject one and take the per-image path above)."""
     N, A = pos.shape
     dev = pos.device
     B = sampler.batch_size_per_image
     cap_p = int(B * sampler.positive_fraction)
     # 30 random bits per candidate (collision probability per row ~A^2 / 2^31: a handful of ties in a million draws, broken
-    # by position); positives in [0, 2^30), negatives in [2^30, 2^31), everything else at the top: an int32 radix sort
+    # arbitrarily).  Only the B smallest keys of each population are ever used, so a row-wise top-k (one radix-select block
+    # per row) over [positives' keys ; negatives' keys] replaces the full sort of every row (rocprim merge sort: ~20 launches
+    # for the RPN's 21 765 anchors per image).
     r = torch.randint(0, 1 << 30, (N, A), dtype=torch.int32, device=dev)
-    keys = torch.where(pos, r, torch.where(neg, r + (1 << 30), 0x7FFFFFFF))
-    order = torch.sort(keys, dim=1)[1]
+    big = torch.full_like(r, 0x7FFFFFFF)
+    k = min(B, A)
+    keys = torch.stack([torch.where(pos, r, big), torch.where(neg, r, big)], dim=0).reshape(2 * N, A)
+    order = torch.topk(keys, k, dim=1, largest=False, sorted=True)[1].reshape(2, N, k)
     P, Nn = pos.sum(1), neg.sum(1)
     num_pos = P.clamp(max=cap_p)
     num_neg = torch.minimum(Nn, B - num_pos)
-    ar = torch.arange(A, device=dev)[None, :]
-    sp = ar < num_pos[:, None]
-    sn = (ar >= P[:, None]) & (ar < (P + num_neg)[:, None])
-    pos_sel = torch.zeros_like(pos).scatter_(1, order, sp)
-    neg_sel = torch.zeros_like(neg).scatter_(1, order, sn)
+    ar = torch.arange(k, device=dev)[None, :]
+    pos_sel = torch.zeros_like(pos).scatter_(1, order[0], ar < num_pos[:, None])
+    neg_sel = torch.zeros_like(neg).scatter_(1, order[1], ar < num_neg[:, None])
     if not host_counts:          # caller only needs the totals as device scalars: no host synchronisation at all
         return pos_sel, neg_sel, torch.stack([num_pos, num_neg], dim=1)
     picked = [tuple(t) for t in torch.stack([num_pos, num_neg], dim=1).tolist()]     # the one host sync of the sampler
@@ -1198,8 +1219,26 @@ def _sample_batched_keys(sampler, pos, neg, host_counts=True):
 
 
 def _compact(mask_flat, total):
-    """Indices of the True entries of a flat bool mask, in order, when their number `total` is already known on the host."""
-    return torch.sort((~mask_flat).to(torch.uint8), stable=True)[1][:total]
+    """Indices of the True entries of a flat bool mask, in order, when their number `total` is already known on the host:
+    rank by prefix sum, scatter the positions (False entries go to a spare slot) -- no sort."""
+    n = mask_flat.numel()
+    rank = torch.cumsum(mask_flat, 0) - 1
+    tgt = torch.where(mask_flat, rank, torch.full_like(rank, total))
+    out = torch.zeros(total + 1, dtype=torch.int64, device=mask_flat.device)
+    out.scatter_(0, tgt, torch.arange(n, device=mask_flat.device))
+    return out[:total]
+
+
+def _front(sel, top):
+    """[B,top] column indices of the True entries of sel [B,n], in order (rows with fewer than `top` are padded with 0):
+    the stable-sort-by-flag this replaces cost a multi-pass merge sort per call."""
+    B, n = sel.shape
+    top = min(top, n)
+    rank = torch.cumsum(sel, dim=1) - 1
+    tgt = torch.where(sel & (rank < top), rank, torch.full_like(rank, top))
+    out = torch.zeros((B, top + 1), dtype=torch.int64, device=sel.device)
+    out.scatter_(1, tgt, torch.arange(n, device=sel.device)[None, :].expand(B, n))
+    return out[:, :top]
 
 
 def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
@@ -1207,14 +1246,11 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
     the network), so a training step can run it -- and take the sampler's host sync -- before the detector trunk is
     even launched.  Returns what `rpn_loss_from_samples` needs."""
     N = gvalid.shape[0]
-    iou = ops.box_iou_batched(gt, anchors0)
-    m = _match_batched(iou, gvalid, rpn.proposal_matcher.high_threshold, rpn.proposal_matcher.low_threshold, True)
-    has_gt = gvalid.any(dim=1)
-    labels = (m >= 0).to(torch.float32)
-    labels = torch.where(m == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(labels), labels)
-    labels = torch.where(m == Matcher.BETWEEN_THRESHOLDS, torch.full_like(labels, -1.0), labels)
-    labels = torch.where(has_gt[:, None], labels, torch.zeros_like(labels))
-    matched = torch.gather(gt, 1, m.clamp(min=0)[:, :, None].expand(-1, -1, 4))
+    # IoU + Matcher(0.7, 0.3, low-quality) + labels (1 / 0 / -1; 0 for GT-less images) + box_coder.encode of the matched GT
+    # in two launches (ops.match_targets) instead of ~70 elementwise launches over [N,G,A] / [N,A] tensors
+    _, lab, reg_t = ops.match_targets(gt, gvalid, None, anchors0, rpn.proposal_matcher.high_threshold, rpn.proposal_matcher.low_threshold,
+                                      True, coder_weights=rpn.box_coder.weights)
+    labels = lab.to(torch.float32)
     # the RPN losses only need the NUMBER of sampled anchors: keep it on the device (no host sync) unless a permutation
     # function is injected (parity tests), whose per-image loop needs the counts on the host anyway
     pos_sel, neg_sel, picked = _sample_batched(rpn.fg_bg_sampler, labels, host_counts=False)
@@ -1226,8 +1262,7 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
     pos_f = pos_sel.reshape(-1)
     samp_f = pos_f | neg_sel.reshape(-1)
     # regression targets are only ever read at sampled positives (elsewhere they may be inf for GT-less images)
-    reg_t = rpn.box_coder.encode_single(matched.reshape(-1, 4), anchors0.repeat(N, 1))
-    return dict(labels=labels.reshape(-1).clamp(min=0), reg_t=reg_t, pos_f=pos_f, samp_f=samp_f, n_sampled=n_sampled)
+    return dict(labels=labels.reshape(-1).clamp(min=0), reg_t=reg_t.reshape(-1, 4), pos_f=pos_f, samp_f=samp_f, n_sampled=n_sampled)
 
 
 def rpn_loss_from_samples(st, objectness, deltas):
@@ -1263,12 +1298,10 @@ def filter_proposals_padded(rpn, proposals, objectness, image_shape, num_anchors
     valid = (ws >= rpn.min_size) & (hs >= rpn.min_size) & (prob >= rpn.score_thresh)
     post = rpn.post_nms_top_n()
     order, sel, counts = _batched_nms_padded(boxes, prob, levels, valid, rpn.nms_thresh, post)
-    sboxes = torch.gather(boxes, 1, order[:, :, None].expand(-1, -1, 4))
-    sscores = torch.gather(prob, 1, order)
-    # bring the selected entries to the front, keeping their order
-    front = torch.sort((~sel).to(torch.uint8), dim=1, stable=True)[1][:, :post]
-    out_b = torch.gather(sboxes, 1, front[:, :, None].expand(-1, -1, 4))
-    out_s = torch.gather(sscores, 1, front)
+    # bring the selected entries to the front, keeping their (score) order; rows past counts[i] are padding
+    pick = torch.gather(order, 1, _front(sel, post))
+    out_b = torch.gather(boxes, 1, pick[:, :, None].expand(-1, -1, 4))
+    out_s = torch.gather(prob, 1, pick)
     return out_b, out_s, counts
 
 
@@ -1282,13 +1315,9 @@ def select_training_samples_batched(rh, props, pcounts, gt, glabels, gvalid):
     comb = torch.cat([props, gt], dim=1)                     # torchvision order: proposals, then GT boxes
     cvalid = torch.cat([pvalid, gvalid], dim=1)
     T = Pm + G
-    iou = ops.box_iou_batched(gt, comb)
-    m = _match_batched(iou, gvalid, rh.proposal_matcher.high_threshold, rh.proposal_matcher.low_threshold, False)
-    lab = torch.gather(glabels, 1, m.clamp(min=0)).to(torch.int64)
-    lab = torch.where(m == Matcher.BELOW_LOW_THRESHOLD, torch.zeros_like(lab), lab)
-    lab = torch.where(m == Matcher.BETWEEN_THRESHOLDS, torch.full_like(lab, -1), lab)
+    # IoU + Matcher(0.5, 0.5) + class lookup (0 below the threshold and for GT-less images) in one launch
+    m, lab, _ = ops.match_targets(gt, gvalid, glabels, comb, rh.proposal_matcher.high_threshold, rh.proposal_matcher.low_threshold, False)
     has_gt = gvalid.any(dim=1)
-    lab = torch.where(has_gt[:, None], lab, torch.zeros_like(lab))
     lab = torch.where(cvalid, lab, torch.full_like(lab, -1))   # padding slots are neither positive nor negative
     pos_sel, neg_sel, picked = _sample_batched(rh.fg_bg_sampler, lab)
     per = [a + b for a, b in picked]
@@ -1352,14 +1381,10 @@ def postprocess_detections_flat(rh, class_logits, box_regression, rois, per, ima
     Lb = torch.arange(1, num_classes, device=device).view(1, 1, K).expand(n_img, cap, K).reshape(n_img, cap * K)
     B, S, V = B.view(n_img, cap * K, 4), S.view(n_img, cap * K), V.view(n_img, cap * K)
     order, sel, counts = _batched_nms_padded(B, S, Lb, V, rh.nms_thresh, rh.detections_per_img)
-    sb = torch.gather(B, 1, order[:, :, None].expand(-1, -1, 4))
-    ss = torch.gather(S, 1, order)
-    sl = torch.gather(Lb, 1, order)
-    top = rh.detections_per_img
-    front = torch.sort((~sel).to(torch.uint8), dim=1, stable=True)[1][:, :top]
-    sb = torch.gather(sb, 1, front[:, :, None].expand(-1, -1, 4))
-    ss = torch.gather(ss, 1, front)
-    sl = torch.gather(sl, 1, front)
+    pick = torch.gather(order, 1, _front(sel, rh.detections_per_img))
+    sb = torch.gather(B, 1, pick[:, :, None].expand(-1, -1, 4))
+    ss = torch.gather(S, 1, pick)
+    sl = torch.gather(Lb, 1, pick)
     return sb, ss, sl, counts
 
 

@@ -271,9 +271,7 @@ class RetinaNet(nn.Module):
             lo += n
         cb, cs, cl, cv = torch.cat(cb, 1), torch.cat(cs, 1), torch.cat(cl, 1), torch.cat(cv, 1)
         order, sel, counts = D._batched_nms_padded(cb, cs, cl, cv, self.nms_thresh, self.detections_per_img)
-        top = min(self.detections_per_img, cs.shape[1])
-        front = torch.sort((~sel).to(torch.uint8), dim=1, stable=True)[1][:, :top]
-        pick = torch.gather(order, 1, front)
+        pick = torch.gather(order, 1, D._front(sel, self.detections_per_img))
         return (torch.gather(cb, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(cs, 1, pick), torch.gather(cl, 1, pick), counts)
 
 
@@ -292,9 +290,8 @@ def retinanet_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pret
 # ======================================================================================================================
 def retinanet_match_batched(model, anchors0, gt, gvalid):
     """:165-175: box_iou + proposal_matcher per image; GT-less images are all -1.  -> matched idx [B, A]."""
-    iou = ops.box_iou_batched(gt, anchors0)
     pm = model.proposal_matcher
-    return D._match_batched(iou, gvalid, pm.high_threshold, pm.low_threshold, pm.allow_low_quality_matches)
+    return ops.match_targets(gt, gvalid, None, anchors0, pm.high_threshold, pm.low_threshold, pm.allow_low_quality_matches, want_labels=False)[0]
 
 
 def retinanet_loss_batched(model, anchors0, gt, glab, gvalid, cls_logits, bbox_regression, matched=None):

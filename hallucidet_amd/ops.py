@@ -505,6 +505,31 @@ def box_iou_batched(gt, boxes):
     return iou
 
 
+def match_targets(gt, gvalid, glabels, boxes, high, low, allow_low_quality, coder_weights=None, want_labels=True):
+    """Fused box_iou + Matcher + label lookup (+ BoxCoder.encode when `coder_weights` is given) for N images.
+    gt [N,G,4] f32, gvalid [N,G] bool, glabels [N,G] int64 or None, boxes [A,4] (shared) or [N,A,4].
+    Returns (matched [N,A] int64 with -1/-2 codes, labels [N,A] int64 or None, reg_t [N,A,4] f32 or None)."""
+    _need_cuda(gt, gvalid, boxes, glabels)
+    N, G, _ = gt.shape
+    shared = boxes.dim() == 2
+    A = boxes.shape[-2]
+    dev = gt.device
+    gt, boxes = gt.contiguous().float(), boxes.contiguous().float()
+    gv = gvalid.contiguous().view(torch.uint8) if gvalid.dtype == torch.bool else gvalid.to(torch.uint8).contiguous()
+    gl = None if glabels is None else glabels.contiguous().to(torch.int64)
+    matched = torch.empty((N, A), dtype=torch.int64, device=dev)
+    labels = torch.empty((N, A), dtype=torch.int64, device=dev) if want_labels else None
+    reg_t = w = None
+    if coder_weights is not None:
+        reg_t = torch.empty((N, A, 4), dtype=torch.float32, device=dev)
+        w = (C.c_float * 4)(*[float(x) for x in coder_weights])
+    ws = torch.empty((N * G,), dtype=torch.float32, device=dev) if allow_low_quality else None
+    check(_abi.load().hd_match_targets(ptr(gt), ptr(gv), ptr(gl), G, ptr(boxes), A, N, 1 if shared else 0, float(high), float(low),
+                                       1 if allow_low_quality else 0, C.cast(w, C.c_void_p) if w is not None else None, ptr(ws), ptr(matched),
+                                       ptr(labels), ptr(reg_t), _stream()), "hd_match_targets")
+    return matched, labels, reg_t
+
+
 def adam_step(p, g, m, v, *, lr, beta1, beta2, eps, weight_decay, clip_value, inv_scale, step, found_inf=None):
     bc1 = 1.0 - beta1 ** step
     bc2 = 1.0 - beta2 ** step

@@ -252,6 +252,18 @@ int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int 
 int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream);
 /* iou[n][g][a] for N images; shared_boxes != 0: one [A][4] box set (anchors) for every image, else boxes is [N][A][4] */
 int hd_box_iou_batched(const float* gt, int G, const float* boxes, int A, int N, int shared_boxes, float* iou, void* stream);
+/* Fused target assignment for N images: box_iou + Matcher(high, low, allow_low_quality) + label lookup + BoxCoder.encode
+ * (torchvision RegionProposalNetwork.assign_targets_to_anchors / RoIHeads.assign_targets_to_proposals + box_coder.encode
+ * [EXT], called from src/utils/eval_forward_fasterrcnn.py:88-93,127 in the reference).
+ *   gt [N][G][4] f32, gvalid [N][G] u8 (padding rows 0), glabels [N][G] i64 or NULL (NULL: every match is class 1),
+ *   boxes [A][4] (shared_boxes != 0) or [N][A][4];
+ *   matched [N][A] i64: GT index, -1 below `low`, -2 between the thresholds (first maximal GT on ties);
+ *   labels  [N][A] i64 or NULL: class of the match, 0 below, -1 between, 0 for images without GT;
+ *   reg_t   [N][A][4] f32 or NULL: encode(gt[matched.clamp(0)], box) with coder_weights[4] (both NULL or both set);
+ *   best_ws [N*G] f32 workspace, needed when allow_low_quality != 0. */
+int hd_match_targets(const float* gt, const uint8_t* gvalid, const int64_t* glabels, int G, const float* boxes, int A, int N,
+                     int shared_boxes, float high, float low, int allow_low_quality, const float* coder_weights,
+                     float* best_ws, int64_t* matched, int64_t* labels, float* reg_t, void* stream);
 
 /* ------------------------------------------------------------------------
  * Optimizer: unscale + clip_grad_value_ + Adam in one pass over a flat buffer

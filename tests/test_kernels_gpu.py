@@ -537,3 +537,49 @@ def test_nms_topk_early_stop_equals_full_prefix(dev):
             if int(kf.sum()) > mk:
                 last = int(surv_f[-1]) // 64 * 64 + 64
                 assert torch.equal(kp[:last], kf[:last]) and not kp[last:].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shared,allow_lq", [(True, True), (False, False), (False, True)])
+def test_match_targets_equals_per_op_path(dev, shared, allow_lq):
+    """hd_match_targets (fused IoU + Matcher + labels + encode) against the per-op path it replaces (box_iou_batched +
+    detection._match_batched + label `where`s + BoxCoder.encode_single): match indices and labels bit-exact -- including
+    padded GT rows, a GT-less image, duplicated GT boxes (ties -> first maximal index) -- regression targets to 1 ulp-ish."""
+    from hallucidet_amd import ops
+    import hallucidet_amd.models.detection as D
+    torch.manual_seed(3)
+    N, G, A = 5, 6, 3000
+    xy = torch.rand(N, G, 2, device=dev) * 200
+    gt = torch.cat([xy, xy + 8 + torch.rand(N, G, 2, device=dev) * 120], dim=2)
+    gt[1, 3] = gt[1, 1]                                   # duplicate GT: tie between indices 1 and 3
+    gvalid = torch.ones(N, G, dtype=torch.bool, device=dev)
+    gvalid[0, 4:] = False
+    gvalid[2, :] = False                                  # image without GT
+    gt = torch.where(gvalid[:, :, None], gt, torch.zeros_like(gt))
+    glabels = torch.randint(1, 5, (N, G), device=dev)
+    bxy = torch.rand(N, A, 2, device=dev) * 260
+    boxes = torch.cat([bxy, bxy + 4 + torch.rand(N, A, 2, device=dev) * 100], dim=2)
+    boxes[:, :G] = gt                                     # exact overlaps (IoU 1) and equal-IoU ties
+    if shared:
+        boxes = boxes[0].contiguous()
+    hi, lo = (0.7, 0.3) if allow_lq else (0.5, 0.5)
+    w = (1.0, 1.0, 1.0, 1.0) if allow_lq else (10.0, 10.0, 5.0, 5.0)
+    m, lab, reg = ops.match_targets(gt, gvalid, glabels, boxes, hi, lo, allow_lq, coder_weights=w)
+    iou = ops.box_iou_batched(gt, boxes)
+    m_ref = D._match_batched(iou, gvalid, hi, lo, allow_lq)
+    assert torch.equal(m, m_ref)
+    lab_ref = torch.gather(glabels, 1, m_ref.clamp(min=0))
+    lab_ref = torch.where(m_ref == -1, torch.zeros_like(lab_ref), lab_ref)
+    lab_ref = torch.where(m_ref == -2, torch.full_like(lab_ref, -1), lab_ref)
+    lab_ref = torch.where(gvalid.any(dim=1)[:, None], lab_ref, torch.zeros_like(lab_ref))
+    assert torch.equal(lab, lab_ref)
+    m1, lab1, _ = ops.match_targets(gt, gvalid, None, boxes, hi, lo, allow_lq)
+    assert torch.equal(m1, m_ref) and torch.equal(lab1 > 0, lab_ref > 0) and int(lab1.max()) <= 1
+    matched = torch.gather(gt, 1, m_ref.clamp(min=0)[:, :, None].expand(-1, -1, 4)).reshape(-1, 4)
+    props = (boxes[None].expand(N, -1, -1) if shared else boxes).reshape(-1, 4)
+    reg_ref = D.BoxCoder(w).encode_single(matched, props).reshape(N, A, 4)
+    pos = (m_ref >= 0) & gvalid.any(dim=1)[:, None]
+    assert pos.any()
+    assert torch.allclose(reg[pos], reg_ref[pos], rtol=1e-6, atol=1e-6)
+    fin = torch.isfinite(reg_ref)
+    assert torch.equal(torch.isfinite(reg), fin)

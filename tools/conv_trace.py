@@ -52,18 +52,18 @@ for name, N, H, W, Cin, Cout, KH, stats, ov in SHAPES:
     e1.record(); e1.synchronize()
     t_us = e0.elapsed_time(e1) * 100
     nblk_max = 1 << 16
-    buf = torch.zeros(nblk_max * 8, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nblk_max * 12, dtype=torch.int64, device=dev)
     lib.hd_conv_trace_buffer(buf.data_ptr())
     ops.conv2d(x, w, KH, KH, pad=KH // 2, want_stats=stats)
     torch.cuda.synchronize()
     lib.hd_conv_trace_buffer(None)
-    t = buf.cpu().numpy().reshape(-1, 8)
+    t = buf.cpu().numpy().reshape(-1, 12)
     t = t[t[:, 0] != 0]
     nb = len(t)
     if nb == 0:
         print("%-28s no stamps (not a 64-deep launch)" % name)
         continue
-    wall0, c0, c_pro, c_land, c_loop, c_end, wall1, hw = [t[:, i] for i in range(8)]
+    wall0, c0, c_pro, c_land, c_loop, c_end, wall1, hw, c_tr, c_rows = [t[:, i] for i in range(10)]
     span_us = (wall1.max() - wall0.min()) / 100.0
     cu = (hw & 0xF00) >> 8
     se = (hw >> 13) & 0x7
@@ -78,6 +78,13 @@ for name, N, H, W, Cin, Cout, KH, stats, ov in SHAPES:
           (name, t_us, flops / t_us / 1e6, span_us, nb, len(uniq), cnt.min(), cnt.max(), nk))
     print("    median cycles: setup+prologue issue %5.0f | first tile lands %5.0f | K loop %6.0f (%4.0f per step) | epilogue %5.0f | block life %6.0f = %.2f us" %
           (med(c_pro - c0), med(c_land - c_pro), med(c_loop - c_land), med(c_loop - c_land) / nk, med(c_end - c_loop), med(life), med(life) / CLK_GHZ / 1e3))
+    print("    epilogue split: acc->LDS transpose + barrier %5.0f | row loop (LDS read, math, stores) %5.0f | BN partial sums %5.0f" %
+          (med(c_tr - c_loop), med(c_rows - c_tr), med(c_end - c_rows)))
+    if os.environ.get("TRACE_CU"):
+        for c in uniq[:2]:
+            sel = np.where(cuid == c)[0]
+            order = sel[np.argsort(wall0[sel])]
+            print("    CU %d: " % c + "  ".join("[%.1f-%.1f]" % ((wall0[i] - wall0.min()) / 100.0, (wall1[i] - wall0.min()) / 100.0) for i in order))
     start_us = (wall0 - wall0.min()) / 100.0
     print("    block start times: p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us;   sum of block lives / (CUs x span) = %.2f blocks in flight per CU" %
           (np.percentile(start_us, 10), np.percentile(start_us, 50), np.percentile(start_us, 90), start_us.max(),
