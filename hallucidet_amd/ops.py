@@ -505,6 +505,24 @@ def box_iou_batched(gt, boxes):
     return iou
 
 
+def topk_rows_segments(scores, seg_sizes, k):
+    """Per row of scores [B, sum(seg_sizes)] and per segment: the indices (into the row) of the min(k, n) largest entries
+    of the segment in descending score order, equal scores by ascending index -- torch.sort(seg, descending=True,
+    stable=True)[1][:, :k] + offset for every segment, concatenated.  -> int64 [B, sum(min(k, n))]."""
+    _need_cuda(scores)
+    assert scores.dim() == 2 and scores.dtype == torch.float32 and scores.stride(1) == 1
+    B = scores.shape[0]
+    ks = [min(k, n) for n in seg_sizes]
+    out = torch.empty((B, sum(ks)), dtype=torch.int64, device=scores.device)
+    lib, off, ooff = _abi.load(), 0, 0
+    for n, kk in zip(seg_sizes, ks):
+        check(lib.hd_topk_select_rows(ptr(scores), B, scores.stride(0), off, n, kk, ptr(out), out.stride(0), ooff, off, _stream()),
+              "hd_topk_select_rows")
+        off += n
+        ooff += kk
+    return out
+
+
 def match_targets(gt, gvalid, glabels, boxes, high, low, allow_low_quality, coder_weights=None, want_labels=True):
     """Fused box_iou + Matcher + label lookup (+ BoxCoder.encode when `coder_weights` is given) for N images.
     gt [N,G,4] f32, gvalid [N,G] bool, glabels [N,G] int64 or None, boxes [A,4] (shared) or [N,A,4].

@@ -252,6 +252,12 @@ int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int 
 int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream);
 /* iou[n][g][a] for N images; shared_boxes != 0: one [A][4] box set (anchors) for every image, else boxes is [N][A][4] */
 int hd_box_iou_batched(const float* gt, int G, const float* boxes, int A, int N, int shared_boxes, float* iou, void* stream);
+/* Per-row top-k selection of a row segment (RegionProposalNetwork._get_top_n_idx [EXT]: `ob.topk(pre_nms_top_n, dim=1)` per
+ * feature level): out[b][out_off + j], j < min(k, n), = idx_add + the indices (relative to seg_off) of the k largest
+ * scores[b][seg_off .. seg_off+n) in descending score order, equal scores by ascending index (= a stable descending sort
+ * cut at k).  min(k, n) <= 4096. */
+int hd_topk_select_rows(const float* scores, int B, long row_stride, int seg_off, int n, int k, int64_t* out, long out_stride,
+                        int out_off, int64_t idx_add, void* stream);
 /* Fused target assignment for N images: box_iou + Matcher(high, low, allow_low_quality) + label lookup + BoxCoder.encode
  * (torchvision RegionProposalNetwork.assign_targets_to_anchors / RoIHeads.assign_targets_to_proposals + box_coder.encode
  * [EXT], called from src/utils/eval_forward_fasterrcnn.py:88-93,127 in the reference).

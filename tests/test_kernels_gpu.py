@@ -583,3 +583,26 @@ def test_match_targets_equals_per_op_path(dev, shared, allow_lq):
     assert torch.allclose(reg[pos], reg_ref[pos], rtol=1e-6, atol=1e-6)
     fin = torch.isfinite(reg_ref)
     assert torch.equal(torch.isfinite(reg), fin)
+
+
+@pytest.mark.gpu
+def test_topk_rows_segments_equals_stable_sort(dev):
+    """hd_topk_select_rows against torch.sort(descending=True, stable=True)[1][:, :k] per segment: bit-exact index lists,
+    including heavy ties (quantised scores), segments shorter than k, negative scores and -inf."""
+    from hallucidet_amd import ops
+    torch.manual_seed(11)
+    segs = [16875, 4332, 1083, 300, 75]
+    B, k = 6, 1000
+    x = torch.randn(B, sum(segs), device=dev)
+    x[1] = torch.round(x[1] * 4) / 4                       # many exact ties, also at the cut
+    x[2] = -torch.rand(sum(segs), device=dev)              # all negative
+    x[3, ::7] = float("-inf")
+    x[4] = 0.0                                             # all equal: lowest indices win
+    got = ops.topk_rows_segments(x, segs, k)
+    ref, off = [], 0
+    for n in segs:
+        ref.append(torch.sort(x[:, off:off + n], dim=1, descending=True, stable=True)[1][:, :min(k, n)] + off)
+        off += n
+    assert torch.equal(got, torch.cat(ref, dim=1))
+    got2 = ops.topk_rows_segments(x[:, :5000].contiguous(), [5000], 3000)     # P = 4096 path
+    assert torch.equal(got2, torch.sort(x[:, :5000], dim=1, descending=True, stable=True)[1][:, :3000])
