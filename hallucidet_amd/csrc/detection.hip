@@ -704,8 +704,15 @@ __device__ __forceinline__ uint32_t order_key(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);        // larger float <=> larger key
 }
 
-__global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, long row_stride, int seg_off, int n, int k,
-                                                           int64_t* __restrict__ out, long out_stride, int out_off, int64_t idx_add) {
+struct TopkSegs {
+  int nseg;
+  int seg_off[8], n[8], k[8], out_off[8];
+};
+
+__global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restrict__ scores, long row_stride, TopkSegs segs,
+                                                           int64_t* __restrict__ out, long out_stride) {
+  const int seg_off = segs.seg_off[blockIdx.y], n = segs.n[blockIdx.y], k = segs.k[blockIdx.y], out_off = segs.out_off[blockIdx.y];
+  const int64_t idx_add = seg_off;
   __shared__ int hist[256];
   __shared__ uint32_t s_prefix;
   __shared__ int s_remaining;
@@ -794,6 +801,62 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
     }
   }
   for (int i = tid; i < k; i += 1024) orow[i] = (int64_t)(uint32_t)~(uint32_t)s_pair[i] + idx_add;
+}
+
+// ---- fused box decoding (BoxCoder.decode_single + clip_boxes_to_image + validity tests) ----------------------------------
+// The arithmetic follows the separate torch ops in order (fp-contract is off): dx = c*(1/wx), dw = min(c*(1/ww), clip) with NaN
+// kept, pcx = dx*w + cx, pw = exp(dw)*w, corners = pc -/+ 0.5*pw, then clamp to [0, W] x [0, H].
+// (torch divides a tensor by a python scalar as a multiplication by the fp32 reciprocal: the callers pass 1/weight)
+__device__ __forceinline__ float4 decode_clip_dev(const float* c, const float* b, float iwx, float iwy, float iww, float iwh, float xclip,
+                                                  float img_h, float img_w) {
+  const float w = b[2] - b[0], h = b[3] - b[1];
+  const float cx = b[0] + 0.5f * w, cy = b[1] + 0.5f * h;
+  const float dx = c[0] * iwx, dy = c[1] * iwy;
+  float dw = c[2] * iww, dh = c[3] * iwh;
+  dw = dw > xclip ? xclip : dw;
+  dh = dh > xclip ? xclip : dh;
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  float4 o;
+  o.x = pcx - 0.5f * pw;
+  o.y = pcy - 0.5f * ph;
+  o.z = pcx + 0.5f * pw;
+  o.w = pcy + 0.5f * ph;
+  // torch.clamp(min=0, max=L): NaN stays NaN
+  o.x = o.x < 0.f ? 0.f : (o.x > img_w ? img_w : o.x);
+  o.z = o.z < 0.f ? 0.f : (o.z > img_w ? img_w : o.z);
+  o.y = o.y < 0.f ? 0.f : (o.y > img_h ? img_h : o.y);
+  o.w = o.w < 0.f ? 0.f : (o.w > img_h ? img_h : o.w);
+  return o;
+}
+
+// RPN: for image n and candidate t: a = top[n][t]; box = clip(decode(deltas[n][a], anchors[a])); prob = sigmoid(obj[n][a]);
+// valid = w >= min_size && h >= min_size && prob >= score_thresh   (RegionProposalNetwork.filter_proposals [EXT])
+__global__ void rpn_decode_filter_kernel(const float* __restrict__ deltas, const float* __restrict__ obj, const float* __restrict__ anchors,
+                                         const int64_t* __restrict__ top, int N, int A, int K, float xclip, float img_h, float img_w,
+                                         float min_size, float score_thresh, float* __restrict__ boxes, float* __restrict__ prob,
+                                         uint8_t* __restrict__ valid) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N * K) return;
+  const int n = j / K;
+  const int64_t a = top[j];
+  const float4 o = decode_clip_dev(deltas + ((size_t)n * A + a) * 4, anchors + (size_t)a * 4, 1.f, 1.f, 1.f, 1.f, xclip, img_h, img_w);
+  const float x = obj[(size_t)n * A + a];
+  const float p = 1.f / (1.f + expf(-x));
+  *reinterpret_cast<float4*>(boxes + (size_t)j * 4) = o;
+  prob[j] = p;
+  valid[j] = ((o.z - o.x) >= min_size) && ((o.w - o.y) >= min_size) && (p >= score_thresh);
+}
+
+// RoI heads: codes [R][K*4], rois [R][4] -> boxes [R][K][4] clipped
+__global__ void roi_decode_clip_kernel(const float* __restrict__ codes, const float* __restrict__ rois, long roi_stride, int R, int K,
+                                       float wx, float wy, float ww, float wh, float xclip, float img_h, float img_w,
+                                       float* __restrict__ boxes) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R * K) return;
+  const int r = j / K;
+  *reinterpret_cast<float4*>(boxes + (size_t)j * 4) = decode_clip_dev(codes + (size_t)j * 4, rois + (size_t)r * roi_stride, wx, wy, ww, wh, xclip,
+                                                                      img_h, img_w);
 }
 
 // ---- fused target assignment (box_iou + Matcher + label lookup + BoxCoder.encode), one thread per (image, box) ---------
@@ -895,13 +958,43 @@ extern "C" int hd_box_iou_batched(const float* gt, int G, const float* boxes, in
 }
 
 
-extern "C" int hd_topk_select_rows(const float* scores, int B, long row_stride, int seg_off, int n, int k, int64_t* out, long out_stride,
-                                   int out_off, int64_t idx_add, void* stream) {
-  HD_CHECK_ARG(scores && out && B >= 0 && n >= 0 && k >= 0 && seg_off >= 0 && out_off >= 0, "hd_topk_select_rows: bad args");
-  HD_CHECK_ARG((k < n ? k : n) <= 4096, "hd_topk_select_rows: at most 4096 selected entries per segment (k=%d, n=%d)", k, n);
-  if (B == 0 || n == 0 || k == 0) return HD_OK;
-  hipLaunchKernelGGL(topk_select_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, scores, row_stride, seg_off, n, k < n ? k : n, out,
-                     out_stride, out_off, idx_add);
+extern "C" int hd_rpn_decode_filter(const float* deltas, const float* objectness, const float* anchors, const int64_t* top, int N, int A, int K,
+                                    float bbox_xform_clip, float img_h, float img_w, float min_size, float score_thresh, float* boxes,
+                                    float* prob, uint8_t* valid, void* stream) {
+  HD_CHECK_ARG(deltas && objectness && anchors && top && boxes && prob && valid && N >= 0 && A >= 0 && K >= 0, "hd_rpn_decode_filter: bad args");
+  if (N * K == 0) return HD_OK;
+  hipLaunchKernelGGL(rpn_decode_filter_kernel, dim3((N * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, deltas, objectness, anchors, top, N,
+                     A, K, bbox_xform_clip, img_h, img_w, min_size, score_thresh, boxes, prob, valid);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_decode_clip(const float* codes, const float* rois, long roi_stride, int R, int K, const float* coder_weights,
+                                  float bbox_xform_clip, float img_h, float img_w, float* boxes, void* stream) {
+  HD_CHECK_ARG(codes && rois && coder_weights && boxes && R >= 0 && K >= 0 && roi_stride >= 4, "hd_roi_decode_clip: bad args");
+  if (R * K == 0) return HD_OK;
+  hipLaunchKernelGGL(roi_decode_clip_kernel, dim3((R * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, codes, rois, roi_stride, R, K,
+                     1.0f / coder_weights[0], 1.0f / coder_weights[1], 1.0f / coder_weights[2], 1.0f / coder_weights[3], bbox_xform_clip, img_h,
+                     img_w, boxes);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_topk_select_rows(const float* scores, int B, long row_stride, const int* seg_sizes, int nseg, int k, int64_t* out,
+                                   long out_stride, void* stream) {
+  HD_CHECK_ARG(scores && out && seg_sizes && B >= 0 && nseg >= 1 && nseg <= 8 && k >= 1, "hd_topk_select_rows: bad args (1 <= nseg <= 8)");
+  TopkSegs sg;
+  sg.nseg = nseg;
+  int off = 0, ooff = 0;
+  for (int i = 0; i < nseg; ++i) {
+    const int n = seg_sizes[i], kk = k < n ? k : n;
+    HD_CHECK_ARG(n >= 1 && kk <= 4096, "hd_topk_select_rows: segments must be non-empty, at most 4096 selected entries each (k=%d, n=%d)", k, n);
+    sg.seg_off[i] = off; sg.n[i] = n; sg.k[i] = kk; sg.out_off[i] = ooff;
+    off += n;
+    ooff += kk;
+  }
+  if (B == 0) return HD_OK;
+  hipLaunchKernelGGL(topk_select_kernel, dim3(B, nseg), dim3(1024), 0, (hipStream_t)stream, scores, row_stride, sg, out, out_stride);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

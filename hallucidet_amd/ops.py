@@ -505,6 +505,37 @@ def box_iou_batched(gt, boxes):
     return iou
 
 
+def rpn_decode_filter(deltas, objectness, anchors, top, bbox_xform_clip, image_shape, min_size, score_thresh):
+    """deltas [N,A,4] f32, objectness [N,A] f32, anchors [A,4] f32, top [N,K] int64 -> (boxes [N,K,4], prob [N,K], valid [N,K] bool):
+    decode + clip + sigmoid + min-size / score tests of the selected anchors in one launch."""
+    _need_cuda(deltas, objectness, anchors, top)
+    N, A = objectness.shape
+    K = top.shape[1]
+    dev = deltas.device
+    deltas, objectness, anchors, top = deltas.contiguous().float(), objectness.contiguous().float(), anchors.contiguous().float(), top.contiguous()
+    boxes = torch.empty((N, K, 4), dtype=torch.float32, device=dev)
+    prob = torch.empty((N, K), dtype=torch.float32, device=dev)
+    valid = torch.empty((N, K), dtype=torch.bool, device=dev)
+    check(_abi.load().hd_rpn_decode_filter(ptr(deltas), ptr(objectness), ptr(anchors), ptr(top), N, A, K, float(bbox_xform_clip),
+                                           float(image_shape[0]), float(image_shape[1]), float(min_size), float(score_thresh), ptr(boxes),
+                                           ptr(prob), ptr(valid), _stream()), "hd_rpn_decode_filter")
+    return boxes, prob, valid
+
+
+def roi_decode_clip(codes, rois, coder_weights, bbox_xform_clip, image_shape):
+    """codes [R, K*4] f32, rois [R, 4 or 5] f32 (box in the last four columns) -> boxes [R, K, 4] decoded and clipped."""
+    _need_cuda(codes, rois)
+    R = codes.shape[0]
+    K = codes.shape[1] // 4
+    codes, rois = codes.contiguous().float(), rois.contiguous().float()
+    boxes = torch.empty((R, K, 4), dtype=torch.float32, device=codes.device)
+    w = (C.c_float * 4)(*[float(x) for x in coder_weights])
+    off = rois.shape[1] - 4
+    check(_abi.load().hd_roi_decode_clip(ptr(codes), rois.data_ptr() + off * 4, rois.shape[1], R, K, C.cast(w, C.c_void_p), float(bbox_xform_clip),
+                                         float(image_shape[0]), float(image_shape[1]), ptr(boxes), _stream()), "hd_roi_decode_clip")
+    return boxes
+
+
 def topk_rows_segments(scores, seg_sizes, k):
     """Per row of scores [B, sum(seg_sizes)] and per segment: the indices (into the row) of the min(k, n) largest entries
     of the segment in descending score order, equal scores by ascending index -- torch.sort(seg, descending=True,
@@ -512,14 +543,12 @@ def topk_rows_segments(scores, seg_sizes, k):
     _need_cuda(scores)
     assert scores.dim() == 2 and scores.dtype == torch.float32 and scores.stride(1) == 1
     B = scores.shape[0]
-    ks = [min(k, n) for n in seg_sizes]
-    out = torch.empty((B, sum(ks)), dtype=torch.int64, device=scores.device)
-    lib, off, ooff = _abi.load(), 0, 0
-    for n, kk in zip(seg_sizes, ks):
-        check(lib.hd_topk_select_rows(ptr(scores), B, scores.stride(0), off, n, kk, ptr(out), out.stride(0), ooff, off, _stream()),
-              "hd_topk_select_rows")
-        off += n
-        ooff += kk
+    seg_sizes = [int(n) for n in seg_sizes]
+    assert sum(seg_sizes) == scores.shape[1]
+    out = torch.empty((B, sum(min(k, n) for n in seg_sizes)), dtype=torch.int64, device=scores.device)
+    segs = (C.c_int * len(seg_sizes))(*seg_sizes)
+    check(_abi.load().hd_topk_select_rows(ptr(scores), B, scores.stride(0), C.cast(segs, C.c_void_p), len(seg_sizes), int(k), ptr(out),
+                                          out.stride(0), _stream()), "hd_topk_select_rows")
     return out
 
 

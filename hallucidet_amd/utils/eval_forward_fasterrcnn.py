@@ -139,8 +139,7 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     n_img = len(anchors)
     napl = [o[0].shape[0] * o[0].shape[1] * o[0].shape[2] for o in objectness]
     obj, dl = concat_box_prediction_layers(objectness, deltas)
-    proposals = model.rpn.box_coder.decode(dl.detach(), anchors).view(n_img, -1, 4)
-    pb, _, pc = D.filter_proposals_padded(model.rpn, proposals, obj, shape, napl)
+    pb, _, pc = D.filter_proposals_padded(model.rpn, None, obj, shape, napl, deltas=dl, anchors0=anchors[0])
     if rpn_state is None:
         rpn_state = D.rpn_targets_sample_batched(model.rpn, anchors[0], gt, gvalid, n_loss=n0)
     loss_objectness, loss_rpn_box_reg = D.rpn_loss_from_samples(rpn_state, obj, dl)
@@ -244,9 +243,8 @@ def _heads_batched(model, images, features, objectness, deltas, targets):
     n_img = len(anchors)
     napl = [o[0].shape[0] * o[0].shape[1] * o[0].shape[2] for o in objectness]
     obj, dl = concat_box_prediction_layers(objectness, deltas)
-    proposals = model.rpn.box_coder.decode(dl.detach(), anchors).view(n_img, -1, 4)
     shape = images.image_sizes[0]
-    pb, _, pc = D.filter_proposals_padded(model.rpn, proposals, obj, shape, napl)
+    pb, _, pc = D.filter_proposals_padded(model.rpn, None, obj, shape, napl, deltas=dl, anchors0=anchors[0])
     if targets is None:
         raise ValueError("targets should not be None")
     for t in targets:

@@ -252,12 +252,25 @@ int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int 
 int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream);
 /* iou[n][g][a] for N images; shared_boxes != 0: one [A][4] box set (anchors) for every image, else boxes is [N][A][4] */
 int hd_box_iou_batched(const float* gt, int G, const float* boxes, int A, int N, int shared_boxes, float* iou, void* stream);
-/* Per-row top-k selection of a row segment (RegionProposalNetwork._get_top_n_idx [EXT]: `ob.topk(pre_nms_top_n, dim=1)` per
- * feature level): out[b][out_off + j], j < min(k, n), = idx_add + the indices (relative to seg_off) of the k largest
- * scores[b][seg_off .. seg_off+n) in descending score order, equal scores by ascending index (= a stable descending sort
- * cut at k).  min(k, n) <= 4096. */
-int hd_topk_select_rows(const float* scores, int B, long row_stride, int seg_off, int n, int k, int64_t* out, long out_stride,
-                        int out_off, int64_t idx_add, void* stream);
+/* RPN proposals of the selected anchors only (RegionProposalNetwork.filter_proposals [EXT], reached from
+ * src/utils/eval_forward_fasterrcnn.py:86): for image n, candidate t, a = top[n][t]:
+ *   boxes[n][t] = clip_boxes_to_image(BoxCoder(1,1,1,1).decode(deltas[n][a], anchors[a]), (img_h, img_w));
+ *   prob[n][t] = sigmoid(objectness[n][a]);  valid[n][t] = w >= min_size && h >= min_size && prob >= score_thresh.
+ * deltas [N][A][4], objectness [N][A], anchors [A][4] (shared by the images), top [N][K] i64. */
+int hd_rpn_decode_filter(const float* deltas, const float* objectness, const float* anchors, const int64_t* top, int N, int A, int K,
+                         float bbox_xform_clip, float img_h, float img_w, float min_size, float score_thresh, float* boxes,
+                         float* prob, uint8_t* valid, void* stream);
+/* RoI-head boxes (RoIHeads.postprocess_detections [EXT]): boxes[r][k] = clip(BoxCoder(coder_weights).decode(codes[r][k],
+ * rois[r])); codes [R][K*4], rois rows of `roi_stride` floats with the box in the LAST four, coder_weights = host float[4]. */
+int hd_roi_decode_clip(const float* codes, const float* rois, long roi_stride, int R, int K, const float* coder_weights,
+                       float bbox_xform_clip, float img_h, float img_w, float* boxes, void* stream);
+/* Per-row, per-segment top-k (RegionProposalNetwork._get_top_n_idx [EXT]: `ob.topk(pre_nms_top_n, dim=1)` per feature
+ * level): scores [B][sum(seg_sizes)] with row stride `row_stride`; for segment s (columns off_s .. off_s+n_s) the row's
+ * min(k, n_s) largest entries in descending score order, equal scores by ascending index (= a stable descending sort cut
+ * at k), as indices into the ROW; the segments' lists are concatenated in out [B][sum(min(k, n_s))] (row stride
+ * out_stride).  seg_sizes is a host array, 1 <= nseg <= 8, min(k, n_s) <= 4096. */
+int hd_topk_select_rows(const float* scores, int B, long row_stride, const int* seg_sizes, int nseg, int k, int64_t* out,
+                        long out_stride, void* stream);
 /* Fused target assignment for N images: box_iou + Matcher(high, low, allow_low_quality) + label lookup + BoxCoder.encode
  * (torchvision RegionProposalNetwork.assign_targets_to_anchors / RoIHeads.assign_targets_to_proposals + box_coder.encode
  * [EXT], called from src/utils/eval_forward_fasterrcnn.py:88-93,127 in the reference).

@@ -606,3 +606,37 @@ def test_topk_rows_segments_equals_stable_sort(dev):
     assert torch.equal(got, torch.cat(ref, dim=1))
     got2 = ops.topk_rows_segments(x[:, :5000].contiguous(), [5000], 3000)     # P = 4096 path
     assert torch.equal(got2, torch.sort(x[:, :5000], dim=1, descending=True, stable=True)[1][:, :3000])
+
+
+@pytest.mark.gpu
+def test_fused_box_decoding_equals_per_op_path(dev):
+    """hd_rpn_decode_filter / hd_roi_decode_clip against BoxCoder.decode_single + clip_boxes_to_image + the validity tests
+    they replace: same boxes (<= 1 ulp of the exp), same validity flags."""
+    from hallucidet_amd import ops
+    import hallucidet_amd.models.detection as D
+    torch.manual_seed(5)
+    N, A, K = 3, 5000, 700
+    axy = torch.rand(A, 2, device=dev) * 280
+    anchors = torch.cat([axy, axy + 2 + torch.rand(A, 2, device=dev) * 150], dim=1)
+    deltas = torch.randn(N, A, 4, device=dev) * 0.6
+    deltas[0, :50, 2:] = 9.0                                # beyond bbox_xform_clip
+    obj = torch.randn(N, A, device=dev) * 3
+    top = torch.stack([torch.randperm(A, device=dev)[:K] for _ in range(N)])
+    shape = (300, 300)
+    coder = D.BoxCoder((1.0, 1.0, 1.0, 1.0))
+    boxes, prob, valid = ops.rpn_decode_filter(deltas, obj, anchors, top, coder.bbox_xform_clip, shape, 1e-3, 0.0)
+    ref_all = coder.decode_single(deltas.reshape(-1, 4), anchors.repeat(N, 1)).reshape(N, A, 4)
+    bidx = torch.arange(N, device=dev)[:, None]
+    ref = D.clip_boxes_to_image(ref_all[bidx, top], shape)
+    assert torch.allclose(boxes, ref, rtol=2e-6, atol=1e-4)
+    pref = torch.sigmoid(obj[bidx, top])
+    assert torch.allclose(prob, pref, rtol=1e-6, atol=1e-7)
+    vref = ((ref[..., 2] - ref[..., 0]) >= 1e-3) & ((ref[..., 3] - ref[..., 1]) >= 1e-3) & (pref >= 0.0)
+    assert (valid != vref).float().mean() < 1e-3 and valid.any() and not valid.all()
+    R, Kc = 900, 3
+    rois = torch.cat([torch.randint(0, N, (R, 1), device=dev).float(), anchors[:R]], dim=1)
+    codes = torch.randn(R, Kc * 4, device=dev)
+    rc = D.BoxCoder((10.0, 10.0, 5.0, 5.0))
+    got = ops.roi_decode_clip(codes, rois, rc.weights, rc.bbox_xform_clip, shape)
+    want = D.clip_boxes_to_image(rc.decode_single(codes, rois[:, 1:]).reshape(R, Kc, 4), shape)
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-4)
