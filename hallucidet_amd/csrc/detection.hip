@@ -49,8 +49,11 @@ __global__ void nms_mask_kernel(const float* __restrict__ boxes, const int* __re
 // one 256-thread block per image.  Wave 0 resolves each 64-box chunk serially (ALU only); all four waves then OR the
 // mask rows of the kept boxes into the "removed" words -- 16 row loads in flight per wave, every wave a quarter of the
 // rows -- and the partial words are combined through LDS.  n <= 16384.
+// `pick` (optional): the candidate index order[b][i] of the kept boxes, in order, for the first pick_n of them (rest: order[b][0]), and
+// picked[b] = how many -- the compaction callers otherwise build from `keep` with a prefix sum and a scatter.
 __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ mask, const int* __restrict__ counts, int nmax,
-                                                         uint8_t* __restrict__ keep, int max_keep) {
+                                                         uint8_t* __restrict__ keep, int max_keep, const int64_t* __restrict__ order,
+                                                         int64_t* __restrict__ pick, int pick_n, int64_t* __restrict__ picked) {
   constexpr int MAXW = 4;  // 64*64*4 boxes
   __shared__ uint64_t remv[MAXW * 64];
   __shared__ uint64_t part[4][MAXW * 64];
@@ -65,6 +68,8 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
   const int nchunks = (n + 63) / 64;
   for (int i = tid; i < MAXW * 64; i += 256) remv[i] = 0;
   if (tid == 0) s_kept = 0;
+  if (pick)
+    for (int i = tid; i < pick_n; i += 256) pick[(size_t)b * pick_n + i] = order[(size_t)b * nmax];   // padding = the first candidate, as gather(order, 0) gives
   __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     // callers that only use the first max_keep survivors (post-NMS top-n): once that many are kept, nothing later can be
@@ -87,6 +92,10 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
         }
       }
       if (i < n) kb[i] = (uint8_t)((keepbits >> lane) & 1ull);
+      if (pick && ((keepbits >> lane) & 1ull)) {
+        const int pos = s_kept + __popcll(keepbits & ((1ull << lane) - 1ull));
+        if (pos < pick_n) pick[(size_t)b * pick_n + pos] = order[(size_t)b * nmax + i];
+      }
       if (lane == 0) {
         s_keepbits = keepbits;
         s_kept += __popcll(keepbits);
@@ -119,6 +128,49 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
       for (int i = tid; i < nw; i += 256) remv[c + 1 + i] |= part[0][i] | part[1][i] | part[2][i] | part[3][i];
     }
     __syncthreads();
+  }
+  if (picked && tid == 0) picked[b] = min(s_kept, pick_n);
+}
+
+// sorted, category-shifted boxes for batched NMS (torchvision _batched_nms_coordinate_trick [EXT]): per image
+// counts = #valid, bmax = max coordinate over the valid boxes (0 when there is none),
+// sorted[j] = boxes[order[j]] + idxs[order[j]] * (bmax + 1)
+__global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restrict__ boxes, const int64_t* __restrict__ idxs,
+                                                          const uint8_t* __restrict__ valid, const int64_t* __restrict__ order, int n,
+                                                          float* __restrict__ sorted, int* __restrict__ counts) {
+  __shared__ float s_max[4];
+  __shared__ int s_cnt[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* bb = boxes + (size_t)b * n * 4;
+  const uint8_t* vb = valid + (size_t)b * n;
+  float m = -INFINITY;
+  int cnt = 0;
+  for (int i = tid; i < n; i += 256)
+    if (vb[i]) {
+      const float4 v = *reinterpret_cast<const float4*>(bb + (size_t)i * 4);
+      m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      ++cnt;
+    }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, d));
+    cnt += __shfl_xor(cnt, d);
+  }
+  if ((tid & 63) == 0) {
+    s_max[tid >> 6] = m;
+    s_cnt[tid >> 6] = cnt;
+  }
+  __syncthreads();
+  cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  const float scale = (cnt > 0 ? m : 0.f) + 1.f;
+  if (tid == 0) counts[b] = cnt;
+  for (int j = tid; j < n; j += 256) {
+    const int64_t c = order[(size_t)b * n + j];
+    const float off = (float)idxs[(size_t)b * n + c] * scale;
+    float4 v = *reinterpret_cast<const float4*>(bb + (size_t)c * 4);
+    v.x += off; v.y += off; v.z += off; v.w += off;
+    *reinterpret_cast<float4*>(sorted + ((size_t)b * n + j) * 4) = v;
   }
 }
 
@@ -1029,7 +1081,23 @@ extern "C" int hd_nms_sorted_batched_topk(const float* boxes, const int* counts,
   hipStream_t s = (hipStream_t)stream;
   int cb = (nmax + 63) / 64;
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(64), 0, s, boxes, counts, nmax, iou_thr, mask_ws);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, (const uint64_t*)mask_ws, counts, nmax, keep, max_keep);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, (const uint64_t*)mask_ws, counts, nmax, keep, max_keep,
+                     (const int64_t*)nullptr, (int64_t*)nullptr, 0, (int64_t*)nullptr);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_batched_nms_pick(const float* boxes, const int64_t* idxs, const uint8_t* valid, const int64_t* order, int B, int n,
+                                   float iou_thr, int top_n, float* sorted_ws, int* counts_ws, uint64_t* mask_ws, uint8_t* keep_ws,
+                                   int64_t* pick, int64_t* picked, void* stream) {
+  HD_CHECK_ARG(boxes && idxs && valid && order && sorted_ws && counts_ws && mask_ws && keep_ws && pick && picked && B > 0 && n > 0 &&
+               n <= 16384 && top_n > 0, "hd_batched_nms_pick: bad args (n<=16384)");
+  hipStream_t s = (hipStream_t)stream;
+  const int cb = (n + 63) / 64;
+  hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(256), 0, s, boxes, idxs, valid, order, n, sorted_ws, counts_ws);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(64), 0, s, (const float*)sorted_ws, (const int*)counts_ws, n, iou_thr, mask_ws);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, (const uint64_t*)mask_ws, (const int*)counts_ws, n, keep_ws, top_n, order, pick,
+                     top_n < n ? top_n : n, picked);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -539,6 +539,18 @@ def _batched_nms_padded(boxes, scores, idxs, valid, iou_thr, top_n):
     return order, sel, sel.sum(dim=1)
 
 
+def _batched_nms_pick(boxes, scores, idxs, valid, iou_thr, top_n):
+    """_batched_nms_padded + the compaction its callers do: -> (pick [B, min(top_n, n)] = candidate index of the k-th survivor
+    in descending-score order (padding past the count), counts [B]).  On the GPU: one sort + three launches (ops.batched_nms_pick:
+    shifted sorted boxes, suppression mask, serial reduce that emits the ordered survivors) instead of ~40."""
+    if not boxes.is_cuda:
+        order, sel, counts = _batched_nms_padded(boxes, scores, idxs, valid, iou_thr, top_n)
+        return torch.gather(order, 1, _front(sel, top_n)), counts
+    key = torch.where(valid, scores, torch.full_like(scores, float("-inf")))
+    order = torch.sort(key, dim=1, descending=True, stable=True)[1]
+    return ops.batched_nms_pick(boxes, idxs, valid, order, iou_thr, top_n)
+
+
 # ======================================================================================================================
 # RPN
 # ======================================================================================================================
@@ -1319,9 +1331,8 @@ def filter_proposals_padded(rpn, proposals, objectness, image_shape, num_anchors
         ws, hs = boxes[..., 2] - boxes[..., 0], boxes[..., 3] - boxes[..., 1]
         valid = (ws >= rpn.min_size) & (hs >= rpn.min_size) & (prob >= rpn.score_thresh)
     post = rpn.post_nms_top_n()
-    order, sel, counts = _batched_nms_padded(boxes, prob, levels, valid, rpn.nms_thresh, post)
-    # bring the selected entries to the front, keeping their (score) order; rows past counts[i] are padding
-    pick = torch.gather(order, 1, _front(sel, post))
+    # survivors in score order at the front; rows past counts[i] are padding
+    pick, counts = _batched_nms_pick(boxes, prob, levels, valid, rpn.nms_thresh, post)
     out_b = torch.gather(boxes, 1, pick[:, :, None].expand(-1, -1, 4))
     out_s = torch.gather(prob, 1, pick)
     return out_b, out_s, counts
@@ -1405,8 +1416,7 @@ def postprocess_detections_flat(rh, class_logits, box_regression, rois, per, ima
     B[slot], S[slot], V[slot] = b, s, (s > rh.score_thresh) & (ws >= 1e-2) & (hs >= 1e-2)
     Lb = torch.arange(1, num_classes, device=device).view(1, 1, K).expand(n_img, cap, K).reshape(n_img, cap * K)
     B, S, V = B.view(n_img, cap * K, 4), S.view(n_img, cap * K), V.view(n_img, cap * K)
-    order, sel, counts = _batched_nms_padded(B, S, Lb, V, rh.nms_thresh, rh.detections_per_img)
-    pick = torch.gather(order, 1, _front(sel, rh.detections_per_img))
+    pick, counts = _batched_nms_pick(B, S, Lb, V, rh.nms_thresh, rh.detections_per_img)
     sb = torch.gather(B, 1, pick[:, :, None].expand(-1, -1, 4))
     ss = torch.gather(S, 1, pick)
     sl = torch.gather(Lb, 1, pick)

@@ -270,8 +270,7 @@ class RetinaNet(nn.Module):
             cv.append(valid)
             lo += n
         cb, cs, cl, cv = torch.cat(cb, 1), torch.cat(cs, 1), torch.cat(cl, 1), torch.cat(cv, 1)
-        order, sel, counts = D._batched_nms_padded(cb, cs, cl, cv, self.nms_thresh, self.detections_per_img)
-        pick = torch.gather(order, 1, D._front(sel, self.detections_per_img))
+        pick, counts = D._batched_nms_pick(cb, cs, cl, cv, self.nms_thresh, self.detections_per_img)
         return (torch.gather(cb, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(cs, 1, pick), torch.gather(cl, 1, pick), counts)
 
 

@@ -421,6 +421,28 @@ def nms_sorted_batched(boxes, counts, iou_thr, max_keep=None):
     return keep.bool()
 
 
+def batched_nms_pick(boxes, idxs, valid, order, iou_thr, top_n):
+    """Coordinate-offset batched NMS from unsorted candidates: boxes [B,n,4] f32, idxs [B,n] int64, valid [B,n] bool,
+    order [B,n] int64 (descending score, invalid last).  -> pick [B, min(top_n, n)] int64 (candidate index of the k-th
+    survivor in score order, order[b,0] beyond the count), picked [B] int64."""
+    _need_cuda(boxes, idxs, valid, order)
+    B, n, _ = boxes.shape
+    dev = boxes.device
+    cb = (n + 63) // 64
+    boxes, idxs, order = boxes.contiguous().float(), idxs.contiguous(), order.contiguous()
+    v8 = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8).contiguous()
+    sorted_ws = torch.empty((B, n, 4), dtype=torch.float32, device=dev)
+    counts_ws = torch.empty((B,), dtype=torch.int32, device=dev)
+    mask_ws = torch.empty((B, n, cb), dtype=torch.int64, device=dev)
+    keep_ws = torch.empty((B, n), dtype=torch.uint8, device=dev)
+    k = min(int(top_n), n)
+    pick = torch.empty((B, k), dtype=torch.int64, device=dev)
+    picked = torch.empty((B,), dtype=torch.int64, device=dev)
+    check(_abi.load().hd_batched_nms_pick(ptr(boxes), ptr(idxs), ptr(v8), ptr(order), B, n, float(iou_thr), int(top_n), ptr(sorted_ws),
+                                          ptr(counts_ws), ptr(mask_ws), ptr(keep_ws), ptr(pick), ptr(picked), _stream()), "hd_batched_nms_pick")
+    return pick, picked
+
+
 def roi_align(feat, rois, PH, PW, spatial_scale, sampling_ratio):
     N, H, W, C_ = feat.shape
     R = rois.shape[0]

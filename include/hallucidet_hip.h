@@ -252,6 +252,14 @@ int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int 
 int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream);
 /* iou[n][g][a] for N images; shared_boxes != 0: one [A][4] box set (anchors) for every image, else boxes is [N][A][4] */
 int hd_box_iou_batched(const float* gt, int G, const float* boxes, int A, int N, int shared_boxes, float* iou, void* stream);
+/* torchvision.ops.batched_nms (coordinate-offset form [EXT]) over B padded candidate lists, from the unsorted candidates to
+ * the ordered list of survivors: boxes [B][n][4], idxs [B][n] i64 (level / class), valid [B][n] u8, order [B][n] i64 =
+ * candidate indices by descending score (stable) with the invalid ones last.  pick [B][min(top_n, n)] i64 = candidate
+ * index of the k-th surviving box in score order (order[b][0] beyond picked[b]); picked [B] i64.  Workspaces: sorted_ws [B][n][4] f32,
+ * counts_ws [B] i32, mask_ws [B][n][ceil(n/64)] u64, keep_ws [B][n] u8.  n <= 16384. */
+int hd_batched_nms_pick(const float* boxes, const int64_t* idxs, const uint8_t* valid, const int64_t* order, int B, int n,
+                        float iou_thr, int top_n, float* sorted_ws, int* counts_ws, uint64_t* mask_ws, uint8_t* keep_ws,
+                        int64_t* pick, int64_t* picked, void* stream);
 /* RPN proposals of the selected anchors only (RegionProposalNetwork.filter_proposals [EXT], reached from
  * src/utils/eval_forward_fasterrcnn.py:86): for image n, candidate t, a = top[n][t]:
  *   boxes[n][t] = clip_boxes_to_image(BoxCoder(1,1,1,1).decode(deltas[n][a], anchors[a]), (img_h, img_w));

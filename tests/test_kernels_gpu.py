@@ -640,3 +640,28 @@ def test_fused_box_decoding_equals_per_op_path(dev):
     got = ops.roi_decode_clip(codes, rois, rc.weights, rc.bbox_xform_clip, shape)
     want = D.clip_boxes_to_image(rc.decode_single(codes, rois[:, 1:]).reshape(R, Kc, 4), shape)
     assert torch.allclose(got, want, rtol=2e-6, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_batched_nms_pick_equals_padded_path(dev):
+    """hd_batched_nms_pick (shifted sorted boxes + mask + reduce emitting the ordered survivors) against the per-op path
+    (_batched_nms_padded + prefix-sum compaction): identical survivor lists and counts, with invalid candidates, an image
+    without any valid candidate and fewer survivors than top_n."""
+    import hallucidet_amd.models.detection as D
+    torch.manual_seed(9)
+    B, n, top = 4, 1500, 300
+    xy = torch.rand(B, n, 2, device=dev) * 250
+    boxes = torch.cat([xy, xy + 5 + torch.rand(B, n, 2, device=dev) * 80], dim=2)
+    scores = torch.rand(B, n, device=dev)
+    scores[0, :200] = scores[0, 200:400]                  # exact score ties
+    idxs = torch.randint(0, 4, (B, n), device=dev)
+    valid = torch.rand(B, n, device=dev) > 0.2
+    valid[2] = False
+    valid[3, 40:] = False                                 # fewer survivors than top
+    for thr in (0.7, 0.3):
+        order, sel, counts = D._batched_nms_padded(boxes, scores, idxs, valid, thr, top)
+        ref = torch.gather(order, 1, D._front(sel, top))
+        pick, picked = D._batched_nms_pick(boxes, scores, idxs, valid, thr, top)
+        assert torch.equal(picked, counts)
+        assert torch.equal(pick, ref)
+        assert int(picked[2]) == 0 and 0 < int(picked[3]) < top
