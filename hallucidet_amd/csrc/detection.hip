@@ -911,6 +911,54 @@ __global__ void roi_decode_clip_kernel(const float* __restrict__ codes, const fl
                                                                       img_h, img_w);
 }
 
+// ---- RoI sampling tail + FPN level mapping -------------------------------------------------------------------------------
+// RoIHeads.select_training_samples after the sampler [EXT]: for the r-th selected candidate (flat index sel[r] into [N][T]):
+// rois[r] = (image, box), labels[r], regression target = BoxCoder.encode(matched GT (zeros for GT-less images), box).
+__global__ void roi_samples_finish_kernel(const int64_t* __restrict__ sel, int R, const float* __restrict__ comb, const int64_t* __restrict__ lab,
+                                          const int64_t* __restrict__ matched, const float* __restrict__ gt, const uint8_t* __restrict__ gvalid,
+                                          int T, int G, float wx, float wy, float ww, float wh, float* __restrict__ rois,
+                                          int64_t* __restrict__ labels, float* __restrict__ reg_t) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const int64_t s = sel[r];
+  const int n = (int)(s / T);
+  const float4 b = *reinterpret_cast<const float4*>(comb + (size_t)s * 4);
+  bool has_gt = false;
+  for (int g = 0; g < G; ++g) has_gt = has_gt || gvalid[(size_t)n * G + g];
+  const int64_t m = matched[s];
+  float4 rg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (has_gt) rg = *reinterpret_cast<const float4*>(gt + ((size_t)n * G + (m > 0 ? m : 0)) * 4);
+  rois[(size_t)r * 5 + 0] = (float)n;
+  rois[(size_t)r * 5 + 1] = b.x;
+  rois[(size_t)r * 5 + 2] = b.y;
+  rois[(size_t)r * 5 + 3] = b.z;
+  rois[(size_t)r * 5 + 4] = b.w;
+  labels[r] = lab[s];
+  const float ew = b.z - b.x, eh = b.w - b.y;
+  const float ecx = b.x + 0.5f * ew, ecy = b.y + 0.5f * eh;
+  const float gw = rg.z - rg.x, gh = rg.w - rg.y;
+  const float gcx = rg.x + 0.5f * gw, gcy = rg.y + 0.5f * gh;
+  float4 t;
+  t.x = wx * (gcx - ecx) / ew;
+  t.y = wy * (gcy - ecy) / eh;
+  t.z = ww * logf(gw / ew);
+  t.w = wh * logf(gh / eh);
+  *reinterpret_cast<float4*>(reg_t + (size_t)r * 4) = t;
+}
+
+// torchvision LevelMapper [EXT]: level = clamp(floor(k0 + log2(sqrt(area) / s0) + eps), k_min, k_max) - k_min
+// (the division by the python scalar s0 is a multiplication by its fp32 reciprocal, as torch evaluates it)
+__global__ void roi_levels_kernel(const float* __restrict__ rois, long stride, int R, float inv_s0, float k0, float eps, float k_min,
+                                  float k_max, int* __restrict__ levels) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* b = rois + (size_t)r * stride;
+  const float area = (b[2] - b[0]) * (b[3] - b[1]);
+  float t = floorf((k0 + log2f(sqrtf(area) * inv_s0)) + eps);
+  t = t < k_min ? k_min : (t > k_max ? k_max : t);
+  levels[r] = (int)((long long)t - (long long)k_min);
+}
+
 // ---- fused target assignment (box_iou + Matcher + label lookup + BoxCoder.encode), one thread per (image, box) ---------
 // Replaces ~70 elementwise launches over [N, G, A] / [N, A] tensors per call (detection.py: _match_batched and its callers).
 // Arithmetic order follows the separate torch ops (fp-contract is off for this library), so the results are the ones
@@ -1028,6 +1076,29 @@ extern "C" int hd_roi_decode_clip(const float* codes, const float* rois, long ro
   hipLaunchKernelGGL(roi_decode_clip_kernel, dim3((R * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, codes, rois, roi_stride, R, K,
                      1.0f / coder_weights[0], 1.0f / coder_weights[1], 1.0f / coder_weights[2], 1.0f / coder_weights[3], bbox_xform_clip, img_h,
                      img_w, boxes);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_samples_finish(const int64_t* sel, int R, const float* comb, const int64_t* lab, const int64_t* matched, const float* gt,
+                                     const uint8_t* gvalid, int T, int G, const float* coder_weights, float* rois, int64_t* labels, float* reg_t,
+                                     void* stream) {
+  HD_CHECK_ARG(R >= 0 && T > 0 && G > 0 && coder_weights, "hd_roi_samples_finish: bad args");
+  if (R == 0) return HD_OK;
+  HD_CHECK_ARG(sel && comb && lab && matched && gt && gvalid && rois && labels && reg_t, "hd_roi_samples_finish: null pointer");
+  hipLaunchKernelGGL(roi_samples_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, sel, R, comb, lab, matched, gt, gvalid, T,
+                     G, coder_weights[0], coder_weights[1], coder_weights[2], coder_weights[3], rois, labels, reg_t);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_levels(const float* boxes, long stride, int R, float canonical_scale, float canonical_level, float eps, int k_min, int k_max,
+                             int* levels, void* stream) {
+  HD_CHECK_ARG(R >= 0 && stride >= 4 && k_max >= k_min && canonical_scale > 0.f, "hd_roi_levels: bad args");
+  if (R == 0) return HD_OK;
+  HD_CHECK_ARG(boxes && levels, "hd_roi_levels: null pointer");
+  hipLaunchKernelGGL(roi_levels_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, stride, R, 1.0f / canonical_scale,
+                     canonical_level, eps, (float)k_min, (float)k_max, levels);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -1356,6 +1356,9 @@ def select_training_samples_batched(rh, props, pcounts, gt, glabels, gvalid):
     per = [a + b for a, b in picked]
     R = sum(per)
     sel = _compact((pos_sel | neg_sel).reshape(-1), R)
+    if comb.is_cuda:               # gathers + box_coder.encode + roi assembly in one launch (was ~40)
+        rois, labels, reg_t = ops.roi_samples_finish(sel, comb, lab, m, gt, gvalid, rh.box_coder.weights)
+        return rois, labels, reg_t, per
     img = torch.div(sel, T, rounding_mode="floor")
     boxes = comb.reshape(-1, 4)[sel]
     labels = lab.reshape(-1)[sel]
@@ -1372,11 +1375,15 @@ def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
     device = rois.device
     scales = [pool.infer_scale((f.shape[1], f.shape[2]), image_shape) for f in feats]
     k_min, k_max = int(-math.log2(scales[0])), int(-math.log2(scales[-1]))
-    b = rois[:, 1:]
-    s = torch.sqrt(box_area(b).float())
-    t = torch.floor(pool.canonical_level + torch.log2(s / pool.canonical_scale) + pool.eps)   # fp32 scalar add, no H2D copy
-    levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
-    return _RoIAlignFn.apply(rois.float().contiguous(), levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), *feats)
+    rois = rois.float().contiguous()
+    if rois.is_cuda:               # LevelMapper in one launch (was 12)
+        levels = ops.roi_levels(rois, pool.canonical_scale, pool.canonical_level, pool.eps, k_min, k_max)
+    else:
+        b = rois[:, 1:]
+        s = torch.sqrt(box_area(b).float())
+        t = torch.floor(pool.canonical_level + torch.log2(s / pool.canonical_scale) + pool.eps)   # fp32 scalar add, no H2D copy
+        levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
+    return _RoIAlignFn.apply(rois, levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), *feats)
 
 
 def fastrcnn_loss_flat(class_logits, box_regression, labels, regression_targets):

@@ -232,7 +232,7 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
     C_ = y.shape[-1]
     npix = y.numel() // C_
     if rows is None:
-        rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere
+        rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
     lib = _abi.load()
     part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
     check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
@@ -419,6 +419,37 @@ def nms_sorted_batched(boxes, counts, iou_thr, max_keep=None):
     check(_abi.load().hd_nms_sorted_batched_topk(ptr(boxes.contiguous()), ptr(counts), B, nmax, iou_thr, ptr(ws), ptr(keep),
                                                  0x7fffffff if max_keep is None else int(max_keep), _stream()), "hd_nms_sorted_batched")
     return keep.bool()
+
+
+def roi_samples_finish(sel, comb, lab, matched, gt, gvalid, coder_weights):
+    """sel [R] int64 (flat indices into the [N,T] candidates), comb [N,T,4] f32, lab / matched [N,T] int64, gt [N,G,4],
+    gvalid [N,G] bool -> rois [R,5] f32, labels [R] int64, regression targets [R,4] f32 (one launch)."""
+    _need_cuda(sel, comb, lab, matched, gt, gvalid)
+    N, T, _ = comb.shape
+    G = gt.shape[1]
+    R = sel.shape[0]
+    dev = comb.device
+    rois = torch.empty((R, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((R,), dtype=torch.int64, device=dev)
+    reg_t = torch.empty((R, 4), dtype=torch.float32, device=dev)
+    gv = gvalid.contiguous().view(torch.uint8) if gvalid.dtype == torch.bool else gvalid.to(torch.uint8).contiguous()
+    w = (C.c_float * 4)(*[float(x) for x in coder_weights])
+    check(_abi.load().hd_roi_samples_finish(ptr(sel.contiguous()), R, ptr(comb.contiguous().float()), ptr(lab.contiguous()), ptr(matched.contiguous()),
+                                            ptr(gt.contiguous().float()), ptr(gv), T, G, C.cast(w, C.c_void_p), ptr(rois), ptr(labels), ptr(reg_t),
+                                            _stream()), "hd_roi_samples_finish")
+    return rois, labels, reg_t
+
+
+def roi_levels(rois, canonical_scale, canonical_level, eps, k_min, k_max):
+    """rois [R, 4 or 5] f32 (box in the last four columns) -> FPN level index [R] int32 (LevelMapper)."""
+    _need_cuda(rois)
+    rois = rois.contiguous().float()
+    R = rois.shape[0]
+    levels = torch.empty((R,), dtype=torch.int32, device=rois.device)
+    off = rois.shape[1] - 4
+    check(_abi.load().hd_roi_levels(rois.data_ptr() + off * 4 if R else None, rois.shape[1], R, float(canonical_scale), float(canonical_level),
+                                    float(eps), int(k_min), int(k_max), ptr(levels), _stream()), "hd_roi_levels")
+    return levels
 
 
 def batched_nms_pick(boxes, idxs, valid, order, iou_thr, top_n):

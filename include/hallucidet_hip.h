@@ -272,6 +272,17 @@ int hd_rpn_decode_filter(const float* deltas, const float* objectness, const flo
  * rois[r])); codes [R][K*4], rois rows of `roi_stride` floats with the box in the LAST four, coder_weights = host float[4]. */
 int hd_roi_decode_clip(const float* codes, const float* rois, long roi_stride, int R, int K, const float* coder_weights,
                        float bbox_xform_clip, float img_h, float img_w, float* boxes, void* stream);
+/* Tail of RoIHeads.select_training_samples [EXT] (src/utils/eval_forward_fasterrcnn.py:127 in the reference): for the r-th
+ * sampled candidate, sel[r] = flat index into the [N][T] candidate arrays: rois[r] = (image, box) [R][5], labels[r] = lab[sel],
+ * reg_t[r] = BoxCoder(coder_weights).encode(gt[image][max(matched[sel], 0)] or zeros for an image without GT, box).
+ * comb [N*T][4] f32, lab / matched [N*T] i64, gt [N][G][4] f32, gvalid [N][G] u8, coder_weights host float[4]. */
+int hd_roi_samples_finish(const int64_t* sel, int R, const float* comb, const int64_t* lab, const int64_t* matched, const float* gt,
+                          const uint8_t* gvalid, int T, int G, const float* coder_weights, float* rois, int64_t* labels, float* reg_t,
+                          void* stream);
+/* torchvision.ops.poolers.LevelMapper [EXT]: levels[r] = clamp(floor(canonical_level + log2(sqrt(area_r) / canonical_scale) +
+ * eps), k_min, k_max) - k_min; boxes = pointer to x1 of the first box, `stride` floats between boxes. */
+int hd_roi_levels(const float* boxes, long stride, int R, float canonical_scale, float canonical_level, float eps, int k_min, int k_max,
+                  int* levels, void* stream);
 /* Per-row, per-segment top-k (RegionProposalNetwork._get_top_n_idx [EXT]: `ob.topk(pre_nms_top_n, dim=1)` per feature
  * level): scores [B][sum(seg_sizes)] with row stride `row_stride`; for segment s (columns off_s .. off_s+n_s) the row's
  * min(k, n_s) largest entries in descending score order, equal scores by ascending index (= a stable descending sort cut
