@@ -959,6 +959,115 @@ __global__ void roi_levels_kernel(const float* __restrict__ rois, long stride, i
   levels[r] = (int)((long long)t - (long long)k_min);
 }
 
+// ---- BalancedPositiveNegativeSampler over N images in one launch ---------------------------------------------------------
+// torchvision semantics [EXT]: per image take min(P, cap_p) random positives and min(Nneg, B - num_pos) random negatives.
+// A uniformly random subset of size k = the k smallest of iid random keys: `keys` holds one random int32 >= 0 per
+// candidate (torch.randint, so the generator stream is the framework's); a block radix-selects the k-th smallest key of
+// each class and marks the members (equal keys at the cut: lowest index first).
+__device__ __forceinline__ void select_smallest_marked(const int32_t* __restrict__ keys, const int64_t* __restrict__ labels, int A, bool want_pos,
+                                                       int k, int population, uint8_t* __restrict__ out, int* hist, uint32_t* s_prefix,
+                                                       int* s_remaining, int* s_wave_l, int* s_wave_e) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto member = [&](int i) { const int64_t l = labels[i]; return want_pos ? (l >= 1) : (l == 0); };
+  if (k <= 0) {
+    for (int i = tid; i < A; i += 1024) out[i] = 0;
+    return;
+  }
+  if (k >= population) {
+    for (int i = tid; i < A; i += 1024) out[i] = member(i) ? 1 : 0;
+    return;
+  }
+  uint32_t prefix = 0, mask = 0;
+  int remaining = k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < A; i += 1024) {
+      if (!member(i)) continue;
+      const uint32_t u = (uint32_t)keys[i];
+      if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int cum = 0, d = 0;
+      for (; d < 255; ++d) {
+        if (cum + hist[d] >= remaining) break;
+        cum += hist[d];
+      }
+      *s_prefix = prefix | ((uint32_t)d << shift);
+      *s_remaining = remaining - cum;
+    }
+    __syncthreads();
+    prefix = *s_prefix;
+    remaining = *s_remaining;
+    mask |= 255u << shift;
+    __syncthreads();
+  }
+  const uint32_t T = prefix;                  // the k-th smallest key; `remaining` of the members equal to it are taken
+  int base_e = 0;
+  for (int i0 = 0; i0 < A; i0 += 1024) {
+    const int i = i0 + tid;
+    const bool mem = i < A && member(i);
+    const uint32_t u = mem ? (uint32_t)keys[i] : 0xFFFFFFFFu;
+    const bool lt = mem && u < T, eq = mem && u == T;
+    const uint64_t be = __ballot(eq);
+    if (lane == 0) s_wave_e[wave] = __popcll(be);
+    __syncthreads();
+    int e_before = base_e + __popcll(be & ((1ull << lane) - 1ull));
+    int tot_e = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wave) e_before += s_wave_e[w];
+      tot_e += s_wave_e[w];
+    }
+    if (i < A) out[i] = (lt || (eq && e_before < remaining)) ? 1 : 0;
+    base_e += tot_e;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(1024) void sample_pos_neg_kernel(const int64_t* __restrict__ labels, const int32_t* __restrict__ keys, int A,
+                                                              int batch_size, int cap_pos, uint8_t* __restrict__ pos_sel,
+                                                              uint8_t* __restrict__ neg_sel, int64_t* __restrict__ counts) {
+  __shared__ int hist[256];
+  __shared__ uint32_t s_prefix;
+  __shared__ int s_remaining;
+  __shared__ int s_wave_l[16], s_wave_e[16];
+  __shared__ int s_P, s_N;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int64_t* lb = labels + (size_t)n * A;
+  const int32_t* kb = keys + (size_t)n * A;
+  if (tid == 0) s_P = s_N = 0;
+  __syncthreads();
+  int p = 0, q = 0;
+  for (int i = tid; i < A; i += 1024) {
+    const int64_t l = lb[i];
+    p += l >= 1;
+    q += l == 0;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    p += __shfl_xor(p, d);
+    q += __shfl_xor(q, d);
+  }
+  if ((tid & 63) == 0) {
+    atomicAdd(&s_P, p);
+    atomicAdd(&s_N, q);
+  }
+  __syncthreads();
+  const int P = s_P, Nn = s_N;
+  const int num_pos = min(P, cap_pos);
+  const int num_neg = min(Nn, batch_size - num_pos);
+  if (tid == 0) {
+    counts[(size_t)n * 2 + 0] = num_pos;
+    counts[(size_t)n * 2 + 1] = num_neg;
+  }
+  select_smallest_marked(kb, lb, A, true, num_pos, P, pos_sel + (size_t)n * A, hist, &s_prefix, &s_remaining, s_wave_l, s_wave_e);
+  __syncthreads();
+  select_smallest_marked(kb, lb, A, false, num_neg, Nn, neg_sel + (size_t)n * A, hist, &s_prefix, &s_remaining, s_wave_l, s_wave_e);
+}
+
 // ---- fused target assignment (box_iou + Matcher + label lookup + BoxCoder.encode), one thread per (image, box) ---------
 // Replaces ~70 elementwise launches over [N, G, A] / [N, A] tensors per call (detection.py: _match_batched and its callers).
 // Arithmetic order follows the separate torch ops (fp-contract is off for this library), so the results are the ones
@@ -1099,6 +1208,17 @@ extern "C" int hd_roi_levels(const float* boxes, long stride, int R, float canon
   HD_CHECK_ARG(boxes && levels, "hd_roi_levels: null pointer");
   hipLaunchKernelGGL(roi_levels_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, boxes, stride, R, 1.0f / canonical_scale,
                      canonical_level, eps, (float)k_min, (float)k_max, levels);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_sample_pos_neg(const int64_t* labels, const int32_t* keys, int N, int A, int batch_size, int cap_pos, uint8_t* pos_sel,
+                                 uint8_t* neg_sel, int64_t* counts, void* stream) {
+  HD_CHECK_ARG(N >= 0 && A >= 0 && batch_size > 0 && cap_pos >= 0 && cap_pos <= batch_size, "hd_sample_pos_neg: bad args");
+  if (N == 0 || A == 0) return HD_OK;
+  HD_CHECK_ARG(labels && keys && pos_sel && neg_sel && counts, "hd_sample_pos_neg: null pointer");
+  hipLaunchKernelGGL(sample_pos_neg_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, labels, keys, A, batch_size, cap_pos, pos_sel, neg_sel,
+                     counts);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

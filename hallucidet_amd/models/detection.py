@@ -1184,6 +1184,15 @@ def _sample_batched(sampler, labels, host_counts=True):
     Returns (pos_sel, neg_sel) bool [N,A] and the per-image (num_pos, num_neg) python ints."""
     N, A = labels.shape
     dev = labels.device
+    if sampler.randperm_fn is None and labels.is_cuda:
+        # one launch (ops.sample_pos_neg: class counts, radix select of the smallest random keys per class, membership
+        # masks) after the key draw -- the same draw and the same subsets as _sample_batched_keys below, which took ~35
+        B = sampler.batch_size_per_image
+        keys = torch.randint(0, 1 << 30, (N, A), dtype=torch.int32, device=dev)
+        pos_sel, neg_sel, counts = ops.sample_pos_neg(labels.to(torch.int64), keys, B, int(B * sampler.positive_fraction))
+        if not host_counts:
+            return pos_sel, neg_sel, counts
+        return pos_sel, neg_sel, [tuple(t) for t in counts.tolist()]     # the one host sync of the sampler
     pos, neg = labels >= 1, labels == 0
     if sampler.randperm_fn is None:
         return _sample_batched_keys(sampler, pos, neg, host_counts)
@@ -1271,10 +1280,10 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
     # in two launches (ops.match_targets) instead of ~70 elementwise launches over [N,G,A] / [N,A] tensors
     _, lab, reg_t = ops.match_targets(gt, gvalid, None, anchors0, rpn.proposal_matcher.high_threshold, rpn.proposal_matcher.low_threshold,
                                       True, coder_weights=rpn.box_coder.weights)
-    labels = lab.to(torch.float32)
+    labels = lab.to(torch.float32)                   # BCE target dtype; the sampler takes the int64 labels as they are
     # the RPN losses only need the NUMBER of sampled anchors: keep it on the device (no host sync) unless a permutation
     # function is injected (parity tests), whose per-image loop needs the counts on the host anyway
-    pos_sel, neg_sel, picked = _sample_batched(rpn.fg_bg_sampler, labels, host_counts=False)
+    pos_sel, neg_sel, picked = _sample_batched(rpn.fg_bg_sampler, lab, host_counts=False)
     if n_loss is not None and n_loss < N:
         keep_img = (torch.arange(N, device=labels.device) < n_loss)[:, None]
         pos_sel, neg_sel = pos_sel & keep_img, neg_sel & keep_img

@@ -421,6 +421,19 @@ def nms_sorted_batched(boxes, counts, iou_thr, max_keep=None):
     return keep.bool()
 
 
+def sample_pos_neg(labels, keys, batch_size, cap_pos):
+    """labels [N,A] int64, keys [N,A] int32 (random, >= 0) -> pos_sel, neg_sel [N,A] bool, counts [N,2] int64 (num_pos, num_neg)."""
+    _need_cuda(labels, keys)
+    N, A = labels.shape
+    dev = labels.device
+    pos = torch.empty((N, A), dtype=torch.bool, device=dev)
+    neg = torch.empty((N, A), dtype=torch.bool, device=dev)
+    counts = torch.empty((N, 2), dtype=torch.int64, device=dev)
+    check(_abi.load().hd_sample_pos_neg(ptr(labels.contiguous()), ptr(keys.contiguous()), N, A, int(batch_size), int(cap_pos), ptr(pos), ptr(neg),
+                                        ptr(counts), _stream()), "hd_sample_pos_neg")
+    return pos, neg, counts
+
+
 def roi_samples_finish(sel, comb, lab, matched, gt, gvalid, coder_weights):
     """sel [R] int64 (flat indices into the [N,T] candidates), comb [N,T,4] f32, lab / matched [N,T] int64, gt [N,G,4],
     gvalid [N,G] bool -> rois [R,5] f32, labels [R] int64, regression targets [R,4] f32 (one launch)."""

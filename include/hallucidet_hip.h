@@ -272,6 +272,12 @@ int hd_rpn_decode_filter(const float* deltas, const float* objectness, const flo
  * rois[r])); codes [R][K*4], rois rows of `roi_stride` floats with the box in the LAST four, coder_weights = host float[4]. */
 int hd_roi_decode_clip(const float* codes, const float* rois, long roi_stride, int R, int K, const float* coder_weights,
                        float bbox_xform_clip, float img_h, float img_w, float* boxes, void* stream);
+/* BalancedPositiveNegativeSampler [EXT] for N images (reached from src/utils/eval_forward_fasterrcnn.py:90,127): labels [N][A]
+ * i64 (>= 1 positive, 0 negative, < 0 ignored), keys [N][A] i32 >= 0 = one random key per candidate.  Per image
+ * num_pos = min(#pos, cap_pos), num_neg = min(#neg, batch_size - num_pos); pos_sel / neg_sel [N][A] u8 mark the num_pos /
+ * num_neg members with the smallest keys (equal keys at the cut: lowest index first); counts [N][2] i64 = (num_pos, num_neg). */
+int hd_sample_pos_neg(const int64_t* labels, const int32_t* keys, int N, int A, int batch_size, int cap_pos, uint8_t* pos_sel,
+                      uint8_t* neg_sel, int64_t* counts, void* stream);
 /* Tail of RoIHeads.select_training_samples [EXT] (src/utils/eval_forward_fasterrcnn.py:127 in the reference): for the r-th
  * sampled candidate, sel[r] = flat index into the [N][T] candidate arrays: rois[r] = (image, box) [R][5], labels[r] = lab[sel],
  * reg_t[r] = BoxCoder(coder_weights).encode(gt[image][max(matched[sel], 0)] or zeros for an image without GT, box).

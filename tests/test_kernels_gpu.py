@@ -665,3 +665,34 @@ def test_batched_nms_pick_equals_padded_path(dev):
         assert torch.equal(picked, counts)
         assert torch.equal(pick, ref)
         assert int(picked[2]) == 0 and 0 < int(picked[3]) < top
+
+
+@pytest.mark.gpu
+def test_sample_pos_neg_equals_keyed_topk_path(dev):
+    """hd_sample_pos_neg against the per-op keyed sampler (_sample_batched_keys) fed the SAME random keys: identical
+    membership masks and counts -- more positives than the cap, fewer, none, and an image with nothing to sample."""
+    from hallucidet_amd import ops
+    import hallucidet_amd.models.detection as D
+    torch.manual_seed(21)
+    N, A, B, frac = 6, 9000, 256, 0.5
+    labels = torch.randint(-1, 2, (N, A), device=dev, dtype=torch.int64)         # -1 / 0 / 1
+    labels[1] = torch.where(torch.rand(A, device=dev) < 0.003, torch.ones_like(labels[1]), torch.zeros_like(labels[1]))   # few positives
+    labels[2] = torch.clamp(labels[2], max=0)                                     # no positives
+    labels[3] = -1                                                                # nothing to sample
+    labels[4, 100:] = -1                                                          # fewer candidates than the batch
+    keys = torch.randint(0, 1 << 30, (N, A), dtype=torch.int32, device=dev)
+    pos_sel, neg_sel, counts = ops.sample_pos_neg(labels, keys, B, int(B * frac))
+    pos, neg = labels >= 1, labels == 0
+    big = torch.full_like(keys, 0x7FFFFFFF)
+    k = min(B, A)
+    kk = torch.stack([torch.where(pos, keys, big), torch.where(neg, keys, big)], dim=0).reshape(2 * N, A)
+    order = torch.sort(kk, dim=1, stable=True)[1][:, :k].reshape(2, N, k)
+    P, Nn = pos.sum(1), neg.sum(1)
+    num_pos = P.clamp(max=int(B * frac))
+    num_neg = torch.minimum(Nn, B - num_pos)
+    ar = torch.arange(k, device=dev)[None, :]
+    ref_p = torch.zeros_like(pos).scatter_(1, order[0], ar < num_pos[:, None])
+    ref_n = torch.zeros_like(neg).scatter_(1, order[1], ar < num_neg[:, None])
+    assert torch.equal(counts, torch.stack([num_pos, num_neg], dim=1))
+    assert torch.equal(pos_sel, ref_p) and torch.equal(neg_sel, ref_n)
+    assert int(counts[3].sum()) == 0 and int(counts[0, 0]) == int(B * frac) and int(counts[1, 0]) < int(B * frac)
