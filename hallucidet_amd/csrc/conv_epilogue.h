@@ -52,8 +52,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
         if (ok[it]) mv[it] = *reinterpret_cast<const f16x8*>(maskp + off0 + (size_t)it * RPI * Cout);
     }
     float bias8[8];
+    {   // two 16-byte loads: a VMEM instruction costs the issuing wave ~150 cycles whatever its width
+      f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = q0;
+      if (p.bias && cvalid) {
+        q0 = *reinterpret_cast<const f32x4*>(p.bias + co);
+        q1 = *reinterpret_cast<const f32x4*>(p.bias + co + 4);
+      }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) bias8[k] = (p.bias && cvalid) ? p.bias[co + k] : 0.f;
+      for (int k = 0; k < 8; ++k) bias8[k] = k < 4 ? q0[k] : q1[k - 4];
+    }
 
     float* ct = reinterpret_cast<float*>(lds);   // [BM][BN] fp32
 #pragma unroll
