@@ -281,33 +281,87 @@ __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __r
 }
 
 // all layers of a network in ONE launch: blockIdx.y = layer (descriptor table in device memory), blockIdx.x strides over
-// that layer's elements; blocks beyond a small layer's extent exit at once
-__global__ void weight_prep_multi_kernel(const hd_wprep_desc* __restrict__ tab) {
+// that layer's 32(co) x 32(ci) x taps tiles.  A tile is read in the source's own order (32 runs of 32*taps contiguous
+// floats), parked in LDS and written out twice, each time with the destination's fastest index across the lanes: the first
+// version read the OIHW tensor with a stride of taps (forward layout) / Cin*taps (data-gradient layout) floats between
+// lanes -- 64 cache lines per wave-load -- and took 187 us per step for 24.4 M weights (33 us of HBM traffic).
+__global__ __launch_bounds__(256) void weight_prep_multi_kernel(const hd_wprep_desc* __restrict__ tab) {
   const hd_wprep_desc d = tab[blockIdx.y];
   const float* __restrict__ w = d.w_oihw;
   f16* __restrict__ wf = (f16*)d.w_fwd;
   f16* __restrict__ wd = (f16*)d.w_dgrad;
   const int taps = d.KH * d.KW;
-  if (wf) {
-    const int64_t total = (int64_t)d.Cout * taps * d.Cin_pad;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-      int ci = (int)(i % d.Cin_pad);
-      int t = (int)((i / d.Cin_pad) % taps);
-      int co = (int)(i / ((int64_t)d.Cin_pad * taps));
-      float v = 0.f;
-      if (ci < d.Cin) v = w[((size_t)co * d.Cin + ci) * taps + t];
-      wf[i] = (f16)v;
+  if (taps > 9) {                            // 7x7 stem: a few thousand weights, element-wise form
+    if (wf) {
+      const int64_t total = (int64_t)d.Cout * taps * d.Cin_pad;
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int ci = (int)(i % d.Cin_pad);
+        int t = (int)((i / d.Cin_pad) % taps);
+        int co = (int)(i / ((int64_t)d.Cin_pad * taps));
+        float v = 0.f;
+        if (ci < d.Cin) v = w[((size_t)co * d.Cin + ci) * taps + t];
+        wf[i] = (f16)v;
+      }
     }
+    if (wd) {
+      const int64_t total = (int64_t)d.Cin_pad * taps * d.Cout_pad;
+      for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int co = (int)(i % d.Cout_pad);
+        int t = (int)((i / d.Cout_pad) % taps);
+        int ci = (int)(i / ((int64_t)d.Cout_pad * taps));
+        float v = 0.f;
+        if (ci < d.Cin && co < d.Cout) v = w[((size_t)co * d.Cin + ci) * taps + (taps - 1 - t)];
+        wd[i] = (f16)v;
+      }
+    }
+    return;
   }
-  if (wd) {
-    const int64_t total = (int64_t)d.Cin_pad * taps * d.Cout_pad;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-      int co = (int)(i % d.Cout_pad);
-      int t = (int)((i / d.Cout_pad) % taps);
-      int ci = (int)(i / ((int64_t)d.Cout_pad * taps));
-      float v = 0.f;
-      if (ci < d.Cin && co < d.Cout) v = w[((size_t)co * d.Cin + ci) * taps + (taps - 1 - t)];
-      wd[i] = (f16)v;
+  constexpr int T = 32;
+  __shared__ float tile[T][T * 9 + 1];
+  const int co_ext = wd ? (d.Cout_pad > d.Cout ? d.Cout_pad : d.Cout) : d.Cout;
+  const int nco = (co_ext + T - 1) / T, nci = (d.Cin_pad + T - 1) / T;
+  const int run = T * taps;                  // floats per source run
+  for (int tix = blockIdx.x; tix < nco * nci; tix += gridDim.x) {
+    const int co0 = (tix / nci) * T, ci0 = (tix % nci) * T;
+    __syncthreads();                         // previous tile fully written out
+    // 16-byte accesses throughout: a VMEM instruction costs the issuing wave ~150 cycles whatever its width
+    const bool vec_src = (d.Cin % 4) == 0;   // runs start 16-byte aligned (ci0 % 32 == 0)
+    for (int e4 = threadIdx.x; e4 < T * run / 4; e4 += 256) {
+      const int r = e4 / (run / 4), j = (e4 - r * (run / 4)) * 4;
+      const int co = co0 + r;
+      const float* src = w + ((size_t)co * d.Cin + ci0) * taps + j;
+      if (vec_src && co < d.Cout && ci0 + (j + 3) / taps < d.Cin) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src);
+        tile[r][j] = v[0]; tile[r][j + 1] = v[1]; tile[r][j + 2] = v[2]; tile[r][j + 3] = v[3];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[r][j + q] = (co < d.Cout && ci0 + (j + q) / taps < d.Cin) ? src[q] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (wf) {                                // [co][t][ci_pad]: 8 consecutive ci per lane
+      for (int e = threadIdx.x; e < T * taps * (T / 8); e += 256) {
+        const int c8 = e % (T / 8), t = (e / (T / 8)) % taps, r = e / ((T / 8) * taps);
+        const int co = co0 + r, ci = ci0 + c8 * 8;
+        if (co < d.Cout && ci < d.Cin_pad) {
+          f16x8 o;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (f16)tile[r][(c8 * 8 + q) * taps + t];
+          *reinterpret_cast<f16x8*>(wf + ((size_t)co * taps + t) * d.Cin_pad + ci) = o;
+        }
+      }
+    }
+    if (wd) {                                // [ci_pad][flipped t][co_pad]: 8 consecutive co per lane
+      for (int e = threadIdx.x; e < T * taps * (T / 8); e += 256) {
+        const int r8 = e % (T / 8), t = (e / (T / 8)) % taps, ci_l = e / ((T / 8) * taps);
+        const int co = co0 + r8 * 8, ci = ci0 + ci_l;
+        if (co < d.Cout_pad && ci < d.Cin_pad) {
+          f16x8 o;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) o[q] = (f16)tile[r8 * 8 + q][ci_l * taps + t];
+          *reinterpret_cast<f16x8*>(wd + ((size_t)ci * taps + (taps - 1 - t)) * d.Cout_pad + co) = o;
+        }
+      }
     }
   }
 }

@@ -153,12 +153,16 @@ class WeightPrepPlan:
             wd = torch.empty((cin_pad, KH * KW * cout_pad), dtype=torch.float16, device=dev) if want_d else None
             self.outputs.append((wf, wd))
             descs.append(WprepDesc(w.data_ptr(), wf.data_ptr(), wd.data_ptr() if want_d else None, Cout, Cin, KH, KW, cin_pad, cout_pad))
-            biggest = max(biggest, Cout * KH * KW * cin_pad, cin_pad * KH * KW * cout_pad if want_d else 0)
+            # blocks a layer can use: one per 32(co) x 32(ci) tile (element-wise form for > 9 taps: 1024 elements per block)
+            if KH * KW <= 9:
+                biggest = max(biggest, ((max(Cout, cout_pad if want_d else 0) + 31) // 32) * ((cin_pad + 31) // 32))
+            else:
+                biggest = max(biggest, (Cout * KH * KW * cin_pad + 1023) // 1024)
         self._ptrs = [w.data_ptr() for w, *_ in items]
         raw = bytes(bytearray().join(bytes(d) for d in descs))
         self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.n = len(descs)
-        self.blocks = int(min(2048, (biggest + 4 * 256 - 1) // (4 * 256)))
+        self.blocks = int(min(2048, biggest))          # grid.x of the one launch: the largest layer's tile count (layers with fewer tiles leave blocks idle)
 
     def valid_for(self, params):
         return len(params) == self.n and all(p.data_ptr() == q for p, q in zip(params, self._ptrs))
