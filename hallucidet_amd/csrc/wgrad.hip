@@ -245,6 +245,43 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __res
   }
 }
 
+// Same reduction for SMALL weight tensors with MANY splits (the 16/32-channel full-resolution layers: 2 304 - 9 216
+// weights, 128 - 768 pixel splits): one WAVE per 4 consecutive slab elements, lane l sums the splits l, l+64, ...,
+// then a shuffle tree (fixed order: deterministic).  The one-thread-per-element form above walks all the splits in
+// one dependent chain there: 45 - 67 us per launch for a few KB of output.
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab,
+                                                                int Cout, int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
+  const int taps = KH * KW;
+  const int64_t Ktot = (int64_t)taps * Cin;
+  const int64_t total4 = (int64_t)Cout * Ktot / 4;
+  const size_t sstride = (size_t)Cout_slab * Ktot;
+  const int lane = threadIdx.x & 63;
+  const int64_t i4 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i4 >= total4) return;
+  const int64_t i = i4 * 4;
+  const float* s = slab + i;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < nsplit; k += 64) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * sstride);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], d);
+  }
+  if (lane == 0) {
+    const int co = (int)(i / Ktot);
+    const int kk = (int)(i - (int64_t)co * Ktot);
+    const int t = kk / Cin;
+    const int ci = kk - t * Cin;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (ci + u >= Cin_real) continue;
+      const size_t o = ((size_t)co * Cin_real + ci + u) * taps + t;
+      const float v = acc[u] * scale;
+      dw[o] = accumulate ? dw[o] + v : v;
+    }
+  }
+}
+
 __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ oscale, f16* __restrict__ wf,
                                    f16* __restrict__ wd, int Cout, int Cin, int KH, int KW, int Cin_pad, int Cout_pad) {
   const int taps = KH * KW;
@@ -421,6 +458,12 @@ extern "C" int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, in
   int64_t total = (int64_t)Cout * Cin * KH * KW / 4;
   int g = (int)((total + 255) / 256);
   if (g > 8192) g = 8192;
+  if (total <= 16384 && nsplit >= 64) {      // few outputs, long split chains: one wave per float4 (see wgrad_reduce_wave_kernel)
+    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab,
+                       Cout, KH, KW, Cin, Cin_real, scale, accumulate);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin,
                      Cin_real, scale, accumulate);
   HD_CHECK_LAUNCH();
