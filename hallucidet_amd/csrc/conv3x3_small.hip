@@ -1,0 +1,170 @@
+// 3x3 / stride 1 / pad 1 convolution for SMALL channel counts (Cin in {8,16,32}, Cout in {16,32}): the U-Net decoder's
+// 16/32-channel layers at 256x320 / 512x640 and their data gradients.
+//
+// Why a separate kernel: in the implicit-GEMM family these layers run at ~4x their HBM time (16->16 @512x640: 108 us for
+// 168 MB): a pixel is 32 bytes, the fill moves it as 16-byte pieces, 18 per pixel (9 taps x 2 chunks), and the 32-wide
+// MFMA tile is half empty.  Here a block stages the (8+2)x(32+2) input patch of its 8x32 output tile ONCE (16-byte
+// loads, each input byte read ~1.3x), keeps the whole weight matrix in LDS, and uses v_mfma_f32_16x16x32_f16 with the
+// WEIGHTS as the A operand: C[cout][pixel], so a lane ends up with 4 consecutive output channels of one pixel and a
+// wave-store writes 16 pixels x 32 bytes contiguously -- no transpose through LDS.
+//   K index k = tap*Cin + ci (the igemm weight layout); a 32-deep K step is 4 / 2 / 1 taps for Cin = 8 / 16 / 32; the K
+//   tail (tap >= 9) multiplies zero weights.
+// Epilogue: optional BatchNorm partial sums of the f16-rounded output (per block: [2][Cout]); no bias / residual / mask /
+// activation (the layers that come here have none: conv -> BN -> ReLU units and their data gradients).
+#include "hd_common.h"
+#include "conv_params.h"
+
+namespace {
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+constexpr int TH = 8, TW = 32;               // output tile
+constexpr int PH = TH + 2, PW = TW + 2;      // input patch
+
+template <int CIN, int COUT>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
+  constexpr int KTOT = 9 * CIN;
+  constexpr int KSTEPS = (KTOT + 31) / 32;
+  constexpr int KPAD = KSTEPS * 32;
+  constexpr int MT = COUT / 16;               // 16-row (cout) tiles
+  constexpr int TPS = 32 / CIN;               // taps per K step
+  __shared__ __attribute__((aligned(16))) f16 s_patch[PH * PW * CIN];
+  __shared__ __attribute__((aligned(16))) f16 s_w[COUT * KPAD];
+  __shared__ float s_red[4][COUT][2];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int n = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+
+  // ---- weights -> LDS, zero-padded K tail
+  for (int e = tid; e < COUT * KPAD / 8; e += 256) {
+    const int co = e / (KPAD / 8), k8 = (e - co * (KPAD / 8)) * 8;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k8 < KTOT) v = *reinterpret_cast<const f16x8*>(p.w + (size_t)co * KTOT + k8);     // KTOT % 8 == 0
+    *reinterpret_cast<f16x8*>(s_w + co * KPAD + k8) = v;
+  }
+  // ---- input patch -> LDS (zeros outside the image; up1: nearest-2x upsampled source)
+  {
+    constexpr int C8 = CIN / 8;
+    const f16* xb = p.x + (size_t)n * p.Hsrc * p.Wsrc * CIN;
+    for (int e = tid; e < PH * PW * C8; e += 256) {
+      const int c8 = e % C8, pp = e / C8;
+      const int py = pp / PW, px = pp - py * PW;
+      const int hi = y0 + py - 1, wi = x0 + px - 1;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) {
+        const int hs = p.up1 ? (hi >> 1) : hi, ws = p.up1 ? (wi >> 1) : wi;
+        v = *reinterpret_cast<const f16x8*>(xb + ((size_t)hs * p.Wsrc + ws) * CIN + c8 * 8);
+      }
+      *reinterpret_cast<f16x8*>(s_patch + pp * CIN + c8 * 8) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMA: wave w owns output rows 2w, 2w+1 (4 pixel tiles of 16)
+  const int pl = lane & 15, g = lane >> 4;    // pixel (B column) / cout (A row) index, K group
+  f32x4_t acc[4][MT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[t][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ++ks) {
+    int tap = ks * TPS + (g * 8) / CIN;       // this lane's 8 K values: one tap, channels ci0..ci0+7
+    const int ci0 = (g * 8) % CIN;
+    if (tap > 8) tap = 8;                      // K tail: zero weights; read something valid
+    const int kh = tap / 3, kw = tap - kh * 3;
+    f16x8 af[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const f16x8*>(s_w + (m * 16 + pl) * KPAD + ks * 32 + g * 8);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int oy = wave * 2 + (t >> 1), ox = (t & 1) * 16 + pl;
+      const f16x8 bf = *reinterpret_cast<const f16x8*>(s_patch + ((oy + kh) * PW + ox + kw) * CIN + ci0);
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[t][m], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: lane holds couts m*16 + g*4 .. +3 of pixel (oy, ox)
+  f16* yb = reinterpret_cast<f16*>(p.y) + (size_t)n * p.Ho * p.Wo * COUT;
+  float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int oy = y0 + wave * 2 + (t >> 1), ox = x0 + (t & 1) * 16 + pl;
+    if (oy < p.Ho && ox < p.Wo) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m) {
+        f16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (f16)acc[t][m][r];
+          const float vr = (float)o[r];
+          ssum[m][r] += vr;
+          ssq[m][r] += vr * vr;
+        }
+        *reinterpret_cast<f16x4*>(yb + ((size_t)oy * p.Wo + ox) * COUT + m * 16 + g * 4) = o;
+      }
+    }
+  }
+  if (p.stats) {
+    // the 16 lanes of a K group hold the same couts for 16 different pixels: fold them, then the 4 waves through LDS
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1)
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          ssum[m][r] += __shfl_xor(ssum[m][r], d);
+          ssq[m][r] += __shfl_xor(ssq[m][r], d);
+        }
+    if (pl == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s_red[wave][m * 16 + g * 4 + r][0] = ssum[m][r];
+          s_red[wave][m * 16 + g * 4 + r][1] = ssq[m][r];
+        }
+    }
+    __syncthreads();
+    if (tid < COUT) {
+      float s = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int w4 = 0; w4 < 4; ++w4) {
+        s += s_red[w4][tid][0];
+        s2 += s_red[w4][tid][1];
+      }
+      p.stats[((size_t)blockIdx.x * 2 + 0) * COUT + tid] = s;
+      p.stats[((size_t)blockIdx.x * 2 + 1) * COUT + tid] = s2;
+    }
+  }
+}
+
+}  // namespace
+
+bool hd_conv_small_eligible(const ConvP& p) {
+  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.in_dil == 1 && p.C2 == 0 && p.x2 == nullptr &&
+         (p.C1 == 8 || p.C1 == 16 || p.C1 == 32) && (p.Cout == 16 || p.Cout == 32) && p.out_mode == HD_OUT_NHWC_F16 && !p.bias && !p.res &&
+         !p.mask && p.act == HD_ACT_NONE && p.Ho == p.Hin && p.Wo == p.Win;
+}
+
+int hd_conv_small_tiles(const ConvP& p) { return p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW); }
+
+void hd_conv_launch_small(ConvP& p, hipStream_t s) {
+  dim3 grid(hd_conv_small_tiles(p));
+#define LAUNCH(CI, CO) hipLaunchKernelGGL((conv3x3_small_kernel<CI, CO>), grid, dim3(256), 0, s, p)
+  if (p.C1 == 8) { if (p.Cout == 16) LAUNCH(8, 16); else LAUNCH(8, 32); }
+  else if (p.C1 == 16) { if (p.Cout == 16) LAUNCH(16, 16); else LAUNCH(16, 32); }
+  else { if (p.Cout == 16) LAUNCH(32, 16); else LAUNCH(32, 32); }
+#undef LAUNCH
+}

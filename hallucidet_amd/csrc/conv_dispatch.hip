@@ -64,6 +64,7 @@ int env_int(const char* name, int dflt) {
 // filled per FLOP).  Measured on the hot path's layers it is 5-20 % SLOWER than the igemm family (launches of 9-72 K steps
 // are bound by per-block fixed costs and fill latency, not by fill volume), so it is opt-in (HD_CONV_PATCH=1 or
 // hd_conv2d_patch) until it keeps weights resident across tiles.
+static bool g_small_ok = true;   // cleared while a tuning override forces an igemm variant
 bool patch_eligible(const ConvP& p) {
   return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.in_dil == 1 && !p.up1 && p.C2 == 0 && p.C1 % 64 == 0 &&
          p.out_mode == HD_OUT_NHWC_F16 && p.Cout % 8 == 0 && p.Cout >= 64 && p.Ho == p.Hin && p.Wo == p.Win;
@@ -71,6 +72,13 @@ bool patch_eligible(const ConvP& p) {
 bool use_patch(const ConvP& p) {
   static const int on = env_int("HD_CONV_PATCH", 0);
   return on && patch_eligible(p);
+}
+
+// the 16/32-channel 3x3 layers go to the direct small-channel kernel (conv3x3_small.hip); HD_CONV_SMALL=0 keeps them in the
+// igemm family (A/B)
+bool use_small(const ConvP& p) {
+  static const int on = env_int("HD_CONV_SMALL", 1);
+  return on && g_small_ok && hd_conv_small_eligible(p);
 }
 
 extern "C" int hd_conv2d_patch(const hd_conv_args* a, void* stream) {
@@ -95,6 +103,7 @@ extern "C" int hd_conv_tune_override(int bm, int bn, int bk, int deep) {
   HD_CHECK_ARG((bm == -1 || bm == 64 || bm == 128) && (bn == -1 || bn == 32 || bn == 64 || bn == 128) && (bk == -1 || bk == 32 || bk == 64) &&
                deep >= -1 && deep <= 1, "hd_conv_tune_override: bm in {64,128}, bn in {32,64,128}, bk in {32,64}, deep in {0,1} or -1");
   g_ov_bm = bm; g_ov_bn = bn; g_ov_bk = bk; g_ov_deep = deep;
+  g_small_ok = (bm == -1 && bn == -1 && bk == -1 && deep == -1);
   return HD_OK;
 }
 
@@ -166,6 +175,7 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   int rc = fill_params(a, p);
   if (rc) return rc;
   if (use_patch(p)) return hd_conv_patch_tiles(p);
+  if (use_small(p)) return hd_conv_small_tiles(p);
   return hd_cdiv(p.M, choose_tile(p).bm);
 }
 
@@ -182,6 +192,11 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
 #ifdef HD_CONV_TRACE
   p.trace = g_trace;
 #endif
+  if (use_small(p)) {
+    hd_conv_launch_small(p, s);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
   const TileChoice c = choose_tile(p);
   const int bm = c.bm, bn = c.bn;
   const bool use64 = c.use64, deep = c.deep;

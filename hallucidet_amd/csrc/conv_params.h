@@ -42,3 +42,7 @@ void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 // conv3x3_patch.hip: 3x3 / stride 1 / pad 1, Cin % 64 == 0, NHWC f16 output, LDS-staged input patches
 void hd_conv_launch_patch(ConvP& p, hipStream_t s);
 int hd_conv_patch_tiles(const ConvP& p);
+// conv3x3_small.hip: 3x3 / stride 1 / pad 1, Cin in {8,16,32}, Cout in {16,32}, plain NHWC f16 output (+ BN partial sums)
+bool hd_conv_small_eligible(const ConvP& p);
+int hd_conv_small_tiles(const ConvP& p);
+void hd_conv_launch_small(ConvP& p, hipStream_t s);

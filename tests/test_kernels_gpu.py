@@ -54,6 +54,12 @@ CONV_CASES = [
     (1, 9, 40, 256, 0, 72, 3, 1, 1, False, 0, False, False),      # 4 chunks, Cout not a multiple of 32
     (3, 5, 5, 512, 0, 512, 3, 1, 1, False, 1, True, False),       # image smaller than a tile, 8 chunks, 4 N tiles
     (2, 40, 40, 64, 64, 64, 3, 1, 1, True, 1, False, False),      # dual source, 64-deep, large grid
+    # 16/32-channel 3x3 layers: the direct small-channel kernel (conv3x3_small.hip); also the (1, 13, 11, 32 -> 16) case above
+    (2, 24, 40, 16, 0, 16, 3, 1, 1, False, 0, False, False),      # K = 144: two taps per K step, zero K tail
+    (1, 17, 70, 16, 0, 32, 3, 1, 1, False, 0, False, False),      # ragged tiles both ways, two cout tiles
+    (2, 10, 33, 8, 0, 16, 3, 1, 1, False, 0, False, False),       # Cin = 8: four taps per K step (head data gradient)
+    (2, 8, 10, 32, 0, 16, 3, 1, 1, True, 0, False, False),        # nearest-2x upsampled source
+    (3, 20, 64, 32, 0, 32, 3, 1, 1, False, 0, False, False),      # one tap per K step
 ]
 
 
@@ -696,3 +702,32 @@ def test_sample_pos_neg_equals_keyed_topk_path(dev):
     assert torch.equal(counts, torch.stack([num_pos, num_neg], dim=1))
     assert torch.equal(pos_sel, ref_p) and torch.equal(neg_sel, ref_n)
     assert int(counts[3].sum()) == 0 and int(counts[0, 0]) == int(B * frac) and int(counts[1, 0]) < int(B * frac)
+
+
+SMALL_CASES = [c for c in CONV_CASES if c[6] == 3 and c[7] == 1 and c[8] == 1 and c[4] == 0 and c[3] in (8, 16, 32) and c[5] in (16, 32)
+               and c[10] == 0 and not c[11] and not c[12]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_conv_small_channel_kernel_equals_igemm(dev, case):
+    """conv3x3_small.hip (default route of these shapes) against the implicit-GEMM family (forced through the tuning
+    override): same fp32 accumulation of the same fp16 products, so outputs agree to the last fp16 bit or two; the BN
+    partial-sum rows differ in number (8x32 tiles vs 128-row tiles) but not in their totals."""
+    from hallucidet_amd import ops, _abi
+    assert len(SMALL_CASES) >= 5
+    N, H, W, C1, C2, Cout, K, stride, pad, up1, act, use_bias, use_res = case
+    x = rnd(N, H, W, C1, seed=11).to(dev)
+    w = rnd(Cout, 9 * C1, scale=1.0 / math.sqrt(9 * C1), seed=12).to(dev)
+    lib = _abi.load()
+    got, stats = ops.conv2d(x, w, 3, 3, pad=1, up1=up1, want_stats=True)
+    Ho, Wo = got.shape[1], got.shape[2]
+    assert stats.shape[0] == N * ((Ho + 7) // 8) * ((Wo + 31) // 32)
+    lib.hd_conv_tune_override(128, 32, 32, 0)
+    try:
+        ref, rstats = ops.conv2d(x, w, 3, 3, pad=1, up1=up1, want_stats=True)
+    finally:
+        lib.hd_conv_tune_override(-1, -1, -1, -1)
+    assert rstats.shape[0] == (N * Ho * Wo + 127) // 128          # the igemm family's 128-row tiles really ran
+    assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
+    assert torch.allclose(stats.sum(0), rstats.sum(0), rtol=2e-3, atol=2e-2)
