@@ -9,8 +9,9 @@
 // wave-store writes 16 pixels x 32 bytes contiguously -- no transpose through LDS.
 //   K index k = tap*Cin + ci (the igemm weight layout); a 32-deep K step is 4 / 2 / 1 taps for Cin = 8 / 16 / 32; the K
 //   tail (tap >= 9) multiplies zero weights.
-// Epilogue: optional BatchNorm partial sums of the f16-rounded output (per block: [2][Cout]); no bias / residual / mask /
-// activation (the layers that come here have none: conv -> BN -> ReLU units and their data gradients).
+// Epilogue: NHWC f16 with optional BatchNorm partial sums of the f16-rounded output (per block: [2][Cout]; no bias /
+// activation: conv -> BN -> ReLU units and their data gradients), or NCHW fp32 with bias + activation for <= 16 real
+// output channels (the segmentation head).  No residual / mask.
 #include "hd_common.h"
 #include "conv_params.h"
 
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
   for (int e = tid; e < COUT * KPAD / 8; e += 256) {
     const int co = e / (KPAD / 8), k8 = (e - co * (KPAD / 8)) * 8;
     f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (k8 < KTOT) v = *reinterpret_cast<const f16x8*>(p.w + (size_t)co * KTOT + k8);     // KTOT % 8 == 0
+    if (k8 < KTOT && co < p.Cout) v = *reinterpret_cast<const f16x8*>(p.w + (size_t)co * KTOT + k8);     // KTOT % 8 == 0
     *reinterpret_cast<f16x8*>(s_w + co * KPAD + k8) = v;
   }
   // ---- input patch -> LDS (zeros outside the image; up1: nearest-2x upsampled source)
@@ -92,6 +93,28 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
   }
 
   // ---- epilogue: lane holds couts m*16 + g*4 .. +3 of pixel (oy, ox)
+  if (p.out_mode == HD_OUT_NCHW_F32) {
+    // segmentation head (base/heads.py:23-27): Cout <= 16 real channels, bias, activation, fp32 planes; 16 consecutive
+    // pixels of a plane per store
+    float* yf = reinterpret_cast<float*>(p.y) + (size_t)n * p.Cout * p.Ho * p.Wo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int oy = y0 + wave * 2 + (t >> 1), ox = x0 + (t & 1) * 16 + pl;
+      if (oy < p.Ho && ox < p.Wo) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = g * 4 + r;
+          if (co < p.Cout) {
+            float v = acc[t][0][r] + (p.bias ? p.bias[co] : 0.f);
+            if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+            yf[((size_t)co * p.Ho + oy) * p.Wo + ox] = v;
+          }
+        }
+      }
+    }
+    return;
+  }
   f16* yb = reinterpret_cast<f16*>(p.y) + (size_t)n * p.Ho * p.Wo * COUT;
   float ssum[MT][4], ssq[MT][4];
 #pragma unroll
@@ -153,9 +176,11 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
 }  // namespace
 
 bool hd_conv_small_eligible(const ConvP& p) {
-  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.in_dil == 1 && p.C2 == 0 && p.x2 == nullptr &&
-         (p.C1 == 8 || p.C1 == 16 || p.C1 == 32) && (p.Cout == 16 || p.Cout == 32) && p.out_mode == HD_OUT_NHWC_F16 && !p.bias && !p.res &&
-         !p.mask && p.act == HD_ACT_NONE && p.Ho == p.Hin && p.Wo == p.Win;
+  if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.in_dil == 1 && p.C2 == 0 && p.x2 == nullptr &&
+        (p.C1 == 8 || p.C1 == 16 || p.C1 == 32) && !p.res && !p.mask && p.Ho == p.Hin && p.Wo == p.Win))
+    return false;
+  if (p.out_mode == HD_OUT_NCHW_F32) return p.Cout <= 16 && !p.stats;                       // head: bias + activation allowed
+  return (p.Cout == 16 || p.Cout == 32) && !p.bias && p.act == HD_ACT_NONE;                   // conv -> BN units, data gradients
 }
 
 int hd_conv_small_tiles(const ConvP& p) { return p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW); }
@@ -163,8 +188,8 @@ int hd_conv_small_tiles(const ConvP& p) { return p.N * hd_cdiv(p.Ho, TH) * hd_cd
 void hd_conv_launch_small(ConvP& p, hipStream_t s) {
   dim3 grid(hd_conv_small_tiles(p));
 #define LAUNCH(CI, CO) hipLaunchKernelGGL((conv3x3_small_kernel<CI, CO>), grid, dim3(256), 0, s, p)
-  if (p.C1 == 8) { if (p.Cout == 16) LAUNCH(8, 16); else LAUNCH(8, 32); }
-  else if (p.C1 == 16) { if (p.Cout == 16) LAUNCH(16, 16); else LAUNCH(16, 32); }
-  else { if (p.Cout == 16) LAUNCH(32, 16); else LAUNCH(32, 32); }
+  if (p.C1 == 8) { if (p.Cout <= 16) LAUNCH(8, 16); else LAUNCH(8, 32); }
+  else if (p.C1 == 16) { if (p.Cout <= 16) LAUNCH(16, 16); else LAUNCH(16, 32); }
+  else { if (p.Cout <= 16) LAUNCH(32, 16); else LAUNCH(32, 32); }
 #undef LAUNCH
 }
