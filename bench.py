@@ -5,8 +5,8 @@ resident in HBM.  Prints ONE JSON line (rank 0).
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-`roofline`: the dominant kernel is the implicit-GEMM convolution (conv_igemm_kernel: every conv / data-gradient / FC of
-the U-Net and the detector).  Its launches of one step are recorded and re-issued back to back between HIP events on
+`roofline`: the dominant kernel is the convolution behind hd_conv2d (conv_igemm_kernel, and conv3x3_small_kernel for the
+16/32-channel 3x3 layers: every conv / data-gradient / FC of the U-Net and the detector).  Its launches of one step are recorded and re-issued back to back between HIP events on
 the launch stream; achieved = algorithmic FLOPs of those launches / their summed duration (DESIGN.md "Measurement").
 `cpu_baseline`: the CPU oracle (oracle/step.py, "port") timed on this host's cores on a bounded sample of the same
 workload (rank 0, N=1 only).
@@ -165,7 +165,7 @@ def conv_roofline(lit, batch, reps=5):
     return {"bound": "mfma", "groups": groups, "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": _pmc_traffic(), "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
-            "kernel": "conv_igemm_kernel (implicit-GEMM conv / dgrad / FC)", "launches_per_step": n,
+            "kernel": "hd_conv2d: conv_igemm_kernel (implicit-GEMM conv / dgrad / FC) + conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
             "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2), "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3)}
 
 
