@@ -727,7 +727,8 @@ class RegionProposalNetwork(nn.Module):
         return labels, matched
 
     def _get_top_n_idx(self, objectness, num_anchors_per_level):
-        if objectness.is_cuda and objectness.dtype == torch.float32:
+        if (objectness.is_cuda and objectness.dtype == torch.float32 and len(num_anchors_per_level) <= 8 and
+                min(self.pre_nms_top_n(), max(num_anchors_per_level)) <= 4096):      # limits of hd_topk_select_rows
             # radix select + in-LDS sort per (image, level): the same lists as the per-level stable sorts below (descending
             # score, ties by lowest index) without their ~45 merge-sort launches
             return ops.topk_rows_segments(objectness.contiguous(), list(num_anchors_per_level), self.pre_nms_top_n())

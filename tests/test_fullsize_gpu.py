@@ -1,0 +1,113 @@
+"""BASELINE configs[1] at FULL size (8 x 512x640, 24 x 300x300 detector inputs): the oracle cannot run these sizes in
+seconds, so the hot path is checked through size-independent properties -- exact scaling by a power of two, batch
+independence, graph replay == eager, sortedness / idempotence of the selection kernels, sampler invariants."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rnd(*shape, scale=1.0, seed=0, dev="cuda"):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).half().to(dev)
+
+
+@pytest.mark.parametrize("shape", [(8, 128, 160, 64, 64), (8, 512, 640, 16, 16), (8, 256, 320, 32, 32), (8, 32, 40, 256, 256),
+                                   (24, 75, 75, 256, 256)])
+def test_conv_full_size_scaling_and_batch_independence(dev, shape):
+    """conv(0.5 x) == 0.5 conv(x) bit for bit (power-of-two scaling commutes with every fp16 / fp32 rounding as long as
+    nothing under- or overflows), image n of a batched launch == the same image launched alone (the tile -> block mapping
+    must not leak across images), BN partial sums == sums over the stored output."""
+    from hallucidet_amd import ops
+    N, H, W, Cin, Cout = shape
+    x = _rnd(N, H, W, Cin, seed=1, dev=dev)
+    x = torch.where(x.abs() < 1e-2, torch.full_like(x, 0.5), x)      # no fp16 subnormals after halving
+    w = _rnd(Cout, 9 * Cin, scale=1.0 / math.sqrt(9 * Cin), seed=2, dev=dev)
+    w = torch.where(w.abs() < 1e-3, torch.full_like(w, 0.01), w)
+    y, stats = ops.conv2d(x, w, 3, 3, pad=1, want_stats=True)
+    y_half = ops.conv2d(x * 0.5, w, 3, 3, pad=1)
+    tiny = y.float().abs() < 1e-3                      # halves of subnormal-range outputs may round differently
+    assert torch.equal(torch.where(tiny, torch.zeros_like(y), y * 0.5), torch.where(tiny, torch.zeros_like(y), y_half))
+    for n in (0, N - 1):
+        assert torch.equal(ops.conv2d(x[n:n + 1].contiguous(), w, 3, 3, pad=1)[0], y[n])
+    s = stats.double().sum(0)
+    yf = y.double().reshape(-1, Cout)
+    assert torch.allclose(s[0], yf.sum(0), rtol=1e-5, atol=1e-2) and torch.allclose(s[1], (yf * yf).sum(0), rtol=1e-5, atol=1e-2)
+
+
+def test_full_size_step_graph_replay_equals_eager_and_is_reproducible(dev):
+    """One full-size training step (the bench workload): two modules built from the same seed give the same loss and the
+    same flat gradient bit for bit, with the U-Net replayed from hipGraphs in one and launched eagerly in the other."""
+    from hallucidet_amd import synthetic
+    outs = []
+    for use_graphs in (True, False):
+        lit = synthetic.make_module(seed=321)
+        lit.encoder_decoder.runner.enable_graphs(use_graphs)
+        batch = synthetic.make_batch(8, device=dev)
+        torch.manual_seed(5)
+        lit.encoder_decoder.train()
+        loss = lit.training_step(batch, 0)
+        lit.scaler.scale(loss).backward()
+        g = lit.encoder_decoder.runner.flat_grads
+        assert torch.isfinite(loss) and bool(torch.isfinite(g).all())
+        outs.append((float(loss.detach()), g.clone()))
+        del lit
+    assert outs[0][0] == outs[1][0]
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].abs().sum()) > 0
+
+
+def test_selection_kernels_at_full_proposal_counts(dev):
+    """Pre-NMS top-k over [24, 21765] objectness (5 levels), batched NMS over 24 x 3375 candidates, sampler over
+    [24, 21765] labels: sortedness, cut value, idempotence and counting invariants."""
+    from hallucidet_amd import ops
+    import hallucidet_amd.models.detection as D
+    torch.manual_seed(4)
+    segs = [16875, 4332, 1083, 300, 75]
+    B, k = 24, 1000
+    obj = torch.randn(B, sum(segs), device=dev)
+    top = ops.topk_rows_segments(obj, segs, k)
+    off = ooff = 0
+    for n in segs:
+        kk = min(k, n)
+        idx = top[:, ooff:ooff + kk]
+        assert int(idx.min()) >= off and int(idx.max()) < off + n
+        sc = torch.gather(obj, 1, idx)
+        assert bool((sc[:, :-1] >= sc[:, 1:]).all())                                   # descending
+        assert bool((torch.sort(idx, dim=1)[0][:, 1:] != torch.sort(idx, dim=1)[0][:, :-1]).all())   # distinct
+        if kk < n:                                                                     # nothing left out beats the cut
+            rest = obj[:, off:off + n].clone().scatter_(1, idx - off, float("-inf"))
+            assert bool((rest.max(dim=1).values <= sc[:, -1]).all())
+        off += n
+        ooff += kk
+    # batched NMS: survivors are in descending score order, and NMS of the survivors alone keeps all of them
+    n = top.shape[1]
+    xy = torch.rand(B, n, 2, device=dev) * 260
+    boxes = torch.cat([xy, xy + 4 + torch.rand(B, n, 2, device=dev) * 60], dim=2)
+    scores = torch.rand(B, n, device=dev)
+    lv = torch.zeros((B, n), dtype=torch.int64, device=dev)      # one category: the second pass then repeats the first pass's arithmetic exactly
+    valid = torch.rand(B, n, device=dev) > 0.1
+    pick, cnt = D._batched_nms_pick(boxes, scores, lv, valid, 0.7, 1000)
+    c = cnt.tolist()
+    assert all(0 < ci <= 1000 for ci in c)
+    ps = torch.gather(scores, 1, pick)
+    for b in (0, B - 1):
+        assert bool((ps[b, :c[b] - 1] >= ps[b, 1:c[b]]).all())
+        assert bool(torch.gather(valid, 1, pick)[b, :c[b]].all())
+    kb = torch.gather(boxes, 1, pick[:, :, None].expand(-1, -1, 4))
+    kl = torch.gather(lv, 1, pick)
+    kvalid = torch.arange(pick.shape[1], device=dev)[None, :] < cnt[:, None]
+    pick2, cnt2 = D._batched_nms_pick(kb, ps, kl, kvalid, 0.7, 1000)
+    assert torch.equal(cnt2, cnt)
+    assert all(torch.equal(pick2[b, :c[b]], torch.arange(c[b], device=dev)) for b in range(B))
+    # sampler: members only, counts as torchvision defines them
+    labels = torch.randint(-1, 2, (B, 21765), device=dev, dtype=torch.int64)
+    labels[:, ::3] = torch.clamp(labels[:, ::3], max=0)
+    keys = torch.randint(0, 1 << 30, labels.shape, dtype=torch.int32, device=dev)
+    pos, neg, counts = ops.sample_pos_neg(labels, keys, 256, 128)
+    assert bool((labels[pos] >= 1).all()) and bool((labels[neg] == 0).all())
+    assert torch.equal(pos.sum(1), counts[:, 0]) and torch.equal(neg.sum(1), counts[:, 1])
+    P, Nn = (labels >= 1).sum(1), (labels == 0).sum(1)
+    assert torch.equal(counts[:, 0], P.clamp(max=128)) and torch.equal(counts[:, 1], torch.minimum(Nn, 256 - counts[:, 0]))
