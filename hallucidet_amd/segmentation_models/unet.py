@@ -43,11 +43,33 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
 
-class ResNetEncoder(nn.Module):
-    """torchvision ResNet(BasicBlock, layers) minus avgpool/fc, as the reference's ResNetEncoder exposes it."""
+class Bottleneck(nn.Module):
+    """torchvision Bottleneck [EXT] (v1.5: the stride sits on the 3x3 conv), the block of the reference's resnet50 encoder
+    (src/segmentation_models/encoders/resnet.py:136-144)."""
+    expansion = 4
 
-    def __init__(self, layers=(3, 4, 6, 3), out_channels=(3, 64, 64, 128, 256, 512), depth=5):
+    def __init__(self, cin, planes, stride):
         super().__init__()
+        cout = planes * self.expansion
+        self.conv1 = nn.Conv2d(cin, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+        self.stride = stride
+
+
+class ResNetEncoder(nn.Module):
+    """torchvision ResNet(BasicBlock | Bottleneck, layers) minus avgpool/fc, as the reference's ResNetEncoder exposes it."""
+
+    def __init__(self, layers=(3, 4, 6, 3), out_channels=(3, 64, 64, 128, 256, 512), depth=5, block="basic"):
+        super().__init__()
+        Block = Bottleneck if block == "bottleneck" else BasicBlock
         self._depth, self._out_channels, self._in_channels = depth, out_channels, 3
         self.conv1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False)
         self.bn1 = nn.BatchNorm2d(64)
@@ -57,8 +79,8 @@ class ResNetEncoder(nn.Module):
         for i, (n, c) in enumerate(zip(layers, (64, 128, 256, 512))):
             blocks = []
             for b in range(n):
-                blocks.append(BasicBlock(cin, c, 2 if (b == 0 and i > 0) else 1))
-                cin = c
+                blocks.append(Block(cin, c, 2 if (b == 0 and i > 0) else 1))
+                cin = c * Block.expansion
             setattr(self, "layer%d" % (i + 1), nn.Sequential(*blocks))
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -143,6 +165,7 @@ def initialize_head(module):
 _ENCODERS = {
     "resnet18": dict(layers=(2, 2, 2, 2), out_channels=(3, 64, 64, 128, 256, 512)),
     "resnet34": dict(layers=(3, 4, 6, 3), out_channels=(3, 64, 64, 128, 256, 512)),
+    "resnet50": dict(layers=(3, 4, 6, 3), out_channels=(3, 64, 256, 512, 1024, 2048), block="bottleneck"),
 }
 
 
@@ -192,17 +215,18 @@ class UnetRunner:
             blocks = []
             for bi, blk in enumerate(getattr(enc, "layer%d" % li)):
                 pre = "encoder.layer%d.%d." % (li, bi)
-                u1 = _Unit(pre + "conv1", blk.conv1, blk.bn1)
-                u2 = _Unit(pre + "conv2", blk.conv2, blk.bn2)
+                us = [_Unit(pre + "conv1", blk.conv1, blk.bn1), _Unit(pre + "conv2", blk.conv2, blk.bn2)]
+                if hasattr(blk, "conv3"):             # Bottleneck (resnet50)
+                    us.append(_Unit(pre + "conv3", blk.conv3, blk.bn3))
                 ud = _Unit(pre + "downsample", blk.downsample[0], blk.downsample[1], relu=False) if blk.downsample is not None else None
-                blocks.append((u1, u2, ud))
+                blocks.append((us, ud))
             self.stages.append(blocks)
         self.dec = []
         for i, b in enumerate(dec.blocks):
             pre = "decoder.blocks.%d." % i
             self.dec.append((_Unit(pre + "conv1", b.conv1[0], b.conv1[1]), _Unit(pre + "conv2", b.conv2[0], b.conv2[1]), b.in_channels, b.skip_channels))
         self.head_conv = module.segmentation_head[0]
-        self.units = [self.stem] + [u for st in self.stages for blk in st for u in blk if u is not None] + [u for d in self.dec for u in d[:2]]
+        self.units = [self.stem] + [u for st in self.stages for (us, ud) in st for u in us + ([ud] if ud is not None else [])] + [u for d in self.dec for u in d[:2]]
         self._wplan = {}
 
     # ------------------------------------------------------------------ hipGraph replay
@@ -346,10 +370,12 @@ class UnetRunner:
         feats = [f1]
         pooled = cur
         for blocks in self.stages:
-            for (u1, u2, ud) in blocks:
-                z1 = self._conv_bn(u1, cur, Wt, training, rec)
+            for (us, ud) in blocks:
+                z = cur
+                for u in us[:-1]:
+                    z = self._conv_bn(u, z, Wt, training, rec)
                 idt = cur if ud is None else self._conv_bn(ud, cur, Wt, training, rec)
-                cur = self._conv_bn(u2, z1, Wt, training, rec, res=idt)
+                cur = self._conv_bn(us[-1], z, Wt, training, rec, res=idt)
             feats.append(cur)
         # feats = [f1, f2, f3, f4, f5]
         skips = [feats[3], feats[2], feats[1], feats[0], None]
@@ -428,19 +454,19 @@ class UnetRunner:
         for si in range(3, -1, -1):
             blocks = self.stages[si]
             for bi in range(len(blocks) - 1, -1, -1):
-                u1, u2, ud = blocks[bi]
+                us, ud = blocks[bi]
                 # gradient that the block INPUT also receives from elsewhere (decoder skip) when it is a stage output
                 extra = dfeat[si] if bi == 0 and si > 0 else None
-                dz1, dres = self._unit_bwd(u2, d_out, S, want_dres=True)
-                first_block = (si == 0 and bi == 0)
+                dz1, dres = self._unit_bwd(us[-1], d_out, S, want_dres=True)
+                for u in reversed(us[1:-1]):          # Bottleneck's middle 3x3
+                    dz1, _ = self._unit_bwd(u, dz1, S)
                 if ud is None:
                     acc = dres if extra is None else ops.add_f16(dres, extra)
-                    d_in, _ = self._unit_bwd(u1, dz1, S, dx_res=acc)
+                    d_in, _ = self._unit_bwd(us[0], dz1, S, dx_res=acc)
                 else:
-                    d_in, _ = self._unit_bwd(u1, dz1, S, dx_res=extra)
+                    d_in, _ = self._unit_bwd(us[0], dz1, S, dx_res=extra)
                     d_in, _ = self._unit_bwd(ud, dres, S, dx_res=d_in)
                 d_out = d_in
-                _ = first_block
         # d_out = gradient of the max-pooled stem output
         df1 = ops.maxpool3x3s2_bwd_idx(sv["pool_idx"], d_out, (sv["f1"].shape[1], sv["f1"].shape[2]))
         df1 = ops.add_f16(df1, dfeat[0], out=df1)
@@ -468,7 +494,7 @@ class SegmentationModel(nn.Module):
 
 
 class Unet(SegmentationModel):
-    """`smp.Unet(encoder_name, encoder_depth, encoder_weights, ..., in_channels, classes)` for resnet18/34 encoders."""
+    """`smp.Unet(encoder_name, encoder_depth, encoder_weights, ..., in_channels, classes)` for resnet18/34/50 encoders."""
 
     def __init__(self, encoder_name="resnet34", encoder_depth=5, encoder_weights=None, decoder_use_batchnorm=True,
                  decoder_channels=(256, 128, 64, 32, 16), decoder_attention_type=None, in_channels=3, classes=1,
