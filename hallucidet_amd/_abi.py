@@ -106,6 +106,10 @@ PROTOTYPES = {
     "hd_roi_align_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_box_iou": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
     "hd_box_iou_batched": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "hd_rpn_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_float, vp, C.c_float, vp, vp, vp]),
+    "hd_rpn_loss_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_float, vp, vp, vp, C.c_float, vp, vp, vp]),
+    "hd_fastrcnn_loss": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
+    "hd_fastrcnn_loss_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]),
     "hd_sample_pos_neg": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "hd_roi_samples_finish": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "hd_roi_levels": (C.c_int, [vp, C.c_long, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, vp]),

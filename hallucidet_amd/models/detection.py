@@ -1296,8 +1296,84 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
     return dict(labels=labels.reshape(-1).clamp(min=0), reg_t=reg_t.reshape(-1, 4), pos_f=pos_f, samp_f=samp_f, n_sampled=n_sampled)
 
 
+def _u8(t):
+    return t.contiguous().view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8).contiguous()
+
+
+class _RPNLossFn(torch.autograd.Function):
+    """RegionProposalNetwork.compute_loss as one forward (+ finish) and one backward launch (hd_rpn_loss / hd_rpn_loss_bwd);
+    the torch-op form below is ~15 launches each way over the N*A anchors."""
+
+    @staticmethod
+    def forward(ctx, objectness, deltas, labels, reg_t, pos_f, samp_f, n_sampled):
+        from .. import _abi
+        lib = _abi.load()
+        obj, dl = objectness.detach().reshape(-1).contiguous().float(), deltas.detach().reshape(-1, 4).contiguous().float()
+        lab, rt = labels.reshape(-1).contiguous().float(), reg_t.reshape(-1, 4).contiguous().float()
+        pos, samp = _u8(pos_f.reshape(-1)), _u8(samp_f.reshape(-1))
+        T = obj.numel()
+        dev_n = n_sampled if torch.is_tensor(n_sampled) else None
+        if dev_n is not None:
+            dev_n = dev_n.reshape(1).to(torch.int64)
+        host_n = 0.0 if dev_n is not None else float(n_sampled)
+        ws = torch.empty(512, dtype=torch.float32, device=obj.device)
+        out = torch.empty(2, dtype=torch.float32, device=obj.device)
+        s = torch.cuda.current_stream().cuda_stream
+        _abi.check(lib.hd_rpn_loss(_abi.ptr(obj), _abi.ptr(dl), _abi.ptr(lab), _abi.ptr(rt), _abi.ptr(pos), _abi.ptr(samp), T, 1.0 / 9,
+                                   _abi.ptr(dev_n), host_n, _abi.ptr(ws), _abi.ptr(out), s), "hd_rpn_loss")
+        ctx.save_for_backward(obj, dl, lab, rt, pos, samp)
+        ctx.dev_n, ctx.host_n, ctx.shapes = dev_n, host_n, (objectness.shape, deltas.shape)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_obj, g_box):
+        from .. import _abi
+        lib = _abi.load()
+        obj, dl, lab, rt, pos, samp = ctx.saved_tensors
+        d_obj, d_dl = torch.empty_like(obj), torch.empty_like(dl)
+        go = None if g_obj is None else g_obj.contiguous().float()
+        gb = None if g_box is None else g_box.contiguous().float()
+        _abi.check(lib.hd_rpn_loss_bwd(_abi.ptr(obj), _abi.ptr(dl), _abi.ptr(lab), _abi.ptr(rt), _abi.ptr(pos), _abi.ptr(samp), obj.numel(), 1.0 / 9,
+                                       _abi.ptr(go), _abi.ptr(gb), _abi.ptr(ctx.dev_n), ctx.host_n, _abi.ptr(d_obj), _abi.ptr(d_dl),
+                                       torch.cuda.current_stream().cuda_stream), "hd_rpn_loss_bwd")
+        return d_obj.reshape(ctx.shapes[0]), d_dl.reshape(ctx.shapes[1]), None, None, None, None, None
+
+
+class _FastRCNNLossFn(torch.autograd.Function):
+    """roi_heads.fastrcnn_loss as one forward (+ finish) and one backward launch (hd_fastrcnn_loss / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, class_logits, box_regression, labels, reg_t):
+        from .. import _abi
+        lib = _abi.load()
+        lg, br = class_logits.detach().contiguous().float(), box_regression.detach().contiguous().float()
+        lab, rt = labels.contiguous().to(torch.int64), reg_t.contiguous().float()
+        R, K = lg.shape
+        ws = torch.empty(512, dtype=torch.float32, device=lg.device)
+        out = torch.empty(2, dtype=torch.float32, device=lg.device)
+        _abi.check(lib.hd_fastrcnn_loss(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(ws), _abi.ptr(out),
+                                        torch.cuda.current_stream().cuda_stream), "hd_fastrcnn_loss")
+        ctx.save_for_backward(lg, br, lab, rt)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box):
+        from .. import _abi
+        lib = _abi.load()
+        lg, br, lab, rt = ctx.saved_tensors
+        R, K = lg.shape
+        d_lg, d_br = torch.empty_like(lg), torch.empty_like(br)
+        gc = None if g_cls is None else g_cls.contiguous().float()
+        gb = None if g_box is None else g_box.contiguous().float()
+        _abi.check(lib.hd_fastrcnn_loss_bwd(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(gc), _abi.ptr(gb),
+                                            _abi.ptr(d_lg), _abi.ptr(d_br), torch.cuda.current_stream().cuda_stream), "hd_fastrcnn_loss_bwd")
+        return d_lg, d_br, None, None
+
+
 def rpn_loss_from_samples(st, objectness, deltas):
     pos_f, samp_f, n_sampled = st["pos_f"], st["samp_f"], st["n_sampled"]
+    if objectness.is_cuda and objectness.dtype == torch.float32 and deltas.dtype == torch.float32:
+        return _RPNLossFn.apply(objectness, deltas, st["labels"], st["reg_t"], pos_f, samp_f, n_sampled)
     l1 = F.smooth_l1_loss(deltas, torch.where(pos_f[:, None], st["reg_t"], deltas.detach()), beta=1 / 9, reduction="none").sum(dim=1)
     denom = n_sampled.clamp(min=1) if torch.is_tensor(n_sampled) else max(n_sampled, 1)
     box_loss = torch.where(pos_f, l1, torch.zeros_like(l1)).sum() / denom
@@ -1397,6 +1473,9 @@ def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
 
 
 def fastrcnn_loss_flat(class_logits, box_regression, labels, regression_targets):
+    if (class_logits.is_cuda and class_logits.dtype == torch.float32 and box_regression.dtype == torch.float32 and class_logits.shape[0] > 0
+            and box_regression.shape[1] == 4 * class_logits.shape[1]):
+        return _FastRCNNLossFn.apply(class_logits, box_regression, labels, regression_targets)
     cls_loss = F.cross_entropy(class_logits, labels)
     N = class_logits.shape[0]
     br = box_regression.reshape(N, box_regression.size(-1) // 4, 4)

@@ -272,6 +272,24 @@ int hd_rpn_decode_filter(const float* deltas, const float* objectness, const flo
  * rois[r])); codes [R][K*4], rois rows of `roi_stride` floats with the box in the LAST four, coder_weights = host float[4]. */
 int hd_roi_decode_clip(const float* codes, const float* rois, long roi_stride, int R, int K, const float* coder_weights,
                        float bbox_xform_clip, float img_h, float img_w, float* boxes, void* stream);
+/* RegionProposalNetwork.compute_loss [EXT] (src/utils/eval_forward_fasterrcnn.py:93): objectness [T] f32 logits, deltas /
+ * reg_t [T][4], labels [T] f32 (0/1), pos / samp [T] u8 (sampled positives / all sampled).  out2 = (sum_samp BCEWithLogits,
+ * sum_pos smooth_l1(beta)) / max(n_sampled, 1); n_sampled = *n_sampled_dev (i64 on the device) when given, else
+ * n_sampled_host.  part_ws: 512 floats.  _bwd: gradients w.r.t. objectness [T] and deltas [T][4] for upstream scalars
+ * *g_obj, *g_box (device pointers, NULL = 0). */
+int hd_rpn_loss(const float* objectness, const float* deltas, const float* labels, const float* reg_t, const uint8_t* pos,
+                const uint8_t* samp, int64_t T, float beta, const int64_t* n_sampled_dev, float n_sampled_host, float* part_ws,
+                float* out2, void* stream);
+int hd_rpn_loss_bwd(const float* objectness, const float* deltas, const float* labels, const float* reg_t, const uint8_t* pos,
+                    const uint8_t* samp, int64_t T, float beta, const float* g_obj, const float* g_box,
+                    const int64_t* n_sampled_dev, float n_sampled_host, float* d_objectness, float* d_deltas, void* stream);
+/* roi_heads.fastrcnn_loss [EXT] (src/utils/eval_forward_fasterrcnn.py:141): logits [R][K], box_regression [R][K*4],
+ * labels [R] i64, reg_t [R][4].  out2 = (mean cross entropy, sum over labels>0 of smooth_l1(beta) of the label's box / R). */
+int hd_fastrcnn_loss(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,
+                     float beta, float* part_ws, float* out2, void* stream);
+int hd_fastrcnn_loss_bwd(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,
+                         float beta, const float* g_cls, const float* g_box, float* d_logits, float* d_box_regression,
+                         void* stream);
 /* BalancedPositiveNegativeSampler [EXT] for N images (reached from src/utils/eval_forward_fasterrcnn.py:90,127): labels [N][A]
  * i64 (>= 1 positive, 0 negative, < 0 ignored), keys [N][A] i32 >= 0 = one random key per candidate.  Per image
  * num_pos = min(#pos, cap_pos), num_neg = min(#neg, batch_size - num_pos); pos_sel / neg_sel [N][A] u8 mark the num_pos /

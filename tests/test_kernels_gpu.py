@@ -731,3 +731,46 @@ def test_conv_small_channel_kernel_equals_igemm(dev, case):
     assert rstats.shape[0] == (N * Ho * Wo + 127) // 128          # the igemm family's 128-row tiles really ran
     assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
     assert torch.allclose(stats.sum(0), rstats.sum(0), rtol=2e-3, atol=2e-2)
+
+
+@pytest.mark.gpu
+def test_fused_detector_losses_equal_torch_ops(dev):
+    """hd_rpn_loss / hd_fastrcnn_loss (+ backward) against the torch-op forms they replace: loss values to fp32 summation
+    order, gradients element-wise."""
+    import torch.nn.functional as F
+    import hallucidet_amd.models.detection as D
+    torch.manual_seed(8)
+    T = 30000
+    obj = (torch.randn(T, 1, device=dev) * 3).requires_grad_()
+    dl = (torch.randn(T, 4, device=dev) * 0.3).requires_grad_()
+    labels = (torch.rand(T, device=dev) < 0.3).float()
+    reg_t = torch.randn(T, 4, device=dev) * 0.3
+    samp = torch.rand(T, device=dev) < 0.05
+    pos = samp & (labels > 0)
+    for n_s in (torch.tensor(int(samp.sum()), device=dev), int(samp.sum()), 0):
+        st = dict(labels=labels, reg_t=reg_t, pos_f=pos, samp_f=samp, n_sampled=n_s)
+        lo, lb = D.rpn_loss_from_samples(st, obj, dl)
+        go, gd = torch.autograd.grad(lo * 0.7 + lb * 1.3, (obj, dl))
+        l1 = F.smooth_l1_loss(dl, torch.where(pos[:, None], reg_t, dl.detach()), beta=1 / 9, reduction="none").sum(dim=1)
+        denom = n_s.clamp(min=1) if torch.is_tensor(n_s) else max(n_s, 1)
+        rb = torch.where(pos, l1, torch.zeros_like(l1)).sum() / denom
+        bce = F.binary_cross_entropy_with_logits(obj.flatten(), labels, reduction="none")
+        ro = torch.where(samp, bce, torch.zeros_like(bce)).sum() / denom
+        rgo, rgd = torch.autograd.grad(ro * 0.7 + rb * 1.3, (obj, dl))
+        assert torch.allclose(lo, ro, rtol=2e-6, atol=1e-7) and torch.allclose(lb, rb, rtol=2e-6, atol=1e-7)
+        assert torch.allclose(go, rgo, rtol=1e-5, atol=1e-9) and torch.allclose(gd, rgd, rtol=1e-5, atol=1e-9)
+    R, K = 3000, 2
+    lg = (torch.randn(R, K, device=dev) * 2).requires_grad_()
+    br = (torch.randn(R, K * 4, device=dev) * 0.3).requires_grad_()
+    lab = (torch.rand(R, device=dev) < 0.25).long()
+    rt = torch.randn(R, 4, device=dev) * 0.3
+    lc, lbx = D.fastrcnn_loss_flat(lg, br, lab, rt)
+    g1 = torch.autograd.grad(lc * 0.4 + lbx * 1.1, (lg, br))
+    rc = F.cross_entropy(lg, lab)
+    brr = br.reshape(R, K, 4)
+    picked = torch.gather(brr, 1, lab.clamp(min=0)[:, None, None].expand(-1, 1, 4)).squeeze(1)
+    l1 = F.smooth_l1_loss(picked, torch.where((lab > 0)[:, None], rt, picked.detach()), beta=1 / 9, reduction="none").sum(dim=1)
+    rbx = torch.where(lab > 0, l1, torch.zeros_like(l1)).sum() / R
+    g2 = torch.autograd.grad(rc * 0.4 + rbx * 1.1, (lg, br))
+    assert torch.allclose(lc, rc, rtol=2e-6, atol=1e-7) and torch.allclose(lbx, rbx, rtol=2e-6, atol=1e-7)
+    assert torch.allclose(g1[0], g2[0], rtol=1e-5, atol=1e-9) and torch.allclose(g1[1], g2[1], rtol=1e-5, atol=1e-9)
