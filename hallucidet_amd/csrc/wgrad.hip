@@ -11,6 +11,8 @@
 // The pixel range is split over gridDim.z; each slice writes its fp32 partial tile to
 // a slab and hd_wgrad_reduce sums the slices in a fixed order (deterministic, no
 // float atomics) while converting to the OIHW fp32 layout of the master gradient.
+#include <stdlib.h>
+
 #include "hd_common.h"
 
 namespace {
@@ -419,11 +421,24 @@ extern "C" int hd_wgrad_tune_override(int tm) {
   return HD_OK;
 }
 
+// wgrad3x3_small.hip: 3x3 / s1 / p1, Cin in {16,32}, Cout <= 32 (HD_WGRAD_SMALL=0 or a tile override keeps the general kernel)
+bool hd_wgrad_small_eligible(const hd_wgrad_args* a);
+void hd_wgrad_small_launch(const hd_wgrad_args* a, hipStream_t s);
+
 extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   HD_CHECK_ARG(a && a->x && a->dy && a->slab, "hd_wgrad: null pointer");
   HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->Cout % 8 == 0, "hd_wgrad: channels must be multiples of 8");
   HD_CHECK_ARG((a->C2 == 0) == (a->x2 == nullptr), "hd_wgrad: x2/C2 mismatch");
   HD_CHECK_ARG(a->nsplit >= 1, "hd_wgrad: nsplit");
+  {
+    static const char* env = getenv("HD_WGRAD_SMALL");
+    static const bool small_on = !(env && env[0] == '0');
+    if (small_on && g_wg_tm < 0 && hd_wgrad_small_eligible(a)) {
+      hd_wgrad_small_launch(a, (hipStream_t)stream);
+      HD_CHECK_LAUNCH();
+      return HD_OK;
+    }
+  }
   WgP p;
   p.x = (const f16*)a->x; p.x2 = (const f16*)a->x2; p.dy = (const f16*)a->dy; p.slab = a->slab;
   p.N = a->N; p.Hsrc = a->Hsrc; p.Wsrc = a->Wsrc; p.Hin = a->Hin; p.Win = a->Win; p.C1 = a->C1; p.C2 = a->C2;

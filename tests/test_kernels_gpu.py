@@ -176,6 +176,12 @@ WGRAD_CASES = [
     (2, 15, 15, 64, 0, 128, 1, 2, 0, False, 2),
     (2, 9, 9, 16, 0, 8, 3, 1, 1, False, 2),
     (2, 8, 8, 512, 0, 512, 3, 1, 1, False, 2),
+    # small-channel 3x3 layers: wgrad3x3_small.hip (also the (16 -> 16) and (16 -> 8) cases above)
+    (2, 24, 70, 16, 0, 16, 3, 1, 1, False, 7),      # more tiles than blocks, ragged tiles
+    (1, 17, 40, 32, 0, 32, 3, 1, 1, False, 3),      # two cout tiles x two cin tiles
+    (2, 8, 10, 32, 0, 16, 3, 1, 1, True, 2),        # nearest-2x upsampled source
+    (1, 9, 33, 16, 0, 32, 3, 1, 1, False, 50),      # more blocks than tiles (empty partials)
+    (3, 16, 64, 32, 0, 24, 3, 1, 1, False, 4),      # Cout not a multiple of 16
 ]
 
 
