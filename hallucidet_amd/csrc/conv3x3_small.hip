@@ -3,8 +3,9 @@
 //
 // Why a separate kernel: in the implicit-GEMM family these layers run at ~4x their HBM time (16->16 @512x640: 108 us for
 // 168 MB): a pixel is 32 bytes, the fill moves it as 16-byte pieces, 18 per pixel (9 taps x 2 chunks), and the 32-wide
-// MFMA tile is half empty.  Here a block stages the (8+2)x(32+2) input patch of its 8x32 output tile ONCE (16-byte
-// loads, each input byte read ~1.3x), keeps the whole weight matrix in LDS, and uses v_mfma_f32_16x16x32_f16 with the
+// MFMA tile is half empty.  Here a block walks 8x32 output tiles, stages each tile's (8+2)x(32+2) input patch ONCE (16-byte
+// loads, each input byte read ~1.3x; the next tile's patch is prefetched into registers during the MFMAs), keeps the
+// whole weight matrix in LDS, and uses v_mfma_f32_16x16x32_f16 with the
 // WEIGHTS as the A operand: C[cout][pixel], so a lane ends up with 4 consecutive output channels of one pixel and a
 // wave-store writes 16 pixels x 32 bytes contiguously -- no transpose through LDS.
 //   K index k = tap*Cin + ci (the igemm weight layout); a 32-deep K step is 4 / 2 / 1 taps for Cin = 8 / 16 / 32; the K
@@ -35,140 +36,162 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-  int bid = blockIdx.x;
-  const int tx = bid % tiles_x;
-  bid /= tiles_x;
-  const int ty = bid % tiles_y;
-  const int n = bid / tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW;
+  const int tiles_total = p.N * tiles_x * tiles_y;
 
-  // ---- weights -> LDS, zero-padded K tail
+  // ---- weights -> LDS once per block, zero-padded K tail
   for (int e = tid; e < COUT * KPAD / 8; e += 256) {
     const int co = e / (KPAD / 8), k8 = (e - co * (KPAD / 8)) * 8;
     f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (k8 < KTOT && co < p.Cout) v = *reinterpret_cast<const f16x8*>(p.w + (size_t)co * KTOT + k8);     // KTOT % 8 == 0
     *reinterpret_cast<f16x8*>(s_w + co * KPAD + k8) = v;
   }
-  // ---- input patch -> LDS (zeros outside the image; up1: nearest-2x upsampled source)
-  {
-    constexpr int C8 = CIN / 8;
+  // ---- software pipeline over the block's tiles: the next input patch is in flight while this one is multiplied
+  constexpr int C8 = CIN / 8;
+  constexpr int XL = (PH * PW * C8 + 255) / 256;
+  f16x8 rx[XL];
+  auto gload = [&](int tile) {
+    const bool live = tile < tiles_total;
+    int b = live ? tile : 0;
+    const int tx = b % tiles_x;
+    b /= tiles_x;
+    const int ty = b % tiles_y;
+    const int n = b / tiles_y;
     const f16* xb = p.x + (size_t)n * p.Hsrc * p.Wsrc * CIN;
-    for (int e = tid; e < PH * PW * C8; e += 256) {
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int e = tid + i * 256;
       const int c8 = e % C8, pp = e / C8;
       const int py = pp / PW, px = pp - py * PW;
-      const int hi = y0 + py - 1, wi = x0 + px - 1;
+      const int hi = ty * TH + py - 1, wi = tx * TW + px - 1;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-      if ((unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) {
+      if (live && e < PH * PW * C8 && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) {
         const int hs = p.up1 ? (hi >> 1) : hi, ws = p.up1 ? (wi >> 1) : wi;
         v = *reinterpret_cast<const f16x8*>(xb + ((size_t)hs * p.Wsrc + ws) * CIN + c8 * 8);
       }
-      *reinterpret_cast<f16x8*>(s_patch + pp * CIN + c8 * 8) = v;
+      rx[i] = v;
     }
-  }
-  __syncthreads();
-
-  // ---- MFMA: wave w owns output rows 2w, 2w+1 (4 pixel tiles of 16)
+  };
   const int pl = lane & 15, g = lane >> 4;    // pixel (B column) / cout (A row) index, K group
-  f32x4_t acc[4][MT];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int m = 0; m < MT; ++m) acc[t][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int ks = 0; ks < KSTEPS; ++ks) {
-    int tap = ks * TPS + (g * 8) / CIN;       // this lane's 8 K values: one tap, channels ci0..ci0+7
-    const int ci0 = (g * 8) % CIN;
-    if (tap > 8) tap = 8;                      // K tail: zero weights; read something valid
-    const int kh = tap / 3, kw = tap - kh * 3;
-    f16x8 af[MT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const f16x8*>(s_w + (m * 16 + pl) * KPAD + ks * 32 + g * 8);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int oy = wave * 2 + (t >> 1), ox = (t & 1) * 16 + pl;
-      const f16x8 bf = *reinterpret_cast<const f16x8*>(s_patch + ((oy + kh) * PW + ox + kw) * CIN + ci0);
-#pragma unroll
-      for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[t][m], 0, 0, 0);
-    }
-  }
 
-  // ---- epilogue: lane holds couts m*16 + g*4 .. +3 of pixel (oy, ox)
-  if (p.out_mode == HD_OUT_NCHW_F32) {
-    // segmentation head (base/heads.py:23-27): Cout <= 16 real channels, bias, activation, fp32 planes; 16 consecutive
-    // pixels of a plane per store
-    float* yf = reinterpret_cast<float*>(p.y) + (size_t)n * p.Cout * p.Ho * p.Wo;
+  gload(blockIdx.x);
+  for (int tile = blockIdx.x; tile < tiles_total; tile += gridDim.x) {
+    int bid = tile;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int n = bid / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    __syncthreads();                          // the previous tile's reads of s_patch / s_red are done (first pass: s_w is written)
+#pragma unroll
+    for (int i = 0; i < XL; ++i) {
+      const int e = tid + i * 256;
+      if (e < PH * PW * C8) *reinterpret_cast<f16x8*>(s_patch + (e / C8) * CIN + (e % C8) * 8) = rx[i];
+    }
+    __syncthreads();
+    gload(tile + gridDim.x);
+
+    // ---- MFMA: wave w owns output rows 2w, 2w+1 (4 pixel tiles of 16)
+    f32x4_t acc[4][MT];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int m = 0; m < MT; ++m) acc[t][m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      int tap = ks * TPS + (g * 8) / CIN;       // this lane's 8 K values: one tap, channels ci0..ci0+7
+      const int ci0 = (g * 8) % CIN;
+      if (tap > 8) tap = 8;                      // K tail: zero weights; read something valid
+      const int kh = tap / 3, kw = tap - kh * 3;
+      f16x8 af[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) af[m] = *reinterpret_cast<const f16x8*>(s_w + (m * 16 + pl) * KPAD + ks * 32 + g * 8);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int oy = wave * 2 + (t >> 1), ox = (t & 1) * 16 + pl;
+        const f16x8 bf = *reinterpret_cast<const f16x8*>(s_patch + ((oy + kh) * PW + ox + kw) * CIN + ci0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[m], bf, acc[t][m], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: lane holds couts m*16 + g*4 .. +3 of pixel (oy, ox)
+    if (p.out_mode == HD_OUT_NCHW_F32) {
+      // segmentation head (base/heads.py:23-27): Cout <= 16 real channels, bias, activation, fp32 planes; 16 consecutive
+      // pixels of a plane per store
+      float* yf = reinterpret_cast<float*>(p.y) + (size_t)n * p.Cout * p.Ho * p.Wo;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int oy = y0 + wave * 2 + (t >> 1), ox = x0 + (t & 1) * 16 + pl;
+        if (oy < p.Ho && ox < p.Wo) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = g * 4 + r;
+            if (co < p.Cout) {
+              float v = acc[t][0][r] + (p.bias ? p.bias[co] : 0.f);
+              if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
+              else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+              yf[((size_t)co * p.Ho + oy) * p.Wo + ox] = v;
+            }
+          }
+        }
+      }
+      continue;
+    }
+    f16* yb = reinterpret_cast<f16*>(p.y) + (size_t)n * p.Ho * p.Wo * COUT;
+    float ssum[MT][4], ssq[MT][4];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int oy = y0 + wave * 2 + (t >> 1), ox = x0 + (t & 1) * 16 + pl;
       if (oy < p.Ho && ox < p.Wo) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = g * 4 + r;
-          if (co < p.Cout) {
-            float v = acc[t][0][r] + (p.bias ? p.bias[co] : 0.f);
-            if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-            yf[((size_t)co * p.Ho + oy) * p.Wo + ox] = v;
+        for (int m = 0; m < MT; ++m) {
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = (f16)acc[t][m][r];
+            const float vr = (float)o[r];
+            ssum[m][r] += vr;
+            ssq[m][r] += vr * vr;
           }
+          *reinterpret_cast<f16x4*>(yb + ((size_t)oy * p.Wo + ox) * COUT + m * 16 + g * 4) = o;
         }
       }
     }
-    return;
-  }
-  f16* yb = reinterpret_cast<f16*>(p.y) + (size_t)n * p.Ho * p.Wo * COUT;
-  float ssum[MT][4], ssq[MT][4];
+    if (p.stats) {
+      // the 16 lanes of a K group hold the same couts for 16 different pixels: fold them, then the 4 waves through LDS
 #pragma unroll
-  for (int m = 0; m < MT; ++m)
+      for (int d = 1; d < 16; d <<= 1)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) ssum[m][r] = ssq[m][r] = 0.f;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int oy = y0 + wave * 2 + (t >> 1), ox = x0 + (t & 1) * 16 + pl;
-    if (oy < p.Ho && ox < p.Wo) {
+          for (int r = 0; r < 4; ++r) {
+            ssum[m][r] += __shfl_xor(ssum[m][r], d);
+            ssq[m][r] += __shfl_xor(ssq[m][r], d);
+          }
+      if (pl == 0) {
 #pragma unroll
-      for (int m = 0; m < MT; ++m) {
-        f16x4 o;
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          o[r] = (f16)acc[t][m][r];
-          const float vr = (float)o[r];
-          ssum[m][r] += vr;
-          ssq[m][r] += vr * vr;
-        }
-        *reinterpret_cast<f16x4*>(yb + ((size_t)oy * p.Wo + ox) * COUT + m * 16 + g * 4) = o;
+          for (int r = 0; r < 4; ++r) {
+            s_red[wave][m * 16 + g * 4 + r][0] = ssum[m][r];
+            s_red[wave][m * 16 + g * 4 + r][1] = ssq[m][r];
+          }
       }
-    }
-  }
-  if (p.stats) {
-    // the 16 lanes of a K group hold the same couts for 16 different pixels: fold them, then the 4 waves through LDS
+      __syncthreads();
+      if (tid < COUT) {
+        float s = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int d = 1; d < 16; d <<= 1)
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          ssum[m][r] += __shfl_xor(ssum[m][r], d);
-          ssq[m][r] += __shfl_xor(ssq[m][r], d);
+        for (int w4 = 0; w4 < 4; ++w4) {
+          s += s_red[w4][tid][0];
+          s2 += s_red[w4][tid][1];
         }
-    if (pl == 0) {
-#pragma unroll
-      for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          s_red[wave][m * 16 + g * 4 + r][0] = ssum[m][r];
-          s_red[wave][m * 16 + g * 4 + r][1] = ssq[m][r];
-        }
-    }
-    __syncthreads();
-    if (tid < COUT) {
-      float s = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int w4 = 0; w4 < 4; ++w4) {
-        s += s_red[w4][tid][0];
-        s2 += s_red[w4][tid][1];
+        p.stats[((size_t)tile * 2 + 0) * COUT + tid] = s;
+        p.stats[((size_t)tile * 2 + 1) * COUT + tid] = s2;
       }
-      p.stats[((size_t)blockIdx.x * 2 + 0) * COUT + tid] = s;
-      p.stats[((size_t)blockIdx.x * 2 + 1) * COUT + tid] = s2;
     }
   }
 }
@@ -186,7 +209,9 @@ bool hd_conv_small_eligible(const ConvP& p) {
 int hd_conv_small_tiles(const ConvP& p) { return p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW); }
 
 void hd_conv_launch_small(ConvP& p, hipStream_t s) {
-  dim3 grid(hd_conv_small_tiles(p));
+  // persistent blocks: a few per CU, each walking tiles blockIdx.x, blockIdx.x + grid, ... (BN partial sums stay per TILE)
+  const int tiles = hd_conv_small_tiles(p);
+  dim3 grid(tiles < 1536 ? tiles : 1536);
 #define LAUNCH(CI, CO) hipLaunchKernelGGL((conv3x3_small_kernel<CI, CO>), grid, dim3(256), 0, s, p)
   if (p.C1 == 8) { if (p.Cout <= 16) LAUNCH(8, 16); else LAUNCH(8, 32); }
   else if (p.C1 == 16) { if (p.Cout <= 16) LAUNCH(16, 16); else LAUNCH(16, 32); }
