@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
   constexpr int KPAD = KSTEPS * 32;
   constexpr int MT = COUT / 16;               // 16-row (cout) tiles
   constexpr int TPS = 32 / CIN;               // taps per K step
-  __shared__ __attribute__((aligned(16))) f16 s_patch[PH * PW * CIN];
+  constexpr int PATCH_HALVES = PH * PW * CIN > 16 * TH * TW * 2 ? PH * PW * CIN : 16 * TH * TW * 2;   // also the head's fp32 [16][8][32] staging tile
+  __shared__ __attribute__((aligned(16))) f16 s_patch[PATCH_HALVES];
   __shared__ __attribute__((aligned(16))) f16 s_w[COUT * KPAD];
   __shared__ float s_red[4][COUT][2];
 
@@ -118,22 +119,29 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
     if (p.out_mode == HD_OUT_NCHW_F32) {
       // segmentation head (base/heads.py:23-27): Cout <= 16 real channels, bias, activation, fp32 planes; 16 consecutive
       // pixels of a plane per store
+      // (through LDS: a lane holds 4 channels of ONE pixel, a plane row wants 32 pixels of ONE channel per store)
       float* yf = reinterpret_cast<float*>(p.y) + (size_t)n * p.Cout * p.Ho * p.Wo;
+      float* s_out = reinterpret_cast<float*>(s_patch);      // [Cout <= 16][8][32] fp32 (s_patch is sized for it)
+      __syncthreads();                                       // every wave is done reading the patch
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int oy = y0 + wave * 2 + (t >> 1), ox = x0 + (t & 1) * 16 + pl;
-        if (oy < p.Ho && ox < p.Wo) {
+        const int oyl = wave * 2 + (t >> 1), oxl = (t & 1) * 16 + pl;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = g * 4 + r;
-            if (co < p.Cout) {
-              float v = acc[t][0][r] + (p.bias ? p.bias[co] : 0.f);
-              if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
-              else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
-              yf[((size_t)co * p.Ho + oy) * p.Wo + ox] = v;
-            }
+        for (int r = 0; r < 4; ++r) {
+          const int co = g * 4 + r;
+          if (co < p.Cout) {
+            float v = acc[t][0][r] + (p.bias ? p.bias[co] : 0.f);
+            if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
+            else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
+            s_out[(co * TH + oyl) * TW + oxl] = v;
           }
         }
+      }
+      __syncthreads();
+      {
+        const int oyl = tid / TW, oxl = tid - oyl * TW;
+        if (y0 + oyl < p.Ho && x0 + oxl < p.Wo)
+          for (int co = 0; co < p.Cout; ++co) yf[((size_t)co * p.Ho + y0 + oyl) * p.Wo + x0 + oxl] = s_out[(co * TH + oyl) * TW + oxl];
       }
       continue;
     }
