@@ -745,6 +745,42 @@ __global__ void box_iou_batched_kernel(const float* __restrict__ gt, int G, cons
 }
 
 
+// Radix-select step shared by the selection kernels: given the 256-bin histogram of the current digit, find the bin in which
+// the `remaining`-th element (counting from the largest bin when DESC, from the smallest otherwise) falls, and how many of
+// that bin's elements are still wanted.  Wave 0 does it with a lane-parallel prefix (4 bins per lane); the first version
+// walked the bins in one thread -- 256 dependent LDS reads per pass, 10 us per pass, most of these kernels' time.
+template <bool DESC>
+__device__ __forceinline__ void radix_find_digit(const int* hist, int remaining, uint32_t prefix, int shift, uint32_t* s_prefix,
+                                                 int* s_remaining) {
+  if (threadIdx.x >= 64) return;
+  const int l = threadIdx.x;
+  int h[4], tot = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = hist[DESC ? 255 - (4 * l + j) : 4 * l + j];
+    tot += h[j];
+  }
+  int incl = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(incl, d);
+    if (l >= d) incl += t;
+  }
+  const int excl = incl - tot;
+  const bool hit = excl < remaining && remaining <= incl;
+  const bool fallback = l == 63 && incl < remaining;          // cannot happen for consistent inputs; keeps the state defined
+  if (hit || fallback) {
+    int cum = excl, j = 0;
+    for (; j < 3; ++j) {
+      if (cum + h[j] >= remaining) break;
+      cum += h[j];
+    }
+    const int bin = DESC ? 255 - (4 * l + j) : 4 * l + j;
+    *s_prefix = prefix | ((uint32_t)bin << shift);
+    *s_remaining = remaining - cum;
+  }
+}
+
 // ---- per-row top-k by radix select + in-LDS sort -------------------------------------------------------------------------
 // out = the indices of the k largest scores of a row segment in DESCENDING score order, equal scores by ASCENDING index:
 // exactly what torch.sort(descending=True, stable=True)[1][:k] lists.  One 1024-thread block per (row, segment): 4 histogram
@@ -789,15 +825,7 @@ __global__ __launch_bounds__(1024) void topk_select_kernel(const float* __restri
         if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
       }
       __syncthreads();
-      if (tid == 0) {
-        int cum = 0, d = 255;
-        for (; d > 0; --d) {
-          if (cum + hist[d] >= remaining) break;
-          cum += hist[d];
-        }
-        s_prefix = prefix | ((uint32_t)d << shift);
-        s_remaining = remaining - cum;
-      }
+      radix_find_digit<true>(hist, remaining, prefix, shift, &s_prefix, &s_remaining);
       __syncthreads();
       prefix = s_prefix;
       remaining = s_remaining;
@@ -989,15 +1017,7 @@ __device__ __forceinline__ void select_smallest_marked(const int32_t* __restrict
       if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-      int cum = 0, d = 0;
-      for (; d < 255; ++d) {
-        if (cum + hist[d] >= remaining) break;
-        cum += hist[d];
-      }
-      *s_prefix = prefix | ((uint32_t)d << shift);
-      *s_remaining = remaining - cum;
-    }
+    radix_find_digit<false>(hist, remaining, prefix, shift, s_prefix, s_remaining);
     __syncthreads();
     prefix = *s_prefix;
     remaining = *s_remaining;

@@ -392,9 +392,20 @@ class UnetRunner:
         return out
 
     def _bump_batches_tracked(self):
-        for u in self.units:
-            if u.bn.num_batches_tracked is not None:
-                u.bn.num_batches_tracked += 1
+        """BatchNorm2d.num_batches_tracked += 1 for every unit: the counters are views of ONE int64 buffer (same keys and
+        values in state_dict), so a step bumps them with one launch instead of one per BatchNorm (47 launches of ~4 us)."""
+        bns = [u.bn for u in self.units if u.bn.num_batches_tracked is not None]
+        if not bns:
+            return
+        flat = getattr(self, "_nbt_flat", None)
+        dev = bns[0].num_batches_tracked.device
+        if flat is None or flat.device != dev or flat.numel() != len(bns) or any(
+                b.num_batches_tracked.data_ptr() != flat.data_ptr() + 8 * i for i, b in enumerate(bns)):
+            flat = torch.stack([b.num_batches_tracked.detach().reshape(()).to(torch.int64) for b in bns])
+            for i, b in enumerate(bns):
+                b._buffers["num_batches_tracked"] = flat[i]
+            self._nbt_flat = flat
+        flat += 1
 
     # ------------------------------------------------------------------ backward pieces
     def _unit_bwd(self, u, dz, S, *, want_dres=False, need_dx=True, dx_res=None):
