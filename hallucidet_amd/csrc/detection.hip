@@ -314,6 +314,39 @@ __global__ void roi_align_ml_kernel(MLFeat ml, const float* __restrict__ rois, c
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.f;
     const f16* fb = ml.f[l] + (size_t)n * H * W * C + v * 8;
+    if (sr == 2) {
+      // the detector's setting (MultiScaleRoIAlign(sampling_ratio=2)): all 16 taps of the 2x2 sample grid are requested
+      // before any is used -- the generic loop below waits for each sample's 4 loads in turn (4 dependent L2 round trips
+      // per output vector: the launch was latency-bound at 9x its output-write time).  Same accumulation order.
+      Bilin bs[4];
+      f16x8 t1[4], t2[4], t3[4], t4[4];
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        const int iy = sidx >> 1, ix = sidx & 1;
+        const float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / 2.f;
+        const float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / 2.f;
+        bs[sidx] = bilin_setup(y, x, H, W);
+        if (bs[sidx].valid) {
+          t1[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yl * W + bs[sidx].xl) * C);
+          t2[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yl * W + bs[sidx].xh) * C);
+          t3[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yh * W + bs[sidx].xl) * C);
+          t4[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yh * W + bs[sidx].xh) * C);
+        }
+      }
+#pragma unroll
+      for (int sidx = 0; sidx < 4; ++sidx) {
+        if (!bs[sidx].valid) continue;
+        const Bilin b = bs[sidx];
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          acc[k] += b.w1 * (float)t1[sidx][k] + b.w2 * (float)t2[sidx][k] + b.w3 * (float)t3[sidx][k] + b.w4 * (float)t4[sidx][k];
+      }
+      f16x8 o2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o2[k] = (f16)(acc[k] / count);
+      *reinterpret_cast<f16x8*>(out + (size_t)q * C + v * 8) = o2;
+      continue;
+    }
     for (int iy = 0; iy < gh; ++iy) {
       float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
       for (int ix = 0; ix < gw; ++ix) {
