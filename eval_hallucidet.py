@@ -27,6 +27,7 @@ def main(argv=None):
         load_detector(model.detector, args.detector_path)
     model.encoder_decoder.to(dev)
     model.detector.to(dev)
+    model.eval()            # Lightning's test loop: BatchNorm on the checkpoint's running statistics, detector in eval mode
     maps = Trainer(device=dev).test(model, dm)
     print_ap50(maps)
     return maps

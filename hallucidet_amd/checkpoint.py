@@ -36,8 +36,18 @@ def _load(module, sd, what, strict):
             raise KeyError(f"checkpoint holds no '{what}.*' entries")
         return
     own = module.state_dict()
+    if hasattr(module, "remap_state_dict_keys"):      # torchvision >= 0.13 names first, THEN the name / shape filter
+        sd = module.remap_state_dict_keys(sd)
     if not strict:
-        sd = OrderedDict((k, v) for k, v in sd.items() if k in own and tuple(own[k].shape) == tuple(v.shape))
+        kept = OrderedDict((k, v) for k, v in sd.items() if k in own and tuple(own[k].shape) == tuple(v.shape))
+        dropped = [k for k in sd if k not in kept]
+        missing = [k for k in own if k not in kept]
+        if dropped or missing:
+            import warnings
+            warnings.warn("%s: strict=False skipped %d checkpoint entries (%s%s) and left %d module entries unset (%s%s)" % (
+                what, len(dropped), ", ".join(dropped[:4]), " ..." if len(dropped) > 4 else "",
+                len(missing), ", ".join(missing[:4]), " ..." if len(missing) > 4 else ""))
+        sd = kept
     module.load_state_dict(sd, strict=strict)
 
 

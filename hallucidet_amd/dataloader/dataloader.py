@@ -11,8 +11,13 @@ MI355X-first differences (values identical, traffic not):
   * the next batch's copy runs on a side stream while the current step computes.
 Host-side python: `PIL` decodes (imageio / cv2 / albumentations are not installed offline); a `data_augmentation`
 callable with the albumentations call signature is accepted and applied exactly where the reference applies it
-(dataloaderPL.py:21-88), `None` skips it.  KAIST index lists are dataset curation data of the reference and are not
-reproduced: dataset='kaist' raises.
+(dataloaderPL.py:21-88), `None` skips it.  KAIST (dataloader.py:102-113,210-217): frame lists come from the dataset's own
+`{train,test}-all-20-{rgb,ir}.txt`; the reference hard-codes the 1 300 training positions whose annotation is non-empty
+("clean empty bbox from annotation") -- here that set is COMPUTED from the annotations by the same criterion (or read from
+`<root>/train-indices.txt` when the user supplies one), not stored in the source.
+
+Data parallelism: every rank builds the SAME train / validation split (one seed) and reads the rank-th interleaved shard of
+each epoch's permutation (`ShardedBatchSampler`), so an epoch is one pass over the training set across all ranks.
 """
 import glob
 import os
@@ -26,6 +31,8 @@ from PIL import Image
 
 # ------------------------------------------------------------------------------------------------ annotations
 def _annotation_path(filename, dataset):
+    if dataset == 'kaist':       # utils.py:350-351: the xml sits next to the frame
+        return filename
     if dataset == 'llvip':       # utils.py:353: <root>/LLVIP/Annotations/<stem>.xml, whatever split folder the image is in
         return os.path.join(filename[:filename.index('LLVIP')], 'LLVIP', 'Annotations', filename.split('/')[-1])
     if dataset == 'flir':        # utils.py:356-357
@@ -40,7 +47,12 @@ def get_bbox(filename, dataset='llvip', train=False):
     bboxes, labels = [], []
     for obj in root.findall("object"):
         bb = obj.find("bndbox")
-        b = [int(bb.find(k).text) for k in ("xmin", "ymin", "xmax", "ymax")]
+        if dataset == 'kaist':   # utils.py:366,387-389: x, y, w, h
+            b = [int(bb.find(k).text) for k in ("x", "y", "w", "h")]
+            b[2] += b[0]
+            b[3] += b[1]
+        else:
+            b = [int(bb.find(k).text) for k in ("xmin", "ymin", "xmax", "ymax")]
         xmin, ymin, xmax, ymax = min(b[0], b[2]), min(b[1], b[3]), max(b[0], b[2]), max(b[1], b[3])
         box = [xmin, ymin, xmax, ymax]
         area = abs(xmax - xmin) * abs(ymax - ymin)
@@ -85,8 +97,20 @@ class SingleModalDetectionDataset(torch.utils.data.Dataset):
             names = sorted(open_txt_file(Path(path_images + '/' + ('align_train.txt' if train else 'align_validation.txt')), path_images))
             self.list_names = [os.path.join(path_images, 'JPEGImages', x.split(path_images)[-1] if modality == 'infrared'
                                             else x.split(path_images)[-1].split('PreviewData')[0] + 'RGB') for x in names]
+        elif dataset == 'kaist':
+            which = 'rgb' if modality in ('rgb', 'both') else 'ir'
+            self.list_names = sorted(open_txt_file(Path(path_images + '/' + ('train' if train else 'test') + '-all-20-%s.txt' % which), path_images))
+            if train:
+                self.indices = self._kaist_nonempty(path_images)
         else:
-            raise NotImplementedError("hallucidet_amd: dataset %r (the KAIST frame lists are curation data of the reference)" % (dataset,))
+            raise Exception("Dataset not supported")
+
+    def _kaist_nonempty(self, root):
+        """Training positions with at least one kept `person` box (the criterion behind dataloader.py:106)."""
+        f = os.path.join(root, 'train-indices.txt')
+        if os.path.exists(f):
+            return [int(t) for t in open(f).read().replace(',', ' ').split()]
+        return [i for i, n in enumerate(self.list_names) if len(get_bbox(n + ".xml", 'kaist', True)["bboxes"]) > 0]
 
     def __len__(self):
         return len(self.indices) if self.indices is not None else len(self.list_names)
@@ -115,6 +139,8 @@ class MultiModalDetectionDataset(SingleModalDetectionDataset):
         self.list_names_rgb = self.list_names
         if dataset == 'llvip':
             self.list_names_ir = [x.split('.jpg')[0] for x in sorted(glob.glob(os.path.join(self.path_images, 'infrared', 'train' if train else 'test', '*.jpg')))]
+        elif dataset == 'kaist':
+            self.list_names_ir = sorted(open_txt_file(Path(path_images_ir + '/' + ('train' if train else 'test') + '-all-20-ir.txt'), path_images_ir))
         else:   # flir
             names = sorted(open_txt_file(Path(self.path_images + '/' + ('align_train.txt' if train else 'align_validation.txt')), self.path_images))
             self.list_names_ir = [os.path.join(self.path_images, 'JPEGImages', x.split(self.path_images)[-1]) for x in names]
@@ -164,22 +190,50 @@ class DatasetTransform(torch.utils.data.Dataset):
 
 
 # ------------------------------------------------------------------------------------------------ data modules
-def _loader(ds, batch_size, shuffle, num_workers, seed):
-    kw = dict(batch_size=batch_size, shuffle=shuffle, collate_fn=collate_fn, drop_last=True, num_workers=num_workers,
-              pin_memory=torch.cuda.is_available())
+class ShardedBatchSampler(torch.utils.data.Sampler):
+    """Per-rank batches of a data-parallel epoch: ONE permutation per epoch (seed + epoch, identical on every rank), cut to a
+    multiple of world * batch (drop_last, dataloaderPL.py:207-216), rank r takes positions r, r+world, ...  World size 1
+    degenerates to a shuffled, drop_last loader."""
+
+    def __init__(self, n, batch_size, rank=0, world_size=1, shuffle=True, seed=123):
+        self.n, self.batch_size, self.rank, self.world, self.shuffle, self.seed = n, batch_size, rank, world_size, shuffle, seed
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+    def __len__(self):
+        return self.n // (self.world * self.batch_size)
+
+    def __iter__(self):
+        if self.shuffle:
+            order = torch.randperm(self.n, generator=torch.Generator().manual_seed(self.seed + self.epoch)).tolist()
+        else:
+            order = list(range(self.n))
+        self.epoch += 1
+        per = len(self) * self.batch_size
+        mine = order[self.rank:per * self.world:self.world]
+        for b in range(len(self)):
+            yield mine[b * self.batch_size:(b + 1) * self.batch_size]
+
+
+def _loader(ds, batch_size, shuffle, num_workers, seed, rank=0, world_size=1):
+    kw = dict(collate_fn=collate_fn, num_workers=num_workers, pin_memory=torch.cuda.is_available())
     if num_workers > 0:
         kw["persistent_workers"] = True
     if shuffle:
-        kw["generator"] = torch.Generator().manual_seed(seed)
+        kw["batch_sampler"] = ShardedBatchSampler(len(ds), batch_size, rank, world_size, True, seed)
+    else:
+        kw.update(batch_size=batch_size, shuffle=False, drop_last=True)
     return torch.utils.data.DataLoader(ds, **kw)
 
 
 class SingleModalDataModule:
     def __init__(self, dataset, path_images_train, path_images_test, batch_size=4, num_workers=4, ext='.png', seed=123,
-                 split_ratio_train_valid=0.8, modality='rgb', data_augmentation=None, fixed_transformations=None):
+                 split_ratio_train_valid=0.8, modality='rgb', data_augmentation=None, fixed_transformations=None, rank=0, world_size=1):
         tr = SingleModalDetectionDataset(dataset, path_images_train, modality=modality, transforms=None, ext=ext, train=True)
         tr, va = split_dataset(tr, split_ratio=split_ratio_train_valid, seed=seed)
-        self._train = _loader(DatasetTransform(tr, data_augmentation, 'single'), batch_size, True, num_workers, seed)
+        self._train = _loader(DatasetTransform(tr, data_augmentation, 'single'), batch_size, True, num_workers, seed, rank, world_size)
         self._valid = _loader(DatasetTransform(va, fixed_transformations, 'single'), batch_size, False, num_workers, seed)
         self._test = _loader(SingleModalDetectionDataset(dataset, path_images_test, modality=modality, ext=ext, train=False), batch_size, False, num_workers, seed)
 
@@ -196,10 +250,10 @@ class SingleModalDataModule:
 class MultiModalDataModule:
     def __init__(self, dataset, path_images_train_rgb, path_images_train_ir, path_images_test_rgb, path_images_test_ir, batch_size=4,
                  num_workers=4, ext='.png', seed=123, split_ratio_train_valid=0.8, data_augmentation=None, fixed_transformations=None,
-                 ablation_flag=False):
+                 ablation_flag=False, rank=0, world_size=1):
         tr = MultiModalDetectionDataset(dataset, path_images_train_rgb, path_images_train_ir, modality="both", ext=ext, train=True)
         tr, va = split_dataset(tr, split_ratio=split_ratio_train_valid, seed=seed)
-        self._train = _loader(DatasetTransform(tr, data_augmentation, 'multimodal'), batch_size, True, num_workers, seed)
+        self._train = _loader(DatasetTransform(tr, data_augmentation, 'multimodal'), batch_size, True, num_workers, seed, rank, world_size)
         self._valid = _loader(DatasetTransform(va, fixed_transformations, 'multimodal'), batch_size, False, num_workers, seed)
         self._test = _loader(MultiModalDetectionDataset(dataset, path_images_test_rgb, path_images_test_ir, modality="both", ext=ext, train=False),
                              batch_size, False, num_workers, seed)

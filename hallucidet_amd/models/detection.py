@@ -1099,16 +1099,21 @@ class FasterRCNN(nn.Module):
     def trainable_parameters(self):
         return [p for p in self.parameters() if p.requires_grad]
 
-    def load_state_dict(self, state_dict, strict=True):
+    @staticmethod
+    def remap_state_dict_keys(state_dict):
+        """torchvision >= 0.13 key names -> the 0.12 names this module (and the reference's checkpoints) use."""
         sd = OrderedDict()
         for k, v in state_dict.items():
-            # torchvision >= 0.13 renames
             for i in range(4):
                 k = k.replace("fpn.inner_blocks.%d.0." % i, "fpn.inner_blocks.%d." % i).replace("fpn.layer_blocks.%d.0." % i, "fpn.layer_blocks.%d." % i)
             k = k.replace("rpn.head.conv.0.0.", "rpn.head.conv.")
             if k.endswith("num_batches_tracked"):
                 continue
             sd[k] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = self.remap_state_dict_keys(state_dict)
         out = super().load_state_dict(sd, strict=strict)
         self.invalidate_packs()
         return out

@@ -197,7 +197,9 @@ class RetinaNet(nn.Module):
     def trainable_parameters(self):
         return [p for p in self.parameters() if p.requires_grad]
 
-    def load_state_dict(self, state_dict, strict=True):
+    @staticmethod
+    def remap_state_dict_keys(state_dict):
+        """torchvision >= 0.13 key names -> the 0.12 names this module (and the reference's checkpoints) use."""
         sd = OrderedDict()
         for k, v in state_dict.items():
             for i in range(3):                       # torchvision >= 0.13 wraps the FPN convs in Conv2dNormActivation
@@ -207,6 +209,10 @@ class RetinaNet(nn.Module):
             if k.endswith("num_batches_tracked"):
                 continue
             sd[k] = v
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = self.remap_state_dict_keys(state_dict)
         out = super().load_state_dict(sd, strict=strict)
         self.invalidate_packs()
         return out

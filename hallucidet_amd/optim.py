@@ -62,7 +62,13 @@ class FusedAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = 0
+        self.skipped_steps = 0
         self.found_inf = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        # the skip decision is made on the device (hd_adam_step returns early when found_inf is set); the host learns of it
+        # through this pinned word, copied behind the optimizer kernel and read at the next step's first host wait
+        self._inf_host = torch.zeros(1, dtype=torch.float32).pin_memory() if flat.is_cuda else torch.zeros(1)
+        self._inf_event = torch.cuda.Event() if flat.is_cuda else None
+        self._inf_pending = False
 
     def zero_grad(self, set_to_none=False):
         # gradients are overwritten (not accumulated) by every backward pass; nothing to do, and the views must stay
@@ -80,6 +86,26 @@ class FusedAdam(torch.optim.Optimizer):
         ops.adam_step(r.flat_params, r.flat_grads, self.exp_avg, self.exp_avg_sq, lr=g["lr"], beta1=g["betas"][0],
                       beta2=g["betas"][1], eps=g["eps"], weight_decay=g["weight_decay"], clip_value=g["clip_value"],
                       inv_scale=inv_scale, step=self.step_count, found_inf=self.found_inf if check_inf else None)
+        if check_inf:
+            self._inf_host.copy_(self.found_inf, non_blocking=True)
+            if self._inf_event is not None:
+                self._inf_event.record()
+            self._inf_pending = True
+
+    def resolve_found_inf(self):
+        """-> True if the LAST `step(check_inf=True)` was skipped on the device (non-finite gradient).  Waits only for that
+        step's own kernels (an event behind the pinned copy), which have long finished by the time the next step asks.  A
+        skipped step does not count: `step_count` (Adam's bias correction) is rolled back, as torch.optim.Adam never sees it."""
+        if not self._inf_pending:
+            return False
+        if self._inf_event is not None:
+            self._inf_event.synchronize()
+        self._inf_pending = False
+        bad = bool(self._inf_host.item() != 0.0)
+        if bad:
+            self.step_count -= 1
+            self.skipped_steps += 1
+        return bad
 
 
 class LossScaler:
@@ -89,21 +115,46 @@ class LossScaler:
         self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
         self.enabled = enabled
         self._good = 0
+        self._optimizer = None
+        self._update_due = False
 
     def scale(self, loss):
+        self.resolve()                      # GradScaler order: the scale of step t+1 reflects step t's overflow check
         self.runner.grad_scale = self.scale_value
         return loss * self.scale_value
 
     def step(self, optimizer):
         """Parameter gradients were already divided by the scale in-kernel; only inf/nan detection remains."""
+        self.resolve()
+        self._optimizer = optimizer
         optimizer.step(check_inf=self.enabled)
         return optimizer.found_inf
 
     def update(self, found_inf_host=None):
-        """`found_inf_host`: python bool if the caller already synchronised, else the device flag is read (one sync)."""
+        """GradScaler.update().  With `found_inf_host` (python bool: the caller already knows) the policy is applied now;
+        otherwise it is applied by `resolve()` -- called from the next `scale()` / `step()` -- which reads the device flag of
+        the step just issued WITHOUT a new host synchronisation point in this step."""
         if not self.enabled:
             return
-        bad = bool(found_inf_host) if found_inf_host is not None else False
+        if found_inf_host is None:
+            self._update_due = True
+            return
+        if self._optimizer is not None:
+            self._optimizer.resolve_found_inf()
+        self._update_due = False
+        self._apply(bool(found_inf_host))
+
+    def resolve(self):
+        """Apply the pending update() (if any) from the optimizer's device flag; -> whether that step was skipped."""
+        if self._optimizer is None:
+            return False
+        bad = self._optimizer.resolve_found_inf()
+        if self._update_due:
+            self._update_due = False
+            self._apply(bad)
+        return bad
+
+    def _apply(self, bad):
         if bad:
             self.scale_value *= self.backoff_factor
             self._good = 0

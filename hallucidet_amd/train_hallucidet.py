@@ -170,7 +170,15 @@ class EncoderDecoderLit(nn.Module):
     def configure_optimizers(self):
         self.encoder_decoder.to(self.dev)
         self.optimizer = Config.config_optimizer(self.encoder_decoder, learning_rate=self.lr, name=self.optimizer_name)
-        self.scaler = LossScaler(self.encoder_decoder, enabled=(self.precision == 16))
+        # Every conv / GEMM of this build stores fp16 (BASELINE configs[1] "fp16"); there is no fp32 trunk, so the loss is
+        # scaled whatever `--precision` says: with the reference's default `--precision 32` and scale 1.0 the detector-loss
+        # gradients underflow through RoIAlign / FPN / the decoder.  GradScaler policy either way.
+        if self.precision != 16 and not getattr(EncoderDecoderLit, "_warned_precision", False):
+            EncoderDecoderLit._warned_precision = True
+            import warnings
+            warnings.warn("hallucidet_amd computes in fp16 storage / fp32 accumulation regardless of --precision=%s; "
+                          "dynamic loss scaling stays enabled" % self.precision)
+        self.scaler = LossScaler(self.encoder_decoder, enabled=True)
         # train_hallucidet.py:436-444: ReduceLROnPlateau(optimizer, mode='min') monitored on val_loss (torch defaults:
         # factor 0.1, patience 10); the fused optimizer reads param_groups[0]['lr'] at every step
         self.lr_scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='min')
@@ -191,6 +199,11 @@ class EncoderDecoderLit(nn.Module):
         bufs = [b for b in self.encoder_decoder.buffers() if b.dtype.is_floating_point]
         broadcast_parameters(r.flat_params, bufs)
         return self
+
+    def eval(self):
+        """Lightning runs validation / test under `model.eval()`: U-Net BatchNorm on running statistics (and no buffer
+        updates), detector in eval mode."""
+        return super().eval()
 
     def fit_step(self, batch, batch_idx=0):
         """What Lightning does around training_step: scale -> backward -> all-reduce -> (unscale+clip+Adam fused)."""

@@ -42,14 +42,51 @@ class Trainer:
                 out[k] = float(v)
         return out
 
+    @staticmethod
+    def _modules(model):
+        return [m for m in (getattr(model, "encoder_decoder", None), getattr(model, "detector", None)) if m is not None]
+
+    def _set_eval(self, model):
+        """Lightning runs the validation / test loops under `model.eval()` + no_grad and restores the previous modes: BatchNorm
+        uses (and does not update) its running statistics, the detector runs its eval-mode RPN (1000/1000) and transform."""
+        mods = self._modules(model)
+        was = [m.training for m in mods]
+        for m in mods:
+            m.eval()
+        return list(zip(mods, was))
+
+    @staticmethod
+    def _restore(state):
+        for m, was in state:
+            m.train(was)
+
+    @staticmethod
+    def _mean_over_ranks(value, count):
+        """Every rank must take the same LR-schedule / early-stop / best-checkpoint decisions: average the monitored scalars."""
+        from .distributed import is_dist
+        if not is_dist():
+            return value / max(count, 1)
+        import torch.distributed as dist
+        t = torch.tensor([float(value), float(count)], dtype=torch.float64,
+                         device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        return float(t[0]) / max(float(t[1]), 1.0)
+
     def validate(self, model, loader):
-        tot, n = 0.0, 0
-        for i, batch in enumerate(DevicePrefetcher(loader, self.device)):
-            r = model.validation_step(batch, i)
-            tot += float(r[0] if isinstance(r, tuple) else r)
-            n += 1
-        m = self._flat(model.on_validation_epoch_end())
-        m["val_loss"] = tot / max(n, 1)
+        state = self._set_eval(model)
+        try:
+            tot, n = 0.0, 0
+            for i, batch in enumerate(DevicePrefetcher(loader, self.device)):
+                r = model.validation_step(batch, i)
+                tot += float(r[0] if isinstance(r, tuple) else r)
+                n += 1
+            m = self._flat(model.on_validation_epoch_end())
+        finally:
+            self._restore(state)
+        m["val_loss"] = self._mean_over_ranks(tot, n)
+        for k in list(m):
+            if k != "val_loss" and not math.isnan(m[k]):
+                m[k] = self._mean_over_ranks(m[k], 1)
         # Lightning logs `val_map` = the hallucinated stream's mAP (train_hallucidet.py:357) / the detector's mAP
         m["val_map"] = m.get("map_hall/map", m.get("map", float("nan")))
         return m
@@ -85,7 +122,8 @@ class Trainer:
                     model.save_checkpoint(os.path.join(self.dirpath, "best.ckpt"), epoch=epoch, global_step=self.global_step)
             else:
                 bad += 1
-            if self.early_stopping and bad > self.early_stopping[2]:
+            # Lightning 1.5.10 EarlyStopping: stop when wait_count >= patience
+            if self.early_stopping and bad >= self.early_stopping[2]:
                 self.log("early stop: %s did not improve for %d epochs" % (self.monitor, bad))
                 break
         return self.history
@@ -95,6 +133,10 @@ class Trainer:
         return model.save_checkpoint(path, epoch=self.current_epoch, global_step=self.global_step)
 
     def test(self, model, datamodule):
-        for i, batch in enumerate(DevicePrefetcher(datamodule.test_dataloader(), self.device)):
-            model.test_step(batch, i)
-        return model.on_test_epoch_end()
+        state = self._set_eval(model)
+        try:
+            for i, batch in enumerate(DevicePrefetcher(datamodule.test_dataloader(), self.device)):
+                model.test_step(batch, i)
+            return model.on_test_epoch_end()
+        finally:
+            self._restore(state)

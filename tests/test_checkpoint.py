@@ -50,6 +50,10 @@ def test_detector_lit_checkpoint_bare_bin_and_torchvision_013_names(tmp_path):
     d = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector
     ck.load_detector(d, binp)
     assert all(torch.equal(v, d.state_dict()[k]) for k, v in a.detector.state_dict().items())
+    # strict=False (what train_hallucidet.py / eval_hallucidet.py pass) must apply the renames BEFORE its name / shape filter
+    d3 = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector
+    ck.load_detector(d3, binp, strict=False)
+    assert all(torch.equal(v, d3.state_dict()[k]) for k, v in a.detector.state_dict().items())
     d2 = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300, eval_path=binp).detector     # the reference's own route
     assert torch.equal(d2.state_dict()["rpn.head.conv.weight"], a.detector.state_dict()["rpn.head.conv.weight"])
 

@@ -48,8 +48,8 @@ def test_single_modal_and_prefetcher_values(llvip):
     ds = SingleModalDetectionDataset("llvip", llvip, modality="ir", ext=".jpg", train=False)
     img, t = ds[0]
     assert len(ds) == 3 and img.shape == (1, 32, 40) and img.dtype == torch.uint8 and t["path_image"].endswith("infrared/test/90000.jpg")
-    with pytest.raises(NotImplementedError):
-        SingleModalDetectionDataset("kaist", llvip, modality="rgb")
+    with pytest.raises(Exception, match="Dataset not supported"):
+        SingleModalDetectionDataset("coco", llvip, modality="rgb")
     dm = MultiModalDataModule("llvip", llvip, llvip, llvip, llvip, batch_size=2, num_workers=0, ext=".jpg")
     batches = list(DevicePrefetcher(dm.test_dataloader(), device="cpu"))
     assert len(batches) == 1
@@ -79,3 +79,50 @@ def test_augmentation_hook_signature_and_empty_fallback(llvip):
     drop_all = lambda **k: {"image": k["image"], "bboxes": [], "labels": [], "image1": k["image1"], "bboxes1": [], "labels1": []}
     _, t2, _, _ = DatasetTransform(ds, drop_all, "multimodal")[1]
     assert torch.equal(t2["boxes"], ds[1][1]["boxes"])                      # fell back to the original targets
+
+
+def test_data_parallel_shards_share_the_split_and_partition_the_epoch(llvip):
+    """every rank must build the SAME train/val split and read a disjoint shard of each epoch."""
+    dms = [MultiModalDataModule("llvip", llvip, llvip, llvip, llvip, batch_size=2, num_workers=0, ext=".jpg", seed=123, rank=r, world_size=2)
+           for r in (0, 1)]
+    tr = [dm.train_dataloader() for dm in dms]
+    assert tr[0].dataset.subset.indices == tr[1].dataset.subset.indices                       # same split on both ranks
+    assert dms[0].val_dataloader().dataset.subset.indices == dms[1].val_dataloader().dataset.subset.indices
+    assert len(tr[0]) == len(tr[1]) == 2                                                      # 8 training samples / (2 ranks * batch 2)
+    for epoch in range(2):
+        seen = [[i for b in tr[r].batch_sampler for i in b] for r in (0, 1)]
+        assert len(seen[0]) == len(seen[1]) == 4 and not set(seen[0]) & set(seen[1])
+        assert sorted(seen[0] + seen[1]) == list(range(8))                                    # one pass over the set per epoch
+        if epoch == 0:
+            first = seen
+    assert first != seen                                                                      # reshuffled per epoch
+
+
+def test_kaist_lists_boxes_and_nonempty_training_positions(tmp_path):
+    """dataloader.py:102-113 / utils.py:366,387-389: frame lists from <root>/{train,test}-all-20-{rgb,ir}.txt, x/y/w/h boxes,
+    training restricted to the frames that keep at least one person box."""
+    root = str(tmp_path / "kaist")
+    os.makedirs(os.path.join(root, "set00"))
+    names = []
+    for i, objs in enumerate([[("person", 5, 6, 10, 12)], [], [("cyclist", 1, 1, 9, 9)], [("person", 2, 3, 4, 5), ("person", 0, 0, 1, 2)]]):
+        for mod in ("rgb", "ir"):
+            stem = os.path.join("set00", "%s_%d" % (mod, i))
+            Image.fromarray(np.full((32, 40, 3) if mod == "rgb" else (32, 40), 10 * i, np.uint8)).save(os.path.join(root, stem + ".jpg"))
+            with open(os.path.join(root, stem + ".xml"), "w") as f:
+                f.write("<annotation>" + "".join("<object><name>%s</name><bndbox><x>%d</x><y>%d</y><w>%d</w><h>%d</h></bndbox></object>" % o
+                                                 for o in objs) + "</annotation>")
+        names.append(i)
+    for mod in ("rgb", "ir"):
+        for split in ("train", "test"):
+            with open(os.path.join(root, "%s-all-20-%s.txt" % (split, mod)), "w") as f:
+                f.write("\n".join(os.path.join("set00", "%s_%d" % (mod, i)) for i in names) + "\n")
+    a = get_bbox(os.path.join(root, "set00", "rgb_3.xml"), "kaist", True)
+    assert a["bboxes"].tolist() == [[2.0, 3.0, 6.0, 8.0]]                     # w,h added; the 1x2 box (area 2 <= 5) dropped
+    ds = MultiModalDetectionDataset("kaist", root, root, modality="both", ext=".jpg", train=True)
+    assert ds.indices == [0, 3] and len(ds) == 2
+    rgb, t_rgb, ir, t_ir = ds[1]
+    assert rgb.shape == (3, 32, 40) and ir.shape == (1, 32, 40) and int(rgb[0, 0, 0]) == 30 and t_ir["boxes"].tolist() == [[2.0, 3.0, 6.0, 8.0]]
+    assert len(SingleModalDetectionDataset("kaist", root, modality="ir", ext=".jpg", train=False)) == 4
+    with open(os.path.join(root, "train-indices.txt"), "w") as f:
+        f.write("3")
+    assert SingleModalDetectionDataset("kaist", root, modality="rgb", ext=".jpg", train=True).indices == [3]

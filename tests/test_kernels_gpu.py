@@ -440,6 +440,33 @@ def test_adam_step(dev):
     assert float(found) == 1.0 and torch.equal(P, before)
 
 
+def test_inf_gradient_halves_the_scale_and_leaves_parameters_and_step_count(dev):
+    """the scaler must act on the DEVICE found_inf flag: an overflowing step is skipped on the device, the scale
+    halves before the next backward, Adam's step count (bias correction) does not advance, and a clean step then updates."""
+    from hallucidet_amd.optim import FusedAdam, LossScaler, ParamArena
+    ps = [torch.nn.Parameter(torch.randn(1000, device=dev)), torch.nn.Parameter(torch.randn(37, 5, device=dev))]
+    arena = ParamArena(ps)
+    opt = FusedAdam(arena, lr=1e-2, clip_value=0.5)
+    sc = LossScaler(arena, init_scale=2.0 ** 16)
+    loss = torch.tensor(1.0, device=dev)
+    assert float(sc.scale(loss)) == 65536.0
+    arena.flat_grads.fill_(0.25)
+    arena.flat_grads[7] = float("inf")
+    before = arena.flat_params.clone()
+    sc.step(opt)
+    sc.update()
+    assert float(sc.scale(loss)) == 32768.0 and sc.scale_value == 32768.0           # resolved at the next scale(), no explicit sync
+    assert torch.equal(arena.flat_params, before) and opt.step_count == 0 and opt.skipped_steps == 1
+    arena.flat_grads.fill_(0.25)
+    sc.step(opt)
+    sc.update()
+    sc.resolve()
+    assert sc.scale_value == 32768.0 and opt.step_count == 1 and opt.skipped_steps == 1
+    assert not torch.equal(arena.flat_params, before)
+    want = before - 1e-2 * 0.25 / (0.25 + 1e-8)           # first Adam step: m_hat / (sqrt(v_hat) + eps) = g / (|g| + eps)
+    assert torch.allclose(arena.flat_params[:1000], want[:1000], rtol=1e-5, atol=1e-6)
+
+
 def test_roi_align_multilevel_bwd_patch_and_direct_paths(dev):
     """Multi-level RoIAlign backward: small / medium RoIs go through the LDS-patch kernels, large ones through direct
     atomics; all must equal the autograd of the oracle's RoIAlign."""

@@ -35,7 +35,7 @@ def main(argv=None):
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
     ext = args.ext or ".jpg"
     dm = MultiModalDataModule(dataset, args.train, args.train, args.test, args.test, batch_size=args.batch, num_workers=args.num_workers,
-                              ext=ext, seed=args.seed + rank, ablation_flag=args.ablation_flag)
+                              ext=ext, seed=args.seed, rank=rank, world_size=world, ablation_flag=args.ablation_flag)
     kw = dict(batch_size=args.batch, model_name=args.decoder_backbone, in_channels=Config.EncoderDecoder.in_channels_encoder,
               output_channels=Config.EncoderDecoder.out_channels_decoder, lr=1e-4 if args.lr is None else args.lr,
               detector_name=Config.Detector.name, train_det=Config.Detector.train_det, fuse_data=args.fuse_data, precision=args.precision, device=dev)
