@@ -43,6 +43,9 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.nchunks = a->KH * a->KW * p.cin8;
   p.nk = 0;
   p.Ktot = a->KH * a->KW * p.Cin;
+  p.ws = nullptr;
+  p.tickets = nullptr;
+  p.prio = 0;
   p.inv_cin8 = 1.0f / (float)p.cin8;
   p.inv_kw = 1.0f / (float)a->KW;
   int64_t xb = (int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2;
@@ -119,7 +122,40 @@ extern "C" int hd_conv_trace_buffer(void* buf) {
 struct TileChoice {
   int bm, bn;
   bool use64, deep;
+  int w8cfg, w8slices;   // w8cfg >= 0: the 8-wave family (conv_igemm_w8.hip) with that tile id / split-K factor
+  int p8cfg;             // p8cfg >= 0: the 8-wave input-patch family (conv3x3_w8.hip) with that tile id
 };
+
+// Workspace of the 8-wave family's split-K path, owned by the caller (PyTorch): [HD_W8_TICKETS ints, zeroed once by the
+// caller][fp32 slabs].  Without one, split-K is never chosen.
+constexpr int HD_W8_TICKETS = 16384;
+static char* g_ws = nullptr;
+static int64_t g_ws_bytes = 0;
+extern "C" int hd_conv_set_workspace(void* ws, int64_t bytes) {
+  HD_CHECK_ARG(ws == nullptr || bytes > (int64_t)HD_W8_TICKETS * 4, "hd_conv_set_workspace: needs more than %d bytes", HD_W8_TICKETS * 4);
+  HD_CHECK_ARG(((uintptr_t)ws & 255) == 0, "hd_conv_set_workspace: 256-byte alignment");
+  g_ws = (char*)ws;
+  g_ws_bytes = ws ? bytes : 0;
+  return HD_OK;
+}
+static int max_slices(const ConvP& p, int bm, int bn) {
+  if (!g_ws) return 1;
+  const int64_t tiles = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
+  if (tiles > HD_W8_TICKETS) return 1;
+  const int64_t per = (int64_t)p.M * p.Cout * 4;
+  const int64_t n = (g_ws_bytes - (int64_t)HD_W8_TICKETS * 4) / per;
+  return n < 1 ? 1 : (n > 64 ? 64 : (int)n);
+}
+
+// tuning hook of the 8-wave family (tools/tune_conv.py): cfg -1 = heuristic, -2 = never, >= 0 = force that tile wherever
+// the family is eligible; nslices <= 0 = heuristic
+static int g_w8_cfg = -1, g_w8_slices = 0;
+extern "C" int hd_conv_tune_w8(int cfg, int nslices) {
+  HD_CHECK_ARG(cfg >= -2 && cfg <= 13 && !(cfg > 6 && cfg < 10) && nslices <= 64, "hd_conv_tune_w8: cfg in [-2, 6] or [10, 13], nslices <= 64");
+  g_w8_cfg = cfg;
+  g_w8_slices = nslices;
+  return HD_OK;
+}
 
 // Tile / K-depth / stage choice of the igemm family.  Rules come from an exhaustive per-shape search over the 136 launch
 // shapes of one training step (tools/tune_conv.py; 7.71 ms with the previous rules, 7.37 ms with these, 7.13 ms with a
@@ -166,6 +202,19 @@ static TileChoice choose_tile(const ConvP& p) {
   if (g_ov_bk == 64) c.use64 = can64_ch;
   if (force_deep >= 0) c.deep = force_deep != 0;
   if (g_ov_deep >= 0) c.deep = g_ov_deep != 0;
+  c.w8cfg = -1;
+  c.w8slices = 1;
+  c.p8cfg = -1;
+  if (g_w8_cfg >= 10 && hd_conv_p8_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
+  if (g_w8_cfg >= 0 && g_w8_cfg < 10 && hd_conv_w8_eligible(p) && g_small_ok) {
+    c.w8cfg = g_w8_cfg;
+    c.w8slices = g_w8_slices > 0 ? g_w8_slices : 1;
+  }
+  if (c.w8cfg >= 0) {
+    hd_conv_w8_tile(c.w8cfg, &c.bm, &c.bn);
+    const int cap = max_slices(p, c.bm, c.bn);
+    if (c.w8slices > cap) c.w8slices = cap;
+  }
   return c;
 }
 
@@ -176,7 +225,9 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (rc) return rc;
   if (use_patch(p)) return hd_conv_patch_tiles(p);
   if (use_small(p)) return hd_conv_small_tiles(p);
-  return hd_cdiv(p.M, choose_tile(p).bm);
+  const TileChoice c = choose_tile(p);
+  if (c.p8cfg >= 0) return hd_conv_p8_tiles(p, c.p8cfg);
+  return hd_cdiv(p.M, c.bm);
 }
 
 extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
@@ -191,6 +242,7 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   }
 #ifdef HD_CONV_TRACE
   p.trace = g_trace;
+  p.trace_tid = env_int("HD_TRACE_TID", 0);
 #endif
   if (use_small(p)) {
     hd_conv_launch_small(p, s);
@@ -198,9 +250,17 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
     return HD_OK;
   }
   const TileChoice c = choose_tile(p);
+  static const int w8_prio = env_int("HD_W8_PRIO", 0);
+  p.prio = w8_prio;
   const int bm = c.bm, bn = c.bn;
   const bool use64 = c.use64, deep = c.deep;
-  if (use64) hd_conv_launch_bk64(p, bm, bn, deep, s);
+  if (c.p8cfg >= 0) {
+    hd_conv_launch_p8(p, c.p8cfg, s);
+  } else if (c.w8cfg >= 0) {
+    p.tickets = (int*)g_ws;
+    p.ws = (float*)(g_ws + (size_t)HD_W8_TICKETS * 4);
+    hd_conv_launch_w8(p, c.w8cfg, c.w8slices, s);
+  } else if (use64) hd_conv_launch_bk64(p, bm, bn, deep, s);
   else hd_conv_launch_bk32(p, bm, bn, deep, s);
   HD_CHECK_LAUNCH();
   return HD_OK;

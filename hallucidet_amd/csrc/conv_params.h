@@ -16,8 +16,12 @@ struct ConvP {
   int M, cin8, nchunks, nk, Ktot;
   int gm, gn;          // grid extent in M / N tiles
   float inv_cin8, inv_kw;
+  int prio;            // 8-wave families: s_setprio policy (experiment knob HD_W8_PRIO: 0 none, 1 MFMA phase, 2 MEM phase)
+  float* ws;           // split-K slabs of the 8-wave family (hd_conv_set_workspace), fp32 [slice][M][Cout]
+  int* tickets;        // per-tile arrival counters of the split-K reduction (zero between launches)
 #ifdef HD_CONV_TRACE
-  unsigned long long* trace;   // profiling builds only (tools/conv_trace.py): 12 stamps per block
+  unsigned long long* trace;   // profiling builds only (tools/conv_trace.py): 16 stamps per block
+  int trace_tid;               // which thread of the block stamps (HD_TRACE_TID, default 0)
 #endif
 };
 
@@ -31,7 +35,7 @@ __device__ __forceinline__ unsigned long long hw_ids() {
 }
 #define HD_TRACE(slot, expr)                                                            \
   do {                                                                                  \
-    if (threadIdx.x == 0 && p.trace) p.trace[(size_t)blockIdx.x * 12 + (slot)] = (expr); \
+    if (threadIdx.x == p.trace_tid && p.trace) p.trace[(size_t)blockIdx.x * 16 + (slot)] = (expr); \
   } while (0)
 #else
 #define HD_TRACE(slot, expr) do {} while (0)
@@ -42,6 +46,14 @@ void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 // conv3x3_patch.hip: 3x3 / stride 1 / pad 1, Cin % 64 == 0, NHWC f16 output, LDS-staged input patches
 void hd_conv_launch_patch(ConvP& p, hipStream_t s);
 int hd_conv_patch_tiles(const ConvP& p);
+// conv_igemm_w8.hip: 8-wave family (NHWC f16 output, Cout % 8 == 0); cfg = tile id, nslices = split-K factor
+bool hd_conv_w8_eligible(const ConvP& p);
+void hd_conv_w8_tile(int cfg, int* bm, int* bn);
+void hd_conv_launch_w8(ConvP& p, int cfg, int nslices, hipStream_t s);
+// conv3x3_w8.hip: 8-wave family with LDS-staged input patches (3x3 / s1 / p1, Cin % 64 == 0); cfg = tile id
+bool hd_conv_p8_eligible(const ConvP& p);
+int hd_conv_p8_tiles(const ConvP& p, int cfg);
+void hd_conv_launch_p8(ConvP& p, int cfg, hipStream_t s);
 // conv3x3_small.hip: 3x3 / stride 1 / pad 1, Cin in {8,16,32}, Cout in {16,32}, plain NHWC f16 output (+ BN partial sums)
 bool hd_conv_small_eligible(const ConvP& p);
 int hd_conv_small_tiles(const ConvP& p);

@@ -29,6 +29,23 @@ def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
+_WS = {}
+_WS_BYTES = int(os.environ.get("HD_CONV_WS_MB", "96")) << 20
+
+
+def _ensure_workspace(lib, device):
+    """Scratch of hd_conv2d's split-K path: a torch-owned buffer registered once per process (the library allocates nothing).
+    The first 64 KiB are the per-tile arrival counters and start at zero; the kernels leave them at zero."""
+    key = (device.type, device.index)
+    if key not in _WS:
+        if _WS:
+            raise RuntimeError("hallucidet_amd: one GPU per process (hd_conv_set_workspace is process-wide)")
+        buf = torch.zeros(_WS_BYTES, dtype=torch.uint8, device=device)
+        check(lib.hd_conv_set_workspace(buf.data_ptr(), _WS_BYTES), "hd_conv_set_workspace")
+        _WS[key] = buf
+    return _WS[key]
+
+
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
            out_nchw_f32=False, want_stats=False, out_hw=None, cout=None, out=None, patch_kernel=False):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
@@ -38,6 +55,7 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
     """
     _need_cuda(x, w, x2, bias, res, mask)
     lib = _abi.load()
+    _ensure_workspace(lib, x.device)
     N, Hs, Ws, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     Cout = w.shape[0] if cout is None else cout

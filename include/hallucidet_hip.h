@@ -92,6 +92,15 @@ int hd_conv2d_patch(const hd_conv_args* a, void* stream);
  * -1 = the built-in heuristic.  Process-wide; not for production use. */
 int hd_conv_tune_override(int bm, int bn, int bk, int deep);
 int hd_conv2d_patch_stats_rows(const hd_conv_args* a);
+/* Caller-owned scratch of hd_conv2d's 8-wave family (split-K partial tiles): the first 65 536 bytes are per-tile arrival
+ * counters and must be ZERO when registered (the kernels leave them zero), the rest holds fp32 slabs.  The library keeps the
+ * pointer (nothing is allocated on its side, SURVEY 8b "Ownership"); NULL unregisters.  Launches that share it must be
+ * stream-ordered (the boundary is not re-entrant, SURVEY 8b "Threading"). */
+int hd_conv_set_workspace(void* ws, int64_t bytes);
+/* tuning hook of the 8-wave families: cfg -1 heuristic, -2 never, 0..6 force the im2col tile {256x128, 128x128, 256x64, 128x64,
+ * 128x256, 64x128, 64x256} wherever eligible (nslices > 0 forces the split-K factor), 10..13 force the input-patch kernel
+ * (3x3 / stride 1) with tile {256x128, 128x128, 256x64, 128x64} wherever eligible */
+int hd_conv_tune_w8(int cfg, int nslices);
 
 /* ------------------------------------------------------------------------
  * Weight-gradient implicit GEMM: dW[co][kh][kw][ci] = sum_pix dY[pix,co] * X[pix@(kh,kw),ci]

@@ -52,12 +52,12 @@ for name, N, H, W, Cin, Cout, KH, stats, ov in SHAPES:
     e1.record(); e1.synchronize()
     t_us = e0.elapsed_time(e1) * 100
     nblk_max = 1 << 16
-    buf = torch.zeros(nblk_max * 12, dtype=torch.int64, device=dev)
+    buf = torch.zeros(nblk_max * 16, dtype=torch.int64, device=dev)
     lib.hd_conv_trace_buffer(buf.data_ptr())
     ops.conv2d(x, w, KH, KH, pad=KH // 2, want_stats=stats)
     torch.cuda.synchronize()
     lib.hd_conv_trace_buffer(None)
-    t = buf.cpu().numpy().reshape(-1, 12)
+    t = buf.cpu().numpy().reshape(-1, 16)
     t = t[t[:, 0] != 0]
     nb = len(t)
     if nb == 0:
