@@ -49,7 +49,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
   constexpr int B_LOADS = BN / 64;
   constexpr int BSTAGE = BN * LDS_ROW;
   constexpr int RING = 2 * PSTAGE + 3 * BSTAGE;
-  constexpr int EPI_HALVES = WK * BM * BN * 2;
+  constexpr int CP = BN + 4;                            // epilogue tile pitch in floats (16-byte LDS writes conflict-free)
+  constexpr int EPI_HALVES = WK * BM * CP * 2;
   constexpr int LDS_HALVES = RING > EPI_HALVES ? RING : EPI_HALVES;
   __shared__ __attribute__((aligned(1024))) f16 lds[LDS_HALVES];
   f16* const patch0 = lds;
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
       _Pragma("unroll") for (int q = 0; q < KSP; ++q)                                                                      \
         _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                      \
           _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                    \
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[q][a], bf[q][b], acc[a][b], 0, 0, 0);                    \
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[q][b], af[q][a], acc[a][b], 0, 0, 0);                    \
       __builtin_amdgcn_s_setprio(0);                                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                                                   \
       TR_MARK(tr_mfma);                                                                                                    \
@@ -243,16 +244,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
 #endif
 
   // ---------------- epilogue (as conv_igemm_w8.hip; tile row r = pixel (ty0 + r/8, tx0 + r%8)) ----------------
+  // The weights are the MFMA's A operand, so a lane's accumulator registers 4g..4g+3 are four CONSECUTIVE output channels of
+  // one pixel (C/D map: row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) = channel, column = lane & 31 = pixel): one 16-byte LDS
+  // write per quad (16 per lane instead of 64 four-byte ones), pitch BN + 4 floats keeps the 8-lane write groups on
+  // distinct banks.
   float* ct = reinterpret_cast<float*>(lds);
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int col = wn * 64 + b * 32 + (lane & 31);
-        ct[(wk * BM + row) * BN + col] = acc[a][b][r];
+      for (int g = 0; g < 4; ++g) {
+        const int row = wm * 64 + a * 32 + (lane & 31);
+        const int col = wn * 64 + b * 32 + 8 * g + 4 * (lane >> 5);
+        f32x4 v4 = {acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(ct + (wk * BM + row) * CP + col) = v4;
       }
 
   constexpr int CPR = BN / 8;
@@ -307,12 +313,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
   for (int it = 0; it < ITER; ++it) {
     if (ok[it]) {
       const int row = r0 + it * RPI;
-      f32x4 c0 = *reinterpret_cast<const f32x4*>(ct + row * BN + cch * 8);
-      f32x4 c1 = *reinterpret_cast<const f32x4*>(ct + row * BN + cch * 8 + 4);
+      f32x4 c0 = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8);
+      f32x4 c1 = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8 + 4);
 #pragma unroll
       for (int g = 1; g < WK; ++g) {
-        c0 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * BN + cch * 8);
-        c1 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * BN + cch * 8 + 4);
+        c0 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8);
+        c1 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8 + 4);
       }
       float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
       if (resp) {
@@ -348,33 +354,30 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
   }
   HD_TRACE(13, clock64());
   if (statsp) {
-#pragma unroll
-    for (int d = CPR; d < 64; d <<= 1) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        ssum8[k] += __shfl_xor(ssum8[k], d);
-        ssq8[k] += __shfl_xor(ssq8[k], d);
-      }
+    // per-thread partial sums -> LDS [thread row r0][BN][2] -> 2*BN threads add the RPI rows in a fixed order (deterministic;
+    // 48 cross-lane shuffles per thread took 3 600 clocks here, this takes a few hundred)
+    // raw barriers: __syncthreads() would first drain this wave's output stores (s_waitcnt vmcnt(0): ~3 000 clocks with every
+    // CU storing); only LDS traffic has to be ordered here
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();         // everyone is done reading the C tile
+    float* red = reinterpret_cast<float*>(lds);
+    {
+      float* d = red + (r0 * BN + cch * 8) * 2;
+      f32x4 w0 = {ssum8[0], ssq8[0], ssum8[1], ssq8[1]}, w1 = {ssum8[2], ssq8[2], ssum8[3], ssq8[3]};
+      f32x4 w2 = {ssum8[4], ssq8[4], ssum8[5], ssq8[5]}, w3 = {ssum8[6], ssq8[6], ssum8[7], ssq8[7]};
+      *reinterpret_cast<f32x4*>(d) = w0;
+      *reinterpret_cast<f32x4*>(d + 4) = w1;
+      *reinterpret_cast<f32x4*>(d + 8) = w2;
+      *reinterpret_cast<f32x4*>(d + 12) = w3;
     }
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(lds);   // [8 waves][BN][2]
-    if (lane < CPR) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        red[((wave * BN) + lane * 8 + k) * 2 + 0] = ssum8[k];
-        red[((wave * BN) + lane * 8 + k) * 2 + 1] = ssq8[k];
-      }
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < Cout) {
-      float s = 0.f, s2 = 0.f;
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        s += red[(m * BN + tid) * 2 + 0];
-        s2 += red[(m * BN + tid) * 2 + 1];
-      }
-      statsp[((size_t)tile_m * 2 + 0) * Cout + n0 + tid] = s;
-      statsp[((size_t)tile_m * 2 + 1) * Cout + n0 + tid] = s2;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (tid < 2 * BN) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int m = 0; m < RPI; ++m) s += red[m * BN * 2 + tid];
+      const int c = tid >> 1;
+      if (n0 + c < Cout) statsp[((size_t)tile_m * 2 + (tid & 1)) * Cout + n0 + c] = s;
     }
   }
   HD_TRACE(5, clock64());

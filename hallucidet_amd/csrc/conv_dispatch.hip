@@ -119,6 +119,37 @@ extern "C" int hd_conv_trace_buffer(void* buf) {
 }
 #endif
 
+// 3x3 / stride-1 layers with >= 128 output channels (or a decoder concat) go to the 8-wave input-patch family when its 8-wide
+// tiles cover the feature map well.  Tile choice by a cost model fitted to per-block timelines (tools/w8_trace.py, shader clocks):
+// one block per CU, so a launch costs ceil(blocks / 256) rounds of (fixed + K steps x step), fixed = set-up + first stage +
+// epilogue.  Measured against the per-shape sweep of one training step's 136 launch shapes (tools/tune_w8.py).
+static int choose_p8(const ConvP& p) {
+  static const int on = env_int("HD_CONV_P8", 1);
+  if (!on || !hd_conv_p8_eligible(p)) return -1;
+  if (p.Cout < 128 && !p.x2) return -1;                     // 64 -> 64 layers: the 4-wave family's 2-3 blocks per CU win
+  static const int th[4] = {32, 16, 32, 16}, bn[4] = {128, 128, 64, 64};
+  static const double step[4] = {1270., 790., 800., 540.}, fixed[4] = {11500., 8000., 9000., 7000.};
+  const int nk = p.nchunks / 8;
+  int best = -1;
+  double best_t = 1e30;
+  // The tiles split K differently (WK), so they do not round identically: the choice must not depend on the batch size, or
+  // image n of a batched launch would differ from the same image alone.  The model is evaluated at the training batch (8).
+  const int nominal_batch = 8;
+  for (int c = 0; c < 4; ++c) {
+    if (bn[c] == 128 && p.Cout <= 64) continue;
+    const int64_t tm = (int64_t)nominal_batch * hd_cdiv(p.Ho, th[c]) * hd_cdiv(p.Wo, 8);
+    const double eff = (double)((int64_t)nominal_batch * p.Ho * p.Wo) / (double)(tm * th[c] * 8);
+    if (eff < 0.7) continue;
+    const int64_t blocks = tm * hd_cdiv(p.Cout, bn[c]);
+    const double t = (double)hd_cdiv(blocks, 256) * (fixed[c] + nk * step[c])   /* nothing here may depend on p.stats: hd_conv2d_stats_rows asks before the slab exists */;
+    if (t < best_t) {
+      best_t = t;
+      best = c;
+    }
+  }
+  return best;
+}
+
 struct TileChoice {
   int bm, bn;
   bool use64, deep;
@@ -206,6 +237,7 @@ static TileChoice choose_tile(const ConvP& p) {
   c.w8slices = 1;
   c.p8cfg = -1;
   if (g_w8_cfg >= 10 && hd_conv_p8_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
+  if (g_w8_cfg == -1 && g_small_ok && g_ov_bm < 0 && g_ov_bn < 0 && g_ov_bk < 0) c.p8cfg = choose_p8(p);
   if (g_w8_cfg >= 0 && g_w8_cfg < 10 && hd_conv_w8_eligible(p) && g_small_ok) {
     c.w8cfg = g_w8_cfg;
     c.w8slices = g_w8_slices > 0 ? g_w8_slices : 1;

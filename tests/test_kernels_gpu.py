@@ -88,6 +88,61 @@ def test_conv2d_forward(dev, case):
     assert torch.allclose(s[1], wstats[1], rtol=3e-3, atol=1e-2)
 
 
+W8_CASES = [
+    # N, H, W, C1, C2, Cout, K, stride, pad, up1, act, bias, res, mask
+    (2, 40, 24, 64, 0, 128, 3, 1, 1, False, 1, True, True, False),     # 3x3: both 8-wave families; ragged 8-wide tiles (W = 24 exact, H = 40)
+    (3, 19, 21, 128, 0, 192, 3, 1, 1, False, 0, False, False, True),   # ragged in both directions, 2 channel chunks, partial N tile, ReLU mask
+    (1, 33, 9, 256, 0, 72, 3, 1, 1, False, 1, True, False, False),     # 4 chunks, Cout not a multiple of 64
+    (2, 12, 20, 64, 64, 64, 3, 1, 1, True, 0, False, False, False),    # decoder concat: upsampled + skip source
+    (1, 10, 12, 128, 64, 128, 3, 1, 1, True, 1, False, False, False),  # concat with chunks on both sides of the boundary
+    (2, 15, 15, 256, 0, 256, 1, 1, 0, False, 1, True, True, False),    # 1x1 (im2col family only)
+    (2, 16, 20, 64, 0, 128, 3, 2, 1, False, 1, True, False, False),    # stride 2 (im2col family only)
+    (1, 7, 7, 256, 0, 256, 7, 1, 0, False, 1, True, False, False),     # fc6-like 7x7 valid
+    (2, 24, 24, 24, 0, 64, 3, 1, 1, False, 0, False, False, False),    # Cin % 64 != 0: per-lane taps (im2col family only)
+]
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13])
+def test_conv2d_eight_wave_families(dev, cfg):
+    """Every tile of the 8-wave families (conv_igemm_w8.hip: cfg 0-6, incl. split-K over blocks; conv3x3_w8.hip: cfg 10-13),
+    forced through hd_conv_tune_w8, against the oracle: outputs, BN partial sums per tile, bias / residual / ReLU-mask / ReLU."""
+    from hallucidet_amd import ops, _abi
+    lib = _abi.load()
+    try:
+        for case in W8_CASES:
+            N, H, W, C1, C2, Cout, K, stride, pad, up1, act, use_bias, use_res, use_mask = case
+            x = rnd(N, H, W, C1, seed=1)
+            Hin, Win = (2 * H, 2 * W) if up1 else (H, W)
+            x2 = rnd(N, Hin, Win, C2, seed=2) if C2 else None
+            Kt = K * K * (C1 + C2)
+            w = rnd(Cout, Kt, scale=1.0 / math.sqrt(Kt), seed=3)
+            bias = torch.randn(Cout, generator=torch.Generator().manual_seed(4)) if use_bias else None
+            Ho, Wo = ops.conv_out_size(Hin, K, stride, pad), ops.conv_out_size(Win, K, stride, pad)
+            res = rnd(N, Ho, Wo, Cout, seed=5) if use_res else None
+            mask = (torch.rand(N, Ho, Wo, Cout, generator=torch.Generator().manual_seed(6)) > 0.4).half() if use_mask else None
+            want, wstats = ok.conv2d_nhwc(x, w, K, K, x2=x2, bias=bias, res=res, stride=stride, pad=pad, up1=up1, act=0)
+            if use_mask:
+                want = want * mask.float()
+                wstats = (want.half().float().sum(dim=(0, 1, 2)), (want.half().float() ** 2).sum(dim=(0, 1, 2)))
+            if act == 1:
+                want = want.clamp_min(0)
+            d = lambda t: None if t is None else t.to(dev)
+            for slices in ((1, 2, 3) if cfg < 10 else (1,)):
+                lib.hd_conv_tune_w8(cfg, slices)
+                got, stats = ops.conv2d(d(x), d(w), K, K, x2=d(x2), bias=d(bias), res=d(res), mask=d(mask), stride=stride, pad=pad, up1=up1,
+                                        act=act, want_stats=True)
+                torch.cuda.synchronize()
+                close(got, want.half())
+                s_ = stats.sum(dim=0).cpu()
+                assert torch.allclose(s_[0], wstats[0], rtol=2e-3, atol=2e-3 * (N * Ho * Wo) ** 0.5 + 1e-2), (cfg, slices, case)
+                assert torch.allclose(s_[1], wstats[1], rtol=3e-3, atol=1e-2), (cfg, slices, case)
+                again, _ = ops.conv2d(d(x), d(w), K, K, x2=d(x2), bias=d(bias), res=d(res), mask=d(mask), stride=stride, pad=pad, up1=up1,
+                                      act=act, want_stats=True)
+                assert torch.equal(got, again), "split-K reduction must not depend on block arrival order"
+    finally:
+        lib.hd_conv_tune_w8(-1, 0)
+
+
 PATCH_CASES = [c for c in CONV_CASES if c[6] == 3 and c[7] == 1 and c[8] == 1 and not c[9] and c[4] == 0 and c[3] % 64 == 0 and c[5] >= 64]
 
 

@@ -71,7 +71,7 @@ def flat(o):
 
 
 rows, dump = [], []
-tot_h = tot_b = 0.0
+tot_h = tot_b = tot_a = 0.0
 bad = 0
 for s, lst in groups.items():
     x, w, KH, KW, kw = lst[0]
@@ -138,16 +138,18 @@ for s, lst in groups.items():
             if t < best[0]:
                 best = (t, (cfg, 1))
     lib.hd_conv_tune_w8(-1, 0)
+    ta = timeit(x, w, KH, KW, kw)
+    tot_a += ta * n
     tot_h += th * n
     tot_b += best[0] * n
     fl = 2.0 * M * cout * K / (kw.get("in_dil", 1) ** 2)
     rows.append((th * n - best[0] * n, n, th, best, s, fl, M, K, cout))
-    dump.append(dict(sig=[list(v) if isinstance(v, tuple) else v for v in s], n=n, M=M, K=K, cout=cout, four_wave=th, w8=allt))
+    dump.append(dict(sig=[list(v) if isinstance(v, tuple) else v for v in s], n=n, M=M, K=K, cout=cout, four_wave=th, auto=ta, w8=allt))
 rows.sort(key=lambda r_: -r_[0])
 for gain, n, th, best, s, fl, M, K, cout in rows[:70]:
     print("gain %7.1f us x%2d  4w %7.1f us (%4.0f TF)  best %7.1f us (%4.0f TF) %-10s M=%6d K=%5d N=%4d k=%d s=%d dil=%d up=%d x2=%s st=%d res=%d mask=%d" % (
         gain, n, th, fl / th / 1e6, best[0], fl / best[0] / 1e6, best[1], M, K, cout, s[3], s[4], s[6], s[7], None if s[1] is None else s[1][3], s[8], s[9], s[10]))
-print("total 4-wave %.2f ms ; with the per-shape best %.2f ms (%.1f%% less) over %d launches / %d shapes ; mismatches %d" % (
-    tot_h / 1e3, tot_b / 1e3, 100 * (1 - tot_b / tot_h), len(rec), len(groups), bad))
+print("total 4-wave %.2f ms ; shipped dispatcher %.2f ms ; per-shape best %.2f ms (%.1f%% less than 4-wave) over %d launches / %d shapes ; mismatches %d" % (
+    tot_h / 1e3, tot_a / 1e3, tot_b / 1e3, 100 * (1 - tot_b / tot_h), len(rec), len(groups), bad))
 os.makedirs("gpurun_out", exist_ok=True)
 json.dump(dump, open("gpurun_out/tune_w8.json", "w"))
