@@ -46,6 +46,7 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.ws = nullptr;
   p.tickets = nullptr;
   p.prio = 0;
+  p.par = p.ph = p.pw = p.Hc = p.Wc = p.t0h = p.t0w = 0;
   p.inv_cin8 = 1.0f / (float)p.cin8;
   p.inv_kw = 1.0f / (float)a->KW;
   int64_t xb = (int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2;
@@ -281,11 +282,22 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
     HD_CHECK_LAUNCH();
     return HD_OK;
   }
+  // stride-2 data gradients: four output-parity classes, each walking only the taps that meet non-zero input (conv_params.h)
+  static const int par_on = env_int("HD_CONV_PARITY", 1);
+  const bool par = par_on && p.in_dil == 2 && !p.stats && p.stride == 1 && (p.cin8 % 4) == 0 && p.out_mode == HD_OUT_NHWC_F16 && g_small_ok &&
+                   g_w8_cfg < 0;
+  const int M_full = p.M;
+  if (par) p.M = p.N * ((p.Ho + 1) / 2) * ((p.Wo + 1) / 2);      // tile choice / grid for the largest class (ph = pw = 0)
   const TileChoice c = choose_tile(p);
   static const int w8_prio = env_int("HD_W8_PRIO", 0);
   p.prio = w8_prio;
   const int bm = c.bm, bn = c.bn;
   const bool use64 = c.use64, deep = c.deep;
+  if (par && c.p8cfg < 0 && c.w8cfg < 0 && (c.use64 ? (p.cin8 % 8) == 0 : true)) {
+    p.par = 1;                     // the launchers add gridDim.y = 4
+  } else {
+    p.M = M_full;
+  }
   if (c.p8cfg >= 0) {
     hd_conv_launch_p8(p, c.p8cfg, s);
   } else if (c.w8cfg >= 0) {

@@ -34,22 +34,26 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
     float* __restrict__ statsp = p.stats;
     const int act = p.act;
     const int Cout = p.Cout;
-    const size_t off0 = (size_t)(m0 + r0) * Cout + co;
     bool ok[ITER];
+    size_t offs[ITER];     // element offset of (output pixel of row r0 + it*RPI, channel co)
 #pragma unroll
-    for (int it = 0; it < ITER; ++it) ok[it] = cvalid && (m0 + r0 + it * RPI < p.M);
+    for (int it = 0; it < ITER; ++it) {
+      const int m = m0 + r0 + it * RPI;
+      ok[it] = cvalid && (m < p.M);
+      offs[it] = (size_t)(p.par ? hd_par_pixel(p, ok[it] ? m : 0) : m) * Cout + co;
+    }
 
     // residual / mask rows: all requested up front
     f16x8 rv[ITER], mv[ITER];
     if (resp) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it)
-        if (ok[it]) rv[it] = *reinterpret_cast<const f16x8*>(resp + off0 + (size_t)it * RPI * Cout);
+        if (ok[it]) rv[it] = *reinterpret_cast<const f16x8*>(resp + offs[it]);
     }
     if (maskp) {
 #pragma unroll
       for (int it = 0; it < ITER; ++it)
-        if (ok[it]) mv[it] = *reinterpret_cast<const f16x8*>(maskp + off0 + (size_t)it * RPI * Cout);
+        if (ok[it]) mv[it] = *reinterpret_cast<const f16x8*>(maskp + offs[it]);
     }
     float bias8[8];
     {   // two 16-byte loads: a VMEM instruction costs the issuing wave ~150 cycles whatever its width
@@ -115,7 +119,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
         f16x8 o;
 #pragma unroll
         for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
-        *reinterpret_cast<f16x8*>(yp + off0 + (size_t)it * RPI * Cout) = o;
+        *reinterpret_cast<f16x8*>(yp + offs[it]) = o;
       }
     }
     HD_TRACE(9, clock64());
@@ -170,8 +174,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = wm * MT * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int pix = m0 + row;
-        if (pix < p.M && cvalid) {
+        const int mrow = m0 + row;
+        const int pix = (p.par && mrow < p.M) ? hd_par_pixel(p, mrow) : mrow;
+        if (mrow < p.M && cvalid) {
           float v = acc[a][b][r];
           if (p.res) v += (float)p.res[(size_t)pix * p.Cout + co];
           v += bias;

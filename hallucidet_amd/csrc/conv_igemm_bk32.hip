@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   }
   const int tile_m = bid / p.gn, tile_n = bid - tile_m * p.gn;
+  if (p.par && !hd_par_setup<BM, 4>(p, tile_m)) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int j = (tid & 3) ^ ((tid >> 4) & 3);   // logical chunk this lane fetches into slot tid&3 of row tid>>2
   const int HoWo = p.Ho * p.Wo;
@@ -80,10 +81,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     int pix = m0 + (tid >> 2) + i * 64;
     rvalid[i] = pix < p.M;
     int pp = rvalid[i] ? pix : 0;
-    int n = pp / HoWo;
-    int rem = pp - n * HoWo;
-    int ho = rem / p.Wo;
-    int wo = rem - ho * p.Wo;
+    int n, ho, wo;
+    if (p.par) {
+      const int hw = p.Hc * p.Wc;
+      n = pp / hw;
+      const int rem = pp - n * hw;
+      const int ii = rem / p.Wc;
+      ho = 2 * ii + p.ph;
+      wo = 2 * (rem - ii * p.Wc) + p.pw;
+    } else {
+      n = pp / HoWo;
+      const int rem = pp - n * HoWo;
+      ho = rem / p.Wo;
+      wo = rem - ho * p.Wo;
+    }
     hb[i] = ho * p.stride - p.pad;
     wb[i] = wo * p.stride - p.pad;
     nb1[i] = (unsigned)n * (unsigned)(p.Hsrc * p.Wsrc) * (unsigned)p.C1 * 2u;
@@ -115,7 +126,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   // offset / validity is recomputed only when the tap changes (every Cin/32 tiles); between changes a load address is
   // one add.  Generic path (Cin in {8,16,24,...}: stem, last decoder block, head): per-lane tap, full recompute.
   int kt_issue = 0;
-  int kh_u = 0, kw_u = 0, c8_u = 0;
+  int kh_u = p.par ? p.t0h : 0, kw_u = p.par ? p.t0w : 0, c8_u = 0;
+  const int tap_step = p.par ? 2 : 1;
   unsigned po1[A_LOADS], po2[A_LOADS];   // byte offset of (pixel at the current tap, channel 0) in x / x2
   bool pv[A_LOADS];
 
@@ -138,14 +150,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   };
   if (!KGEN) {
 #pragma unroll
-    for (int i = 0; i < A_LOADS; ++i) pixel_state(0, 0, i, po1[i], po2[i], pv[i]);
+    for (int i = 0; i < A_LOADS; ++i) pixel_state(kh_u, kw_u, i, po1[i], po2[i], pv[i]);
   }
 
   auto gload = [&](int stage) {
     f16* sa = lds + stage * STAGE + wave * (16 * LDS_ROW);
     f16* sb = sa + BM * LDS_ROW;
-    const int q = kt_issue * 4 + j;
-    const bool kvalid = q < p.nchunks;
+    const int q = (!KGEN && p.par) ? (kh_u * p.KW + kw_u) * p.cin8 + c8_u + j : kt_issue * 4 + j;
+    const bool kvalid = (!KGEN && p.par) ? kt_issue < p.nk : q < p.nchunks;
     int c;
     if (KGEN) {
       const int tap = (int)(((float)q + 0.5f) * p.inv_cin8);
@@ -174,9 +186,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
       c8_u += 4;
       if (c8_u >= p.cin8) {      // uniform branch, no loads inside
         c8_u = 0;
-        if (++kw_u == p.KW) {
-          kw_u = 0;
-          ++kh_u;
+        kw_u += tap_step;
+        if (kw_u >= p.KW) {
+          kw_u = p.par ? p.t0w : 0;
+          kh_u += tap_step;
         }
 #pragma unroll
         for (int i = 0; i < A_LOADS; ++i) pixel_state(kh_u, kw_u, i, po1[i], po2[i], pv[i]);
@@ -234,7 +247,7 @@ template <int BM, int BN, int WM, int WN, int NS>
 static void launch_variant_bk32(ConvP& p, hipStream_t s) {
   p.gm = hd_cdiv(p.M, BM);
   p.gn = hd_cdiv(p.Cout, BN);
-  dim3 grid(p.gm * p.gn);
+  dim3 grid(p.gm * p.gn, p.par ? 4 : 1);
   const bool dual = p.x2 != nullptr;
   const bool kgen = (p.cin8 % (32 / 8)) != 0;
   if (dual) {

@@ -16,6 +16,10 @@ struct ConvP {
   int M, cin8, nchunks, nk, Ktot;
   int gm, gn;          // grid extent in M / N tiles
   float inv_cin8, inv_kw;
+  // Data gradient of a stride-2 convolution as FOUR output-parity classes (blockIdx.y = 2*ph + pw): output pixel (2i+ph, 2j+pw)
+  // only sees the taps with kh = (pad - ph) mod 2 (+2, +4, ...) -- the others hit the zeros of the dilated input -- so a class
+  // walks a quarter of the taps (none at all for three classes of a 1x1).  `par` is set by the dispatcher, the rest by the kernel.
+  int par, ph, pw, Hc, Wc, t0h, t0w;
   int prio;            // 8-wave families: s_setprio policy (experiment knob HD_W8_PRIO: 0 none, 1 MFMA phase, 2 MEM phase)
   float* ws;           // split-K slabs of the 8-wave family (hd_conv_set_workspace), fp32 [slice][M][Cout]
   int* tickets;        // per-tile arrival counters of the split-K reduction (zero between launches)
@@ -40,6 +44,32 @@ __device__ __forceinline__ unsigned long long hw_ids() {
 #else
 #define HD_TRACE(slot, expr) do {} while (0)
 #endif
+
+// Parity-class set-up (device): picks the class from blockIdx.y, shrinks M / nk to the class; returns false if this block has
+// no tile in its class.
+template <int BM, int CPT_>
+__device__ __forceinline__ bool hd_par_setup(ConvP& p, int tile_m) {
+  p.ph = blockIdx.y >> 1;
+  p.pw = blockIdx.y & 1;
+  p.Hc = (p.Ho - p.ph + 1) >> 1;
+  p.Wc = (p.Wo - p.pw + 1) >> 1;
+  p.M = p.N * p.Hc * p.Wc;
+  p.t0h = (p.pad - p.ph) & 1;
+  p.t0w = (p.pad - p.pw) & 1;
+  const int nth = p.t0h < p.KH ? (p.KH - 1 - p.t0h) / 2 + 1 : 0;
+  const int ntw = p.t0w < p.KW ? (p.KW - 1 - p.t0w) / 2 + 1 : 0;
+  p.nk = nth * ntw * (p.cin8 / CPT_);
+  return tile_m * BM < p.M;
+}
+// output pixel index (in the full N x Ho x Wo image) of GEMM row `m` of this block's class
+__device__ __forceinline__ int hd_par_pixel(const ConvP& p, int m) {
+  const int hw = p.Hc * p.Wc;
+  const int n = m / hw;
+  const int rem = m - n * hw;
+  const int i = rem / p.Wc;
+  const int jj = rem - i * p.Wc;
+  return (n * p.Ho + 2 * i + p.ph) * p.Wo + 2 * jj + p.pw;
+}
 
 void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
