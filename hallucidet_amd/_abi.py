@@ -110,6 +110,9 @@ PROTOTYPES = {
     "hd_box_iou_batched": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "hd_rpn_loss": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_float, vp, C.c_float, vp, vp, vp]),
     "hd_rpn_loss_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int64, C.c_float, vp, vp, vp, C.c_float, vp, vp, vp]),
+    "hd_retinanet_loss": (C.c_int, [vp] * 6 + [C.c_int] * 4 + [C.c_float] * 3 + [vp, vp, vp, vp, vp]),
+    "hd_retinanet_loss_bwd": (C.c_int, [vp] * 6 + [C.c_int] * 4 + [C.c_float] * 3 + [vp] * 7),
+    "hd_sigmoid_focal_loss": (C.c_int, [vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp]),
     "hd_fastrcnn_loss": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "hd_fastrcnn_loss_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]),
     "hd_sample_pos_neg": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),

@@ -124,35 +124,30 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
     }
     HD_TRACE(9, clock64());
     if (statsp) {
-      // lanes that share a channel chunk sit CPR apart: fold the 64/CPR rows of this wave with shuffles, then the 4 waves
-      // through LDS (fixed order: the partial sums are deterministic)
-#pragma unroll
-      for (int d = CPR; d < 64; d <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          ssum8[k] += __shfl_xor(ssum8[k], d);
-          ssq8[k] += __shfl_xor(ssq8[k], d);
-        }
+      // per-thread partial sums -> LDS [thread row r0][BN][2] -> 2*BN threads add the RPI rows in a fixed order (deterministic).
+      // (The first version folded rows with 32-48 cross-lane shuffles per thread: ~3 000 clocks per block, measured with
+      // tools/w8_trace.py on the 8-wave kernels' copy of this code.)  Raw barriers: only LDS traffic is ordered here, a
+      // __syncthreads() would also wait for this wave's output stores.
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                 // everyone is done reading the C tile
+      float* red = reinterpret_cast<float*>(lds);
+      {
+        float* d = red + (r0 * BN + cch * 8) * 2;
+        f32x4 w0 = {ssum8[0], ssq8[0], ssum8[1], ssq8[1]}, w1 = {ssum8[2], ssq8[2], ssum8[3], ssq8[3]};
+        f32x4 w2 = {ssum8[4], ssq8[4], ssum8[5], ssq8[5]}, w3 = {ssum8[6], ssq8[6], ssum8[7], ssq8[7]};
+        *reinterpret_cast<f32x4*>(d) = w0;
+        *reinterpret_cast<f32x4*>(d + 4) = w1;
+        *reinterpret_cast<f32x4*>(d + 8) = w2;
+        *reinterpret_cast<f32x4*>(d + 12) = w3;
       }
-      __syncthreads();                     // everyone is done reading the C tile
-      float* red = reinterpret_cast<float*>(lds);   // [4 waves][BN][2]
-      if (lane < CPR) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          red[((wave * BN) + lane * 8 + k) * 2 + 0] = ssum8[k];
-          red[((wave * BN) + lane * 8 + k) * 2 + 1] = ssq8[k];
-        }
-      }
-      __syncthreads();
-      if (tid < BN && n0 + tid < Cout) {
-        float s = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          s += red[(m * BN + tid) * 2 + 0];
-          s2 += red[(m * BN + tid) * 2 + 1];
-        }
-        statsp[((size_t)tile_m * 2 + 0) * Cout + n0 + tid] = s;
-        statsp[((size_t)tile_m * 2 + 1) * Cout + n0 + tid] = s2;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (tid < 2 * BN) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int m = 0; m < RPI; ++m) s += red[m * BN * 2 + tid];
+        const int c = tid >> 1;
+        if (n0 + c < Cout) statsp[((size_t)tile_m * 2 + (tid & 1)) * Cout + n0 + c] = s;
       }
     }
     return;

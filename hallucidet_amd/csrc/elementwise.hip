@@ -33,28 +33,39 @@ __global__ void colsum_stage(const float* __restrict__ in, int rows, int W, floa
 }
 
 // ---------------------------------------------------------------- BN finalize
-// part [rows][2][C] partial (sum, sumsq) rows are added here (rows <= 128: the conv epilogue slab after one hd_rowsum)
-// block = 16 row lanes x 16 channels: the partial rows are summed with 16-way row parallelism (fixed order), then finalized
+// part [rows][2][C] partial (sum, sumsq) rows of the conv epilogue are added here, ANY number of rows: block = 64 row lanes x
+// 4 channels (fixed order: deterministic), so a 1 280-tile layer costs each thread 20 independent loads instead of a separate
+// row-sum launch in front of this one (46 launches per training step).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int rows, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum, float eps,
                                                           float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][16][16];
-  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  __shared__ double red[2][64][4];
+  const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
+  const int c = blockIdx.x * 4 + cl;
   double s1 = 0.0, s2 = 0.0;
-  if (c < C)
-    for (int r = rl; r < rows; r += 16) {
+  if (c < C) {
+    int r = rl;
+    for (; r + 192 < rows; r += 256) {           // four loads of each kind in flight
+      const float a0 = part[(size_t)r * 2 * C + c], a1 = part[(size_t)(r + 64) * 2 * C + c];
+      const float a2 = part[(size_t)(r + 128) * 2 * C + c], a3 = part[(size_t)(r + 192) * 2 * C + c];
+      const float b0 = part[(size_t)r * 2 * C + C + c], b1 = part[(size_t)(r + 64) * 2 * C + C + c];
+      const float b2 = part[(size_t)(r + 128) * 2 * C + C + c], b3 = part[(size_t)(r + 192) * 2 * C + C + c];
+      s1 += (double)a0 + (double)a1 + (double)a2 + (double)a3;
+      s2 += (double)b0 + (double)b1 + (double)b2 + (double)b3;
+    }
+    for (; r < rows; r += 64) {
       s1 += (double)part[(size_t)r * 2 * C + c];
       s2 += (double)part[(size_t)r * 2 * C + C + c];
     }
+  }
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
   __syncthreads();
   if (rl != 0 || c >= C) return;
   s1 = s2 = 0.0;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
+  for (int q = 0; q < 64; ++q) {
     s1 += red[0][q][cl];
     s2 += red[1][q][cl];
   }
@@ -763,8 +774,8 @@ extern "C" int hd_rowsum(const float* in, int rows, int W, float* out, int out_r
 extern "C" int hd_bn_finalize(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                               float* scale, float* shift, void* stream) {
-  HD_CHECK_ARG(part && rows > 0 && rows <= 128 && scale && shift && C > 0 && count > 0, "hd_bn_finalize: bad args (rows <= 128)");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 16)), dim3(256), 0, S_, part, rows, C, count, gamma, beta, running_mean,
+  HD_CHECK_ARG(part && rows > 0 && scale && shift && C > 0 && count > 0, "hd_bn_finalize: bad args");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(hd_cdiv(C, 4)), dim3(256), 0, S_, part, rows, C, count, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift);
   HD_CHECK_LAUNCH();
   return HD_OK;

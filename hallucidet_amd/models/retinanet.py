@@ -18,6 +18,8 @@ import math
 import re
 from collections import OrderedDict
 
+import ctypes
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -299,25 +301,52 @@ def retinanet_match_batched(model, anchors0, gt, gvalid):
     return ops.match_targets(gt, gvalid, None, anchors0, pm.high_threshold, pm.low_threshold, pm.allow_low_quality_matches, want_labels=False)[0]
 
 
-def retinanet_loss_batched(model, anchors0, gt, glab, gvalid, cls_logits, bbox_regression, matched=None):
-    """compute_retinanet_loss for B images sharing one anchor set: focal loss over the non-ignored anchors and smooth-L1
-    (beta 1) over the foreground anchors, each / max(1, num_foreground) per image, averaged over images."""
-    from ..utils.eval_forward_retinanet import sigmoid_focal_loss
-    B = cls_logits.shape[0]
+class _RetinaNetLossFn(torch.autograd.Function):
+    """Both RetinaNet losses of a batch as one forward (+ finish) and one backward launch (hd_retinanet_loss / _bwd): focal
+    loss over the counted anchors, smooth-L1 against box targets that are encoded in-kernel from the matched ground truth."""
+
+    @staticmethod
+    def forward(ctx, cls_logits, bbox_regression, matched, gt, glab, anchors0, coder_weights, alpha, gamma, beta):
+        from .. import _abi
+        lib = _abi.load()
+        lg, br = cls_logits.detach().contiguous().float(), bbox_regression.detach().contiguous().float()
+        m, g, gl, an = matched.contiguous().to(torch.int64), gt.contiguous().float(), glab.contiguous().to(torch.int64), anchors0.contiguous().float()
+        B, A, K = lg.shape
+        G = g.shape[1]
+        dev = lg.device
+        ws = torch.empty(B * 32 * 3, dtype=torch.float32, device=dev)
+        nfg = torch.empty(B, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        cw = (ctypes.c_float * 4)(*[float(w) for w in coder_weights])
+        _abi.check(lib.hd_retinanet_loss(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(m), _abi.ptr(g), _abi.ptr(gl), _abi.ptr(an), B, A, K, G, alpha, gamma, beta,
+                                         cw, _abi.ptr(ws), _abi.ptr(nfg), _abi.ptr(out), torch.cuda.current_stream().cuda_stream), "hd_retinanet_loss")
+        ctx.save_for_backward(lg, br, m, g, gl, an, nfg)
+        ctx.consts = (cw, alpha, gamma, beta)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg):
+        from .. import _abi
+        lib = _abi.load()
+        lg, br, m, g, gl, an, nfg = ctx.saved_tensors
+        cw, alpha, gamma, beta = ctx.consts
+        B, A, K = lg.shape
+        d_lg, d_br = torch.empty_like(lg), torch.empty_like(br)
+        gc = None if g_cls is None else g_cls.contiguous().float()
+        gr = None if g_reg is None else g_reg.contiguous().float()
+        _abi.check(lib.hd_retinanet_loss_bwd(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(m), _abi.ptr(g), _abi.ptr(gl), _abi.ptr(an), B, A, K, g.shape[1], alpha,
+                                             gamma, beta, cw, _abi.ptr(nfg), _abi.ptr(gc), _abi.ptr(gr), _abi.ptr(d_lg), _abi.ptr(d_br),
+                                             torch.cuda.current_stream().cuda_stream), "hd_retinanet_loss_bwd")
+        return d_lg, d_br, None, None, None, None, None, None, None, None
+
+
+def retinanet_loss_batched(model, anchors0, gt, glab, gvalid, cls_logits, bbox_regression, matched=None, alpha=0.25, gamma=2.0, beta=1.0):
+    """compute_retinanet_loss (eval_forward_retinanet.py:163-244) for B images sharing one anchor set: focal loss (alpha .25,
+    gamma 2) over the non-ignored anchors and smooth-L1 (beta 1) over the foreground anchors, each / max(1, num_foreground) per
+    image, averaged over images -- two HIP launches forward, one backward."""
     m = retinanet_match_batched(model, anchors0, gt, gvalid) if matched is None else matched
-    fg = m >= 0
-    num_fg = fg.sum(dim=1).clamp(min=1).to(cls_logits.dtype)
-    mi = m.clamp(min=0)
-    lab = torch.gather(glab, 1, mi)
-    tgt = torch.zeros_like(cls_logits)
-    tgt.scatter_(2, lab[:, :, None], fg[:, :, None].to(cls_logits.dtype))
-    valid = (m != D.Matcher.BETWEEN_THRESHOLDS)[:, :, None]
-    fl = sigmoid_focal_loss(cls_logits, tgt, reduction="none")
-    cls_loss = (torch.where(valid, fl, torch.zeros_like(fl)).sum(dim=(1, 2)) / num_fg).sum() / B
-    mgt = torch.gather(gt, 1, mi[:, :, None].expand(-1, -1, 4))
-    anc = anchors0[None].expand(B, -1, -1)
-    mgt = torch.where(fg[:, :, None], mgt, anc)                      # background rows: encode(anchor, anchor) = 0, finite
-    reg_t = model.box_coder.encode_single(mgt.reshape(-1, 4), anc.reshape(-1, 4)).reshape(B, -1, 4)
-    l1 = F.smooth_l1_loss(bbox_regression, torch.where(fg[:, :, None], reg_t, bbox_regression.detach()), reduction="none", beta=1.0)
-    reg_loss = (torch.where(fg[:, :, None], l1, torch.zeros_like(l1)).sum(dim=(1, 2)) / num_fg).sum() / max(1, B)
+    if gt.shape[1] == 0:                                  # no ground truth anywhere: one dummy (never matched) target row
+        gt = torch.zeros((gt.shape[0], 1, 4), dtype=torch.float32, device=cls_logits.device)
+        glab = torch.zeros((gt.shape[0], 1), dtype=torch.int64, device=cls_logits.device)
+    cls_loss, reg_loss = _RetinaNetLossFn.apply(cls_logits, bbox_regression, m, gt, glab, anchors0, tuple(model.box_coder.weights), alpha, gamma, beta)
     return {"classification": cls_loss, "bbox_regression": reg_loss}

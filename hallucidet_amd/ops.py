@@ -214,8 +214,8 @@ def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, e
         part = part.reshape(part.shape[0], -1)
     elif part.dim() == 1:
         part = part.reshape(1, -1)
-    if part.shape[0] > 128:        # one row-range stage; the finalize kernel sums the remaining <= 128 rows itself
-        part = rowsum(part, 128)
+    if part.shape[0] > 4096:       # (never on the hot path) the finalize kernel sums any number of rows; keep its loop short
+        part = rowsum(part, 1024)
     rows, W = part.shape
     C_ = W // 2
     dev = part.device
@@ -254,13 +254,15 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
     C_ = y.shape[-1]
     npix = y.numel() // C_
     if rows is None:
-        rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
+        # <= 16 384 pixels (layer3 / layer4 / first decoder block: latency chains, not bandwidth): at most 64 partial rows, which
+        # the apply kernel's coefficient prologue sums itself -- no row-sum launch in between (20 launches per step)
+        rows = int(max(1, min(512, npix // 64))) if npix > 16384 else int(max(1, min(64, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
     lib = _abi.load()
     part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
     check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
                                1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
-    if rows > 16:                  # one row-range stage; every block of the apply kernel sums the remaining 16 rows in its
-        part = rowsum(part, 16)    # coefficient prologue (16 x 2C floats per block)
+    if rows > 64:                  # one row-range stage; every block of the apply kernel sums the remaining rows in its
+        part = rowsum(part, 16)    # coefficient prologue (<= 64 x 2C floats per block)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     if dgamma is None:

@@ -7,56 +7,73 @@ anchor_generator -> losses -> postprocess_detections -> transform.postprocess).
 The per-image python loops of the loss and the per-image / per-level loops of the post-processing run in padded,
 batched form when `model.batched_heads` is set (hallucidet_amd.models.retinanet; same arithmetic -- the GPU tests assert
 equality with the list-based functions below, which stay for exactly that purpose and for API compatibility)."""
-from collections import OrderedDict
-from typing import Dict, List, Optional, Tuple
+from typing import Dict, Optional
 
 import torch
-import torch.nn.functional as F
 
 from .eval_forward_fasterrcnn import _check_degenerate, _check_targets
 from ..models import detection as D
 from ..models import retinanet as R
 
 
-def _sum(x: List[torch.Tensor]) -> torch.Tensor:
-    res = x[0]
-    for i in x[1:]:
-        res = res + i
-    return res
+class _FocalElementwiseFn(torch.autograd.Function):
+    """hd_sigmoid_focal_loss: the per-element loss and its input gradient, one launch each."""
+
+    @staticmethod
+    def forward(ctx, inputs, targets, alpha, gamma):
+        from .. import _abi
+        x, t = inputs.detach().contiguous().float(), targets.detach().contiguous().float()
+        out = torch.empty_like(x)
+        _abi.check(_abi.load().hd_sigmoid_focal_loss(_abi.ptr(x), _abi.ptr(t), x.numel(), alpha, gamma, None, _abi.ptr(out),
+                                                     torch.cuda.current_stream().cuda_stream), "hd_sigmoid_focal_loss")
+        ctx.save_for_backward(x, t)
+        ctx.consts = (alpha, gamma)
+        return out.view(inputs.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _abi
+        x, t = ctx.saved_tensors
+        gi = torch.empty_like(x)
+        go = g.contiguous().float().expand_as(x).contiguous()
+        _abi.check(_abi.load().hd_sigmoid_focal_loss(_abi.ptr(x), _abi.ptr(t), x.numel(), ctx.consts[0], ctx.consts[1], _abi.ptr(go), _abi.ptr(gi),
+                                                     torch.cuda.current_stream().cuda_stream), "hd_sigmoid_focal_loss")
+        return gi.view(g.shape), None, None, None
+
+
+_REDUCTIONS = {"none": lambda v: v, "mean": torch.mean, "sum": torch.sum}
 
 
 def sigmoid_focal_loss(inputs: torch.Tensor, targets: torch.Tensor, alpha: float = 0.25, gamma: float = 2,
                        reduction: str = "none") -> torch.Tensor:
-    p = torch.sigmoid(inputs)
-    ce_loss = F.binary_cross_entropy_with_logits(inputs, targets, reduction="none")
-    p_t = p * targets + (1 - p) * (1 - targets)
-    loss = ce_loss * ((1 - p_t) ** gamma)
-    if alpha >= 0:
-        alpha_t = alpha * targets + (1 - alpha) * (1 - targets)
-        loss = alpha_t * loss
-    if reduction == "none":
-        pass
-    elif reduction == "mean":
-        loss = loss.mean()
-    elif reduction == "sum":
-        loss = loss.sum()
-    else:
+    """Reference signature (:22-50); `targets` are the 0/1 class indicators the reference builds (:199-206).  The arithmetic
+    is the HIP kernel's (losses.hip `focal_value` / `focal_grad`)."""
+    if reduction not in _REDUCTIONS:
         raise ValueError(f"Invalid Value for arg 'reduction': '{reduction} \n Supported reduction modes: 'none', 'mean', 'sum'")
-    return loss
+    if not inputs.is_cuda:
+        raise RuntimeError("hallucidet_amd: sigmoid_focal_loss runs on the GPU (no CPU fallback; the CPU statement is oracle/retinanet.py)")
+    return _REDUCTIONS[reduction](_FocalElementwiseFn.apply(inputs, targets, float(alpha), float(gamma)))
 
 
 def box_loss(type: str, box_coder, anchors_per_image: torch.Tensor, matched_gt_boxes_per_image: torch.Tensor,
              bbox_regression_per_image: torch.Tensor, cnf: Optional[Dict[str, float]] = None) -> torch.Tensor:
+    """Reference signature (:53-80): the regression loss of ONE image over its foreground anchors (sum reduction).  Evaluated
+    by the batched kernel with every row foreground and matched to itself: B = 1, G = A."""
     torch._assert(type in ["l1", "smooth_l1", "ciou", "diou", "giou"], f"Unsupported loss: {type}")
-    if type == "l1":
-        target_regression = box_coder.encode_single(matched_gt_boxes_per_image, anchors_per_image)
-        return F.l1_loss(bbox_regression_per_image, target_regression, reduction="sum")
-    if type == "smooth_l1":
-        target_regression = box_coder.encode_single(matched_gt_boxes_per_image, anchors_per_image)
-        beta = cnf["beta"] if cnf is not None and "beta" in cnf else 1.0
-        return F.smooth_l1_loss(bbox_regression_per_image, target_regression, reduction="sum", beta=beta)
-    raise NotImplementedError("hallucidet_amd: the reference only ever calls box_loss with its default 'smooth_l1' "
-                              "(eval_forward_retinanet.py:215); the IoU-family losses live in the un-vendored torchvision.ops")
+    if type not in ("l1", "smooth_l1"):
+        raise NotImplementedError("hallucidet_amd: the reference only ever calls box_loss with its default 'smooth_l1' "
+                                  "(eval_forward_retinanet.py:215); the IoU-family losses live in the un-vendored torchvision.ops")
+    n = anchors_per_image.shape[0]
+    if n == 0:
+        return bbox_regression_per_image.sum() * 0.0
+    # beta -> 0 turns smooth-L1 into L1 (|d| - beta/2 for |d| >= beta); 1e-12 is exact in fp32 for any representable |d| > 1e-12
+    beta = 1e-12 if type == "l1" else float(cnf["beta"] if cnf is not None and "beta" in cnf else 1.0)
+    dev = bbox_regression_per_image.device
+    own = torch.arange(n, device=dev, dtype=torch.int64)[None]
+    zeros = torch.zeros((1, n, 1), dtype=torch.float32, device=dev)
+    _, reg = R._RetinaNetLossFn.apply(zeros, bbox_regression_per_image[None], own, matched_gt_boxes_per_image[None].float(),
+                                      torch.zeros((1, n), dtype=torch.int64, device=dev), anchors_per_image, tuple(box_coder.weights), 0.25, 2.0, beta)
+    return reg * float(n)          # the kernel divides by max(1, #foreground) = n
 
 
 def eval_forward_retinanet(model, images, targets, train_det=False, model_name='retinanet'):
@@ -67,43 +84,37 @@ def eval_forward_retinanet(model, images, targets, train_det=False, model_name='
     else:
         model.eval()
     _check_targets(targets)
-    original_image_sizes: List[Tuple[int, int]] = []
-    for img in images:
-        val = img.shape[-2:]
-        torch._assert(len(val) == 2, f"expecting the last two dimensions of the Tensor to be H and W instead got {img.shape[-2:]}")
-        original_image_sizes.append((val[0], val[1]))
+    original_image_sizes = [_hw_of(img) for img in images]
 
     images, targets = model.transform(images, targets)
     if targets is not None:
         _check_degenerate(targets)
 
     features = model.backbone(images.tensors)
-    if isinstance(features, torch.Tensor):
-        features = OrderedDict([("0", features)])
-    features = list(features.values())
-    head_outputs = model.head(features)
-    anchors = model.anchor_generator(images, features)
-
-    # recover level sizes (features are NHWC here: H, W = size(1), size(2))
-    num_anchors_per_level = [x.size(1) * x.size(2) for x in features]
-    HW = sum(num_anchors_per_level)
-    A = head_outputs["cls_logits"].size(1) // HW
-    num_anchors_per_level = [hw * A for hw in num_anchors_per_level]
+    features = [features] if isinstance(features, torch.Tensor) else list(features.values())
+    head_outputs, anchors = model.head(features), model.anchor_generator(images, features)
+    # anchors per level (the feature maps are NHWC here: H, W = size(1), size(2)); A = anchors per location
+    cells = [f.size(1) * f.size(2) for f in features]
+    per_cell = head_outputs["cls_logits"].size(1) // sum(cells)
+    napl = [c * per_cell for c in cells]
 
     if getattr(model, "batched_heads", False):
         gt, glab, gvalid = D.pad_targets(targets, images.tensors.device)
         losses = R.retinanet_loss_batched(model, anchors[0], gt, glab, gvalid, head_outputs["cls_logits"], head_outputs["bbox_regression"])
-        detections = _detections_padded(model, head_outputs, anchors[0], num_anchors_per_level, images.image_sizes, original_image_sizes)
-        return losses, detections
+        return losses, _detections_padded(model, head_outputs, anchors[0], napl, images.image_sizes, original_image_sizes)
 
+    # list-based route (API compatibility with the reference's model methods; the GPU tests compare it with the batched one)
     losses = compute_retinanet_loss(targets, head_outputs, anchors, model)
-    split_head_outputs: Dict[str, List[torch.Tensor]] = {}
-    for k in head_outputs:
-        split_head_outputs[k] = list(head_outputs[k].split(num_anchors_per_level, dim=1))
-    split_anchors = [list(a.split(num_anchors_per_level)) for a in anchors]
-    detections = model.postprocess_detections(split_head_outputs, split_anchors, images.image_sizes)
-    detections = model.transform.postprocess(detections, images.image_sizes, original_image_sizes)
-    return losses, detections
+    per_level_outputs = {k: list(v.split(napl, dim=1)) for k, v in head_outputs.items()}
+    per_level_anchors = [list(a.split(napl)) for a in anchors]
+    raw = model.postprocess_detections(per_level_outputs, per_level_anchors, images.image_sizes)
+    return losses, model.transform.postprocess(raw, images.image_sizes, original_image_sizes)
+
+
+def _hw_of(img):
+    hw = img.shape[-2:]
+    torch._assert(len(hw) == 2, f"expecting the last two dimensions of the Tensor to be H and W instead got {img.shape[-2:]}")
+    return (hw[0], hw[1])
 
 
 def _detections_padded(model, head_outputs, anchors0, napl, image_sizes, original_image_sizes):
@@ -150,43 +161,36 @@ def eval_forward_retinanet_multi(model, image_batches, target_lists, model_name=
     return [(losses if k == 0 else {}, d) for k, d in enumerate(dets)]
 
 
+def _matched_padded(targets, anchors, model):
+    """[B, A] matched-GT table of the list inputs (box_iou + proposal_matcher per image, :165-175), via the fused target assignment."""
+    gt, glab, gvalid = D.pad_targets(targets, anchors[0].device)
+    return R.retinanet_match_batched(model, anchors[0], gt, gvalid), gt, glab
+
+
 def compute_retinanet_loss(targets, head_outputs, anchors, model):
-    matched_idxs = []
-    for anchors_per_image, targets_per_image in zip(anchors, targets):
-        if targets_per_image["boxes"].numel() == 0:
-            matched_idxs.append(torch.full((anchors_per_image.size(0),), -1, dtype=torch.int64, device=anchors_per_image.device))
-            continue
-        match_quality_matrix = D.box_iou(targets_per_image["boxes"], anchors_per_image)
-        matched_idxs.append(model.proposal_matcher(match_quality_matrix))
-    return {"classification": compute_loss_classification_head(targets, head_outputs, matched_idxs, model),
-            "bbox_regression": compute_loss_regression_head(targets, head_outputs, anchors, matched_idxs, model)}
+    """Reference signature (:163-178).  All images of a batch share one anchor set here (fixed 300 x 300 inputs), so the
+    per-image loop of the reference is one batched evaluation."""
+    m, gt, glab = _matched_padded(targets, anchors, model)
+    return R.retinanet_loss_batched(model, anchors[0], gt, glab, None, head_outputs["cls_logits"], head_outputs["bbox_regression"], matched=m)
 
 
 def compute_loss_classification_head(targets, head_outputs, matched_idxs, model):
-    losses = []
-    cls_logits = head_outputs["cls_logits"]
-    for targets_per_image, cls_logits_per_image, matched_idxs_per_image in zip(targets, cls_logits, matched_idxs):
-        foreground_idxs_per_image = matched_idxs_per_image >= 0
-        num_foreground = foreground_idxs_per_image.sum()
-        gt_classes_target = torch.zeros_like(cls_logits_per_image)
-        gt_classes_target[foreground_idxs_per_image,
-                          targets_per_image["labels"][matched_idxs_per_image[foreground_idxs_per_image]]] = 1.0
-        valid_idxs_per_image = matched_idxs_per_image != model.head.classification_head.BETWEEN_THRESHOLDS
-        losses.append(sigmoid_focal_loss(cls_logits_per_image[valid_idxs_per_image], gt_classes_target[valid_idxs_per_image],
-                                         reduction="sum") / max(1, num_foreground))
-    return _sum(losses) / len(targets)
+    """Reference signature (:181-211): `matched_idxs` is the per-image list the reference's matcher returns."""
+    dev = head_outputs["cls_logits"].device
+    gt, glab, _ = D.pad_targets(targets, dev)
+    m = torch.stack([v.to(dev) for v in matched_idxs])
+    a0 = torch.tensor([[0.0, 0.0, 1.0, 1.0]], device=dev).expand(m.shape[1], 4).contiguous()      # boxes are not read by this head
+    reg0 = torch.zeros(m.shape + (4,), dtype=torch.float32, device=dev)
+    return R._RetinaNetLossFn.apply(head_outputs["cls_logits"], reg0, m, gt, glab, a0, (1.0, 1.0, 1.0, 1.0), 0.25, 2.0, 1.0)[0]
 
 
 def compute_loss_regression_head(targets, head_outputs, anchors, matched_idxs, model, loss_reg='smooth_l1'):
-    losses = []
-    bbox_regression = head_outputs["bbox_regression"]
-    for targets_per_image, bbox_regression_per_image, anchors_per_image, matched_idxs_per_image in zip(
-            targets, bbox_regression, anchors, matched_idxs):
-        foreground_idxs_per_image = torch.where(matched_idxs_per_image >= 0)[0]
-        num_foreground = foreground_idxs_per_image.numel()
-        matched_gt_boxes_per_image = targets_per_image["boxes"][matched_idxs_per_image[foreground_idxs_per_image]]
-        bbox_regression_per_image = bbox_regression_per_image[foreground_idxs_per_image, :]
-        anchors_per_image = anchors_per_image[foreground_idxs_per_image, :]
-        losses.append(box_loss(loss_reg, model.box_coder, anchors_per_image, matched_gt_boxes_per_image,
-                               bbox_regression_per_image) / max(1, num_foreground))
-    return _sum(losses) / max(1, len(targets))
+    """Reference signature (:215-244)."""
+    if loss_reg != 'smooth_l1':
+        raise NotImplementedError("hallucidet_amd: the reference trains with its default smooth-L1 (beta 1) regression loss")
+    dev = head_outputs["bbox_regression"].device
+    gt, glab, _ = D.pad_targets(targets, dev)
+    m = torch.stack([v.to(dev) for v in matched_idxs])
+    cls0 = torch.zeros(m.shape + (1,), dtype=torch.float32, device=dev)
+    return R._RetinaNetLossFn.apply(cls0, head_outputs["bbox_regression"], m, gt, torch.zeros_like(glab), anchors[0], tuple(model.box_coder.weights),
+                                    0.25, 2.0, 1.0)[1]

@@ -156,7 +156,7 @@ int hd_weight_prep_multi(const hd_wprep_desc* table_dev, int n_layers, int block
 int hd_colsum(const float* in, int rows, int W, float* out, float* ws, void* stream);
 /* one deterministic reduction stage: out[r][W] = sum of the r-th slice of in's rows (out_rows <= rows) */
 int hd_rowsum(const float* in, int rows, int W, float* out, int out_rows, void* stream);
-/* part[rows][2][C] partial (sum x, sum x^2) rows (rows <= 128, summed in-kernel) -> mean/invstd/scale/shift
+/* part[rows][2][C] partial (sum x, sum x^2) rows (any number of rows, summed in-kernel in a fixed order) -> mean/invstd/scale/shift
  * (+ running stats update when running_mean != NULL; unbiased variance for the running estimate, momentum as
  * nn.BatchNorm2d) */
 int hd_bn_finalize(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
@@ -292,6 +292,23 @@ int hd_rpn_loss(const float* objectness, const float* deltas, const float* label
 int hd_rpn_loss_bwd(const float* objectness, const float* deltas, const float* labels, const float* reg_t, const uint8_t* pos,
                     const uint8_t* samp, int64_t T, float beta, const float* g_obj, const float* g_box,
                     const int64_t* n_sampled_dev, float n_sampled_host, float* d_objectness, float* d_deltas, void* stream);
+/* RetinaNet losses for B images sharing one anchor set (reference src/utils/eval_forward_retinanet.py:163-244 with its own
+ * sigmoid_focal_loss :22-50 and smooth-L1 box loss :53-80 folded in): cls_logits [B][A][K], bbox_regression [B][A][4] (fp32),
+ * matched [B][A] int64 (>= 0 GT index, -1 background, -2 between thresholds = not counted), gt [B][G][4] / glab [B][G] padded
+ * targets, anchors [A][4], coder_weights [4] (HOST array: BoxCoder weights).  out2 = {classification, bbox_regression}, each
+ * the mean over images of (sum over the image / max(1, #foreground)); num_fg [B] is kept for the backward pass.
+ * part_ws: B * 32 * 3 floats. */
+int hd_retinanet_loss(const float* cls_logits, const float* bbox_regression, const int64_t* matched, const float* gt, const int64_t* glab,
+                      const float* anchors, int B, int A, int K, int G, float alpha, float gamma, float beta, const float* coder_weights,
+                      float* part_ws, float* num_fg, float* out2, void* stream);
+int hd_retinanet_loss_bwd(const float* cls_logits, const float* bbox_regression, const int64_t* matched, const float* gt, const int64_t* glab,
+                          const float* anchors, int B, int A, int K, int G, float alpha, float gamma, float beta, const float* coder_weights,
+                          const float* num_fg, const float* g_cls, const float* g_reg, float* d_cls_logits, float* d_bbox_regression,
+                          void* stream);
+/* element-wise focal loss of the reference's `sigmoid_focal_loss(inputs, targets, alpha, gamma, reduction="none")`
+ * (eval_forward_retinanet.py:22-50; targets are 0/1); with grad_out != NULL writes d loss / d inputs * grad_out instead */
+int hd_sigmoid_focal_loss(const float* inputs, const float* targets, int64_t n, float alpha, float gamma, const float* grad_out, float* out,
+                          void* stream);
 /* roi_heads.fastrcnn_loss [EXT] (src/utils/eval_forward_fasterrcnn.py:141): logits [R][K], box_regression [R][K*4],
  * labels [R] i64, reg_t [R][4].  out2 = (mean cross entropy, sum over labels>0 of smooth_l1(beta) of the label's box / R). */
 int hd_fastrcnn_loss(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,

@@ -241,8 +241,20 @@ def test_calculate_loss_contract_and_end_to_end(dev, case):
     oracle.rpn.fg_bg_sampler.randperm_fn = perms
     oracle.roi_heads.fg_bg_sampler.randperm_fn = perms
     ol, od_ = od.eval_forward_fasterrcnn(oracle, images, targets)
+    oracle.rpn.fg_bg_sampler.randperm_fn = oracle.roi_heads.fg_bg_sampler.randperm_fn = None
+    # the product replays the oracle's RPN draws (populations = f(anchors, targets): identical on both sides); its RoI sampler
+    # draws from the same generator state the oracle's did
+    rp = Perms(21)
+    rp.replay = perms.log[:4]              # 2 images x (positives, negatives)
+    roi = Perms(21)
+    for n in (p_.numel() for p_ in perms.log[:4]):
+        torch.randperm(n, generator=roi.g)
+    det.rpn.fg_bg_sampler.randperm_fn, det.roi_heads.fg_bg_sampler.randperm_fn, det.fused_passes = rp, roi, False
     x = images.to(dev).requires_grad_(True)
-    losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="fasterrcnn")
+    try:
+        losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="fasterrcnn")
+    finally:
+        det.rpn.fg_bg_sampler.randperm_fn = det.roi_heads.fg_bg_sampler.randperm_fn = None
     assert set(losses) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"}
     assert not det.training
     for k, v in losses.items():
@@ -253,10 +265,15 @@ def test_calculate_loss_contract_and_end_to_end(dev, case):
         assert d["boxes"].shape[0] <= 100
         if d["boxes"].numel():
             assert float(d["boxes"][:, 0::2].max()) <= 128.0 + 1e-3 and float(d["boxes"][:, 1::2].max()) <= 96.0 + 1e-3
-    # the RPN sampler sees the same anchors/targets on both sides -> its losses are directly comparable; the RoI
-    # losses depend on proposals that fp16 features may reorder, so they are bounded loosely
+    # identical RPN samples on both sides: the two RPN losses differ by the fp16 trunk only.  The RoI losses depend on proposals
+    # that fp16 features may reorder: tight when the RoI sampler saw the oracle's populations (then the subsets are identical)
     for k in ("loss_objectness", "loss_rpn_box_reg"):
-        assert abs(float(losses[k].detach()) - float(ol[k].detach())) < 0.25 * abs(float(ol[k].detach())) + 5e-2, (k, float(losses[k].detach()), float(ol[k].detach()))
+        assert abs(float(losses[k].detach()) - float(ol[k].detach())) < 0.03 * abs(float(ol[k].detach())) + 2e-3, (k, float(losses[k].detach()), float(ol[k].detach()))
+    same_roi = [p_.numel() for p_ in roi.log] == [p_.numel() for p_ in perms.log[4:]]
+    print("RoI sampler populations product %s oracle %s" % ([p_.numel() for p_ in roi.log], [p_.numel() for p_ in perms.log[4:]]))
+    for k in ("loss_classifier", "loss_box_reg"):
+        tol_k = 0.03 if same_roi else 0.3
+        assert abs(float(losses[k].detach()) - float(ol[k].detach())) < tol_k * abs(float(ol[k].detach())) + 2e-3, (k, float(losses[k].detach()), float(ol[k].detach()), same_roi)
     # gradient reaches the image, only on the 300x300 nearest-selected source pixels
     total = sum(losses.values())
     total.backward()
@@ -311,7 +328,7 @@ def test_detector_image_gradient_matches_oracle(dev, case):
     cos = float(torch.nn.functional.cosine_similarity(gx.flatten(), go.flatten(), dim=0))
     print("image-gradient rel-L2 %.4f cosine %.5f" % (rel, cos))
     # ReLU decisions of ~70 layers are re-taken on fp16-noisy activations on the oracle side (not pinned here)
-    assert cos > 0.90 and rel < 0.5
+    assert cos > 0.95 and rel < 0.35          # measured 0.968 / 0.254
     # exact structural property: pixels that the nearest resize never selects get exactly zero gradient
     sel = (go.abs().sum(dim=1) > 0)
     assert (gx.abs().sum(dim=1)[~sel] == 0).all()

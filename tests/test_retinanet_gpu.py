@@ -204,3 +204,42 @@ def test_three_pass_fusion_equals_three_single_passes(dev, case):
     for (_, dm), ds in zip(out, singles):
         for x, y in zip(dm, ds):
             assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["scores"], y["scores"]) and torch.equal(x["boxes"], y["boxes"])
+
+
+def test_loss_kernels_against_reference_vectors_and_oracle_gradients(dev):
+    """hd_sigmoid_focal_loss / hd_retinanet_loss behind the reference-shaped `sigmoid_focal_loss` and `box_loss`:
+    values against vectors produced by the REFERENCE's own functions (tests/golden/glue_retinanet.npz, made by
+    tests/golden/make_golden.py), gradients against the oracle's autograd."""
+    import os
+    import numpy as np
+    from hallucidet_amd.utils import eval_forward_retinanet as G
+    z = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(os.path.dirname(__file__), "golden", "glue_retinanet.npz")).items()}
+    x, t = z["focal.x"].to(dev), z["focal.t"].to(dev)
+    assert torch.allclose(G.sigmoid_focal_loss(x, t).cpu(), z["focal.none"], rtol=1e-5, atol=1e-7)
+    assert torch.allclose(G.sigmoid_focal_loss(x, t, reduction="sum").cpu(), z["focal.sum"], rtol=1e-5)
+    assert torch.allclose(G.sigmoid_focal_loss(x, t, alpha=-1, gamma=0, reduction="mean").cpu(), z["focal.mean_a-1_g0"], rtol=1e-5)
+    with pytest.raises(ValueError, match="Invalid Value for arg 'reduction'"):
+        G.sigmoid_focal_loss(x, t, reduction="max")
+    # gradients: a larger random case incl. saturated logits, two gammas
+    g = torch.Generator().manual_seed(3)
+    xx = torch.randn(257, 3, generator=g) * 4
+    tt = (torch.rand(257, 3, generator=g) > 0.8).float()
+    for gamma, alpha in ((2.0, 0.25), (1.5, 0.6), (0.0, -1.0)):
+        xo = xx.clone().requires_grad_(True)
+        (orn.sigmoid_focal_loss(xo, tt, alpha=alpha, gamma=gamma, reduction="none") * torch.arange(1, 4)).sum().backward()
+        xg = xx.to(dev).requires_grad_(True)
+        (G.sigmoid_focal_loss(xg, tt.to(dev), alpha=alpha, gamma=gamma, reduction="none") * torch.arange(1, 4, device=dev)).sum().backward()
+        assert torch.allclose(xg.grad.cpu(), xo.grad, rtol=2e-4, atol=1e-6), (gamma, alpha)
+    bc = od.BoxCoder((1.0,) * 4)
+    a, gts, br = z["boxloss.anchors"].to(dev), z["boxloss.gts"].to(dev), z["boxloss.breg"].to(dev)
+    assert torch.allclose(G.box_loss("smooth_l1", bc, a, gts, br).cpu(), z["boxloss.smooth_l1"], rtol=1e-5)
+    assert torch.allclose(G.box_loss("l1", bc, a, gts, br).cpu(), z["boxloss.l1"], rtol=1e-5)
+    assert torch.allclose(G.box_loss("smooth_l1", bc, a, gts, br, cnf={"beta": 0.3}).cpu(),
+                          torch.nn.functional.smooth_l1_loss(z["boxloss.breg"], bc.encode_single(z["boxloss.gts"], z["boxloss.anchors"]), reduction="sum", beta=0.3), rtol=1e-5)
+    bo = z["boxloss.breg"].clone().requires_grad_(True)
+    torch.nn.functional.smooth_l1_loss(bo, bc.encode_single(z["boxloss.gts"], z["boxloss.anchors"]), reduction="sum", beta=1.0).backward()
+    bg = br.clone().requires_grad_(True)
+    G.box_loss("smooth_l1", bc, a, gts, bg).backward()
+    assert torch.allclose(bg.grad.cpu(), bo.grad, rtol=1e-5, atol=1e-7)
+    with pytest.raises(Exception, match="Unsupported loss"):
+        G.box_loss("huber", bc, a, gts, br)

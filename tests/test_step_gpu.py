@@ -47,11 +47,34 @@ def _pair(dev, detector_name, seed):
     tr32.det.set_quant(lambda t: t)
     if detector_name == "fasterrcnn":
         for t_, sd in ((tr, 1), (tr32, 1)):       # same sampler draws on both oracle sides
-            g = torch.Generator().manual_seed(sd)
-            fn = (lambda gg: (lambda n: torch.randperm(n, generator=gg)))(g)
+            fn = Draws(sd)
             t_.det.rpn.fg_bg_sampler.randperm_fn = fn
             t_.det.roi_heads.fg_bg_sampler.randperm_fn = fn
+        # ... and on the product side: the reference's per-pass call order (RPN sampler, then RoI sampler, image by image;
+        # `fused_passes` / the batched three-pass evaluation draw in a different order) with the same seeded permutations
+        lit.batch_detector_passes = False
+        lit.detector.fused_passes = False
+        fn = Draws(1)
+        lit.detector.rpn.fg_bg_sampler.randperm_fn = fn
+        lit.detector.roi_heads.fg_bg_sampler.randperm_fn = fn
     return lit, tr, tr32
+
+
+class Draws:
+    """torch.randperm from a private seeded generator; logs the population sizes so that a test can tell whether two sides
+    drew for the same populations (then the sampled index sets are identical)."""
+
+    def __init__(self, seed):
+        self.seed = seed
+        self.reset()
+
+    def reset(self):
+        self.g = torch.Generator().manual_seed(self.seed)
+        self.sizes = []
+
+    def __call__(self, n):
+        self.sizes.append(int(n))
+        return torch.randperm(n, generator=self.g)
 
 
 def _to_cpu(batch):
@@ -81,24 +104,35 @@ def test_training_step_matches_oracle(dev, detector_name):
     keymap = ({"det_classification": "classification", "det_regression": "bbox_regression"} if detector_name == "retinanet" else
               {"det_classification": "loss_classifier", "det_regression": "loss_box_reg", "det_objectness": "loss_objectness",
                "det_rpn_box_reg": "loss_rpn_box_reg"})
-    # RetinaNet has no sampler: every loss is a deterministic function of the features -> tight; Faster R-CNN draws
-    # different random subsets on the two sides and proposals reorder under fp16 noise -> loose (see test_detector_gpu)
-    tol = 0.03 if detector_name == "retinanet" else 0.3
+    # RetinaNet has no sampler: every loss is a deterministic function of the features -> 3 %.  Faster R-CNN: both sides draw
+    # the SAME seeded permutations in the same call order; the RPN sampler's populations depend on anchors and targets only, so
+    # its subsets are identical -> 3 %.  The RoI sampler's populations depend on the proposals, which fp16 noise may reorder at
+    # the NMS / top-k margins: where the first pass's populations coincide the subsets are identical and the RoI losses are
+    # held to 3 % too, otherwise (different random subsets of ~512 of ~1000 RoIs) to 30 %.
+    tol = {k: 0.03 for k in keymap}
+    if detector_name == "fasterrcnn":
+        ps, os_ = lit.detector.rpn.fg_bg_sampler.randperm_fn.sizes, tr.det.rpn.fg_bg_sampler.randperm_fn.sizes
+        n_img = 2
+        assert ps[:2 * n_img] == os_[:2 * n_img], "RPN sampler populations must coincide (anchors and targets are identical)"
+        same_roi = ps[2 * n_img:4 * n_img] == os_[2 * n_img:4 * n_img]
+        print("sampler populations (first pass) product %s oracle %s -> RoI subsets %s" % (ps[:4 * n_img], os_[:4 * n_img],
+                                                                                         "identical" if same_roi else "differ"))
+        if not same_roi:
+            tol["det_classification"] = tol["det_regression"] = 0.3
     for pk, ok_ in keymap.items():
         a, b = float(out["loss"][pk]), 0.1 * float(olosses[ok_])
-        assert abs(a - b) < tol * abs(b) + 2e-3, (pk, a, b)
+        assert abs(a - b) < tol[pk] * abs(b) + 2e-3, (pk, a, b, tol[pk])
     if detector_name == "retinanet":
         assert out["loss"]["det_objectness"] == 0.0 and out["loss"]["det_rpn_box_reg"] == 0.0 and out["loss"]["det_bbox_ctrness"] == 0.0
-        assert abs(float(out["loss"]["total"]) - float(total)) < tol * abs(float(total)) + 2e-3
+        assert abs(float(out["loss"]["total"]) - float(total)) < 0.03 * abs(float(total)) + 2e-3
     hall = out["output"]["imgs_hallucinated"]
     assert hall.shape == (2, 3, 128, 160) and float(hall.min()) >= 0.0 and float(hall.max()) <= 1.0
 
     # ---- one optimisation step on both sides (fresh forward: BN running statistics advance once more on both)
+    if detector_name == "fasterrcnn":                # re-seed so that both optimisation steps draw what tr32's single step drew
+        lit.detector.rpn.fg_bg_sampler.randperm_fn.reset()
+        tr.det.rpn.fg_bg_sampler.randperm_fn.reset()
     loss = lit.fit_step(batch)
-    if detector_name == "fasterrcnn":                # re-seed so that train_step draws what tr32's single step drew
-        g = torch.Generator().manual_seed(1)
-        fn = lambda n: torch.randperm(n, generator=g)
-        tr.det.rpn.fg_bg_sampler.randperm_fn = tr.det.roi_heads.fg_bg_sampler.randperm_fn = fn
     tr.train_step(_to_cpu(batch))
     assert torch.isfinite(loss)
     after = {k: v.detach().cpu() for k, v in lit.encoder_decoder.state_dict().items()}
