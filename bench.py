@@ -5,11 +5,15 @@ resident in HBM.  Prints ONE JSON line (rank 0).
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-`roofline`: the dominant kernel is the convolution behind hd_conv2d (conv_igemm_kernel, and conv3x3_small_kernel for the
-16/32-channel 3x3 layers: every conv / data-gradient / FC of the U-Net and the detector).  Its launches of one step are recorded and re-issued back to back between HIP events on
-the launch stream; achieved = algorithmic FLOPs of those launches / their summed duration (DESIGN.md "Measurement").
-`cpu_baseline`: the CPU oracle (oracle/step.py, "port") timed on this host's cores on a bounded sample of the same
-workload (rank 0, N=1 only).
+`roofline`: the dominant kernel is the convolution behind hd_conv2d (the conv_igemm / conv3x3_w8 / conv3x3_small kernels: every
+conv / data-gradient / FC of the U-Net and the detector).  `achieved` = algorithmic FLOPs of the launches of ONE real
+training step / the duration of those launches replayed once each, in step order, between HIP events on the launch stream -- the
+number a rocprofv3 kernel summary of the step reproduces; `achieved_isolated` re-issues every launch 5x back to back (warm caches:
+the upper bound the first round quoted).  `mfma_util` / `traffic` come from the rocprofv3 PMC passes committed under profiles/.
+`cpu_baseline`: the CPU oracle (oracle/step.py, "port") on this host's cores (rank 0, N=1 only): batch 8, all cores, one warm-up
+(batch 2) + one timed step, plus the U-Net alone at the reference's 8 threads -- bounded so that the default run stays within
+minutes; `--cpu-protocol full` runs SURVEY 8d's protocol (2 warm-ups + 3 timed steps at batch 8, 8 threads and all cores).
+Other BASELINE configs: `--config retinanet16` (configs[3]) and `--config detector16` (configs[4]) print their own lines.
 """
 import argparse
 import json
@@ -28,13 +32,32 @@ BATCH_PER_GPU = 8
 H, W = 512, 640
 
 
+def _profile_json(names):
+    for n in names:
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", n)))
+        except Exception:
+            continue
+    return None
+
+
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in two separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py) committed under profiles/ for this round.
     bench.py itself cannot collect PMCs (they need rocprofv3 around the process): null if the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_traffic.json")
+    j = _profile_json(["r02_conv_traffic.json", "r01_conv_traffic.json"])
     try:
-        return round(json.load(open(path))["traffic_bytes_per_launch"])
+        return round(j["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def _pmc_mfma_util():
+    """MFMA-pipe utilisation of the conv kernels in a training step (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy
+    clocks), tools/pmc_mfma.py on a `rocprofv3 --pmc` run of tools/bench_step.py), committed under profiles/."""
+    j = _profile_json(["r02_conv_mfma_util.json"])
+    try:
+        return {"value": j["mfma_util"], "by_kernel": j.get("by_kernel"), "source": "profiles/r02_conv_mfma_util.json"}
     except Exception:
         return None
 
@@ -115,6 +138,25 @@ def conv_roofline(lit, batch, reps=5):
         r.enable_graphs(was)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     tot_ms, tot_fl, tot_by = 0.0, 0.0, 0.0
+
+    # STEP-ORDER replay: every recorded launch ONCE, in the order of the step, on its own operands (each launch finds its inputs as
+    # cold in L2 as in the step: 257 different tensors, ~9 GB per pass), one event pair around each group's sequence.  This is
+    # what a rocprofv3 kernel summary of the training step reproduces (profiles/README.md); re-issuing one launch 5x back to back
+    # (`*_isolated`) reads 10-15 % faster.
+    def replay(items, call, passes=3):
+        for it in items:
+            call(it)
+        e0.record()
+        for _ in range(passes):
+            for it in items:
+                call(it)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / passes
+    conv_call = lambda it: orig(it[1][0], it[1][1], it[1][2], it[1][3], **it[0])
+    grp_step = {k: replay([r_ for r_ in rec if r_[4] == k], conv_call) for k in ("unet", "detector")}
+    step_conv_ms = replay(rec, conv_call)
+    wg_seq_ms = replay(wrec, lambda it: orig_wg(*it[0], **it[1])) if wrec else 0.0
     dump = os.environ.get("HD_BENCH_DUMP")
     rows = []
     grp = {"unet": [0.0, 0.0], "detector": [0.0, 0.0]}
@@ -142,7 +184,8 @@ def conv_roofline(lit, batch, reps=5):
                 f.write("%8.1f us %8.2f GF %7.1f TF  x=%s c2=%d w=%s k=%d s=%d dil=%d up=%d stats=%d mask=%d res=%d\n"
                         % (r_[0], r_[1], r_[1] / r_[0] * 1e-3 * 1e3, *r_[2:]))
     n = len(rec)
-    achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+    iso = tot_fl / (tot_ms * 1e-3) / 1e12
+    achieved = tot_fl / (step_conv_ms * 1e-3) / 1e12
     wg_ms = wg_fl = 0.0
     for (x, dy, KH, KW), kw, fl in wrec:
         orig_wg(x, dy, KH, KW, **kw)
@@ -154,19 +197,123 @@ def conv_roofline(lit, batch, reps=5):
         wg_ms += e0.elapsed_time(e1) / reps
         wg_fl += fl
     tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None
-    u_ms, u_fl = grp["unet"][0] + wg_ms, grp["unet"][1] + wg_fl
+    # groups are IN-STEP times (isolated re-timing in *_isolated_ms)
+    wg_s = wg_seq_ms
+    u_ms, u_fl = grp_step["unet"] + wg_s, grp["unet"][1] + wg_fl
     groups = {
-        "unet_conv_fwd_dgrad": {"ms": round(grp["unet"][0], 3), "tflops": tf(grp["unet"][1], grp["unet"][0])},
-        "unet_wgrad": {"ms": round(wg_ms, 3), "tflops": tf(wg_fl, wg_ms), "kernel": "wgrad_kernel"},
+        "unet_conv_fwd_dgrad": {"ms": round(grp_step["unet"], 3), "tflops": tf(grp["unet"][1], grp_step["unet"]), "isolated_ms": round(grp["unet"][0], 3)},
+        "unet_wgrad": {"ms": round(wg_s, 3), "tflops": tf(wg_fl, wg_s), "isolated_ms": round(wg_ms, 3), "kernel": "wgrad_kernel"},
         "unet_conv_blocks_total": {"ms": round(u_ms, 3), "tflops": tf(u_fl, u_ms), "frac": round(u_fl / (u_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if u_ms else None,
                                    "gflop_per_image": round(u_fl / 1e9 / BATCH_PER_GPU, 1)},
-        "detector_conv": {"ms": round(grp["detector"][0], 3), "tflops": tf(grp["detector"][1], grp["detector"][0])},
+        "detector_conv": {"ms": round(grp_step["detector"], 3), "tflops": tf(grp["detector"][1], grp_step["detector"]), "isolated_ms": round(grp["detector"][0], 3)},
     }
-    return {"bound": "mfma", "groups": groups, "achieved": round(achieved, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "traffic": _pmc_traffic(), "traffic_unit": "HBM bytes per launch (PMC)",
+    return {"bound": "mfma", "groups": groups, "achieved": round(achieved, 2), "achieved_isolated": round(iso, 2), "peak": MFMA_F16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "frac_isolated": round(iso / MFMA_F16_PEAK_TFLOPS, 4),
+            "timing": "step-order replay: the 257 hd_conv2d launches of one training step, each once, in step order, between HIP events on the "
+                      "launch stream (3 passes); `*_isolated`: each launch 5x back to back",
+            "mfma_util": _pmc_mfma_util(), "traffic": _pmc_traffic(), "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
-            "kernel": "hd_conv2d: conv_igemm_kernel (implicit-GEMM conv / dgrad / FC) + conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
-            "avg_launch_us": round(tot_ms * 1e3 / max(n, 1), 2), "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3)}
+            "kernel": "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + "
+                      "conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
+            "avg_launch_us": round(step_conv_ms * 1e3 / max(n, 1), 2), "avg_launch_us_isolated": round(tot_ms * 1e3 / max(n, 1), 2),
+            "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3)}
+
+
+def cpu_baseline(protocol):
+    """The CPU oracle (oracle/step.py: fp32 torch restatement of the training step, `kind` "port") on this host's cores.
+    SURVEY 8d asks for batch 8, 2 warm-ups + >= 3 timed steps, at the reference's 8 threads (src/config/config.py:10-11) and
+    at all cores, plus the U-Net alone -- about ten minutes of CPU time, which the default run cannot afford; `bounded` keeps
+    batch 8 / all cores for the full step but takes one warm-up (batch 2) and ONE timed step, and times the U-Net alone
+    (forward + backward, batch 2) at 8 threads."""
+    from hallucidet_amd import synthetic
+    from oracle.step import OracleTrainer
+    host = _cpu_model()
+    ncores = os.cpu_count() or 1
+    res = {"unit": "images/s", "kind": "port", "protocol": protocol}
+
+    def timed_steps(batch_n, threads, warm, steps, warm_n=None):
+        torch.set_num_threads(threads)
+        tr = OracleTrainer()
+        for _ in range(warm):
+            tr.train_step(synthetic.make_batch(warm_n or batch_n, H, W, seed=123, device="cpu"))
+        b = synthetic.make_batch(batch_n, H, W, seed=123, device="cpu")
+        t0 = time.time()
+        for _ in range(steps):
+            tr.train_step(b)
+        return batch_n * steps / (time.time() - t0)
+
+    def unet_only(batch_n, threads, reps):
+        from oracle import unet as ou
+        torch.set_num_threads(threads)
+        net = ou.Unet(classes=3).train()
+        x = torch.rand(batch_n, 3, H, W)
+        net(x).mean().backward()                 # warm-up
+        t0 = time.time()
+        for _ in range(reps):
+            net(x).mean().backward()
+        return batch_n * reps / (time.time() - t0)
+
+    if protocol == "full":
+        v_all = timed_steps(8, ncores, 2, 3)
+        v_8 = timed_steps(8, 8, 2, 3)
+        res.update(value=round(v_all, 4), cores=ncores, value_8_threads=round(v_8, 4), unet_only_all_cores=round(unet_only(8, ncores, 3), 4),
+                   unet_only_8_threads=round(unet_only(8, 8, 3), 4),
+                   sample="SURVEY 8d protocol: batch 8 x 512x640, 2 warm-up + 3 timed full training steps of the CPU oracle at all %d cores "
+                          "(`value`) and at the reference's 8 threads; U-Net forward+backward alone likewise; host: %s" % (ncores, host))
+    else:
+        v_all = timed_steps(8, ncores, 1, 1, warm_n=2)
+        res.update(value=round(v_all, 4), cores=ncores, unet_only_8_threads=round(unet_only(2, 8, 1), 4),
+                   sample="bounded: ONE timed full training step of the CPU oracle (oracle/step.py, fp32 torch) on batch 8 x 512x640 at all %d "
+                          "cores after one warm-up step on batch 2; U-Net forward+backward alone on batch 2 at the reference's 8 threads "
+                          "(src/config/config.py:10-11); the full SURVEY 8d protocol (`--cpu-protocol full`) is recorded in "
+                          "profiles/r02_cpu_baseline_full.json; host: %s" % (ncores, host))
+    return res
+
+
+def bench_detector_training(args, dev, rank, world):
+    """BASELINE configs[4]: train_detector.py (Faster R-CNN, RGB, batch 16/GPU): detector forward + backward with parameter
+    gradients for torchvision's trainable set, Adam, all-reduce of those gradients."""
+    from hallucidet_amd import synthetic
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.train_detector import DetectorLit
+    torch.manual_seed(1)
+    det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector.to(dev)
+    rgb, trgb, _, _ = synthetic.make_batch(BATCH_PER_GPU, H, W, seed=123 + rank, device=dev)
+    il, _ = det.transform(rgb[:2], None)
+    det.backbone.calibrate_(il.tensors)
+    lit = DetectorLit(batch_size=BATCH_PER_GPU, detector=det, pretrained=False, device=dev).prepare()
+    for _ in range(args.warmup):
+        lit.fit_step((rgb, trgb))
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = lit.fit_step((rgb, trgb))
+    torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    if not torch.isfinite(loss):
+        raise SystemExit("non-finite loss in the timed region")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec train_detector (640x512 RGB, batch %d/GPU)" % BATCH_PER_GPU, "value": round(BATCH_PER_GPU * world * args.steps / elapsed, 2),
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "train_detector.py fasterrcnn RGB batch=%d/GPU (BASELINE configs[4], NOT the headline config): Faster R-CNN "
+                                   "R50-FPN @300x300 forward + backward with weight gradients (layer2-4, FPN, RPN, RoI heads), Adam" % BATCH_PER_GPU,
+                       "global_batch": BATCH_PER_GPU * world, "parallelism": "dp%d" % world},
+            "final_loss": round(float(loss), 5), "skipped_steps": lit.optimizer.skipped_steps}), flush=True)
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -178,7 +325,19 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--detector", default="fasterrcnn", choices=["fasterrcnn", "retinanet"],
                     help="fasterrcnn = the configuration BASELINE.json's metric is quoted on (default); retinanet = configs[3]")
+    ap.add_argument("--batch", type=int, default=0, help="images per GPU (default 8: BASELINE configs[1])")
+    ap.add_argument("--config", default="", choices=["", "retinanet16", "detector16"],
+                    help="retinanet16 = BASELINE configs[3] (train_hallucidet, RetinaNet, batch 16/GPU); detector16 = configs[4] "
+                         "(train_detector.py, Faster R-CNN, RGB, batch 16/GPU).  Not the headline metric: their own JSON lines")
+    ap.add_argument("--cpu-protocol", default="bounded", choices=["bounded", "full"])
     args = ap.parse_args()
+    global BATCH_PER_GPU
+    if args.config == "retinanet16":
+        args.detector, args.batch = "retinanet", args.batch or 16
+    if args.config == "detector16":
+        args.batch = args.batch or 16
+    if args.batch:
+        BATCH_PER_GPU = args.batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -195,6 +354,8 @@ def main():
 
     from hallucidet_amd import synthetic
     dev = "cuda:%d" % local
+    if args.config == "detector16":
+        return bench_detector_training(args, dev, rank, world)
     lit = synthetic.make_module(seed=123, device=dev, precision=16, detector_name=args.detector)
     batch = synthetic.make_batch(BATCH_PER_GPU, H, W, seed=123 + rank, device=dev)   # per-rank shard, resident in HBM
 
@@ -224,6 +385,8 @@ def main():
         # already waiting at the final barrier), so the gradient averager is detached for the extra steps
         lit.averager.start = lambda g: None
         lit.averager.finish = lambda g: None
+        lit.averager.bucket_ready = lambda lo, hi: None
+        lit.overlap_allreduce = False
         value = BATCH_PER_GPU * world * args.steps / elapsed
         out = {
             "metric": "images/sec train_hallucidet (640x512, batch 8/GPU)",
@@ -233,12 +396,14 @@ def main():
             "config": {"workload": ("train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
                                     "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300, loss scaling, "
                                     "value clip 0.5, Adam") if args.detector == "fasterrcnn" else
-                                   ("train_hallucidet.py retinanet batch=8 fp16 (BASELINE configs[3], NOT the headline config); "
+                                   ("train_hallucidet.py retinanet batch=%d/GPU fp16 (BASELINE configs[3], NOT the headline config); " % BATCH_PER_GPU +
                                     "U-Net resnet34 fwd+bwd, 3 frozen RetinaNet R50-FPN passes @300x300, loss scaling, clip, Adam"),
                        "global_batch": BATCH_PER_GPU * world, "image": "1x512x640 IR + 3x512x640 RGB",
+                       "batch_per_gpu": BATCH_PER_GPU,
                        "parallelism": "dp%d" % world, "alg_gflop_per_image": 428.5 if args.detector == "fasterrcnn" else None,
                        "step_alg_tflops": round(428.5e9 * value / 1e12, 1) if args.detector == "fasterrcnn" else None},
             "final_loss": round(float(loss), 5),
+            "skipped_steps": lit.optimizer.skipped_steps,       # overflow-skipped optimizer steps in the whole run (must be 0)
         }
         if world == 1:
             # PCIe-inclusive rate (never `value`): the same step with the batch copied from pinned host memory every step
@@ -254,15 +419,10 @@ def main():
                 h2d_step()
             torch.cuda.synchronize()
             out["pcie_inclusive_images_per_s"] = round(BATCH_PER_GPU * 10 / (time.perf_counter() - t1), 2)
-        if not args.no_roofline:
+        if not args.no_roofline and args.detector == "fasterrcnn" and BATCH_PER_GPU == 8:
             out["roofline"] = conv_roofline(lit, batch)
-        if world == 1 and not args.no_cpu_baseline:
-            from oracle.step import time_cpu_step
-            cb = synthetic.make_batch(2, H, W, seed=123, device="cpu")
-            v, steps, cores = time_cpu_step(cb, budget_s=25.0, max_steps=2)
-            out["cpu_baseline"] = {"value": round(v, 4), "unit": "images/s", "cores": cores, "kind": "port",
-                                   "sample": "%d full training step(s) of the CPU oracle (oracle/step.py, fp32 torch) on a batch of 2 "
-                                             "synthetic 512x640 images; host: %s" % (steps, _cpu_model())}
+        if world == 1 and not args.no_cpu_baseline and not args.config:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_protocol)
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()                 # ranks > 0 wait here while rank 0 finishes its roofline / baseline legs

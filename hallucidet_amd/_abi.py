@@ -67,6 +67,7 @@ PROTOTYPES = {
     "hd_conv2d_patch_stats_rows": (C.c_int, [C.POINTER(ConvArgs)]),
     "hd_conv_set_workspace": (C.c_int, [vp, C.c_int64]),
     "hd_conv_tune_w8": (C.c_int, [C.c_int, C.c_int]),
+    "hd_wgrad_w8_blocks": (C.c_int, [C.POINTER(WgradArgs)]),
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "hd_wgrad_tune_override": (C.c_int, [C.c_int]),
     "hd_wgrad_reduce": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
@@ -78,7 +79,7 @@ PROTOTYPES = {
     "hd_bn_eval_scale_shift": (C.c_int, [vp, vp, vp, vp, c_f, C.c_int, vp, vp, vp]),
     "hd_bn_apply": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, C.c_int, vp]),
     "hd_bn_bwd_reduce": (C.c_int, [vp] * 8 + [C.c_int, c_i64, C.c_int, C.c_int, vp]),
-    "hd_bn_bwd_apply": (C.c_int, [vp] * 8 + [C.c_int] + [vp] * 4 + [c_f, C.c_int, c_i64, C.c_int, C.c_int, vp]),
+    "hd_bn_bwd_apply": (C.c_int, [vp] * 8 + [C.c_int] + [vp] * 5 + [c_f, C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "hd_maxpool3x3s2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_maxpool3x3s2_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_maxpool3x3s2_idx": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),

@@ -424,6 +424,15 @@ extern "C" int hd_wgrad_tune_override(int tm) {
 // wgrad3x3_small.hip: 3x3 / s1 / p1, Cin in {16,32}, Cout <= 32 (HD_WGRAD_SMALL=0 or a tile override keeps the general kernel)
 bool hd_wgrad_small_eligible(const hd_wgrad_args* a);
 void hd_wgrad_small_launch(const hd_wgrad_args* a, hipStream_t s);
+// wgrad3x3_w8.hip: 3x3 / s1 / p1, >= 64 channels in and out: 8-wave patch-staged kernel (HD_WGRAD_W8=0 keeps the general kernel)
+bool hd_wgrad_w8_eligible(const hd_wgrad_args* a);
+void hd_wgrad_w8_launch(const hd_wgrad_args* a, hipStream_t s);
+extern "C" int hd_wgrad_w8_blocks(const hd_wgrad_args* a) {
+  if (!a) return 0;
+  static const char* env = getenv("HD_WGRAD_W8");
+  if ((env && env[0] == '0') || !hd_wgrad_w8_eligible(a)) return 0;
+  return ((a->C1 + a->C2) / 64) * (a->Cout / 64);
+}
 
 extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   HD_CHECK_ARG(a && a->x && a->dy && a->slab, "hd_wgrad: null pointer");
@@ -435,6 +444,15 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
     static const bool small_on = !(env && env[0] == '0');
     if (small_on && g_wg_tm < 0 && hd_wgrad_small_eligible(a)) {
       hd_wgrad_small_launch(a, (hipStream_t)stream);
+      HD_CHECK_LAUNCH();
+      return HD_OK;
+    }
+  }
+  {
+    static const char* env8 = getenv("HD_WGRAD_W8");
+    static const bool w8_on = !(env8 && env8[0] == '0');
+    if (w8_on && g_wg_tm < 0 && hd_wgrad_w8_eligible(a)) {
+      hd_wgrad_w8_launch(a, (hipStream_t)stream);
       HD_CHECK_LAUNCH();
       return HD_OK;
     }

@@ -2,8 +2,11 @@
 over xGMI, gradients of the 24.4 M U-Net parameters only (the detector is frozen and replicated).
 
 All parameters and gradients live in ONE flat fp32 arena (UnetRunner.flatten_parameters), so the exchange is a handful of
-large all-reduces over contiguous slices (default 4 buckets of ~24 MB: xGMI is point-to-point, per-link bound, so few big
-messages beat many small ones) issued asynchronously and waited on right before the optimizer step.  BatchNorm statistics
+large all-reduces over contiguous slices (xGMI is point-to-point, per-link bound: few big messages beat many small ones).
+OVERLAP: the backward pass completes the arena from its end (head + decoder, then layer4 ... layer1 + stem), and the runner
+calls `bucket_ready(lo, hi)` at each of those five boundaries -- the all-reduce of a bucket is issued while the kernels of the
+following encoder stages still run (the 52 MB layer4 bucket is ready after ~35 % of the backward) and `finish()` waits right
+before the optimizer step.  Without hooks `start()` issues the whole arena after backward (4 buckets).  BatchNorm statistics
 stay per rank (the reference has no SyncBatchNorm).  The same code runs on the gloo backend for CPU tests.
 """
 import os
@@ -30,23 +33,60 @@ class GradientAverager:
     def __init__(self, n_buckets=4):
         self.n_buckets = n_buckets
         self._work = []
+        self._flat = None
+        self._covered = []
+        self.issued = []          # [(lo, hi)] of the current step, in issue order (tests / diagnostics)
+
+    def begin(self, flat_grads):
+        """Start of a step's backward pass: buckets will arrive through bucket_ready()."""
+        self._flat, self._covered, self._work, self.issued = flat_grads, [], [], []
+
+    def bucket_ready(self, lo, hi):
+        """Gradient slice [lo, hi) is final: launch its SUM all-reduce now (async; ordered after the kernels already enqueued on
+        the current stream, concurrent with everything enqueued afterwards)."""
+        if self._flat is None or hi <= lo:
+            return
+        self._covered.append((lo, hi))
+        self.issued.append((lo, hi))
+        if is_dist():
+            self._work.append(dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def start(self, flat_grads):
-        """Launch bucketed SUM all-reduces (async)."""
-        self._work = []
-        if not is_dist():
-            return
+        """Launch SUM all-reduces (async) for whatever part of the arena the bucket hooks have not covered yet (all of it when
+        no hook ran: n_buckets equal slices)."""
+        if self._flat is not flat_grads:
+            self.begin(flat_grads)
         n = flat_grads.numel()
-        step = (n + self.n_buckets - 1) // self.n_buckets
-        step = (step + 1023) // 1024 * 1024
-        for o in range(0, n, step):
-            self._work.append(dist.all_reduce(flat_grads[o:min(n, o + step)], op=dist.ReduceOp.SUM, async_op=True))
+        done = sorted(self._covered)
+        gaps, pos = [], 0
+        for lo, hi in done:
+            if lo > pos:
+                gaps.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < n:
+            gaps.append((pos, n))
+        for lo, hi in gaps:
+            step = (hi - lo + self.n_buckets - 1) // self.n_buckets
+            step = max(1024, (step + 1023) // 1024 * 1024)
+            for o in range(lo, hi, step):
+                self.bucket_ready(o, min(hi, o + step))
 
     def finish(self, flat_grads):
         """Wait and divide by the world size (mean gradient, as DDP)."""
+        work, self._work, self._flat = self._work, [], None
         if not is_dist():
             return
-        for w in self._work:
+        for w in work:
             w.wait()
-        self._work = []
         flat_grads.mul_(1.0 / dist.get_world_size())
+
+
+def exchange_and_step(averager, flat_grads, scaler, optimizer):
+    """What follows backward() in a data-parallel training step (EncoderDecoderLit.fit_step): cover the slices no bucket hook
+    reported, wait for every all-reduce, take the mean, then the (replicated) unscale / overflow check / clip / Adam step and the
+    GradScaler update.  Every rank sees the same averaged gradient -- an inf on one rank is an inf on all -- so the skip decision,
+    the loss scale and the parameters stay identical across ranks without any further communication."""
+    averager.start(flat_grads)
+    averager.finish(flat_grads)
+    scaler.step(optimizer)
+    scaler.update()

@@ -106,7 +106,16 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None):
     K = KH * KW * (C1 + C2)
     M = N * Ho * Wo
     if nsplit is None:
-        nsplit = pick_nsplit(M, Cout, K)
+        probe = WgradArgs(ptr(x), ptr(x2), ptr(dy), None, N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad, 1 if up1 else 0, 1)
+        blocks8 = lib.hd_wgrad_w8_blocks(C.byref(probe))
+        if blocks8 > 0:
+            # 8-wave patch kernel: one 512-thread block per CU, at least four 16x8-pixel tiles per block
+            tiles = N * ((Ho + 15) // 16) * ((Wo + 7) // 8)
+            nsplit = max(1, min(_WGRAD8_BLOCKS // blocks8, tiles // 4))
+            while nsplit > 1 and nsplit * Cout * K * 4 > (64 << 20):
+                nsplit //= 2
+        else:
+            nsplit = pick_nsplit(M, Cout, K)
     slab = torch.empty((nsplit, Cout, K), dtype=torch.float32, device=x.device)
     a = WgradArgs(ptr(x), ptr(x2), ptr(dy), ptr(slab), N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
                   1 if up1 else 0, nsplit)
@@ -115,6 +124,7 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None):
 
 
 _WGRAD_BLOCKS = int(os.environ.get("HD_WGRAD_BLOCKS", "0"))   # 0: per-class targets below
+_WGRAD8_BLOCKS = int(os.environ.get("HD_WGRAD8_BLOCKS", "256"))   # one 512-thread block per CU: every block writes a 147 KB fp32 partial, so more blocks = more slab traffic (swept 128 / 256 / 512)
 
 
 def pick_nsplit(M, Cout, K, target_blocks=None):
@@ -254,15 +264,12 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
     C_ = y.shape[-1]
     npix = y.numel() // C_
     if rows is None:
-        # <= 16 384 pixels (layer3 / layer4 / first decoder block: latency chains, not bandwidth): at most 64 partial rows, which
-        # the apply kernel's coefficient prologue sums itself -- no row-sum launch in between (20 launches per step)
-        rows = int(max(1, min(512, npix // 64))) if npix > 16384 else int(max(1, min(64, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
+        rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
     lib = _abi.load()
     part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
     check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
                                1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
-    if rows > 64:                  # one row-range stage; every block of the apply kernel sums the remaining rows in its
-        part = rowsum(part, 16)    # coefficient prologue (<= 64 x 2C floats per block)
+    coef = torch.empty((5, C_), dtype=torch.float32, device=y.device)      # A, B, D, scale, shift: written by the coefficient launch
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None
     if dgamma is None:
@@ -270,7 +277,7 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
     if dbeta is None:
         dbeta = torch.empty(C_, dtype=torch.float32, device=y.device)
     check(lib.hd_bn_bwd_apply(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), part.shape[0],
-                              ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), gscale, 1 if accumulate else 0, npix, C_,
+                              ptr(coef), ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), gscale, 1 if accumulate else 0, npix, C_,
                               1 if relu else 0, _stream()), "hd_bn_bwd_apply")
     return dy, dres, dgamma, dbeta
 

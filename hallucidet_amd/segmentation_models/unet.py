@@ -208,6 +208,12 @@ class UnetRunner:
         self.saved = None
         self.use_graphs = False        # replay the (static-shape) schedule as two hipGraphs: see enable_graphs()
         self._g = None
+        # data parallelism: called as hook(lo, hi) when the gradient-arena slice [lo, hi) is final, decoder + head first, then
+        # layer4 .. layer1 + stem (the arena is in parameter order, so backward completes it from the end).  With a hook the
+        # backward graph is captured in SEGMENTS and the hook runs between their replays (the collective of bucket k then
+        # overlaps the kernels of segment k+1).
+        self.bucket_hook = None
+        self._cut = None
         enc, dec = module.encoder, module.decoder
         self.stem = _Unit("encoder.conv1", enc.conv1, enc.bn1)
         self.stages = []
@@ -264,22 +270,74 @@ class UnetRunner:
         self.saved = g["saved"]
         return g["out"]
 
+    def bucket_ranges(self):
+        """[(lo, hi)] slices of the flat gradient arena in the order the backward pass completes them."""
+        self.flatten_parameters()
+        off = {id(p): o for p, o in zip(self._params, self._offsets)}
+        total = self._gflat.numel()
+        first = lambda mod: min(off[id(p)] for p in mod.parameters())
+        enc = self.module.encoder
+        cuts = [first(self.module.decoder)] + [first(getattr(enc, "layer%d" % li)) for li in (4, 3, 2)] + [0]
+        out, hi = [], total
+        for lo in cuts:
+            out.append((lo, hi))
+            hi = lo
+        return out
+
+    def _segment_done(self, k):
+        """Called by backward() at segment boundary k (0 = decoder + head done, 1..3 = layer4..layer2, 4 = everything)."""
+        if self._cut is not None:
+            self._cut(k)
+        elif self.bucket_hook is not None:
+            self.bucket_hook(*self.bucket_ranges()[k])
+
     def run_backward(self, dout):
         if not self.use_graphs:
             return self.backward(dout.contiguous())
         g = self._g
         S = float(self.grad_scale)
-        if g["bwd"] is None or g["scale"] != S:
+        segmented = self.bucket_hook is not None
+        if g["bwd"] is None or g["scale"] != S or g.get("segmented") != segmented:
             g["dout"] = torch.empty(g["out"].shape, dtype=torch.float32, device=g["dev"])
             g["dout"].copy_(dout)
             self.saved = g["saved"]
-            g["bwd"] = torch.cuda.CUDAGraph()
-            g["scale"] = S
+            g["scale"], g["segmented"] = S, segmented
             torch.cuda.synchronize()
-            with torch.cuda.graph(g["bwd"], pool=g["pool"]):
-                self.backward(g["dout"], keep_saved=True)
+            if not segmented:
+                g["bwd"] = [torch.cuda.CUDAGraph()]
+                with torch.cuda.graph(g["bwd"][0], pool=g["pool"]):
+                    self.backward(g["dout"], keep_saved=True)
+            else:
+                # one graph per bucket: end the running capture at every boundary and begin the next one in the same pool
+                graphs = [torch.cuda.CUDAGraph()]
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                hook, self.bucket_hook = self.bucket_hook, None
+                with torch.cuda.stream(side):
+                    graphs[0].capture_begin(pool=g["pool"])
+
+                    def cut(k):
+                        if k < 4:
+                            graphs[-1].capture_end()
+                            graphs.append(torch.cuda.CUDAGraph())
+                            graphs[-1].capture_begin(pool=g["pool"])
+                    self._cut = cut
+                    try:
+                        self.backward(g["dout"], keep_saved=True)
+                    finally:
+                        self._cut = None
+                        graphs[-1].capture_end()
+                        self.bucket_hook = hook
+                torch.cuda.current_stream().wait_stream(side)
+                g["bwd"] = graphs
         g["dout"].copy_(dout)
-        g["bwd"].replay()
+        if not segmented:
+            g["bwd"][0].replay()
+        else:
+            ranges = self.bucket_ranges()
+            for k, gr in enumerate(g["bwd"]):
+                gr.replay()
+                self.bucket_hook(*ranges[k])
         return None
 
     # ------------------------------------------------------------------ parameters
@@ -459,6 +517,7 @@ class UnetRunner:
             if cskip:
                 dskip[i] = torch.empty_like(skips[i])
                 ops.slice_channels(dcat, dskip[i], cin, accumulate=False)
+        self._segment_done(0)                  # head + decoder parameter gradients are final
         # dz is now the gradient of f5; dskip[0..3] belong to f4, f3, f2, f1
         dfeat = {4: dz, 3: dskip[0], 2: dskip[1], 1: dskip[2], 0: dskip[3]}
         d_out = dfeat[4]
@@ -478,6 +537,8 @@ class UnetRunner:
                     d_in, _ = self._unit_bwd(us[0], dz1, S, dx_res=extra)
                     d_in, _ = self._unit_bwd(ud, dres, S, dx_res=d_in)
                 d_out = d_in
+            if si > 0:
+                self._segment_done(4 - si)     # layer4 -> 1, layer3 -> 2, layer2 -> 3
         # d_out = gradient of the max-pooled stem output
         df1 = ops.maxpool3x3s2_bwd_idx(sv["pool_idx"], d_out, (sv["f1"].shape[1], sv["f1"].shape[2]))
         df1 = ops.add_f16(df1, dfeat[0], out=df1)
@@ -485,6 +546,7 @@ class UnetRunner:
         if need_dx:
             raise NotImplementedError("gradient w.r.t. the Unet input is not on the hot path (IR images are data)")
         self._unit_bwd(self.stem, df1, S, need_dx=False)
+        self._segment_done(4)                  # layer1 + stem
         if not keep_saved:
             self.saved = None
         return dx

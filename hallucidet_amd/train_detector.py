@@ -152,6 +152,7 @@ class DetectorLit:
         g.zero_()                                     # optimizer_zero_grad (train_detector.py:344-345); kernels accumulate
         loss = self.training_step(batch, batch_idx)
         (loss * self.loss_scale).backward()
+        self.averager.begin(g)
         self.averager.start(g)
         self.averager.finish(g)
         self.scaler.step(self.optimizer)

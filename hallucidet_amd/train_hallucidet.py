@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .config import Config
-from .distributed import GradientAverager, broadcast_parameters
+from .distributed import GradientAverager, broadcast_parameters, exchange_and_step
 from .models.detector import Detector
 from .models.encoder_decoder import EncoderDecoder
 from .optim import LossScaler
@@ -55,6 +55,7 @@ class EncoderDecoderLit(nn.Module):
         self.scaler = None
         self.optimizer = None
         self.averager = GradientAverager()
+        self.overlap_allreduce = True        # False: one exchange after the whole backward (A/B knob)
 
     # ------------------------------------------------------------------------------------------------------------
     def forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train'):
@@ -209,10 +210,13 @@ class EncoderDecoderLit(nn.Module):
         """What Lightning does around training_step: scale -> backward -> all-reduce -> (unscale+clip+Adam fused)."""
         self.encoder_decoder.train()
         loss = self.training_step(batch, batch_idx)
+        r = self.encoder_decoder.runner
+        g = r.flat_grads
+        from .distributed import is_dist
+        # data parallel: the runner reports finished arena slices during backward (decoder first), their all-reduces overlap the
+        # rest of the backward pass; start() covers what no hook reported, finish() waits right before the optimizer
+        r.bucket_hook = self.averager.bucket_ready if (is_dist() and self.overlap_allreduce) else None
+        self.averager.begin(g)
         self.scaler.scale(loss).backward()
-        g = self.encoder_decoder.runner.flat_grads
-        self.averager.start(g)
-        self.averager.finish(g)
-        self.scaler.step(self.optimizer)
-        self.scaler.update()
+        exchange_and_step(self.averager, g, self.scaler, self.optimizer)
         return loss.detach()

@@ -119,6 +119,9 @@ typedef struct hd_wgrad_args {
   int32_t nsplit;
 } hd_wgrad_args;
 int hd_wgrad(const hd_wgrad_args* a, void* stream);
+/* blocks per pixel slice the 8-wave 3x3 weight-gradient kernel uses for this problem ((Cin/64) * (Cout/64)), 0 if hd_wgrad
+ * will not route it there: lets the caller choose `nsplit` so that nsplit * blocks fills the GPU */
+int hd_wgrad_w8_blocks(const hd_wgrad_args* a);
 /* tuning hook (tools/tune_wgrad.py): force hd_wgrad's Cout tile (32 / 64 / 128 rows); -1 = by channel count. Process-wide. */
 int hd_wgrad_tune_override(int tm);
 /* dw_oihw[co][ci][kh][kw] (=|+=) scale * sum_s slab[s][co][(kh,kw,ci)] ; Cin_real <= Cin, Cout <= Cout_slab
@@ -174,9 +177,10 @@ int hd_bn_apply(const void* y, const void* res, const float* scale, const float*
 int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                      const float* gamma, const float* beta, float* part, int rows, int64_t npix, int C, int relu, void* stream);
 /* dy = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g (optional); also emits dgamma/dbeta (fp32, scaled by gscale).
- * part[rows][2][C] (rows <= 64) are the partial rows of hd_bn_bwd_reduce (after hd_rowsum), summed in-kernel. */
+ * part[rows][2][C] (any number of rows) are the partial rows of hd_bn_bwd_reduce: a coefficient launch sums them once (fixed
+ * order) into coef_ws [5][C] (caller-owned scratch), the apply launch streams the tensor. */
 int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
-                    const float* gamma, const float* beta, const float* part, int rows, void* dy, void* dres,
+                    const float* gamma, const float* beta, const float* part, int rows, float* coef_ws, void* dy, void* dres,
                     float* dgamma, float* dbeta, float gscale, int accumulate, int64_t npix, int C, int relu, void* stream);
 
 /* ------------------------------------------------------------------------

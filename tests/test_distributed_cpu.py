@@ -63,6 +63,104 @@ def test_gradient_mean_and_broadcast_world2(n):
         assert torch.equal(p, torch.zeros(n)) and torch.equal(b, torch.full((7,), 10.0)), "rank 0 state was not broadcast"
 
 
+def _model_worker(rank, world, port, inject_inf, q):
+    """One data-parallel training step of an EncoderDecoderLit-shaped object on CPU: the REAL ParamArena / LossScaler /
+    GradientAverager / broadcast_parameters / exchange_and_step, bucket hooks fired in backward-completion order, and a torch
+    restatement of the fused Adam kernel (hd_adam_step is GPU-only) with the same skip-on-overflow contract."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import torch.nn as nn
+    from hallucidet_amd.distributed import GradientAverager, broadcast_parameters, exchange_and_step
+    from hallucidet_amd.optim import FusedAdam, LossScaler, ParamArena
+
+    class CpuAdam(FusedAdam):
+        def step(self, closure=None, inv_scale=1.0, check_inf=False):
+            r, g_ = self.runner, self.param_groups[0]
+            grads = r.flat_grads
+            self.found_inf.fill_(0.0 if bool(torch.isfinite(grads).all()) else 1.0)
+            self.step_count += 1
+            if not (check_inf and float(self.found_inf) != 0.0):
+                gg = grads.clamp(-g_["clip_value"], g_["clip_value"])
+                b1, b2 = g_["betas"]
+                self.exp_avg.mul_(b1).add_(gg, alpha=1 - b1)
+                self.exp_avg_sq.mul_(b2).addcmul_(gg, gg, value=1 - b2)
+                mh = self.exp_avg / (1 - b1 ** self.step_count)
+                vh = self.exp_avg_sq / (1 - b2 ** self.step_count)
+                r.flat_params.addcdiv_(mh, vh.sqrt().add_(g_["eps"]), value=-g_["lr"])
+            self._inf_host.copy_(self.found_inf)
+            self._inf_pending = True
+
+    torch.manual_seed(7 + rank)                       # every rank starts from DIFFERENT weights: the broadcast must fix that
+    net = nn.Sequential(nn.Conv2d(1, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(), nn.Conv2d(4, 4, 3, padding=1), nn.BatchNorm2d(4), nn.ReLU(),
+                        nn.Conv2d(4, 3, 3, padding=1))
+    arena = ParamArena(net.parameters())
+    bufs = [b for b in net.buffers() if b.dtype.is_floating_point]
+    bufs[0].fill_(float(rank + 1))
+    broadcast_parameters(arena.flat_params, bufs)
+    start, buf_start = arena.flat_params.clone(), bufs[0].clone()      # (running statistics then evolve per rank: no SyncBN in the reference)
+    opt = CpuAdam(arena, lr=1e-2, clip_value=0.5)
+    scaler = LossScaler(arena, init_scale=1024.0)
+    av = GradientAverager()
+    x = torch.rand(2, 1, 8, 8, generator=torch.Generator().manual_seed(50 + rank))         # per-rank shard
+    loss = net(x).square().mean()
+    g = arena.flat_grads
+    g.zero_()
+    av.begin(g)
+    scaler.scale(loss).backward()
+    g.div_(scaler.scale_value)                         # the HIP kernels emit parameter gradients already divided by the scale
+    own = g.clone()
+    if inject_inf and rank == 1:
+        g[3] = float("inf")
+    n = g.numel()
+    cuts = [n, n * 3 // 4 // 4 * 4, n // 2 // 4 * 4, 16, 0]      # five buckets, reported from the END of the arena (as backward does)
+    for hi, lo in zip(cuts[:-2], cuts[1:-1]):
+        av.bucket_ready(lo, hi)                        # the last slice [0, 16) is left to start(): no hook may be assumed
+    issued_by_hooks = list(av.issued)
+    exchange_and_step(av, g, scaler, opt)
+    skipped = scaler.resolve()
+    q.put((rank, own.numpy().copy(), g.numpy().copy(), start.numpy().copy(), arena.flat_params.detach().numpy().copy(), issued_by_hooks,
+           list(av.issued), bool(skipped), scaler.scale_value, opt.step_count, buf_start.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("inject_inf", [False, True])
+def test_model_level_data_parallel_step_world2(inject_inf):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_model_worker, args=(r, world, port, inject_inf, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get(timeout=180)
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    own0, avg0, start0, after0, hooks0, issued0, skip0, scale0, steps0, buf0 = res[0]
+    own1, avg1, start1, after1, hooks1, issued1, skip1, scale1, steps1, buf1 = res[1]
+    n = own0.size
+    assert (start0 == start1).all() and (buf0 == buf1).all(), "ranks must start from rank 0's parameters and BatchNorm buffers"
+    # buckets: hooks fire from the end of the arena, start() adds what they left, together exactly one cover of [0, n)
+    assert hooks0 == hooks1 and [hi for _, hi in hooks0] == sorted([hi for _, hi in hooks0], reverse=True) and hooks0[0][1] == n
+    cover = sorted(issued0)
+    assert cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    if not inject_inf:
+        import numpy as np
+        assert np.allclose(avg0, (own0 + own1) / 2, rtol=1e-6, atol=1e-9) and (avg0 == avg1).all(), "averaged gradient != mean of per-rank gradients"
+        assert not skip0 and not skip1 and steps0 == steps1 == 1
+        assert (after0 == after1).all() and not (after0 == start0).all(), "ranks must hold identical, updated parameters after the step"
+    else:
+        assert skip0 and skip1, "an overflow on one rank must skip the step on every rank"
+        assert (after0 == start0).all() and (after1 == start1).all() and steps0 == steps1 == 0
+        assert scale0 == scale1 == 512.0
+
+
 def test_single_process_is_a_noop():
     sys.path.insert(0, ROOT)
     from hallucidet_amd.distributed import GradientAverager, is_dist

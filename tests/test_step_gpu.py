@@ -199,3 +199,38 @@ def test_skip_unused_train_passes_is_opt_in_and_keeps_the_losses(dev):
     for k in ("det_classification", "det_regression", "total"):
         assert float(a["loss"][k]) == float(b["loss"][k]) == float(c["loss"][k]), k
     assert lit._last_detections["rgb"] is not None and len(lit._last_detections["rgb"]) == 2      # validation still runs all three
+
+
+def test_overlapped_allreduce_buckets_rccl_world1(dev):
+    """The data-parallel exchange on the GPU (RCCL, world size 1 via HD_FORCE_DIST): with the bucket hooks the U-Net backward is
+    replayed as five graph segments and each finished arena slice is all-reduced while the next segment runs.  Must give the
+    same step, bit for bit, as the un-overlapped exchange, report the arena from its end, and cover it exactly once."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from hallucidet_amd import synthetic
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["HD_FORCE_DIST"] = "1"
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device(dev))
+    try:
+        batch = synthetic.make_batch(2, 128, 160, seed=6, device=str(dev))
+        results = []
+        for overlap in (False, True):
+            lit = synthetic.make_module(seed=5, device=str(dev), precision=16)
+            lit.overlap_allreduce = overlap
+            torch.manual_seed(0)
+            for _ in range(3):                      # capture step + two replays
+                loss = lit.fit_step(batch)
+            r = lit.encoder_decoder.runner
+            results.append((float(loss), r.flat_grads.clone(), r.flat_params.clone(), list(lit.averager.issued), r.bucket_ranges(), r.flat_grads.numel()))
+        (l0, g0, p0, issued0, _, n), (l1, g1, p1, issued1, ranges, _) = results
+        assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
+        assert issued1[:5] == ranges and ranges[0][1] == n and ranges[-1][0] == 0
+        assert all(a[0] == b[1] for a, b in zip(ranges, ranges[1:])), "buckets must tile the arena from its end"
+        assert len(issued0) == 4 and sorted(issued0)[0][0] == 0 and sorted(issued0)[-1][1] == n      # no hooks: four equal slices after backward
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("HD_FORCE_DIST", None)
