@@ -111,3 +111,66 @@ def test_selection_kernels_at_full_proposal_counts(dev):
     assert torch.equal(pos.sum(1), counts[:, 0]) and torch.equal(neg.sum(1), counts[:, 1])
     P, Nn = (labels >= 1).sum(1), (labels == 0).sum(1)
     assert torch.equal(counts[:, 0], P.clamp(max=128)) and torch.equal(counts[:, 1], torch.minimum(Nn, 256 - counts[:, 0]))
+
+
+def test_full_size_retinanet16_step_graph_replay_equals_eager(dev):
+    """BASELINE configs[3] at its stated size (train_hallucidet, RetinaNet, batch 16 per GPU, 512x640): graph replay == eager ==
+    same seed rerun (loss and the whole flat gradient bit for bit), and the selection invariants of its post-processing at
+    17 451 anchors per image: <= 300 detections per image in descending score order, every box inside its image."""
+    from hallucidet_amd import synthetic
+    outs = []
+    for use_graphs in (True, False):
+        lit = synthetic.make_module(seed=322, detector_name="retinanet")
+        lit.encoder_decoder.runner.enable_graphs(use_graphs)
+        batch = synthetic.make_batch(16, device=dev)
+        torch.manual_seed(5)
+        lit.encoder_decoder.train()
+        loss = lit.training_step(batch, 0)
+        lit.scaler.scale(loss).backward()
+        g = lit.encoder_decoder.runner.flat_grads
+        assert torch.isfinite(loss) and bool(torch.isfinite(g).all())
+        dets = [{k: v.clone() for k, v in d.items()} for d in lit._last_detections["hall"]]
+        outs.append((float(loss.detach()), g.clone(), dets))
+        del lit
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1]) and float(outs[0][1].abs().sum()) > 0
+    dets = outs[0][2]
+    assert len(dets) == 16
+    for d0, d1 in zip(dets, outs[1][2]):
+        assert torch.equal(d0["boxes"], d1["boxes"]) and torch.equal(d0["labels"], d1["labels"])
+        n = d0["boxes"].shape[0]
+        assert n <= 300 and d0["labels"].dtype == torch.int64
+        if n > 1:
+            assert bool((d0["scores"][:-1] >= d0["scores"][1:]).all())
+        if n:
+            assert float(d0["boxes"][:, 0::2].max()) <= 640 + 1e-3 and float(d0["boxes"][:, 1::2].max()) <= 512 + 1e-3 and float(d0["boxes"].min()) >= 0.0
+
+
+def test_full_size_detector16_training_step_is_reproducible(dev):
+    """BASELINE configs[4] at its stated size (train_detector.py, Faster R-CNN, RGB, batch 16 per GPU): train-mode RPN keeps up
+    to 2000 proposals per image from 2000 pre-NMS candidates per level; two runs from the same seed give the same loss and the
+    same parameter-gradient arena bit for bit; the step moves the trainable parameters and nothing else."""
+    from hallucidet_amd import synthetic
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.train_detector import DetectorLit
+    rgb, trgb, _, _ = synthetic.make_batch(16, device=dev)
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(9)
+        det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector.to(dev)
+        il, _ = det.transform(rgb[:2], None)
+        det.backbone.calibrate_(il.tensors)
+        lit = DetectorLit(batch_size=16, detector=det, pretrained=False, device=str(dev)).prepare()
+        frozen = {k: v.clone() for k, v in det.state_dict().items() if k.startswith("backbone.body.conv1") or k.startswith("backbone.body.layer1")}
+        before = lit.arena.flat_params.clone()
+        torch.manual_seed(10)
+        loss = lit.fit_step((rgb, trgb))
+        assert torch.isfinite(loss) and float(lit.optimizer.found_inf) == 0.0
+        g = lit.arena.flat_grads
+        assert bool(torch.isfinite(g).all()) and float(g.abs().sum()) > 0
+        assert not torch.equal(lit.arena.flat_params, before)
+        for k, v in frozen.items():
+            assert torch.equal(det.state_dict()[k], v), k       # conv1 / layer1 stay fixed (trainable_layers = 3)
+        dets = lit._last_detections
+        assert len(dets) == 16 and all(d["boxes"].shape[0] <= 100 for d in dets)
+        outs.append((float(loss), g.clone()))
+    assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
