@@ -138,21 +138,32 @@ def conv_roofline(lit, batch, reps=5):
         r.enable_graphs(was)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     tot_ms, tot_fl, tot_by = 0.0, 0.0, 0.0
+    roof_ms, hbm_bound = 0.0, 0                      # every launch at ITS binding roof (MFMA peak or 8 TB/s)
 
     # STEP-ORDER replay: every recorded launch ONCE, in the order of the step, on its own operands (each launch finds its inputs as
     # cold in L2 as in the step: 257 different tensors, ~9 GB per pass), one event pair around each group's sequence.  This is
     # what a rocprofv3 kernel summary of the training step reproduces (profiles/README.md); re-issuing one launch 5x back to back
     # (`*_isolated`) reads 10-15 % faster.
     def replay(items, call, passes=3):
+        # captured in a hipGraph: issued from Python the 257 launches are host-bound (~35 us per ctypes call), which is not what
+        # the step (itself replayed from graphs) or a rocprofv3 kernel summary sees
         for it in items:
             call(it)
-        e0.record()
-        for _ in range(passes):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
             for it in items:
                 call(it)
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(passes):
+            g.replay()
         e1.record()
         e1.synchronize()
-        return e0.elapsed_time(e1) / passes
+        ms = e0.elapsed_time(e1) / passes
+        del g
+        return ms
     conv_call = lambda it: orig(it[1][0], it[1][1], it[1][2], it[1][3], **it[0])
     grp_step = {k: replay([r_ for r_ in rec if r_[4] == k], conv_call) for k in ("unet", "detector")}
     step_conv_ms = replay(rec, conv_call)
@@ -162,6 +173,8 @@ def conv_roofline(lit, batch, reps=5):
     grp = {"unet": [0.0, 0.0], "detector": [0.0, 0.0]}
     for kw, (x, w, KH, KW), fl, by, origin in rec:
         tot_by += by
+        roof_ms += max(fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / 8e12) * 1e3
+        hbm_bound += int(by / 8e12 > fl / (MFMA_F16_PEAK_TFLOPS * 1e12))
         kw = dict(kw)                                 # same epilogue (bias / res / mask / BN statistics) as in the step
         orig(x, w, KH, KW, **kw)                      # warm
         e0.record()
@@ -209,26 +222,50 @@ def conv_roofline(lit, batch, reps=5):
     }
     return {"bound": "mfma", "groups": groups, "achieved": round(achieved, 2), "achieved_isolated": round(iso, 2), "peak": MFMA_F16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "frac_isolated": round(iso / MFMA_F16_PEAK_TFLOPS, 4),
-            "timing": "step-order replay: the 257 hd_conv2d launches of one training step, each once, in step order, between HIP events on the "
-                      "launch stream (3 passes); `*_isolated`: each launch 5x back to back",
+            "timing": "step-order replay: the 257 hd_conv2d launches of one training step, each once, in step order, captured in one hipGraph and "
+                      "replayed between HIP events on the launch stream (3 passes); `*_isolated`: each launch 5x back to back",
             "mfma_util": _pmc_mfma_util(), "traffic": _pmc_traffic(), "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
             "kernel": "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + "
                       "conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
             "avg_launch_us": round(step_conv_ms * 1e3 / max(n, 1), 2), "avg_launch_us_isolated": round(tot_ms * 1e3 / max(n, 1), 2),
-            "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3)}
+            "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3),
+            "two_roof_floor_ms": round(roof_ms, 3), "launches_hbm_bound_at_floor": hbm_bound,
+            "frac_of_two_roof_floor": round(roof_ms / step_conv_ms, 4) if step_conv_ms else None}
+
+
+def _usable_cpus():
+    """CPUs this process may really use: the affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the host's 256
+    hardware threads on the GPU boxes while the container is throttled to a fraction of them: 256 OpenMP threads then spin against
+    each other and a step takes ten minutes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(q / per + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def cpu_baseline(protocol):
     """The CPU oracle (oracle/step.py: fp32 torch restatement of the training step, `kind` "port") on this host's cores.
     SURVEY 8d asks for batch 8, 2 warm-ups + >= 3 timed steps, at the reference's 8 threads (src/config/config.py:10-11) and
-    at all cores, plus the U-Net alone -- about ten minutes of CPU time, which the default run cannot afford; `bounded` keeps
-    batch 8 / all cores for the full step but takes one warm-up (batch 2) and ONE timed step, and times the U-Net alone
-    (forward + backward, batch 2) at 8 threads."""
+    at all cores, plus the U-Net alone -- more than ten minutes of CPU time, which the default run cannot afford.  `bounded`
+    (default, ~30 s): the thread count is picked by a short sweep of the oracle U-Net on one image (the boxes report more hardware
+    threads than the container may use), then one warm-up step (batch 2) and ONE timed full training step on batch 8; the U-Net
+    alone (forward + backward, batch 2) is timed at the reference's 8 threads."""
     from hallucidet_amd import synthetic
     from oracle.step import OracleTrainer
+    from oracle import unet as ou
     host = _cpu_model()
-    ncores = os.cpu_count() or 1
+    usable = _usable_cpus()
     res = {"unit": "images/s", "kind": "port", "protocol": protocol}
 
     def timed_steps(batch_n, threads, warm, steps, warm_n=None):
@@ -242,10 +279,9 @@ def cpu_baseline(protocol):
             tr.train_step(b)
         return batch_n * steps / (time.time() - t0)
 
-    def unet_only(batch_n, threads, reps):
-        from oracle import unet as ou
+    def unet_only(batch_n, threads, reps, net=None):
         torch.set_num_threads(threads)
-        net = ou.Unet(classes=3).train()
+        net = net or ou.Unet(classes=3).train()
         x = torch.rand(batch_n, 3, H, W)
         net(x).mean().backward()                 # warm-up
         t0 = time.time()
@@ -253,20 +289,28 @@ def cpu_baseline(protocol):
             net(x).mean().backward()
         return batch_n * reps / (time.time() - t0)
 
+    # thread sweep (a few seconds): powers of two up to the usable count, never beyond 128
+    net = ou.Unet(classes=3).train()
+    cand = sorted({min(usable, t) for t in (8, 16, 32, 64, 128)})
+    sweep = {t: unet_only(1, t, 1, net) for t in cand}
+    best = max(sweep, key=sweep.get)
+    res["thread_sweep_unet_images_per_s"] = {str(t): round(v, 3) for t, v in sweep.items()}
     if protocol == "full":
-        v_all = timed_steps(8, ncores, 2, 3)
+        v_all = timed_steps(8, best, 2, 3)
         v_8 = timed_steps(8, 8, 2, 3)
-        res.update(value=round(v_all, 4), cores=ncores, value_8_threads=round(v_8, 4), unet_only_all_cores=round(unet_only(8, ncores, 3), 4),
+        res.update(value=round(v_all, 4), cores=best, value_8_threads=round(v_8, 4), unet_only_best_threads=round(unet_only(8, best, 3), 4),
                    unet_only_8_threads=round(unet_only(8, 8, 3), 4),
-                   sample="SURVEY 8d protocol: batch 8 x 512x640, 2 warm-up + 3 timed full training steps of the CPU oracle at all %d cores "
-                          "(`value`) and at the reference's 8 threads; U-Net forward+backward alone likewise; host: %s" % (ncores, host))
+                   sample="SURVEY 8d protocol: batch 8 x 512x640, 2 warm-up + 3 timed full training steps of the CPU oracle at %d threads "
+                          "(`value`; best of the sweep, %d CPUs usable) and at the reference's 8 threads; U-Net forward+backward alone "
+                          "likewise; host: %s" % (best, usable, host))
     else:
-        v_all = timed_steps(8, ncores, 1, 1, warm_n=2)
-        res.update(value=round(v_all, 4), cores=ncores, unet_only_8_threads=round(unet_only(2, 8, 1), 4),
-                   sample="bounded: ONE timed full training step of the CPU oracle (oracle/step.py, fp32 torch) on batch 8 x 512x640 at all %d "
-                          "cores after one warm-up step on batch 2; U-Net forward+backward alone on batch 2 at the reference's 8 threads "
-                          "(src/config/config.py:10-11); the full SURVEY 8d protocol (`--cpu-protocol full`) is recorded in "
-                          "profiles/r02_cpu_baseline_full.json; host: %s" % (ncores, host))
+        v = timed_steps(8, best, 1, 1, warm_n=2)
+        res.update(value=round(v, 4), cores=best, unet_only_8_threads=round(unet_only(2, 8, 1, net), 4),
+                   sample="bounded: ONE timed full training step of the CPU oracle (oracle/step.py, fp32 torch) on batch 8 x 512x640 at %d "
+                          "threads (best of a sweep over %s; %d CPUs usable) after one warm-up step on batch 2; U-Net forward+backward alone "
+                          "on batch 2 at the reference's 8 threads (src/config/config.py:10-11); the full SURVEY 8d protocol is "
+                          "`--cpu-protocol full`; host: %s" % (best, cand, usable, host))
+    torch.set_num_threads(min(usable, 16))
     return res
 
 
@@ -342,6 +386,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # host-side torch ops (batch staging, small CPU tensors) with a thread pool sized to what this process may use: torch's default is
+    # one thread per hardware thread of the HOST (256), which a throttled container turns into spinning
+    torch.set_num_threads(max(1, min(_usable_cpus() // max(world, 1), 16)))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
     torch.cuda.set_device(local)
@@ -406,19 +453,29 @@ def main():
             "skipped_steps": lit.optimizer.skipped_steps,       # overflow-skipped optimizer steps in the whole run (must be 0)
         }
         if world == 1:
-            # PCIe-inclusive rate (never `value`): the same step with the batch copied from pinned host memory every step
-            hb = [t.cpu().pin_memory() if torch.is_tensor(t) else [{k: v.cpu().pin_memory() for k, v in d.items()} for d in t] for t in batch]
-            def h2d_step():
-                db = [t.to(dev, non_blocking=True) if torch.is_tensor(t) else [{k: v.to(dev, non_blocking=True) for k, v in d.items()} for d in t] for t in hb]
+            # PCIe-inclusive rate (never `value`): every step's batch comes from host memory through the product's input path
+            # (hallucidet_amd.dataloader.DevicePrefetcher: uint8 images stacked into pinned memory, copied on a side HIP stream
+            # while the previous step computes, divided by 255 on the GPU) -- reference: the DataLoader -> .to(device) of pl.Trainer
+            from hallucidet_amd.dataloader.dataloader import DevicePrefetcher
+            host = lambda t: [{k: v.cpu() for k, v in d.items()} for d in t]
+            u8 = lambda t: list((t * 255.0).round().clamp_(0, 255).to(torch.uint8).cpu())
+            hb = (u8(batch[0]), host(batch[1]), u8(batch[2]), host(batch[3]))
+
+            class _HostBatches:
+                def __len__(self):
+                    return 13
+
+                def __iter__(self):
+                    return iter([hb] * 13)
+            t1 = None
+            for i, db in enumerate(DevicePrefetcher(_HostBatches(), dev)):
+                if i == 3:                         # first copies out of freshly pinned pages are not representative
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
                 lit.fit_step(db)
-            for _ in range(2):                     # first copies out of freshly pinned pages are not representative
-                h2d_step()
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(10):
-                h2d_step()
             torch.cuda.synchronize()
             out["pcie_inclusive_images_per_s"] = round(BATCH_PER_GPU * 10 / (time.perf_counter() - t1), 2)
+            out["pcie_inclusive_note"] = "uint8 host batch -> pinned -> side-stream H2D overlapped with the previous step (DevicePrefetcher), 10 steps"
         if not args.no_roofline and args.detector == "fasterrcnn" and BATCH_PER_GPU == 8:
             out["roofline"] = conv_roofline(lit, batch)
         if world == 1 and not args.no_cpu_baseline and not args.config:

@@ -273,48 +273,121 @@ class MultiModalDataModule:
 # ------------------------------------------------------------------------------------------------ host -> HBM staging
 class DevicePrefetcher:
     """Iterates a loader of collated uint8 batches and yields what `training_step` takes -- (imgs_rgb [N,3,H,W] f32 in [0,1],
-    targets_rgb, imgs_ir [N,1,H,W] f32, targets_ir) or (imgs, targets) -- resident in HBM.  The uint8 batch is stacked in
-    pinned memory, copied on a side HIP stream while the previous step computes, and divided by 255 on the GPU."""
+    targets_rgb, imgs_ir [N,1,H,W] f32, targets_ir) or (imgs, targets) -- resident in HBM.
+
+    Batch i+1 is staged by a helper thread while the main thread issues step i: the uint8 images are stacked straight into one
+    of two reusable pinned buffers per image group, copied on a side HIP stream and divided by 255 on the GPU; the per-image target tensors of one key travel as ONE concatenated pinned copy and are split into views on
+    the device (a pageable .to(device) per tensor is a blocking copy each: 64 of them per LLVIP batch)."""
 
     def __init__(self, loader, device="cuda"):
         self.loader, self.device = loader, torch.device(device)
-        self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.cuda = self.device.type == "cuda"
+        self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
+        self._slots = {}            # (group, parity) -> [pinned buffer, event of the last copy out of it]
+        self._turn = 0
 
     def __len__(self):
         return len(self.loader)
 
+    def _pinned(self, key, shape, dtype):
+        slot = self._slots.get(key)
+        if slot is None or slot[0].shape != shape or slot[0].dtype != dtype:
+            slot = self._slots[key] = [torch.empty(shape, dtype=dtype).pin_memory(), None]
+        elif slot[1] is not None:
+            slot[1].synchronize()                      # the copy that last read this buffer has finished
+        return slot
+
+    def _upload(self, key, pieces, stack):
+        """pieces: CPU tensors; stacked (images) or concatenated along dim 0 (targets) into a pinned slot, one async copy."""
+        if not self.cuda:
+            return torch.stack(pieces) if stack else torch.cat(pieces)
+        shape = ((len(pieces),) + tuple(pieces[0].shape)) if stack else ((sum(int(p_.shape[0]) for p_ in pieces),) + tuple(pieces[0].shape[1:]))
+        slot = self._pinned((key, self._turn & 1), torch.Size(shape), pieces[0].dtype)
+        if stack:
+            torch.stack(pieces, out=slot[0])
+        elif shape[0]:
+            torch.cat(pieces, out=slot[0])
+        dev = slot[0].to(self.device, non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record(torch.cuda.current_stream(self.device))
+        return dev
+
     def _stage(self, batch):
-        def imgs(seq):
-            u8 = torch.stack(list(seq))
-            if self.device.type == "cuda":
-                u8 = u8.pin_memory().to(self.device, non_blocking=True)
+        def imgs(g, seq):
+            seq = list(seq)
+            if seq and seq[0].is_cuda:
+                u8 = torch.stack(seq)
+            else:
+                u8 = self._upload(("img", g), seq, True)
             return u8.float().div_(255.0) if u8.dtype == torch.uint8 else u8.float()
 
-        def tgts(seq):
-            return [{k: (v.to(self.device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in t.items()} for t in seq]
+        def tgts(g, seq):
+            seq = list(seq)
+            out = [dict(t) for t in seq]
+            keys = [k for k, v in seq[0].items() if torch.is_tensor(v)] if seq else []
+            for k in keys:
+                vals = [t[k] for t in seq]
+                same = all(torch.is_tensor(v) and v.dim() >= 1 and not v.is_cuda and v.dtype == vals[0].dtype and v.shape[1:] == vals[0].shape[1:] for v in vals)
+                if same:
+                    flat = self._upload(("tgt", g, k), vals, False)
+                    for o, part in zip(out, flat.split([int(v.shape[0]) for v in vals])):
+                        o[k] = part
+                else:
+                    for o, v in zip(out, vals):
+                        o[k] = v.to(self.device, non_blocking=True)
+            return out
         if len(batch) == 4:
-            return imgs(batch[0]), tgts(batch[1]), imgs(batch[2]), tgts(batch[3])
-        return imgs(batch[0]), tgts(batch[1])
+            return imgs(0, batch[0]), tgts(0, batch[1]), imgs(1, batch[2]), tgts(1, batch[3])
+        return imgs(0, batch[0]), tgts(0, batch[1])
 
     def __iter__(self):
         it = iter(self.loader)
-        nxt = None
 
         def fetch():
             try:
                 b = next(it)
             except StopIteration:
                 return None
+            self._turn += 1
             if self.stream is None:
                 return self._stage(b)
+            torch.cuda.set_device(self.device)
             with torch.cuda.stream(self.stream):
-                return self._stage(b)
-        nxt = fetch()
-        while nxt is not None:
-            if self.stream is not None:
-                torch.cuda.current_stream(self.device).wait_stream(self.stream)
-                for t in nxt:
-                    if torch.is_tensor(t):
-                        t.record_stream(torch.cuda.current_stream(self.device))
-            cur, nxt = nxt, fetch()
-            yield cur
+                staged = self._stage(b)
+                ready = torch.cuda.Event()
+                ready.record(self.stream)
+            return staged, ready
+
+        def tensors(x):
+            if torch.is_tensor(x):
+                yield x
+            elif isinstance(x, dict):
+                for v in x.values():
+                    yield from tensors(v)
+            elif isinstance(x, (list, tuple)):
+                for v in x:
+                    yield from tensors(v)
+        if self.stream is None:
+            nxt = fetch()
+            while nxt is not None:
+                cur, nxt = nxt, None
+                yield cur
+                nxt = fetch()
+            return
+        # one staging thread: batch i+1 is collated, stacked into pinned memory and enqueued on the side stream while the main
+        # thread issues the launches of step i (stack / cat / memcpy release the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="hd-stage") as pool:
+            fut = pool.submit(fetch)
+            while True:
+                got = fut.result()
+                if got is None:
+                    return
+                cur, ready = got
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ready)
+                for t in tensors(cur):
+                    if t.is_cuda:
+                        t.record_stream(main)
+                fut = pool.submit(fetch)
+                yield cur

@@ -33,3 +33,36 @@ def test_train_eval_and_detector_scripts(dev, tmp_path, capsys, monkeypatch):
     train_detector.main(common + ["--detector", "fasterrcnn", "--modality", "rgb", "--epochs", "1", "--wandb-name", "t2"])
     out = capsys.readouterr().out
     assert "test:" in out and "map_50" in out
+
+
+def test_device_prefetcher_stages_batches_exactly(dev):
+    """Five different host batches through the pinned double buffers and the side stream: every image tensor equals u8 / 255 (the division runs on the GPU: within one ulp)
+    and every target tensor equals its host original (the slots are reused every second batch: a copy that was still in flight
+    when its buffer was overwritten would show up here), including an image without boxes."""
+    from hallucidet_amd.dataloader import DevicePrefetcher
+    g = torch.Generator().manual_seed(11)
+    host = []
+    for b in range(5):
+        rgb = [torch.randint(0, 256, (3, 64, 96), generator=g, dtype=torch.uint8) for _ in range(4)]
+        ir = [torch.randint(0, 256, (1, 64, 96), generator=g, dtype=torch.uint8) for _ in range(4)]
+        def tg():
+            out = []
+            for i in range(4):
+                k = 0 if (i == 2 and b == 1) else int(torch.randint(1, 6, (1,), generator=g))
+                out.append({"boxes": torch.rand(k, 4, generator=g) * 60, "labels": torch.ones(k, dtype=torch.int64), "name": "img%d" % i})
+            return out
+        host.append((rgb, tg(), ir, tg()))
+    seen = 0
+    for hb, db in zip(host, DevicePrefetcher(host, dev)):
+        burn = torch.randn(2048, 2048, device=dev) @ torch.randn(2048, 2048, device=dev)      # keep the GPU busy between batches
+        for gi in (0, 2):
+            assert db[gi].dtype == torch.float32 and db[gi].is_cuda
+            ref = torch.stack(hb[gi]).float()
+            assert torch.equal((db[gi].cpu() * 255.0).round(), ref) and torch.allclose(db[gi].cpu(), ref / 255.0, rtol=1e-6, atol=0)
+        for gi in (1, 3):
+            for th, td in zip(hb[gi], db[gi]):
+                assert td["name"] == th["name"] and td["boxes"].is_cuda and td["labels"].dtype == torch.int64
+                assert torch.equal(td["boxes"].cpu(), th["boxes"]) and torch.equal(td["labels"].cpu(), th["labels"])
+        seen += 1
+        del burn
+    assert seen == 5
