@@ -114,6 +114,11 @@ PROTOTYPES = {
     "hd_retinanet_loss": (C.c_int, [vp] * 6 + [C.c_int] * 4 + [C.c_float] * 3 + [vp, vp, vp, vp, vp]),
     "hd_retinanet_loss_bwd": (C.c_int, [vp] * 6 + [C.c_int] * 4 + [C.c_float] * 3 + [vp] * 7),
     "hd_sigmoid_focal_loss": (C.c_int, [vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp]),
+    "hd_groupnorm8_relu": (C.c_int, [vp] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, vp]),
+    "hd_groupnorm8_relu_bwd": (C.c_int, [vp] * 6 + [C.c_int] * 4 + [vp]),
+    "hd_fcos_match": (C.c_int, [vp] * 3 + [C.c_int] * 5 + [C.c_float, vp, vp]),
+    "hd_fcos_loss": (C.c_int, [vp] * 7 + [C.c_int] * 4 + [C.c_float] * 2 + [vp] * 4),
+    "hd_fcos_loss_bwd": (C.c_int, [vp] * 7 + [C.c_int] * 4 + [C.c_float] * 2 + [vp] * 6),
     "hd_fastrcnn_loss": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "hd_fastrcnn_loss_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp]),
     "hd_sample_pos_neg": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),

@@ -282,6 +282,8 @@ class DevicePrefetcher:
     def __init__(self, loader, device="cuda"):
         self.loader, self.device = loader, torch.device(device)
         self.cuda = self.device.type == "cuda"
+        if self.cuda and self.device.index is None:          # the staging thread needs the concrete device
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.stream = torch.cuda.Stream(device=self.device) if self.cuda else None
         self._slots = {}            # (group, parity) -> [pinned buffer, event of the last copy out of it]
         self._turn = 0

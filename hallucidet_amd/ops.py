@@ -282,6 +282,27 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
     return dy, dres, dgamma, dbeta
 
 
+def groupnorm8_relu(x, gamma, beta, eps=1e-5, *, relu=True):
+    """GroupNorm with 8 channels per group (+ReLU) over NHWC f16 [N, H, W, C] -> (y, mean_rstd [N, C/8, 2])."""
+    _need_cuda(x, gamma, beta)
+    N, H, W, C_ = x.shape
+    y = torch.empty_like(x)
+    stat = torch.empty((N, C_ // 8, 2), dtype=torch.float32, device=x.device)
+    check(_abi.load().hd_groupnorm8_relu(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stat), N, H * W, C_, float(eps), 1 if relu else 0, _stream()),
+          "hd_groupnorm8_relu")
+    return y, stat
+
+
+def groupnorm8_relu_bwd(dy, x, y, gamma, stat, *, relu=True):
+    """Data gradient of groupnorm8_relu (y = the forward output, used as the ReLU mask)."""
+    _need_cuda(dy, x, gamma, stat)
+    N, H, W, C_ = x.shape
+    dx = torch.empty_like(x)
+    check(_abi.load().hd_groupnorm8_relu_bwd(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(stat), ptr(dx), N, H * W, C_, 1 if relu else 0, _stream()),
+          "hd_groupnorm8_relu_bwd")
+    return dx
+
+
 def maxpool3x3s2(x):
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1

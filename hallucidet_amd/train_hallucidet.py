@@ -16,6 +16,7 @@ from .optim import LossScaler
 from .utils.utils import Utils
 from .utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn_multi
 from .utils.eval_forward_retinanet import eval_forward_retinanet_multi
+from .utils.eval_forward_fcos import eval_forward_fcos_multi
 
 
 class EncoderDecoderLit(nn.Module):
@@ -81,6 +82,9 @@ class EncoderDecoderLit(nn.Module):
                 self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, targets_ir])
         elif self.batch_detector_passes and not train_det and 'retinanet' in self.detector_name:
             (losses_det, detections_hall), (_, detections_rgb), (_, detections_ir) = eval_forward_retinanet_multi(
+                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, targets_ir])
+        elif self.batch_detector_passes and not train_det and 'fcos' in self.detector_name:
+            (losses_det, detections_hall), (_, detections_rgb), (_, detections_ir) = eval_forward_fcos_multi(
                 self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, targets_ir])
         else:
             losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=train_det, model_name=self.detector_name)

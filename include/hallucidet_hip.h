@@ -358,6 +358,35 @@ int hd_match_targets(const float* gt, const uint8_t* gvalid, const int64_t* glab
                      float* best_ws, int64_t* matched, int64_t* labels, float* reg_t, void* stream);
 
 /* ------------------------------------------------------------------------
+ * FCOS (torchvision.models.detection.fcos [EXT], driven by src/utils/eval_forward_fcos.py:54-83; selected at
+ * src/models/detector.py:113-114,135-136)
+ * -------------------------------------------------------------------- */
+/* GroupNorm with eight channels per group (GroupNorm(32, 256) of FCOSClassificationHead / FCOSRegressionHead.conv) + optional
+ * ReLU over NHWC f16 [N][HW][C]; mean_rstd [N][C/8][2] f32 is written for the backward pass.  Replaces nn.GroupNorm + nn.ReLU. */
+int hd_groupnorm8_relu(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int N, int HW, int C,
+                       float eps, int relu, void* stream);
+/* data gradient of the above: dy, x, y (the forward output: ReLU mask; may be NULL when relu == 0) -> dx */
+int hd_groupnorm8_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean_rstd, void* dx, int N,
+                           int HW, int C, int relu, void* stream);
+/* FCOS.compute_loss target assignment: anchors [A][4] (one stride-sized square per location), gt [B][G][4], gvalid [B][G] u8 ->
+ * matched [B][A] i64 (-1 = background): centre sampling (radius x anchor size), location inside the box, scale range
+ * (4, 8) x anchor size (lower bound 0 for the first first_level_count locations, no upper bound from last_level_start on),
+ * smallest box wins. */
+int hd_fcos_match(const float* anchors, const float* gt, const uint8_t* gvalid, int B, int A, int G, int first_level_count,
+                  int last_level_start, float center_sampling_radius, int64_t* matched, void* stream);
+/* FCOSHead.compute_loss: cls_logits [B][A][K], bbox_regression [B][A][4] (after the head's ReLU), bbox_ctrness [B][A], matched
+ * [B][A], gt [B][G][4], glab [B][G] -> out3 = (sigmoid focal, generalized-IoU of the decoded boxes, centre-ness BCE), each summed
+ * over the batch and divided by max(1, #foreground) (= num_fg[0], kept for the backward pass).  part_ws: 64 * 4 floats. */
+int hd_fcos_loss(const float* cls_logits, const float* bbox_regression, const float* bbox_ctrness, const int64_t* matched, const float* gt,
+                 const int64_t* glab, const float* anchors, int B, int A, int K, int G, float alpha, float gamma, float* part_ws,
+                 float* num_fg, float* out3, void* stream);
+/* g3 = upstream gradients of the three losses (device, 3 floats) */
+int hd_fcos_loss_bwd(const float* cls_logits, const float* bbox_regression, const float* bbox_ctrness, const int64_t* matched,
+                     const float* gt, const int64_t* glab, const float* anchors, int B, int A, int K, int G, float alpha, float gamma,
+                     const float* num_fg, const float* g3, float* d_cls_logits, float* d_bbox_regression, float* d_bbox_ctrness,
+                     void* stream);
+
+/* ------------------------------------------------------------------------
  * Optimizer: unscale + clip_grad_value_ + Adam in one pass over a flat buffer
  * (train_hallucidet.py:431-435,498-499; config.py:204-245)
  * -------------------------------------------------------------------- */

@@ -70,6 +70,7 @@ def load_reference():
     ns = ModuleType("ref")
     ns.modules, ns.heads, ns.init, ns.model, ns.decoder, ns.transform, ns.glue, ns.config = modules, heads, init, model, dec, tr, glue, cfg
     ns.glue_retina = glue_retina
+    ns.glue_fcos = _load("ref_eval_forward_fcos", os.path.join(REF, "src", "utils", "eval_forward_fcos.py"))     # torch-only imports
     return ns
 
 
@@ -278,6 +279,48 @@ def gen_glue_retinanet(ref):
     np.savez_compressed(os.path.join(OUT, "glue_retinanet.npz"), **{k: v.numpy() for k, v in blob.items()})
 
 
+def make_fcos_case(seed=17, n_img=3, H=96, W=128):
+    """Oracle FCOS (seeded) + inputs; image 1 has NO boxes (FCOS.compute_loss's all -1 branch), image 2 has two nested boxes (the
+    smallest-area rule decides)."""
+    from oracle import fcos as ofc
+    torch.manual_seed(seed)
+    model = ofc.FCOS(num_classes=2, size=300)
+    tame_detector_(model)
+    with torch.no_grad():   # the prior bias -log(99) keeps every score below 0.2: spread the outputs so post-processing has work
+        model.head.classification_head.cls_logits.weight.normal_(0, 0.05)
+        model.head.classification_head.cls_logits.bias.fill_(0.5)
+        model.head.regression_head.bbox_reg.weight.normal_(0, 0.03)
+        model.head.regression_head.bbox_reg.bias.fill_(0.8)
+        model.head.regression_head.bbox_ctrness.weight.normal_(0, 0.05)
+    images = torch.rand(n_img, 3, H, W)
+    targets = []
+    for i in range(n_img):
+        if i == 1:
+            boxes = torch.zeros(0, 4)
+        elif i == 2:
+            boxes = torch.tensor([[10.0, 8.0, 118.0, 90.0], [40.0, 30.0, 90.0, 70.0]])
+        else:
+            xy = torch.rand(3, 2) * torch.tensor([W * 0.5, H * 0.5])
+            wh = torch.rand(3, 2) * torch.tensor([W * 0.4, H * 0.4]) + 10.0
+            boxes = torch.cat([xy, xy + wh], 1)
+        targets.append({"boxes": boxes.reshape(-1, 4), "labels": torch.ones(boxes.shape[0], dtype=torch.int64)})
+    return model, images, targets
+
+
+def gen_glue_fcos(ref):
+    """The REFERENCE's eval_forward_fcos.py driving the oracle's duck-typed FCOS: pins the call sequence, the argument
+    contract of compute_loss / postprocess_detections, the per-level split and the returned keys."""
+    model, images, targets = make_fcos_case()
+    losses, dets = ref.glue_fcos.eval_forward_fcos(model, images, targets, train_det=False)
+    blob = {"images": images}
+    for k, v in losses.items():
+        blob["loss." + k] = v.detach()
+    for i, d in enumerate(dets):
+        for k, v in d.items():
+            blob["det%d.%s" % (i, k)] = v.detach()
+    np.savez_compressed(os.path.join(OUT, "glue_fcos.npz"), **{k: v.numpy() for k, v in blob.items()})
+
+
 def main():
     ref = load_reference()
     gen_decoder(ref)
@@ -287,6 +330,7 @@ def main():
     gen_config(ref)
     gen_glue(ref)
     gen_glue_retinanet(ref)
+    gen_glue_fcos(ref)
     for f in sorted(os.listdir(OUT)):
         if f.endswith((".npz", ".json")):
             print("%-28s %8d bytes" % (f, os.path.getsize(os.path.join(OUT, f))))

@@ -49,8 +49,12 @@ def test_detector_factory_surface_and_keys():
         assert hasattr(d.rpn, attr)
     for attr in ("select_training_samples", "box_roi_pool", "box_head", "box_predictor", "postprocess_detections"):
         assert hasattr(d.roi_heads, attr)
-    with pytest.raises(NotImplementedError):
-        Detector(name="fcos", pretrained=False)
+    from oracle import fcos as ofc
+    f = Detector(name="fcos", pretrained=False, n_classes=2, size=300).detector       # all three reference detectors are built
+    assert list(f.state_dict().keys()) == list(ofc.FCOS(2).state_dict().keys())
+    assert f.head.classification_head.cls_logits.weight.shape == (2, 256, 3, 3) and f.head.regression_head.bbox_ctrness.out_channels == 1
+    for attr in ("compute_loss", "postprocess_detections", "anchor_generator", "box_coder", "head", "transform", "center_sampling_radius"):
+        assert hasattr(f, attr)
     # torchvision >= 0.13 key names are accepted
     sd = d.state_dict()
     sd2 = {k.replace("fpn.inner_blocks.0.", "fpn.inner_blocks.0.0.").replace("rpn.head.conv.", "rpn.head.conv.0.0."): v for k, v in sd.items()}

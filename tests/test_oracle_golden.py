@@ -211,6 +211,64 @@ def test_retinanet_structure_known_answers():
     assert [tuple(v.shape[-2:]) for v in f.values()] == [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3)] and list(f) == ["0", "1", "2", "p6", "p7"]
 
 
+# ---------------------------------------------------------------------------------- FCOS (row f4)
+def test_fcos_orchestration_equals_reference_glue():
+    """Fixture = the REFERENCE's eval_forward_fcos.py (src/utils/eval_forward_fcos.py:11-83) over the oracle FCOS: one image with
+    three boxes, one without any, one with two nested boxes."""
+    from oracle import fcos as ofc
+    mg = _mg()
+    z = npz("glue_fcos.npz")
+    model, images, targets = mg.make_fcos_case()
+    assert torch.equal(images, z["images"])
+    losses, dets = ofc.eval_forward_fcos(model, images, targets, train_det=False)
+    assert set(losses) == {"classification", "bbox_regression", "bbox_ctrness"}
+    for k in losses:
+        assert torch.allclose(losses[k], z["loss." + k], rtol=1e-6, atol=1e-7), k
+    for i, d in enumerate(dets):
+        assert torch.equal(d["labels"], z["det%d.labels" % i])
+        assert torch.allclose(d["boxes"], z["det%d.boxes" % i], rtol=1e-6, atol=1e-5)
+        assert torch.allclose(d["scores"], z["det%d.scores" % i], rtol=1e-6, atol=1e-7)
+        assert d["boxes"].shape[0] <= 100
+
+
+def test_fcos_structure_and_known_answers():
+    """Hand-worked answers for the torchvision-side pieces of FCOS (parity unpinned against torchvision itself: absent)."""
+    from oracle import fcos as ofc
+    m = ofc.FCOS(num_classes=2, size=300)
+    assert m.anchor_generator.num_anchors_per_location() == [1] * 5
+    cl = m.head.classification_head.cls_logits
+    assert cl.weight.shape == (2, 256, 3, 3) and torch.allclose(cl.bias, torch.full((2,), -math.log(99.0)))
+    keys = set(m.state_dict().keys())
+    for k in ("head.classification_head.conv.1.weight", "head.classification_head.conv.10.bias", "head.regression_head.conv.9.weight",
+              "head.regression_head.bbox_ctrness.bias", "backbone.fpn.extra_blocks.p6.weight"):
+        assert k in keys, k
+    # BoxLinearCoder: ltrb from the anchor centre in anchor sizes, and its inverse
+    bc = ofc.BoxLinearCoder(True)
+    anchor = torch.tensor([[12.0, 20.0, 28.0, 36.0]])                       # centre (20, 28), size 16
+    box = torch.tensor([[4.0, 20.0, 52.0, 44.0]])
+    enc = bc.encode_single(anchor, box)
+    assert torch.equal(enc, torch.tensor([[1.0, 0.5, 2.0, 1.0]]))
+    assert torch.equal(bc.decode_single(enc, anchor), box)
+    # generalized IoU: identical boxes -> 0; disjoint unit squares two apart -> 1 - (0 - (3 - 2) / 3) = 4/3
+    a = torch.tensor([[0.0, 0.0, 1.0, 1.0]])
+    assert float(ofc.generalized_box_iou_loss(a, a)) < 1e-6
+    assert abs(float(ofc.generalized_box_iou_loss(a, torch.tensor([[2.0, 0.0, 3.0, 1.0]]))) - 4.0 / 3.0) < 1e-6
+    # half-overlapping unit squares: iou 1/3, hull 1.5 -> 1 - (1/3 - 0) = 2/3
+    assert abs(float(ofc.generalized_box_iou_loss(a, torch.tensor([[0.5, 0.0, 1.5, 1.0]]))) - 2.0 / 3.0) < 1e-6
+    # target assignment on a 2-level toy: level 0 = stride 8 (size 8, range (0, 64)), level 1 = stride 16 (size 16, range (64, inf))
+    l0 = torch.tensor([[x - 4.0, y - 4.0, x + 4.0, y + 4.0] for y in (4.0, 12.0, 20.0, 28.0) for x in (4.0, 12.0, 20.0, 28.0)])
+    l1 = torch.tensor([[x - 8.0, y - 8.0, x + 8.0, y + 8.0] for y in (8.0, 24.0) for x in (8.0, 24.0)])
+    anchors = torch.cat([l0, l1])
+    t = {"boxes": torch.tensor([[6.0, 6.0, 26.0, 26.0], [10.0, 10.0, 22.0, 22.0]]), "labels": torch.tensor([1, 1])}
+    got = m.match(anchors, t, [16, 4])
+    # level-0 centres (12, 12), (20, 12), (12, 20), (20, 20) lie in both boxes and within 1.5 * 8 of both centres (16, 16): the
+    # smaller box (index 1) wins; nothing else is strictly inside a box and close enough; level 1 needs a side distance > 64
+    want = torch.full((20,), -1, dtype=torch.int64)
+    want[[5, 6, 9, 10]] = 1
+    assert torch.equal(got, want)
+    assert torch.equal(m.match(anchors, {"boxes": torch.zeros(0, 4), "labels": torch.zeros(0, dtype=torch.int64)}, [16, 4]), torch.full((20,), -1))
+
+
 # ---------------------------------------------------------------------------------- known answers (torchvision side)
 def test_anchor_generator_known_answers():
     ag = od.AnchorGenerator()
