@@ -441,8 +441,9 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": ("train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
-                                    "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300, loss scaling, "
-                                    "value clip 0.5, Adam") if args.detector == "fasterrcnn" else
+                                    "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300 (one batched evaluation of 24 images: trunk, "
+                                    "RPN, RoI heads, NMS for all three; the RGB / IR passes' LOSS VALUES, which the reference computes and "
+                                    "discards, are not evaluated), loss scaling, value clip 0.5, Adam") if args.detector == "fasterrcnn" else
                                    ("train_hallucidet.py retinanet batch=%d/GPU fp16 (BASELINE configs[3], NOT the headline config); " % BATCH_PER_GPU +
                                     "U-Net resnet34 fwd+bwd, 3 frozen RetinaNet R50-FPN passes @300x300, loss scaling, clip, Adam"),
                        "global_batch": BATCH_PER_GPU * world, "image": "1x512x640 IR + 3x512x640 RGB",
