@@ -310,7 +310,7 @@ def cpu_baseline(protocol):
                           "threads (best of a sweep over %s; %d CPUs usable) after one warm-up step on batch 2; U-Net forward+backward alone "
                           "on batch 2 at the reference's 8 threads (src/config/config.py:10-11); the full SURVEY 8d protocol is "
                           "`--cpu-protocol full`; host: %s" % (best, cand, usable, host))
-    torch.set_num_threads(min(usable, 16))
+    torch.set_num_threads(8)          # back to Config.set_environment()'s setting
     return res
 
 
@@ -386,9 +386,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # host-side torch ops (batch staging, small CPU tensors) with a thread pool sized to what this process may use: torch's default is
-    # one thread per hardware thread of the HOST (256), which a throttled container turns into spinning
-    torch.set_num_threads(max(1, min(_usable_cpus() // max(world, 1), 16)))
+    # the reference's scripts start with Config.set_environment() (train_hallucidet.py:7): 8 host threads.  torch's default is one
+    # thread per hardware thread of the HOST (256), which a throttled container turns into spinning
+    from hallucidet_amd.config import Config
+    Config.set_environment()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
     torch.cuda.set_device(local)

@@ -13,6 +13,7 @@ from train_hallucidet import print_ap50
 
 
 def main(argv=None):
+    Config.set_environment()
     args = Config.argument_parser(argv)
     torch.manual_seed(args.seed)
     dataset = args.dataset or "llvip"

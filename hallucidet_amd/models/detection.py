@@ -15,6 +15,7 @@ sampling and the four losses are small fp32 tensor ops on the GPU; NMS, RoIAlign
 Sampling uses `torch.randperm` in the reference's call order (injectable for parity tests).
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -163,6 +164,20 @@ def _bgrad_into(param, dy, inv_scale):
     param.grad.add_(s[: param.numel()], alpha=inv_scale)
 
 
+_ACTIVE_VIEWS = os.environ.get("HD_ACTIVE_VIEWS", "1") != "0"
+
+
+def _active_views(feats, n_active):
+    """When only the first `n_active` images of a batched multi-pass evaluation carry a gradient, the backbone hands out, next
+    to every full feature map, its leading [n_active] slice as the tensor autograd differentiates (`_hd_active`): the consumers
+    compute on the full map and return [n_active, ...] gradients for the slice -- no zero-padded 24-image gradient maps, no copies
+    into them, and autograd's accumulation of the branches adds a third of the bytes."""
+    acts = [getattr(f, "_hd_active", None) for f in feats]
+    if all(a is not None and a.shape[0] == n_active and a.requires_grad for a in acts):
+        return acts
+    return None
+
+
 class _BackboneFn(torch.autograd.Function):
     """`n_active`: only the first n_active images of the batch need a data gradient (the hallucinated images when the
     RGB / IR detector passes of a training step are batched with them); the rest is forward-only."""
@@ -172,12 +187,19 @@ class _BackboneFn(torch.autograd.Function):
         outs, saved = bb._forward(x, save=True, n_active=n_active)
         ctx.bb, ctx.saved, ctx.n_active, ctx.n = bb, saved, n_active, x.shape[0]
         ctx.need_dx = x.requires_grad
+        ctx.nout = len(outs)
+        if n_active < x.shape[0] and _ACTIVE_VIEWS:
+            ctx.mark_non_differentiable(*outs)
+            return tuple(outs) + tuple(o[:n_active] for o in outs)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
         na = ctx.n_active
-        grads = [None if g is None else g[:na] for g in grads]
+        if len(grads) > ctx.nout:                      # gradients arrive for the [n_active] views
+            grads = list(grads[ctx.nout:])
+        else:
+            grads = [None if g is None else g[:na] for g in grads]
         dx = ctx.bb._backward(ctx.saved, grads, need_dx=ctx.need_dx)
         ctx.saved = None
         if dx is None:
@@ -369,6 +391,11 @@ class BackboneWithFPN(nn.Module):
             if self._hook is None or self._hook.device != x.device:
                 self._hook = torch.zeros(1, device=x.device, requires_grad=True)
             outs = _BackboneFn.apply(x, self._hook, self, x.shape[0] if n_active is None else n_active)
+            n = len(self.out_names)
+            if len(outs) > n:
+                for full, act in zip(outs[:n], outs[n:]):
+                    full._hd_active = act
+                outs = outs[:n]
         else:
             outs, _ = self._forward(x, save=False)
         return OrderedDict(zip(self.out_names, outs))
@@ -595,7 +622,9 @@ class AnchorGenerator(nn.Module):
 
 class _RPNHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, hook, head, n_active, *feats):
+    def forward(ctx, hook, head, n_active, nlev, *feats):
+        ctx.has_acts = len(feats) > nlev
+        feats = feats[:nlev]
         P = head.pack()
         ts, outs = [], []
         for f in feats:
@@ -638,13 +667,15 @@ class _RPNHeadFn(torch.autograd.Function):
                 _wgrad_into(ctx.head.conv.weight, P["conv"], ctx.feats[i], dt, inv)
                 _bgrad_into(ctx.head.conv.bias, dt, inv)
             df = None if dt is None else _dgrad(P["conv"], dt, hw)
-            if df is not None and na < ctx.n:
+            if df is not None and na < ctx.n and not ctx.has_acts:
                 full = torch.zeros((ctx.n,) + tuple(df.shape[1:]), dtype=df.dtype, device=df.device)
                 full[:na] = df
                 df = full
             dfeats.append(df)
         ctx.ts = None
-        return (None, None, None) + tuple(dfeats)
+        if ctx.has_acts:
+            return (None, None, None, None) + (None,) * len(dfeats) + tuple(dfeats)
+        return (None, None, None, None) + tuple(dfeats)
 
 
 class RPNHead(nn.Module):
@@ -672,7 +703,9 @@ class RPNHead(nn.Module):
         feats = list(x)
         if self._hook is None or self._hook.device != feats[0].device:
             self._hook = torch.zeros(1, device=feats[0].device, requires_grad=True)
-        outs = _RPNHeadFn.apply(self._hook, self, feats[0].shape[0] if n_active is None else n_active, *feats)
+        na = feats[0].shape[0] if n_active is None else n_active
+        acts = _active_views(feats, na) if na < feats[0].shape[0] else None
+        outs = _RPNHeadFn.apply(self._hook, self, na, len(feats), *feats, *(acts or ()))
         return list(outs[0::2]), list(outs[1::2])
 
 
@@ -782,11 +815,13 @@ class RegionProposalNetwork(nn.Module):
 # ======================================================================================================================
 class _RoIAlignFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, rois, levels, cfg, *feats):
+    def forward(ctx, rois, levels, cfg, nlev, *feats):
         scales, P, sr = cfg[:3]
+        ctx.has_acts = len(feats) > nlev
+        acts, feats = feats[nlev:], feats[:nlev]
         ctx.save_for_backward(rois, levels)
         ctx.cfg = cfg
-        ctx.shapes = [tuple(f.shape) for f in feats]
+        ctx.shapes = [tuple(a.shape) for a in acts] if ctx.has_acts else [tuple(f.shape) for f in feats]
         return ops.roi_align_ml(list(feats), scales, rois, levels, P, P, sr)
 
     @staticmethod
@@ -796,9 +831,12 @@ class _RoIAlignFn(torch.autograd.Function):
         if P == 7 and sr == 2 and dout.shape[-1] % 32 == 0:
             # gather form: no atomics, deterministic, fp16 written once; cfg[3] = number of leading images that own RoIs
             n_images = ctx.cfg[3] if len(ctx.cfg) > 3 else None
-            return (None, None, None) + tuple(ops.roi_align_ml_bwd_gather(dout, rois, levels, ctx.shapes, scales, sr, n_images))
-        dfs = ops.roi_align_ml_bwd(dout, rois, levels, ctx.shapes, scales, sr)
-        return (None, None, None) + tuple(ops.f32_to_f16(d) for d in dfs)
+            dfs = ops.roi_align_ml_bwd_gather(dout, rois, levels, ctx.shapes, scales, sr, n_images)
+        else:
+            dfs = [ops.f32_to_f16(d) for d in ops.roi_align_ml_bwd(dout, rois, levels, ctx.shapes, scales, sr)]
+        if ctx.has_acts:               # ctx.shapes are the [n_active] views' shapes: the maps cover exactly the images that own RoIs
+            return (None, None, None, None) + (None,) * len(dfs) + tuple(dfs)
+        return (None, None, None, None) + tuple(dfs)
 
 
 class MultiScaleRoIAlign(nn.Module):
@@ -831,7 +869,7 @@ class MultiScaleRoIAlign(nn.Module):
         s = torch.sqrt(torch.cat([box_area(b) for b in boxes]).float())
         t = torch.floor(self.canonical_level + torch.log2(s / self.canonical_scale) + torch.tensor(self.eps, dtype=s.dtype, device=device))
         levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
-        return _RoIAlignFn.apply(rois, levels, (scales, self.output_size[0], self.sampling_ratio), *feats)
+        return _RoIAlignFn.apply(rois, levels, (scales, self.output_size[0], self.sampling_ratio), len(feats), *feats)
 
 
 class _MLPFn(torch.autograd.Function):
@@ -1474,7 +1512,8 @@ def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
         s = torch.sqrt(box_area(b).float())
         t = torch.floor(pool.canonical_level + torch.log2(s / pool.canonical_scale) + pool.eps)   # fp32 scalar add, no H2D copy
         levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
-    return _RoIAlignFn.apply(rois, levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), *feats)
+    acts = _active_views(feats, n_images) if (n_images is not None and n_images < feats[0].shape[0]) else None
+    return _RoIAlignFn.apply(rois, levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), len(feats), *feats, *(acts or ()))
 
 
 def fastrcnn_loss_flat(class_logits, box_regression, labels, regression_targets):

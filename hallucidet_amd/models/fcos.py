@@ -55,7 +55,9 @@ class _HeadFn(torch.autograd.Function):
     """Both towers + the three output convs over every level.  Outputs per level: (cls, reg, ctr) NCHW fp32 (reg before its ReLU)."""
 
     @staticmethod
-    def forward(ctx, hook, head, n_active, *feats):
+    def forward(ctx, hook, head, n_active, nlev, *feats):
+        ctx.has_acts = len(feats) > nlev        # the [n_active] views the gradients are returned for (detection._active_views)
+        feats = feats[:nlev]
         P = head.pack()
         outs, saved = [], []
         for f in feats:
@@ -99,13 +101,15 @@ class _HeadFn(torch.autograd.Function):
                     dc = ops.groupnorm8_relu_bwd(d, c, z, tower[k][1][0], stat)
                     d = _dgrad(tower[k][0], dc, (H, W), res=df if k == 0 else None)
                 df = d
-            if df is not None and na < ctx.n:
+            if df is not None and na < ctx.n and not ctx.has_acts:
                 full = torch.zeros((ctx.n,) + tuple(df.shape[1:]), dtype=df.dtype, device=df.device)
                 full[:na] = df
                 df = full
             dfeats.append(df)
         ctx.saved = None
-        return (None, None, None) + tuple(dfeats)
+        if ctx.has_acts:
+            return (None, None, None, None) + (None,) * len(dfeats) + tuple(dfeats)
+        return (None, None, None, None) + tuple(dfeats)
 
 
 class _GNTower(nn.Module):
@@ -173,7 +177,9 @@ class FCOSHead(nn.Module):
         feats = list(x)
         if self._hook is None or self._hook.device != feats[0].device:
             self._hook = torch.zeros(1, device=feats[0].device, requires_grad=True)
-        outs = _HeadFn.apply(self._hook, self, feats[0].shape[0] if n_active is None else n_active, *feats)
+        na = feats[0].shape[0] if n_active is None else n_active
+        acts = D._active_views(feats, na) if na < feats[0].shape[0] else None
+        outs = _HeadFn.apply(self._hook, self, na, len(feats), *feats, *(acts or ()))
         K = self.classification_head.cls_logits.out_channels // self.classification_head.num_anchors
 
         def flat(t, k):

@@ -84,7 +84,9 @@ def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name
         hi = lo + n
         ctx = torch.enable_grad() if (k == 0 and n_active) else torch.no_grad()
         with ctx:
-            f_k = OrderedDict((name, v[lo:hi]) for name, v in features.items())
+            # the first pass's slice is the [n_active] view the backbone hands out for differentiation (detection._active_views)
+            f_k = OrderedDict((name, v._hd_active if (k == 0 and getattr(v, "_hd_active", None) is not None and hi == v._hd_active.shape[0]) else v[lo:hi])
+                              for name, v in features.items())
             o_k = [o[lo:hi] for o in objectness]
             d_k = [d[lo:hi] for d in deltas]
             il_k = _ImageSlice(il, lo, hi)

@@ -13,6 +13,7 @@ from hallucidet_amd.trainer import Trainer
 
 
 def main(argv=None):
+    Config.set_environment()
     args = Config.argument_parser(argv)
     torch.manual_seed(args.seed)
     dataset = args.dataset or "llvip"

@@ -23,6 +23,7 @@ def print_ap50(maps):
 
 
 def main(argv=None):
+    Config.set_environment()
     args = Config.argument_parser(argv)
     torch.manual_seed(args.seed)
     dataset = args.dataset or "llvip"
