@@ -305,52 +305,86 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
   __syncthreads();
   HD_TRACE(12, clock64());
 
+  // Row phase, written as whole-tile passes (one option test per pass, not per row): every thread first pulls ALL of its ITER rows
+  // (x WK partial tiles) out of LDS -- 2*ITER*WK independent 16-byte reads in flight, the accumulator registers are free by now --
+  // and then runs straight-line fp32 code over ITER x 8 values.  The per-row form (`if (ok[it]) { read; ...; store; }`) exposed
+  // one LDS round trip per row and kept the compiler from scheduling across rows: 5 700 (+2 500 of wave skew at the next barrier)
+  // clocks per 256 x 128 tile with BN sums, measured with tools/w8_trace.py.
   float ssum8[8], ssq8[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) ssum8[k] = ssq8[k] = 0.f;
   f16* __restrict__ yp = reinterpret_cast<f16*>(p.y);
+  float v[ITER][8];
+  {
+    f32x4 c0[ITER], c1[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int row = r0 + it * RPI;
+      c0[it] = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8);
+      c1[it] = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8 + 4);
+    }
+#pragma unroll
+    for (int g = 1; g < WK; ++g)
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int row = r0 + it * RPI;
+        c0[it] += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8);
+        c1[it] += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8 + 4);
+      }
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[it][k] = k < 4 ? c0[it][k] : c1[it][k - 4];
+  }
+  if (resp) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+      if (ok[it]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[it][k] += (float)rv[it][k];
+      }
+  }
+#pragma unroll
+  for (int it = 0; it < ITER; ++it)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[it][k] += bias8[k];
+  if (maskp) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+      if (ok[it]) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[it][k] = ((float)mv[it][k] > 0.f) ? v[it][k] : 0.f;
+      }
+  }
+  if (statsp) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const float keep = ok[it] ? 1.f : 0.f;        // rows outside the image / channels outside Cout do not count
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float vr = (float)(f16)v[it][k] * keep;
+        ssum8[k] += vr;
+        ssq8[k] += vr * vr;
+      }
+    }
+  }
+  if (act == HD_ACT_RELU) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[it][k] = fmaxf(v[it][k], 0.f);
+  } else if (act == HD_ACT_SIGMOID) {
+#pragma unroll
+    for (int it = 0; it < ITER; ++it)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[it][k] = 1.f / (1.f + __expf(-v[it][k]));
+  }
 #pragma unroll
   for (int it = 0; it < ITER; ++it) {
-    if (ok[it]) {
-      const int row = r0 + it * RPI;
-      f32x4 c0 = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8);
-      f32x4 c1 = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8 + 4);
+    f16x8 o;
 #pragma unroll
-      for (int g = 1; g < WK; ++g) {
-        c0 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8);
-        c1 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8 + 4);
-      }
-      float v[8] = {c0[0], c0[1], c0[2], c0[3], c1[0], c1[1], c1[2], c1[3]};
-      if (resp) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] += (float)rv[it][k];
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += bias8[k];
-      if (maskp) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = ((float)mv[it][k] > 0.f) ? v[k] : 0.f;
-      }
-      if (statsp) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const float vr = (float)(f16)v[k];
-          ssum8[k] += vr;
-          ssq8[k] += vr * vr;
-        }
-      }
-      if (act == HD_ACT_RELU) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.f);
-      } else if (act == HD_ACT_SIGMOID) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = 1.f / (1.f + __expf(-v[k]));
-      }
-      f16x8 o;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o[k] = (f16)v[k];
-      *reinterpret_cast<f16x8*>(yp + off[it]) = o;
-    }
+    for (int k = 0; k < 8; ++k) o[k] = (f16)v[it][k];
+    if (ok[it]) *reinterpret_cast<f16x8*>(yp + off[it]) = o;
   }
   HD_TRACE(13, clock64());
   if (statsp) {
@@ -360,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
     // CU storing); only LDS traffic has to be ordered here
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();         // everyone is done reading the C tile
+    HD_TRACE(14, clock64());
     float* red = reinterpret_cast<float*>(lds);
     {
       float* d = red + (r0 * BN + cch * 8) * 2;
@@ -372,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    HD_TRACE(15, clock64());
     if (tid < 2 * BN) {
       float s = 0.f;
 #pragma unroll 8

@@ -63,4 +63,7 @@ for name, N, H, W, Cin, Cout, KH, stats in SHAPES:
         if e_wr.any():
             print("    epilogue split: acc -> LDS + loads issued + barrier %5.0f | row loop %5.0f | BN sums %5.0f" % (
                 med(e_wr - c_loop), med(e_rows - e_wr), med(c_end - e_rows)))
+            if e_x.any():
+                print("    BN sums split: wait for all waves' rows %5.0f | partials -> LDS + barrier %5.0f | column sums + store %5.0f" % (
+                    med(e_x - e_rows), med(e_y - e_x), med(c_end - e_y)))
 lib.hd_conv_tune_w8(-1, 0)
