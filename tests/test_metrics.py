@@ -99,3 +99,46 @@ def test_filter_dictionary_contract_of_the_hooks():
     d = Detection()
     iou = d.iou_bboxes([[0, 0.9, 0, 0, 0, 10, 10]], [[0, 0.8, 0, 0, 0, 10, 5]])
     assert iou.shape == (1, 1) and abs(float(iou[0, 0]) - 0.5) < 1e-6
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_randomised_scenes_against_the_second_restatement(seed):
+    """hallucidet_amd.metrics vs oracle/coco_map.py (an independently written restatement of COCOeval in scalar loops) on random
+    multi-class scenes: jittered copies of the ground truth, duplicates, pure false positives, tied scores, boxes in all three
+    area ranges, > 100 detections in one image, an image without ground truth and one without detections."""
+    from oracle import coco_map
+    g = torch.Generator().manual_seed(seed)
+    preds, targets = [], []
+    for img in range(6):
+        n_gt = 0 if img == 4 else int(torch.randint(1, 9, (1,), generator=g))
+        side = torch.tensor([12.0, 24.0, 50.0, 80.0, 120.0, 200.0])[torch.randint(0, 6, (n_gt,), generator=g)]
+        xy = torch.rand(n_gt, 2, generator=g) * 300
+        gt = torch.cat([xy, xy + side[:, None] * (0.6 + 0.8 * torch.rand(n_gt, 2, generator=g))], 1)
+        gl = torch.randint(1, 4, (n_gt,), generator=g)
+        boxes, scores, labels = [], [], []
+        for k in range(n_gt):
+            for _ in range(int(torch.randint(0, 4, (1,), generator=g))):          # 0-3 jittered copies (duplicates compete for one match)
+                j = (torch.rand(4, generator=g) - 0.5) * side[k] * float(torch.tensor([0.1, 0.3, 0.6])[torch.randint(0, 3, (1,), generator=g)])
+                boxes.append(gt[k] + j)
+                scores.append(float(torch.randint(1, 20, (1,), generator=g)) / 20.0)      # coarse grid => many tied scores
+                labels.append(int(gl[k]) if torch.rand(1, generator=g) > 0.15 else int(torch.randint(1, 4, (1,), generator=g)))
+        n_fp = 130 if img == 2 else int(torch.randint(0, 6, (1,), generator=g))
+        if img == 5:
+            boxes, scores, labels, n_fp = [], [], [], 0
+        for _ in range(n_fp):
+            p0 = torch.rand(2, generator=g) * 300
+            boxes.append(torch.cat([p0, p0 + 5 + torch.rand(2, generator=g) * 150]))
+            scores.append(float(torch.rand(1, generator=g)))
+            labels.append(int(torch.randint(1, 4, (1,), generator=g)))
+        b = torch.stack(boxes) if boxes else torch.zeros(0, 4)
+        b[:, 2:] = torch.maximum(b[:, 2:], b[:, :2] + 1.0)
+        preds.append({"boxes": b, "scores": torch.tensor(scores), "labels": torch.tensor(labels, dtype=torch.int64)})
+        targets.append({"boxes": gt, "labels": gl})
+    m = MeanAveragePrecision()
+    m.update(preds[:3], targets[:3])
+    m.update(preds[3:], targets[3:])
+    got = m.compute()
+    want = coco_map.evaluate([{k: v.tolist() for k, v in p.items()} for p in preds], [{k: v.tolist() for k, v in t.items()} for t in targets])
+    for k, v in want.items():
+        assert abs(float(got[k]) - v) < 1e-6, (k, float(got[k]), v)
+    assert 0.0 < float(got["map"]) < 1.0 and float(got["mar_1"]) <= float(got["mar_10"]) <= float(got["mar_100"])
