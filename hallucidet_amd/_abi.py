@@ -116,6 +116,7 @@ PROTOTYPES = {
     "hd_sigmoid_focal_loss": (C.c_int, [vp, vp, C.c_int64, C.c_float, C.c_float, vp, vp, vp]),
     "hd_groupnorm8_relu": (C.c_int, [vp] * 5 + [C.c_int] * 3 + [C.c_float, C.c_int, vp]),
     "hd_groupnorm8_relu_bwd": (C.c_int, [vp] * 6 + [C.c_int] * 4 + [vp]),
+    "hd_groupnorm8_param_grad": (C.c_int, [vp] * 6 + [C.c_int] * 4 + [C.c_float, C.c_int, vp]),
     "hd_fcos_match": (C.c_int, [vp] * 3 + [C.c_int] * 5 + [C.c_float, vp, vp]),
     "hd_fcos_loss": (C.c_int, [vp] * 7 + [C.c_int] * 4 + [C.c_float] * 2 + [vp] * 4),
     "hd_fcos_loss_bwd": (C.c_int, [vp] * 7 + [C.c_int] * 4 + [C.c_float] * 2 + [vp] * 6),

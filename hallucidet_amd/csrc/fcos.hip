@@ -133,6 +133,48 @@ __global__ __launch_bounds__(GB) void groupnorm8_bwd_kernel(const f16* __restric
   }
 }
 
+// dgamma[c] (+)= scale * sum_{n,p} g * xh,  dbeta[c] (+)= scale * sum g   (g = dy * [y > 0]); one block per 8-channel group, all
+// images and pixels walked by 1 024 threads, fixed-order LDS reduction (deterministic).  Detector fine-tuning only.
+__global__ __launch_bounds__(GB) void groupnorm8_param_grad_kernel(const f16* __restrict__ dy, const f16* __restrict__ x, const f16* __restrict__ y,
+                                                                   const float* __restrict__ stat, float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta, int N, int HW, int C, int relu, float scale,
+                                                                   int accumulate) {
+  __shared__ float red[GB][17];
+  const int v = blockIdx.x, vecs = C >> 3;
+  float sg[8], sb[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) sg[k] = sb[k] = 0.f;
+  const int64_t T = (int64_t)N * HW;
+  for (int64_t i = threadIdx.x; i < T; i += GB) {
+    const int n = (int)(i / HW);
+    const float m = stat[((size_t)n * vecs + v) * 2], r = stat[((size_t)n * vecs + v) * 2 + 1];
+    const size_t off = (size_t)i * C + v * 8;
+    const f16x8 g = *reinterpret_cast<const f16x8*>(dy + off), a = *reinterpret_cast<const f16x8*>(x + off);
+    f16x8 o;
+    if (relu) o = *reinterpret_cast<const f16x8*>(y + off);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      float gk = (float)g[k];
+      if (relu && !((float)o[k] > 0.f)) gk = 0.f;
+      sb[k] += gk;
+      sg[k] += gk * (((float)a[k] - m) * r);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    red[threadIdx.x][k] = sg[k];
+    red[threadIdx.x][8 + k] = sb[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    for (int i = 0; i < GB; ++i) t += red[i][threadIdx.x];
+    const int c = v * 8 + (threadIdx.x & 7);
+    float* dst = threadIdx.x < 8 ? dgamma : dbeta;
+    dst[c] = accumulate ? dst[c] + t * scale : t * scale;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // FCOS.compute_loss target assignment [EXT]: location a (anchor box = stride-sized square around the location) is matched to
 // ground-truth box j iff  max(|cx_a - cx_j|, |cy_a - cy_j|) < radius * size_a  (centre sampling),  the location lies strictly
@@ -369,6 +411,16 @@ extern "C" int hd_groupnorm8_relu_bwd(const void* dy, const void* x, const void*
   HD_CHECK_ARG(C % 8 == 0 && pow2i(C / 8) && C / 8 <= 128, "hd_groupnorm8_relu_bwd: C/8 must be a power of two <= 128 (C=%d)", C);
   hipLaunchKernelGGL(groupnorm8_bwd_kernel, dim3(N), dim3(GB), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)x, (const f16*)y, gamma, mean_rstd,
                      (f16*)dx, HW, C, relu);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_groupnorm8_param_grad(const void* dy, const void* x, const void* y, const float* mean_rstd, float* dgamma, float* dbeta, int N,
+                                        int HW, int C, int relu, float scale, int accumulate, void* stream) {
+  HD_CHECK_ARG(dy && x && mean_rstd && dgamma && dbeta && (y || !relu) && N > 0 && HW > 0, "hd_groupnorm8_param_grad: bad args");
+  HD_CHECK_ARG(C % 8 == 0 && C / 8 <= 128, "hd_groupnorm8_param_grad: C must be a multiple of 8, at most 1024 (C=%d)", C);
+  hipLaunchKernelGGL(groupnorm8_param_grad_kernel, dim3(C / 8), dim3(GB), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)x, (const f16*)y,
+                     mean_rstd, dgamma, dbeta, N, HW, C, relu, scale, accumulate);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

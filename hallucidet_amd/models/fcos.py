@@ -10,8 +10,9 @@ state_dict keys (`head.classification_head.conv.{0,1,3,4,6,7,9,10}.*`, `head.reg
 
 Execution: frozen detector -- the trunk is RetinaNet's (layer2-4 + FPN + P6/P7: same HIP convs); the two head towers are
 4 x [implicit-GEMM conv3x3 (bias epilogue) -> hd_groupnorm8_relu]; backward = data gradients only (hd_groupnorm8_relu_bwd +
-dgrad convs).  Target assignment (hd_fcos_match), the three losses (hd_fcos_loss / _bwd) and NMS are HIP kernels; score /
-top-k / decode of the post-processing are batched fp32 tensor ops on the GPU.  There is no CPU path.
+dgrad convs; with `set_trainable(True)` also parameter gradients: hd_wgrad for the convs, hd_groupnorm8_param_grad for the GroupNorm
+affines).  Target assignment (hd_fcos_match), the three losses (hd_fcos_loss / _bwd) and NMS are HIP kernels; score / top-k / decode
+of the post-processing are batched fp32 tensor ops on the GPU.  There is no CPU path.
 """
 import math
 from collections import OrderedDict
@@ -81,24 +82,35 @@ class _HeadFn(torch.autograd.Function):
         head = ctx.head
         P = head.pack()
         na = ctx.na
+        tp, inv = head.train_params, 1.0 / head.grad_scale
+        ch, rh = head.classification_head, head.regression_head
         dfeats = []
         for i, lv in enumerate(ctx.saved):
             df = None
-            plan = ((P["cls_tower"], ((P["cls_out"], grads[3 * i]),), lv[0]),
-                    (P["reg_tower"], ((P["reg_out"], grads[3 * i + 1]), (P["ctr_out"], grads[3 * i + 2])), lv[1]))
-            for tower, lasts, acts in plan:
+            plan = ((P["cls_tower"], ((P["cls_out"], grads[3 * i], ch.cls_logits),), lv[0], ch),
+                    (P["reg_tower"], ((P["reg_out"], grads[3 * i + 1], rh.bbox_reg), (P["ctr_out"], grads[3 * i + 2], rh.bbox_ctrness)), lv[1], rh))
+            for tower, lasts, acts, mod in plan:
                 H, W = acts[0][0].shape[1], acts[0][0].shape[2]
                 d = None
-                for last, g in lasts:
+                for last, g, conv in lasts:
                     if g is None:
                         continue
                     gl = ops.nchw_to_nhwc_resize(g[:na].contiguous().float(), H, W, last["cout_p"])
+                    if tp:                               # the towers and their output convs are shared by the 5 levels: accumulate
+                        D._wgrad_into(conv.weight, last, acts[3][2], gl, inv)
+                        D._bgrad_into(conv.bias, gl, inv)
                     d = _dgrad(last, gl, (H, W), res=d)               # gradient w.r.t. the tower output (post-ReLU)
                 if d is None:
                     continue
+                convs = [l for l in mod.conv if isinstance(l, nn.Conv2d)]
+                norms = [l for l in mod.conv if isinstance(l, nn.GroupNorm)]
                 for k in (3, 2, 1, 0):
                     x_in, c, z, stat = acts[k]
                     dc = ops.groupnorm8_relu_bwd(d, c, z, tower[k][1][0], stat)
+                    if tp:
+                        ops.groupnorm8_param_grad(d, c, z, stat, norms[k].weight.grad, norms[k].bias.grad, inv)
+                        D._wgrad_into(convs[k].weight, tower[k][0], x_in, dc, inv)
+                        D._bgrad_into(convs[k].bias, dc, inv)
                     d = _dgrad(tower[k][0], dc, (H, W), res=df if k == 0 else None)
                 df = d
             if df is not None and na < ctx.n and not ctx.has_acts:
@@ -160,6 +172,7 @@ class FCOSHead(nn.Module):
         self.classification_head = FCOSClassificationHead(in_channels, num_anchors, num_classes)
         self.regression_head = FCOSRegressionHead(in_channels, num_anchors)
         self._pack, self._hook = None, None
+        self.train_params, self.grad_scale = False, 1.0
 
     def invalidate(self):
         self._pack = None
@@ -222,9 +235,19 @@ class FCOS(nn.Module):
         self.head.invalidate()
 
     def set_trainable(self, flag=True, grad_scale=1.0):
-        if flag:
-            raise NotImplementedError("hallucidet_amd: FCOS runs as the FROZEN detector of train_hallucidet.py (data gradients only); "
-                                      "detector fine-tuning is built for fasterrcnn and retinanet (train_detector.py's default)")
+        """Detector fine-tuning switch (train_detector.py with detector_name='fcos'): parameter gradients for what torchvision's
+        fcos_resnet50_fpn leaves trainable (trainable_backbone_layers=3 [EXT]: body.layer2-4, FPN incl. P6/P7, both head towers
+        with their GroupNorm affines and the three output convs)."""
+        for m in (self.backbone, self.head):
+            m.train_params, m.grad_scale = bool(flag), float(grad_scale)
+        for name, p in self.backbone.body.named_parameters():
+            p.requires_grad_(bool(flag) and name.split(".")[0] in ("layer2", "layer3", "layer4"))
+        for mod in (self.backbone.fpn, self.head):
+            for p in mod.parameters():
+                p.requires_grad_(bool(flag))
+
+    def trainable_parameters(self):
+        return [p for p in self.parameters() if p.requires_grad]
 
     @staticmethod
     def remap_state_dict_keys(state_dict):

@@ -303,6 +303,14 @@ def groupnorm8_relu_bwd(dy, x, y, gamma, stat, *, relu=True):
     return dx
 
 
+def groupnorm8_param_grad(dy, x, y, stat, dgamma, dbeta, scale=1.0, *, relu=True, accumulate=True):
+    """dgamma / dbeta (fp32 [C], accumulated in place) of groupnorm8_relu over the whole batch."""
+    _need_cuda(dy, x, stat, dgamma, dbeta)
+    N, H, W, C_ = x.shape
+    check(_abi.load().hd_groupnorm8_param_grad(ptr(dy), ptr(x), ptr(y), ptr(stat), ptr(dgamma), ptr(dbeta), N, H * W, C_, 1 if relu else 0,
+                                               float(scale), 1 if accumulate else 0, _stream()), "hd_groupnorm8_param_grad")
+
+
 def maxpool3x3s2(x):
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1

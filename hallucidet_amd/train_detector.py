@@ -6,7 +6,8 @@ backward -> optimizer.step, no gradient clipping in this script, train_detector.
 What runs where: the detector forward is the same HIP path as the frozen detector; `FasterRCNN.set_trainable(True)` makes
 the hand-written backward chains also emit PARAMETER gradients (hd_wgrad / hd_wgrad_reduce for every trainable conv and
 FC, hd_channel_sum_f16 for biases) for what torchvision leaves trainable (body.layer2-4, FPN, RPN, RoI heads; FrozenBN,
-conv1, layer1 fixed), accumulated into one flat fp32 arena; Adam is the fused hd_adam_step over that arena; the data-
+conv1, layer1 fixed; RetinaNet / FCOS: body.layer2-4, FPN incl. P6/P7, the head towers -- FCOS with hd_groupnorm8_param_grad for its
+GroupNorm affines), accumulated into one flat fp32 arena; Adam is the fused hd_adam_step over that arena; the data-
 parallel exchange is the all-reduce of the arena (same GradientAverager as the hallucination network).
 fp16 storage needs a loss scale for the small detector gradients: a fixed power of two (default 1024) that is removed
 inside hd_wgrad_reduce; steps with non-finite gradients are skipped (hd_check_finite), as GradScaler would.
@@ -23,8 +24,8 @@ from .utils.utils import Utils
 class DetectorLit:
     def __init__(self, batch_size=4, wandb_logger=None, lr=0.0001, detector_name='fasterrcnn', pretrained=True, optimizer_name='adam',
                  modality=None, directly_coco=False, detector=None, device='cuda', loss_scale=1024.0):
-        if 'fasterrcnn' not in detector_name and 'retinanet' not in detector_name:
-            raise NotImplementedError("hallucidet_amd: detector fine-tuning is built for fasterrcnn and retinanet")
+        if not any(k in detector_name for k in ('fasterrcnn', 'retinanet', 'fcos')):
+            raise ValueError("unknown detector %r (fasterrcnn / retinanet / fcos)" % (detector_name,))
         self.wandb_logger, self.lr, self.batch_size = wandb_logger, lr, batch_size
         self.optimizer_name, self.detector_name, self.modality = optimizer_name, detector_name, modality
         self.dev = device
@@ -83,7 +84,7 @@ class DetectorLit:
         losses_det['bbox_regression'] = losses_det['bbox_regression'] * w['det_regression']
         losses_det['loss_objectness'] = losses_det['loss_objectness'] * w['det_objectness'] if frcnn else 0.0
         losses_det['loss_rpn_box_reg'] = losses_det['loss_rpn_box_reg'] * w['det_rpn_box_reg'] if frcnn else 0.0
-        losses_det['bbox_ctrness'] = 0.0
+        losses_det['bbox_ctrness'] = losses_det['bbox_ctrness'] * w['det_bbox_ctrness'] if 'fcos' in self.detector_name else 0.0   # train_detector.py:174-175
         total = losses_det['bbox_regression'] + losses_det['classification'] + losses_det['loss_objectness'] + \
             losses_det['loss_rpn_box_reg'] + losses_det['bbox_ctrness']
         return total, losses_det
@@ -113,7 +114,7 @@ class DetectorLit:
         # train_detector.py:224-229: the validation total is the UNWEIGHTED sum
         if 'fasterrcnn' in self.detector_name:
             return losses_det['loss_box_reg'] + losses_det['loss_classifier'] + losses_det['loss_objectness'] + losses_det['loss_rpn_box_reg']
-        return losses_det['bbox_regression'] + losses_det['classification']
+        return losses_det['bbox_regression'] + losses_det['classification'] + (losses_det['bbox_ctrness'] if 'fcos' in self.detector_name else 0.0)
 
     def test_step(self, test_batch, batch_idx):
         imgs, targets = self._unpack(test_batch)

@@ -14,9 +14,11 @@ from ..models import fcos as F_
 
 def eval_forward_fcos(model, images, targets, train_det=False, model_name='fcos'):
     if train_det:
-        raise NotImplementedError("hallucidet_amd: FCOS runs as the frozen detector of train_hallucidet.py; detector fine-tuning "
-                                  "(train_det=True) is built for fasterrcnn and retinanet")
-    model.eval()
+        if not getattr(model.backbone, "train_params", False):
+            raise RuntimeError("hallucidet_amd: train_det=True needs detector.set_trainable(True) first (see "
+                               "hallucidet_amd.train_detector.DetectorLit); the frozen-detector kernels emit data gradients only")
+    else:
+        model.eval()
     _check_targets(targets)
     original_image_sizes = [_hw_of(img) for img in images]
 

@@ -368,6 +368,9 @@ int hd_groupnorm8_relu(const void* x, const float* gamma, const float* beta, voi
 /* data gradient of the above: dy, x, y (the forward output: ReLU mask; may be NULL when relu == 0) -> dx */
 int hd_groupnorm8_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean_rstd, void* dx, int N,
                            int HW, int C, int relu, void* stream);
+/* parameter gradients of the above (detector fine-tuning): dgamma[c] (+)= scale * sum g * xhat, dbeta[c] (+)= scale * sum g */
+int hd_groupnorm8_param_grad(const void* dy, const void* x, const void* y, const float* mean_rstd, float* dgamma, float* dbeta, int N,
+                             int HW, int C, int relu, float scale, int accumulate, void* stream);
 /* FCOS.compute_loss target assignment: anchors [A][4] (one stride-sized square per location), gt [B][G][4], gvalid [B][G] u8 ->
  * matched [B][A] i64 (-1 = background): centre sampling (radius x anchor size), location inside the box, scale range
  * (4, 8) x anchor size (lower bound 0 for the first first_level_count locations, no upper bound from last_level_start on),

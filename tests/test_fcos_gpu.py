@@ -75,8 +75,12 @@ def test_factory_surface_and_state_dict_keys(case):
               "head.regression_head.bbox_ctrness.bias", "head.regression_head.bbox_reg.weight", "backbone.fpn.extra_blocks.p7.weight"):
         assert k in keys, k
     assert (fresh.score_thresh, fresh.nms_thresh, fresh.detections_per_img, fresh.topk_candidates, fresh.center_sampling_radius) == (0.2, 0.6, 100, 1000, 1.5)
-    with pytest.raises(NotImplementedError, match="FROZEN detector"):
-        fresh.set_trainable(True)
+    fresh.set_trainable(True)
+    names = {n for n, p_ in fresh.named_parameters() if p_.requires_grad}
+    assert "head.regression_head.conv.1.weight" in names and "backbone.fpn.extra_blocks.p6.weight" in names and "backbone.body.layer2.0.conv1.weight" in names
+    assert not any(n.startswith(("backbone.body.conv1", "backbone.body.layer1", "backbone.body.bn1")) for n in names)
+    fresh.set_trainable(False)
+    assert not any(p_.requires_grad for p_ in fresh.parameters())
 
 
 def test_groupnorm_kernel_forward_backward(dev):
@@ -264,7 +268,7 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
         assert torch.allclose(l2[k], losses[k].detach(), rtol=1e-5, atol=1e-6), k
     for a, b in zip(d2, dets):
         assert torch.equal(a["labels"], b["labels"]) and torch.allclose(a["boxes"], b["boxes"], atol=1e-4)
-    with pytest.raises(NotImplementedError, match="frozen detector"):
+    with pytest.raises(RuntimeError, match="set_trainable"):
         Detector.calculate_loss(det, images.to(dev), _t2d(targets, dev), train_det=True, model_name="fcos")
 
 
@@ -311,3 +315,85 @@ def test_training_step_with_fcos_detector(dev):
         assert torch.isfinite(loss) and not torch.equal(p0, lit.encoder_decoder.runner.flat_params)
         outs.append((float(loss), lit.encoder_decoder.runner.flat_grads.clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_fcos_parameter_gradients_and_fit_step(dev):
+    """Detector fine-tuning with FCOS (train_detector.py, detector_name='fcos'): parameter gradients of the head (convs, GroupNorm
+    affines, the three output convs: stage-wise on the product's own feature maps, so every ReLU decision is taken on identical
+    numbers) and of the trunk (end to end, statistical) against the oracle's autograd; then DetectorLit learns on its own batch and
+    leaves conv1 / layer1 / FrozenBN untouched."""
+    from hallucidet_amd import synthetic
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.optim import ParamArena
+    from hallucidet_amd.train_detector import DetectorLit
+    torch.manual_seed(53)
+    det = Detector(name="fcos", pretrained=False, n_classes=2, size=300).detector.to(dev)
+    with torch.no_grad():
+        for t in (det.head.classification_head, det.head.regression_head):
+            for l in t.conv:
+                if isinstance(l, torch.nn.Conv2d):
+                    l.weight.normal_(0, 0.03)
+                if isinstance(l, torch.nn.GroupNorm):
+                    l.weight.uniform_(0.5, 1.5)
+                    l.bias.normal_(0, 0.2)
+        det.head.classification_head.cls_logits.bias.fill_(-2.0)
+        det.head.regression_head.bbox_reg.bias.fill_(0.5)
+    rgb, trgb, _, _ = synthetic.make_batch(2, 128, 160, seed=9, device=str(dev))
+    il, _ = det.transform(rgb, None)
+    det.backbone.calibrate_(il.tensors)
+    oracle = ofc.FCOS(num_classes=2, size=300)
+    oracle.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    oracle.set_quant(ou.fp16_round)
+
+    S = 256.0
+    det.train()
+    det.set_trainable(True, grad_scale=S)
+    arena = ParamArena(det.trainable_parameters())
+    det.invalidate_packs()
+    feats = list(det.backbone(il.tensors).values())
+    ho = det.head(feats)
+    g = torch.Generator().manual_seed(6)
+    ws = {k: torch.randn(v.shape, generator=g) for k, v in ho.items()}
+    arena.flat_grads.zero_()
+    (sum((ho[k] * ws[k].to(dev)).sum() for k in ho) * S).backward()
+    got = {n: p.grad.detach().cpu().clone() for n, p in det.named_parameters() if p.requires_grad}
+    prefixes = ("backbone.body.layer2", "backbone.body.layer3", "backbone.body.layer4", "backbone.fpn", "head")
+    assert set(got) == {n for n, _ in det.named_parameters() if n.startswith(prefixes)}
+    oracle.train()
+    for n, p in oracle.named_parameters():
+        p.requires_grad_(n.startswith(prefixes))
+    oho = oracle.head([nchw(t).detach() for t in feats])
+    sum((oho[k] * ws[k]).sum() for k in oho).backward()
+    for n, p in oracle.named_parameters():
+        if n.startswith("head."):
+            a, b = got[n].flatten().double(), p.grad.flatten().double()
+            cos, rel = float((a * b).sum() / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
+            assert cos > 0.999 and rel < 0.05, (n, cos, rel)
+    for p in oracle.parameters():
+        p.grad = None
+    ol, _ = oracle.transform(rgb.cpu(), None)
+    oho = oracle.head(list(oracle.backbone(ol.tensors).values()))
+    sum((oho[k] * ws[k]).sum() for k in oho).backward()
+    worst = {}
+    for n, p in oracle.named_parameters():
+        if p.grad is None:
+            continue
+        a, b = got[n].flatten().double(), p.grad.flatten().double()
+        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        grp = "head" if n.startswith("head") else ("extra" if "extra_blocks" in n else "fpn" if "fpn" in n else n.split(".")[2])
+        worst[grp] = min(worst.get(grp, 1.0), cos)
+    print({k: round(v, 4) for k, v in worst.items()})
+    assert worst["head"] > 0.9 and worst["fpn"] > 0.9 and worst["extra"] > 0.9, worst
+    assert min(worst["layer4"], worst["layer3"], worst["layer2"]) > 0.8, worst
+    det.set_trainable(False)
+
+    lit = DetectorLit(batch_size=2, lr=1e-4, detector_name="fcos", pretrained=False, detector=det, device=str(dev)).prepare()
+    before = {n: p.detach().clone() for n, p in det.named_parameters()}
+    v0 = float(lit.validation_step((rgb, trgb), 0))
+    losses = [float(lit.fit_step((rgb, trgb))) for _ in range(12)]
+    v1 = float(lit.validation_step((rgb, trgb), 0))
+    print("fcos train losses", [round(v, 4) for v in losses], "val", round(v0, 4), "->", round(v1, 4))
+    assert all(v == v for v in losses) and float(lit.optimizer.found_inf) == 0.0 and v1 < v0
+    moved = {n for n, p in det.named_parameters() if not torch.equal(p.detach(), before[n])}
+    assert moved == {n for n, p in det.named_parameters() if p.requires_grad}
+    assert float(lit._last_losses["bbox_ctrness"]) > 0 and lit._last_losses["loss_objectness"] == 0.0
