@@ -284,6 +284,51 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __r
   }
 }
 
+// Split-parallel form for weight tensors whose one-thread-per-quad grid is small while the split chains are long (the 64- and
+// 128-channel 3x3 layers behind the 8-wave weight gradient: 9 216 / 36 864 quads x 256 / 64 splits): a block owns 64
+// CONSECUTIVE quads (every wave-load is 1 KiB of one slice, contiguous) and its G waves each walk every G-th slice, four loads in
+// flight; the G partials are added through LDS in wave order (deterministic).
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce_split_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab,
+                                                                    int Cout, int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
+  __shared__ f32x4 part[G][64];
+  const int taps = KH * KW;
+  const int64_t Ktot = (int64_t)taps * Cin;
+  const int64_t total4 = (int64_t)Cout * Ktot / 4;
+  const size_t sstride = (size_t)Cout_slab * Ktot;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i4 = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i4 < total4;
+  const int64_t i = (live ? i4 : 0) * 4;
+  const float* s = slab + i;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int k = w;
+  for (; k + 3 * G < nsplit; k += 4 * G) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 0 * G) * sstride);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 1 * G) * sstride);
+    f32x4 a2 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 2 * G) * sstride);
+    f32x4 a3 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 3 * G) * sstride);
+    acc += (a0 + a1) + (a2 + a3);
+  }
+  for (; k < nsplit; k += G) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * sstride);
+  part[w][lane] = acc;
+  __syncthreads();
+  if (w != 0 || !live) return;
+#pragma unroll
+  for (int g = 1; g < G; ++g) acc += part[g][lane];
+  const int co = (int)(i / Ktot);
+  const int kk = (int)(i - (int64_t)co * Ktot);
+  const int t = kk / Cin;
+  const int ci = kk - t * Cin;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    if (ci + u >= Cin_real) continue;
+    const size_t o = ((size_t)co * Cin_real + ci + u) * taps + t;
+    const float v = acc[u] * scale;
+    dw[o] = accumulate ? dw[o] + v : v;
+  }
+}
+
 __global__ void weight_prep_kernel(const float* __restrict__ w, const float* __restrict__ oscale, f16* __restrict__ wf,
                                    f16* __restrict__ wd, int Cout, int Cin, int KH, int KW, int Cin_pad, int Cout_pad) {
   const int taps = KH * KW;
@@ -491,6 +536,19 @@ extern "C" int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, in
   int64_t total = (int64_t)Cout * Cin * KH * KW / 4;
   int g = (int)((total + 255) / 256);
   if (g > 8192) g = 8192;
+  static const int split_on = getenv("HD_WGRAD_REDUCE_SPLIT") ? atoi(getenv("HD_WGRAD_REDUCE_SPLIT")) : 1;
+  if (split_on && total >= 4096 && total <= 65536 && nsplit >= 16) {      // see wgrad_reduce_split_kernel
+    const int blocks = (int)((total + 63) / 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (nsplit >= 128 && blocks <= 256)
+      hipLaunchKernelGGL((wgrad_reduce_split_kernel<16>), dim3(blocks), dim3(1024), 0, st, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
+    else if (nsplit >= 32 && blocks <= 1024)
+      hipLaunchKernelGGL((wgrad_reduce_split_kernel<8>), dim3(blocks), dim3(512), 0, st, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
+    else
+      hipLaunchKernelGGL((wgrad_reduce_split_kernel<4>), dim3(blocks), dim3(256), 0, st, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
   if (total <= 16384 && nsplit >= 64) {      // few outputs, long split chains: one wave per float4 (see wgrad_reduce_wave_kernel)
     hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab,
                        Cout, KH, KW, Cin, Cin_real, scale, accumulate);
