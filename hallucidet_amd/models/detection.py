@@ -165,6 +165,7 @@ def _bgrad_into(param, dy, inv_scale):
 
 
 _ACTIVE_VIEWS = os.environ.get("HD_ACTIVE_VIEWS", "1") != "0"
+_DEFER_DETS = os.environ.get("HD_DEFER_DETS", "1") != "0"      # A/B knob of LazyDetections.deferred
 
 
 def _active_views(feats, n_active):
@@ -1566,13 +1567,47 @@ def postprocess_detections_flat(rh, class_logits, box_regression, rois, per, ima
 class LazyDetections(list):
     """list[dict(boxes, labels, scores)] whose per-image slicing (one host sync for the detection counts) happens on
     first access: a training step never reads its detections (train_hallucidet.py:211-215 uses them in validation only),
-    so the step stays free of that synchronisation."""
+    so the step stays free of that synchronisation.
+
+    `deferred(thunk, n)`: the batched post-processing itself (score / top-k / decode / NMS: ~25 small launches, issue-bound on
+    the host) is not launched where the reference's glue calls it but when the result is first touched or when the training step
+    calls `flush()` -- right after it has issued the backward pass, so that those launches queue up behind several milliseconds of
+    GPU work instead of starving the GPU between the RoI heads and the loss.  Still once per step, still inside the step."""
 
     def __init__(self, boxes, scores, labels, counts, box_fn=None):
         super().__init__()
         self._pad = (boxes, scores, labels, counts, box_fn)
+        self._thunk = self._parent = None
+        self._n = int(counts.shape[0])
+
+    @classmethod
+    def deferred(cls, thunk, n):
+        """thunk() -> (boxes [n,D,4], scores, labels, counts [n], box_fn|None), evaluated under no_grad at flush()."""
+        self = cls.__new__(cls)
+        list.__init__(self)
+        self._pad, self._thunk, self._parent, self._n = None, thunk, None, int(n)
+        if not _DEFER_DETS and thunk is not None:
+            self.flush()
+        return self
+
+    def flush(self):
+        """Launch the deferred post-processing now (no host synchronisation)."""
+        if self._parent is not None:
+            par, lo, n = self._parent
+            par.flush()
+            if par._pad is None:                        # the parent was already sliced per image: nothing left to defer
+                raise RuntimeError("LazyDetections: parent materialised before its split views were flushed")
+            b, s, l, counts, fn = par._pad
+            self._pad, self._parent = (b[lo:lo + n], s[lo:lo + n], l[lo:lo + n], counts[lo:lo + n], fn), None
+        elif self._thunk is not None:
+            thunk, self._thunk = self._thunk, None
+            with torch.no_grad():
+                self._pad = tuple(thunk())
+        return self
 
     def _materialize(self):
+        if self._thunk is not None or self._parent is not None:
+            self.flush()
         if self._pad is not None:
             b, s, l, counts, fn = self._pad
             self._pad = None
@@ -1589,7 +1624,7 @@ class LazyDetections(list):
         return super().__iter__()
 
     def __len__(self):
-        return int(self._pad[3].shape[0]) if self._pad is not None else super().__len__()
+        return self._n if (self._pad is not None or self._thunk is not None or self._parent is not None) else super().__len__()
 
     def __add__(self, other):
         self._materialize()
@@ -1597,8 +1632,15 @@ class LazyDetections(list):
 
     def split(self, sizes):
         """Per-pass views of a fused multi-pass result."""
-        b, s, l, counts, fn = self._pad
         out, lo = [], 0
+        if self._thunk is not None:
+            for n in sizes:
+                v = LazyDetections.deferred(None, n)
+                v._parent = (self, lo, n)
+                out.append(v)
+                lo += n
+            return out
+        b, s, l, counts, fn = self._pad
         for n in sizes:
             out.append(LazyDetections(b[lo:lo + n], s[lo:lo + n], l[lo:lo + n], counts[lo:lo + n], fn))
             lo += n

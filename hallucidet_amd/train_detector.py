@@ -153,6 +153,8 @@ class DetectorLit:
         g.zero_()                                     # optimizer_zero_grad (train_detector.py:344-345); kernels accumulate
         loss = self.training_step(batch, batch_idx)
         (loss * self.loss_scale).backward()
+        if hasattr(self._last_detections, "flush"):          # deferred post-processing: queue it behind the backward pass
+            self._last_detections.flush()
         self.averager.begin(g)
         self.averager.start(g)
         self.averager.finish(g)

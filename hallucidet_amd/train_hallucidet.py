@@ -222,5 +222,8 @@ class EncoderDecoderLit(nn.Module):
         r.bucket_hook = self.averager.bucket_ready if (is_dist() and self.overlap_allreduce) else None
         self.averager.begin(g)
         self.scaler.scale(loss).backward()
+        for d in (self._last_detections or {}).values():       # deferred detector post-processing: queue it behind the backward pass
+            if hasattr(d, "flush"):
+                d.flush()
         exchange_and_step(self.averager, g, self.scaler, self.optimizer)
         return loss.detach()

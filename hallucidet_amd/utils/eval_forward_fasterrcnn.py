@@ -155,12 +155,17 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
         f_ng = OrderedDict((k, v.detach()) for k, v in features.items())
         cl1, br1 = pred(head(D.roi_pool_rois(pool, f_ng, rois[r0:], shape)))
     loss_classifier, loss_box_reg = D.fastrcnn_loss_flat(cl0, br0, labels[:r0], reg_t[:r0])
-    class_logits, box_regression = torch.cat([cl0.detach(), cl1]), torch.cat([br0.detach(), br1])
-    sb, ss, sl, counts = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
-    from ..models.custom_generalized_transform import _ratios
-    rh, rw = _ratios(shape, sizes[0][0])
-    scale = _scale_tensor(rw, rh, sb) if not model.transform.training else None
-    dets = D.LazyDetections(sb, ss, sl, counts, (lambda b: b * scale) if scale is not None else None).split(nb)
+    cl0d, br0d, training = cl0.detach(), br0.detach(), model.transform.training
+
+    def postprocess():
+        from ..models.custom_generalized_transform import _ratios
+        class_logits, box_regression = torch.cat([cl0d, cl1]), torch.cat([br0d, br1])
+        sb, ss, sl, counts = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
+        rh, rw = _ratios(shape, sizes[0][0])
+        scale = _scale_tensor(rw, rh, sb) if not training else None
+        return sb, ss, sl, counts, ((lambda b: b * scale) if scale is not None else None)
+    # launched by the first access or by the training step's flush() after it has issued the backward pass (LazyDetections.deferred)
+    dets = D.LazyDetections.deferred(postprocess, sum(nb)).split(nb)
     losses = {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg,
               "loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
     return [(losses if k == 0 else {}, d) for k, d in enumerate(dets)]

@@ -44,13 +44,19 @@ def eval_forward_fcos(model, images, targets, train_det=False, model_name='fcos'
 
 
 def _detections_padded(model, head_outputs, anchors0, napl, image_sizes, original_image_sizes):
-    from ..models.custom_generalized_transform import _ratios
-    sb, ss, sl, counts = model.postprocess_detections_padded(head_outputs, anchors0, napl, image_sizes[0])
-    scale = None
-    if not model.transform.training:
-        rh, rw = _ratios(image_sizes[0], original_image_sizes[0])
-        scale = _scale_tensor(rw, rh, sb)
-    return D.LazyDetections(sb, ss, sl, counts, (lambda b: b * scale) if scale is not None else None)
+    """Deferred (LazyDetections.deferred): launched by the first access or by the training step's flush() after the backward pass."""
+    ho = {k: v.detach() for k, v in head_outputs.items()}
+    training = model.transform.training
+
+    def postprocess():
+        from ..models.custom_generalized_transform import _ratios
+        sb, ss, sl, counts = model.postprocess_detections_padded(ho, anchors0, napl, image_sizes[0])
+        scale = None
+        if not training:
+            rh, rw = _ratios(image_sizes[0], original_image_sizes[0])
+            scale = _scale_tensor(rw, rh, sb)
+        return sb, ss, sl, counts, ((lambda b: b * scale) if scale is not None else None)
+    return D.LazyDetections.deferred(postprocess, ho["cls_logits"].shape[0])
 
 
 def eval_forward_fcos_multi(model, image_batches, target_lists, model_name='fcos'):

@@ -118,15 +118,20 @@ def _hw_of(img):
 
 
 def _detections_padded(model, head_outputs, anchors0, napl, image_sizes, original_image_sizes):
-    from ..models.custom_generalized_transform import _ratios
-    sb, ss, sl, counts = model.postprocess_detections_padded(head_outputs["cls_logits"], head_outputs["bbox_regression"],
-                                                             anchors0, napl, image_sizes[0])
-    scale = None
-    if not model.transform.training:
-        rh, rw = _ratios(image_sizes[0], original_image_sizes[0])
+    """Deferred (LazyDetections.deferred): launched by the first access or by the training step's flush() after the backward pass."""
+    cls_logits, bbox_regression = head_outputs["cls_logits"].detach(), head_outputs["bbox_regression"].detach()
+    training = model.transform.training
+
+    def postprocess():
+        from ..models.custom_generalized_transform import _ratios
         from .eval_forward_fasterrcnn import _scale_tensor
-        scale = _scale_tensor(rw, rh, sb)
-    return D.LazyDetections(sb, ss, sl, counts, (lambda b: b * scale) if scale is not None else None)
+        sb, ss, sl, counts = model.postprocess_detections_padded(cls_logits, bbox_regression, anchors0, napl, image_sizes[0])
+        scale = None
+        if not training:
+            rh, rw = _ratios(image_sizes[0], original_image_sizes[0])
+            scale = _scale_tensor(rw, rh, sb)
+        return sb, ss, sl, counts, ((lambda b: b * scale) if scale is not None else None)
+    return D.LazyDetections.deferred(postprocess, cls_logits.shape[0])
 
 
 def eval_forward_retinanet_multi(model, image_batches, target_lists, model_name='retinanet'):
