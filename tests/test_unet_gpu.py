@@ -95,7 +95,7 @@ def test_forward_backward_train_mode(dev):
         g, w = p.grad.cpu(), pw.grad
         rel = float((g - w).norm() / (w.norm() + 1e-12))
         worst = max(worst, rel)
-        assert rel < 0.05, "%s rel-L2 %.4f" % (n, rel)
+        assert rel < 0.03, "%s rel-L2 %.4f" % (n, rel)         # measured worst: 0.017
         cos = float(torch.nn.functional.cosine_similarity(g.flatten(), w.flatten(), dim=0))
         assert cos > 0.998, "%s cosine %.5f" % (n, cos)
     print("worst per-tensor rel-L2 gradient error: %.4f" % worst)
