@@ -982,6 +982,13 @@ __global__ void roi_samples_finish_kernel(const int64_t* __restrict__ sel, int R
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const int64_t s = sel[r];
+  if (s < 0) {                     // padding row of the fixed-size RoI stage: sel = -(image + 1) -> empty box, label -1, zero target
+    rois[(size_t)r * 5 + 0] = (float)(-s - 1);
+    rois[(size_t)r * 5 + 1] = rois[(size_t)r * 5 + 2] = rois[(size_t)r * 5 + 3] = rois[(size_t)r * 5 + 4] = 0.f;
+    labels[r] = -1;
+    *reinterpret_cast<float4*>(reg_t + (size_t)r * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
   const int n = (int)(s / T);
   const float4 b = *reinterpret_cast<const float4*>(comb + (size_t)s * 4);
   bool has_gt = false;

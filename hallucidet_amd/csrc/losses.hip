@@ -118,6 +118,7 @@ __global__ __launch_bounds__(LB) void frcnn_loss_fwd_kernel(const float* __restr
     float se = 0.f;
     for (int k = 0; k < K; ++k) se += expf(lr[k] - mx);
     const int lab = (int)labels[r];
+    if (lab < 0) continue;                      // padding row of the fixed-size RoI stage (hd_fastrcnn_loss_masked)
     sc += -((lr[lab] - mx) - logf(se));
     if (lab > 0) {
       const float4 d = *reinterpret_cast<const float4*>(breg + ((size_t)r * K + lab) * 4);
@@ -135,8 +136,10 @@ __global__ __launch_bounds__(LB) void frcnn_loss_fwd_kernel(const float* __restr
 __global__ __launch_bounds__(LB) void frcnn_loss_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ breg,
                                                             const int64_t* __restrict__ labels, const float* __restrict__ reg_t, int R, int K,
                                                             float beta, const float* __restrict__ g_cls, const float* __restrict__ g_box,
-                                                            float* __restrict__ d_logits, float* __restrict__ d_breg) {
-  const float dn = R < 1 ? 1.f : (float)R;
+                                                            const int64_t* __restrict__ n_dev, float* __restrict__ d_logits,
+                                                            float* __restrict__ d_breg) {
+  float dn = n_dev ? (float)*n_dev : (float)R;
+  dn = dn < 1.f ? 1.f : dn;
   const float gc = (g_cls ? *g_cls : 0.f) / dn, gb = (g_box ? *g_box : 0.f) / dn;
   for (int r = blockIdx.x * LB + threadIdx.x; r < R; r += gridDim.x * LB) {
     const float* lr = logits + (size_t)r * K;
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(LB) void frcnn_loss_bwd_kernel(const float* __restr
     const int lab = (int)labels[r];
     for (int k = 0; k < K; ++k) {
       const float p = expf(lr[k] - mx) / se;
-      d_logits[(size_t)r * K + k] = (p - (k == lab ? 1.f : 0.f)) * gc;
+      d_logits[(size_t)r * K + k] = lab < 0 ? 0.f : (p - (k == lab ? 1.f : 0.f)) * gc;
       float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
       if (k == lab && lab > 0) {
         const float4 d = *reinterpret_cast<const float4*>(breg + ((size_t)r * K + k) * 4);
@@ -389,7 +392,33 @@ extern "C" int hd_fastrcnn_loss_bwd(const float* logits, const float* box_regres
   if (R == 0) return HD_OK;
   int g = (R + LB - 1) / LB;
   hipLaunchKernelGGL(frcnn_loss_bwd_kernel, dim3(g), dim3(LB), 0, (hipStream_t)stream, logits, box_regression, labels, reg_t, R, K, beta, g_cls,
-                     g_box, d_logits, d_box_regression);
+                     g_box, (const int64_t*)nullptr, d_logits, d_box_regression);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+// Fixed-size RoI stage: R = images x batch_size_per_image rows, rows with label < 0 are padding (no loss, no gradient); both losses
+// divide by the number of REAL rows, read from the device (n_valid_dev) -- no host synchronisation sizes anything.
+extern "C" int hd_fastrcnn_loss_masked(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,
+                                       float beta, const int64_t* n_valid_dev, float* part_ws, float* out2, void* stream) {
+  HD_CHECK_ARG(logits && box_regression && labels && reg_t && n_valid_dev && part_ws && out2 && R >= 0 && K >= 1 && beta > 0.f,
+               "hd_fastrcnn_loss_masked: bad args");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(frcnn_loss_fwd_kernel, dim3(NPART), dim3(LB), 0, s, logits, box_regression, labels, reg_t, R, K, beta, part_ws);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(LB), 0, s, (const float*)part_ws, NPART, n_valid_dev, 0.f, out2);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_fastrcnn_loss_masked_bwd(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,
+                                           float beta, const int64_t* n_valid_dev, const float* g_cls, const float* g_box, float* d_logits,
+                                           float* d_box_regression, void* stream) {
+  HD_CHECK_ARG(logits && box_regression && labels && reg_t && n_valid_dev && d_logits && d_box_regression && R >= 0 && K >= 1,
+               "hd_fastrcnn_loss_masked_bwd: bad args");
+  if (R == 0) return HD_OK;
+  int g = (R + LB - 1) / LB;
+  hipLaunchKernelGGL(frcnn_loss_bwd_kernel, dim3(g), dim3(LB), 0, (hipStream_t)stream, logits, box_regression, labels, reg_t, R, K, beta, g_cls,
+                     g_box, n_valid_dev, d_logits, d_box_regression);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -1387,7 +1387,8 @@ class _FastRCNNLossFn(torch.autograd.Function):
     """roi_heads.fastrcnn_loss as one forward (+ finish) and one backward launch (hd_fastrcnn_loss / _bwd)."""
 
     @staticmethod
-    def forward(ctx, class_logits, box_regression, labels, reg_t):
+    def forward(ctx, class_logits, box_regression, labels, reg_t, n_valid=None):
+        """n_valid (device int64 scalar): fixed-size RoI list, rows with label < 0 are padding and the divisor is n_valid."""
         from .. import _abi
         lib = _abi.load()
         lg, br = class_logits.detach().contiguous().float(), box_regression.detach().contiguous().float()
@@ -1395,23 +1396,36 @@ class _FastRCNNLossFn(torch.autograd.Function):
         R, K = lg.shape
         ws = torch.empty(512, dtype=torch.float32, device=lg.device)
         out = torch.empty(2, dtype=torch.float32, device=lg.device)
-        _abi.check(lib.hd_fastrcnn_loss(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(ws), _abi.ptr(out),
-                                        torch.cuda.current_stream().cuda_stream), "hd_fastrcnn_loss")
-        ctx.save_for_backward(lg, br, lab, rt)
+        st = torch.cuda.current_stream().cuda_stream
+        if n_valid is None:
+            _abi.check(lib.hd_fastrcnn_loss(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(ws), _abi.ptr(out), st),
+                       "hd_fastrcnn_loss")
+            ctx.save_for_backward(lg, br, lab, rt)
+        else:
+            nv = n_valid.reshape(1).to(torch.int64).contiguous()
+            _abi.check(lib.hd_fastrcnn_loss_masked(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(nv), _abi.ptr(ws),
+                                                   _abi.ptr(out), st), "hd_fastrcnn_loss_masked")
+            ctx.save_for_backward(lg, br, lab, rt, nv)
         return out[0], out[1]
 
     @staticmethod
     def backward(ctx, g_cls, g_box):
         from .. import _abi
         lib = _abi.load()
-        lg, br, lab, rt = ctx.saved_tensors
+        saved = ctx.saved_tensors
+        lg, br, lab, rt = saved[:4]
         R, K = lg.shape
         d_lg, d_br = torch.empty_like(lg), torch.empty_like(br)
         gc = None if g_cls is None else g_cls.contiguous().float()
         gb = None if g_box is None else g_box.contiguous().float()
-        _abi.check(lib.hd_fastrcnn_loss_bwd(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(gc), _abi.ptr(gb),
-                                            _abi.ptr(d_lg), _abi.ptr(d_br), torch.cuda.current_stream().cuda_stream), "hd_fastrcnn_loss_bwd")
-        return d_lg, d_br, None, None
+        st = torch.cuda.current_stream().cuda_stream
+        if len(saved) == 4:
+            _abi.check(lib.hd_fastrcnn_loss_bwd(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(gc), _abi.ptr(gb),
+                                                _abi.ptr(d_lg), _abi.ptr(d_br), st), "hd_fastrcnn_loss_bwd")
+        else:
+            _abi.check(lib.hd_fastrcnn_loss_masked_bwd(_abi.ptr(lg), _abi.ptr(br), _abi.ptr(lab), _abi.ptr(rt), R, K, 1.0 / 9, _abi.ptr(saved[4]),
+                                                       _abi.ptr(gc), _abi.ptr(gb), _abi.ptr(d_lg), _abi.ptr(d_br), st), "hd_fastrcnn_loss_masked_bwd")
+        return d_lg, d_br, None, None, None
 
 
 def rpn_loss_from_samples(st, objectness, deltas):
@@ -1500,6 +1514,50 @@ def select_training_samples_batched(rh, props, pcounts, gt, glabels, gvalid):
     return rois, labels, reg_t, per
 
 
+def select_training_samples_padded(rh, props, pcounts, gt, glabels, gvalid):
+    """select_training_samples_batched with a FIXED number of rows per image (S = batch_size_per_image): image i owns rows
+    [i*S, (i+1)*S), its sampled RoIs first (same candidates, same order as the variable-size form), then padding rows (empty box,
+    label -1, zero target).  Returns rois [N*S,5], labels [N*S], regression targets [N*S,4] and the per-image counts as a DEVICE tensor:
+    no host synchronisation sizes anything downstream (RoI pooling, box head, losses, post-processing)."""
+    N, Pm, _ = props.shape
+    dev = props.device
+    pvalid = torch.arange(Pm, device=dev)[None, :] < pcounts[:, None]
+    comb = torch.cat([props, gt], dim=1)                     # torchvision order: proposals, then GT boxes
+    cvalid = torch.cat([pvalid, gvalid], dim=1)
+    T = comb.shape[1]
+    m, lab, _ = ops.match_targets(gt, gvalid, glabels, comb, rh.proposal_matcher.high_threshold, rh.proposal_matcher.low_threshold, False)
+    lab = torch.where(cvalid, lab, torch.full_like(lab, -1))
+    pos_sel, neg_sel, counts = _sample_batched(rh.fg_bg_sampler, lab, host_counts=False)
+    S = rh.fg_bg_sampler.batch_size_per_image
+    mask = (pos_sel | neg_sel).bool()
+    rank = torch.cumsum(mask, dim=1) - 1
+    tgt = torch.where(mask, rank, torch.full_like(rank, S))          # unselected candidates all land in the spare column S
+    base = torch.arange(N, device=dev, dtype=torch.int64)[:, None]
+    out = (-(base + 1)).expand(N, S + 1).contiguous()                # padding code -(image + 1): hd_roi_samples_finish writes an empty row
+    out.scatter_(1, tgt, base * T + torch.arange(T, device=dev, dtype=torch.int64)[None, :])
+    sel = out[:, :S].reshape(-1)
+    rois, labels, reg_t = ops.roi_samples_finish(sel, comb, lab, m, gt, gvalid, rh.box_coder.weights)
+    return rois, labels, reg_t, counts.sum(dim=1)
+
+
+def postprocess_detections_padded_rois(rh, class_logits, box_regression, rois, per_dev, S, image_shape):
+    """postprocess_detections_flat for the fixed-size RoI list (rows [i*S, i*S + per_dev[i]) of image i are real)."""
+    device = class_logits.device
+    num_classes = class_logits.shape[-1]
+    n_img, K = per_dev.shape[0], num_classes - 1
+    s = F.softmax(class_logits.detach(), -1)[:, 1:]
+    b = ops.roi_decode_clip(box_regression.detach(), rois, rh.box_coder.weights, rh.box_coder.bbox_xform_clip, image_shape)[:, 1:]
+    real = (torch.arange(S, device=device)[None, :] < per_dev[:, None]).reshape(-1, 1)
+    ws, hs = b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]
+    V = (s > rh.score_thresh) & (ws >= 1e-2) & (hs >= 1e-2) & real
+    B = torch.where(real[:, :, None], b, torch.zeros_like(b)).reshape(n_img, S * K, 4)
+    Sx = torch.where(real, s, torch.zeros_like(s)).reshape(n_img, S * K)
+    V = V.reshape(n_img, S * K)
+    Lb = torch.arange(1, num_classes, device=device).view(1, 1, K).expand(n_img, S, K).reshape(n_img, S * K)
+    pick, counts = _batched_nms_pick(B, Sx, Lb, V, rh.nms_thresh, rh.detections_per_img)
+    return torch.gather(B, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(Sx, 1, pick), torch.gather(Lb, 1, pick), counts
+
+
 def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
     feats = [v for k, v in feats_dict.items() if k in pool.featmap_names]
     device = rois.device
@@ -1517,10 +1575,12 @@ def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
     return _RoIAlignFn.apply(rois, levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), len(feats), *feats, *(acts or ()))
 
 
-def fastrcnn_loss_flat(class_logits, box_regression, labels, regression_targets):
+def fastrcnn_loss_flat(class_logits, box_regression, labels, regression_targets, n_valid=None):
     if (class_logits.is_cuda and class_logits.dtype == torch.float32 and box_regression.dtype == torch.float32 and class_logits.shape[0] > 0
             and box_regression.shape[1] == 4 * class_logits.shape[1]):
-        return _FastRCNNLossFn.apply(class_logits, box_regression, labels, regression_targets)
+        return _FastRCNNLossFn.apply(class_logits, box_regression, labels, regression_targets, n_valid)
+    if n_valid is not None:
+        raise RuntimeError("hallucidet_amd: the fixed-size RoI stage runs on the GPU only")
     cls_loss = F.cross_entropy(class_logits, labels)
     N = class_logits.shape[0]
     br = box_regression.reshape(N, box_regression.size(-1) // 4, 4)

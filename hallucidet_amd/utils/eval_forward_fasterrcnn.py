@@ -4,6 +4,8 @@ torchvision call sequence (including `select_training_samples` at evaluation tim
 from collections import OrderedDict
 from typing import Dict, List, Tuple
 
+import os
+
 import torch
 
 from ..models.detection import concat_box_prediction_layers, fastrcnn_loss
@@ -23,6 +25,26 @@ def _degenerate_flag(targets):
     """Device-side flag of the reference's degenerate-box check (:41-53); read at the step's first natural sync."""
     allb = torch.cat([t["boxes"] for t in targets], dim=0)
     return (allb[:, 2:] <= allb[:, :2]).any() if allb.numel() else None
+
+
+_PAD_ROIS = os.environ.get("HD_PAD_ROIS", "1") != "0"      # fixed-size RoI stage of the fused three-pass evaluation (A/B knob)
+
+
+class _AsyncFlag:
+    """A device bool on its way to pinned host memory; `raise_if_set()` waits for THAT copy only (an .item() on the tensor would
+    drain everything queued on the stream)."""
+
+    def __init__(self, flag, targets):
+        self.targets = targets
+        self.host = torch.empty(1, dtype=torch.uint8).pin_memory()
+        self.host.copy_(flag.reshape(1).to(torch.uint8), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+    def raise_if_set(self):
+        self.event.synchronize()
+        if int(self.host[0]):
+            _check_degenerate(self.targets)
 
 
 def _raise_if_degenerate(flag, targets):
@@ -145,10 +167,42 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     if rpn_state is None:
         rpn_state = D.rpn_targets_sample_batched(model.rpn, anchors[0], gt, gvalid, n_loss=n0)
     loss_objectness, loss_rpn_box_reg = D.rpn_loss_from_samples(rpn_state, obj, dl)
+    rh = model.roi_heads
+    padded = _PAD_ROIS and pb.is_cuda and rh.fg_bg_sampler.randperm_fn is None
+    pool, head, pred = rh.box_roi_pool, rh.box_head, rh.box_predictor
+    if padded:
+        # Fixed-size RoI stage: S rows per image, padding rows carry label -1, counts stay on the device -> the step has NO host
+        # synchronisation left (the degenerate-box flag of this batch is read, from pinned memory, when the next batch arrives).
+        pend = model.__dict__.pop("_pending_degenerate", None)
+        if pend is not None:
+            pend.raise_if_set()
+        if flag is not None:
+            model.__dict__["_pending_degenerate"] = _AsyncFlag(flag, targets)
+        rois, labels, reg_t, per_dev = D.select_training_samples_padded(rh, pb, pc, gt, glab, gvalid)
+        S = rh.fg_bg_sampler.batch_size_per_image
+        r0 = S * n0
+        bf0 = D.roi_pool_rois(pool, features, rois[:r0], shape, n_images=n0)
+        cl0, br0 = pred(head(bf0))
+        with torch.no_grad():                          # the other passes' RoIs: forward only
+            f_ng = OrderedDict((k, v.detach()) for k, v in features.items())
+            cl1, br1 = pred(head(D.roi_pool_rois(pool, f_ng, rois[r0:], shape)))
+        loss_classifier, loss_box_reg = D.fastrcnn_loss_flat(cl0, br0, labels[:r0], reg_t[:r0], n_valid=per_dev[:n0].sum())
+        cl0d, br0d, training = cl0.detach(), br0.detach(), model.transform.training
+
+        def postprocess_padded():
+            from ..models.custom_generalized_transform import _ratios
+            class_logits, box_regression = torch.cat([cl0d, cl1]), torch.cat([br0d, br1])
+            sb, ss, sl, counts = D.postprocess_detections_padded_rois(rh, class_logits, box_regression, rois, per_dev, S, shape)
+            rh_, rw_ = _ratios(shape, sizes[0][0])
+            scale = _scale_tensor(rw_, rh_, sb) if not training else None
+            return sb, ss, sl, counts, ((lambda b: b * scale) if scale is not None else None)
+        dets = D.LazyDetections.deferred(postprocess_padded, sum(nb)).split(nb)
+        losses = {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg,
+                  "loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
+        return [(losses if k == 0 else {}, d) for k, d in enumerate(dets)]
     rois, labels, reg_t, per = D.select_training_samples_batched(model.roi_heads, pb, pc, gt, glab, gvalid)
     _raise_if_degenerate(flag, targets)            # read at the step's ONE host sync (the RoI sampler's counts, just above)
     r0 = sum(per[:n0])
-    pool, head, pred = model.roi_heads.box_roi_pool, model.roi_heads.box_head, model.roi_heads.box_predictor
     bf0 = D.roi_pool_rois(pool, features, rois[:r0], shape, n_images=n0)
     cl0, br0 = pred(head(bf0))
     with torch.no_grad():                          # the other passes' RoIs: forward only

@@ -320,6 +320,13 @@ int hd_fastrcnn_loss(const float* logits, const float* box_regression, const int
 int hd_fastrcnn_loss_bwd(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,
                          float beta, const float* g_cls, const float* g_box, float* d_logits, float* d_box_regression,
                          void* stream);
+/* the same two losses over a FIXED-SIZE RoI list (images x batch_size_per_image rows): rows with label < 0 are padding (no loss, no
+ * gradient) and the divisor is the number of real rows read from the device (n_valid_dev, one int64) -- nothing is sized on the host */
+int hd_fastrcnn_loss_masked(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,
+                            float beta, const int64_t* n_valid_dev, float* part_ws, float* out2, void* stream);
+int hd_fastrcnn_loss_masked_bwd(const float* logits, const float* box_regression, const int64_t* labels, const float* reg_t, int R, int K,
+                                float beta, const int64_t* n_valid_dev, const float* g_cls, const float* g_box, float* d_logits,
+                                float* d_box_regression, void* stream);
 /* BalancedPositiveNegativeSampler [EXT] for N images (reached from src/utils/eval_forward_fasterrcnn.py:90,127): labels [N][A]
  * i64 (>= 1 positive, 0 negative, < 0 ignored), keys [N][A] i32 >= 0 = one random key per candidate.  Per image
  * num_pos = min(#pos, cap_pos), num_neg = min(#neg, batch_size - num_pos); pos_sel / neg_sel [N][A] u8 mark the num_pos /

@@ -449,3 +449,68 @@ def test_keyed_batch_sampler_distribution_and_counts(dev):
     # row 0: each positive drawn w.p. 4/10, each negative 12/40 ; binomial std ~0.025
     assert (f[0, :10] - 0.4).abs().max() < 0.1 and (f[0, 10:50] - 0.3).abs().max() < 0.1 and f[0, 50:].sum() == 0
     assert (f[2] - 0.25).abs().max() < 0.1
+
+
+def test_fixed_size_roi_stage_equals_variable_size(dev, case, monkeypatch):
+    """The fused three-pass evaluation with the fixed-size RoI stage (S rows per image, padding rows with label -1, device-side
+    counts, no host synchronisation) against the variable-size form under the same RNG stream: the sampler draws the same keys,
+    so the same candidates are selected in the same order -- losses agree to fp32 summation order, detections are identical, and
+    so is the gradient w.r.t. the input images (padding rows contribute nothing)."""
+    from hallucidet_amd.utils import eval_forward_fasterrcnn as G
+    from hallucidet_amd.models import detection as D
+    det, oracle, images, targets = case
+    tg = _t2d(targets, dev)
+    outs = []
+    for pad in (False, True):
+        monkeypatch.setattr(G, "_PAD_ROIS", pad)
+        a = images.to(dev).requires_grad_(True)
+        b, c = (images * 0.5 + 0.2).to(dev), images.flip(-1).contiguous().to(dev)
+        torch.manual_seed(1234)
+        res = G.eval_forward_fasterrcnn_multi(det, [a, b, c], [tg, tg, tg], fused=True)
+        sum(res[0][0].values()).backward()
+        dets = [[{k: v.clone() for k, v in d.items()} for d in r[1]] for r in res]
+        outs.append((res[0][0], dets, a.grad.clone()))
+    det.__dict__.pop("_pending_degenerate", None)
+    (l0, d0, g0), (l1, d1, g1) = outs
+    for k in l0:
+        assert torch.allclose(l0[k], l1[k], rtol=2e-6, atol=1e-7), (k, float(l0[k]), float(l1[k]))
+    for p in range(3):
+        for x, y in zip(d0[p], d1[p]):
+            assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["boxes"], y["boxes"]) and torch.equal(x["scores"], y["scores"])
+    assert torch.allclose(g0, g1, rtol=1e-3, atol=1e-6 + 1e-3 * float(g0.abs().max()))
+    # padded sampling primitive on a case where one image is SHORT of RoIs (fewer candidates than S)
+    rh = det.roi_heads
+    S = rh.fg_bg_sampler.batch_size_per_image
+    g = torch.Generator().manual_seed(3)
+    xy = torch.rand(2, 700, 2, generator=g) * 200
+    props = torch.cat([xy, xy + 10 + torch.rand(2, 700, 2, generator=g) * 60], dim=2).to(dev)
+    pcounts = torch.tensor([700, 300], device=dev)                 # image 1: 300 proposals + 1 GT box < S
+    gt = torch.tensor([[[20.0, 30.0, 120.0, 140.0], [150.0, 40.0, 260.0, 200.0]], [[60.0, 60.0, 180.0, 220.0], [0.0, 0.0, 0.0, 0.0]]], device=dev)
+    glab = torch.tensor([[1, 1], [1, 0]], device=dev)
+    gvalid = torch.tensor([[True, True], [True, False]], device=dev)
+    torch.manual_seed(5)
+    r_v, lab_v, t_v, per = D.select_training_samples_batched(rh, props, pcounts, gt, glab, gvalid)
+    torch.manual_seed(5)
+    r_p, lab_p, t_p, per_dev = D.select_training_samples_padded(rh, props, pcounts, gt, glab, gvalid)
+    assert per_dev.tolist() == per and per[0] == S and per[1] == 301 and r_p.shape == (2 * S, 5)
+    lo = 0
+    for i, n in enumerate(per):
+        assert torch.equal(r_p[i * S:i * S + n], r_v[lo:lo + n]) and torch.equal(lab_p[i * S:i * S + n], lab_v[lo:lo + n])
+        assert torch.equal(t_p[i * S:i * S + n], t_v[lo:lo + n])
+        pad = slice(i * S + n, (i + 1) * S)
+        assert bool((lab_p[pad] == -1).all()) and bool((r_p[pad, 0] == i).all()) and float(r_p[pad, 1:].abs().sum()) == 0.0 and float(t_p[pad].abs().sum()) == 0.0
+        lo += n
+    # masked loss == plain loss over the real rows
+    K = 2
+    logits = torch.randn(2 * S, K, generator=g).to(dev).requires_grad_(True)
+    breg = torch.randn(2 * S, K * 4, generator=g).to(dev).requires_grad_(True)
+    real = lab_p >= 0
+    c0, b0 = D.fastrcnn_loss_flat(logits[real], breg[real], lab_p[real], t_p[real])
+    c1, b1 = D.fastrcnn_loss_flat(logits, breg, lab_p, t_p, n_valid=per_dev.sum())
+    assert torch.allclose(c0, c1, rtol=1e-5) and torch.allclose(b0, b1, rtol=1e-5)
+    (c1 + 2 * b1).backward()
+    gl, gb = logits.grad.clone(), breg.grad.clone()
+    logits.grad = breg.grad = None
+    (c0 + 2 * b0).backward()
+    assert torch.allclose(gl, logits.grad, rtol=1e-5, atol=1e-8) and torch.allclose(gb, breg.grad, rtol=1e-5, atol=1e-8)
+    assert float(gl[~real].abs().sum()) == 0.0 and float(gb[~real].abs().sum()) == 0.0
