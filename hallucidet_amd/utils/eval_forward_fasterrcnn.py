@@ -27,6 +27,21 @@ def _degenerate_flag(targets):
     return (allb[:, 2:] <= allb[:, :2]).any() if allb.numel() else None
 
 
+def check_degenerate_deferred(model, targets):
+    """The reference's degenerate-box check (:41-53) without a host synchronisation inside the step: this batch's device flag
+    travels to pinned memory now and is read when the NEXT batch arrives (a bad box still raises, one call later, with the same
+    message); the flag left by the previous call is read first."""
+    pend = model.__dict__.pop("_pending_degenerate", None)
+    if pend is not None:
+        pend.raise_if_set()
+    flag = _degenerate_flag(targets)
+    if flag is not None:
+        if flag.is_cuda:
+            model.__dict__["_pending_degenerate"] = _AsyncFlag(flag, targets)
+        else:
+            _raise_if_degenerate(flag, targets)
+
+
 _PAD_ROIS = os.environ.get("HD_PAD_ROIS", "1") != "0"      # fixed-size RoI stage of the fused three-pass evaluation (A/B knob)
 
 

@@ -6,7 +6,7 @@ With `model.batched_heads` (the default of hallucidet_amd.models.fcos.FCOS) the 
 post-processing run in padded, batched form (same arithmetic; the GPU tests assert equality with the list route below)."""
 import torch
 
-from .eval_forward_fasterrcnn import _check_degenerate, _check_targets, _scale_tensor
+from .eval_forward_fasterrcnn import _check_degenerate, _check_targets, check_degenerate_deferred, _scale_tensor
 from .eval_forward_retinanet import _hw_of
 from ..models import detection as D
 from ..models import fcos as F_
@@ -72,7 +72,7 @@ def eval_forward_fcos_multi(model, image_batches, target_lists, model_name='fcos
     x = torch.cat([b if isinstance(b, torch.Tensor) else torch.stack(list(b)) for b in image_batches], dim=0)
     flat_targets = [t for tl in target_lists for t in tl]
     il, flat_targets = model.transform(x, flat_targets)
-    _check_degenerate(flat_targets)
+    check_degenerate_deferred(model, flat_targets)          # no host synchronisation inside the step
     n0 = nb[0]
     if image_batches[0].requires_grad:
         features = list(model.backbone(il.tensors, n_active=n0).values())

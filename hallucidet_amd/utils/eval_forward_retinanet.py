@@ -11,7 +11,7 @@ from typing import Dict, Optional
 
 import torch
 
-from .eval_forward_fasterrcnn import _check_degenerate, _check_targets
+from .eval_forward_fasterrcnn import _check_degenerate, _check_targets, check_degenerate_deferred
 from ..models import detection as D
 from ..models import retinanet as R
 
@@ -147,7 +147,7 @@ def eval_forward_retinanet_multi(model, image_batches, target_lists, model_name=
     x = torch.cat([b if isinstance(b, torch.Tensor) else torch.stack(list(b)) for b in image_batches], dim=0)
     flat_targets = [t for tl in target_lists for t in tl]
     il, flat_targets = model.transform(x, flat_targets)
-    _check_degenerate(flat_targets)
+    check_degenerate_deferred(model, flat_targets)          # no host synchronisation inside the step
     n0 = nb[0]
     if image_batches[0].requires_grad:
         features = list(model.backbone(il.tensors, n_active=n0).values())

@@ -243,3 +243,22 @@ def test_loss_kernels_against_reference_vectors_and_oracle_gradients(dev):
     assert torch.allclose(bg.grad.cpu(), bo.grad, rtol=1e-5, atol=1e-7)
     with pytest.raises(Exception, match="Unsupported loss"):
         G.box_loss("huber", bc, a, gts, br)
+
+
+def test_degenerate_box_raises_one_call_later_in_the_fused_path(dev, case):
+    """The fused three-pass evaluation keeps the reference's degenerate-box assertion (eval_forward_retinanet.py:108-120) but reads
+    the device flag without a host synchronisation inside the step: the call that carries the bad box completes, the NEXT call
+    raises with the reference's message."""
+    from hallucidet_amd.utils.eval_forward_retinanet import eval_forward_retinanet_multi
+    det, _, images, targets = case
+    det.__dict__.pop("_pending_degenerate", None)
+    tg = _t2d(targets, dev)
+    bad = [dict(t) for t in tg]
+    bad[0] = {"boxes": torch.tensor([[10.0, 10.0, 10.0, 40.0]], device=dev), "labels": torch.ones(1, dtype=torch.int64, device=dev)}
+    x = images.to(dev)
+    with torch.no_grad():
+        eval_forward_retinanet_multi(det, [x, x, x], [bad, tg, tg])              # carries the flag, does not raise
+        with pytest.raises(AssertionError, match="All bounding boxes should have positive height and width"):
+            eval_forward_retinanet_multi(det, [x, x, x], [tg, tg, tg])
+        eval_forward_retinanet_multi(det, [x, x, x], [tg, tg, tg])               # the flag was consumed
+    det.__dict__.pop("_pending_degenerate", None)
