@@ -189,6 +189,7 @@ class _BackboneFn(torch.autograd.Function):
         ctx.bb, ctx.saved, ctx.n_active, ctx.n = bb, saved, n_active, x.shape[0]
         ctx.need_dx = x.requires_grad
         ctx.nout = len(outs)
+        ctx.set_materialize_grads(False)          # unused levels arrive as None, not as zero-filled maps
         if n_active < x.shape[0] and _ACTIVE_VIEWS:
             ctx.mark_non_differentiable(*outs)
             return tuple(outs) + tuple(o[:n_active] for o in outs)
@@ -625,6 +626,7 @@ class _RPNHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hook, head, n_active, nlev, *feats):
         ctx.has_acts = len(feats) > nlev
+        ctx.set_materialize_grads(False)
         feats = feats[:nlev]
         P = head.pack()
         ts, outs = [], []

@@ -58,6 +58,7 @@ class _HeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hook, head, n_active, nlev, *feats):
         ctx.has_acts = len(feats) > nlev        # the [n_active] views the gradients are returned for (detection._active_views)
+        ctx.set_materialize_grads(False)          # unused outputs arrive as None in backward, not as zero-filled maps
         feats = feats[:nlev]
         P = head.pack()
         outs, saved = [], []

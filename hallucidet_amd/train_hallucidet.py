@@ -96,14 +96,29 @@ class EncoderDecoderLit(nn.Module):
         if 'fasterrcnn' in self.detector_name:
             losses_det['classification'] = losses_det['loss_classifier']
             losses_det['bbox_regression'] = losses_det['loss_box_reg']
-        losses_det['bbox_regression'] = losses_det['bbox_regression'] * w['det_regression']
-        losses_det['classification'] = losses_det['classification'] * w['det_classification']
-        losses_det['loss_objectness'] = (losses_det['loss_objectness'] * w['det_objectness'] if 'fasterrcnn' in self.detector_name else 0.0)
-        losses_det['loss_rpn_box_reg'] = (losses_det['loss_rpn_box_reg'] * w['det_rpn_box_reg'] if 'fasterrcnn' in self.detector_name else 0.0)
-        losses_det['bbox_ctrness'] = (losses_det['bbox_ctrness'] * w['det_bbox_ctrness'] if 'fcos' in self.detector_name else 0.0)
-        loss_det_total = losses_det['bbox_regression'] + losses_det['classification'] + losses_det['loss_objectness'] + \
-            losses_det['loss_rpn_box_reg'] + losses_det['bbox_ctrness']
-        total_loss = loss_det_total + loss_pixel_rgb + loss_perceptual_rgb + loss_pixel_ir + loss_perceptual_ir
+        # train_hallucidet.py:193-210: every detector loss times its weight, their sum, plus the (weight 0.0) pixel / perceptual terms.
+        # One stack, one multiply by a cached weight vector, one sum (the per-key results are views of the product) instead of a
+        # scalar kernel per key and per '+': each of those is a serialised ~3 us launch in a step that is GPU-bound.
+        frcnn, fcos_ = 'fasterrcnn' in self.detector_name, 'fcos' in self.detector_name
+        keys = [('bbox_regression', 'det_regression'), ('classification', 'det_classification')]
+        keys += [('loss_objectness', 'det_objectness'), ('loss_rpn_box_reg', 'det_rpn_box_reg')] if frcnn else []
+        keys += [('bbox_ctrness', 'det_bbox_ctrness')] if fcos_ else []
+        vals = [losses_det[k] for k, _ in keys]
+        wkey = (tuple(float(w[wk]) for _, wk in keys), str(vals[0].device))
+        wvec = self._wvec_cache.get(wkey) if hasattr(self, "_wvec_cache") else None
+        if wvec is None:
+            self.__dict__.setdefault("_wvec_cache", {})[wkey] = wvec = torch.tensor(wkey[0], dtype=torch.float32, device=vals[0].device)
+        weighted = torch.stack([v.reshape(()).float() for v in vals]) * wvec
+        for i, (k, _) in enumerate(keys):
+            losses_det[k] = weighted[i]
+        for k in ('loss_objectness', 'loss_rpn_box_reg', 'bbox_ctrness'):
+            if not any(k == kk for kk, _ in keys):
+                losses_det[k] = 0.0
+        loss_det_total = weighted.sum()
+        total_loss = loss_det_total
+        for extra in (loss_pixel_rgb, loss_perceptual_rgb, loss_pixel_ir, loss_perceptual_ir):
+            if torch.is_tensor(extra) or extra != 0.0:
+                total_loss = total_loss + extra
 
         self._last_detections = dict(hall=detections_hall, rgb=detections_rgb, ir=detections_ir)
         return {
