@@ -125,6 +125,8 @@ PROTOTYPES = {
     "hd_fastrcnn_loss_masked": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp]),
     "hd_fastrcnn_loss_masked_bwd": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp, vp, vp, vp]),
     "hd_sample_pos_neg": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "hd_roi_postprocess": (C.c_int, [vp, vp, vp, C.c_long, vp, C.c_int, C.c_int, C.c_int, vp] + [C.c_float] * 5 + [vp] * 4),
+    "hd_roi_samples_padded": (C.c_int, [vp] * 7 + [C.c_int] * 4 + [vp] * 6),
     "hd_roi_samples_finish": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "hd_roi_levels": (C.c_int, [vp, C.c_long, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, vp]),
     "hd_batched_nms_pick": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp, vp]),

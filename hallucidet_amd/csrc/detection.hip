@@ -972,6 +972,36 @@ __global__ void roi_decode_clip_kernel(const float* __restrict__ codes, const fl
                                                                       img_h, img_w);
 }
 
+// RoIHeads.postprocess_detections up to the NMS [EXT], for the fixed-size RoI list (row r belongs to image r / S and is real iff
+// r % S < counts[image]): softmax over the C class logits, decode + clip of the K = C - 1 foreground boxes, and the candidate test
+// (score > score_thresh, both sides >= min_size) in one launch.  Padding rows give zero boxes / scores and valid = 0.
+__global__ void roi_postprocess_kernel(const float* __restrict__ logits, const float* __restrict__ codes, const float* __restrict__ rois,
+                                       long roi_stride, const int64_t* __restrict__ counts, int R, int C, int S, float wx, float wy, float ww,
+                                       float wh, float xclip, float img_h, float img_w, float score_thresh, float min_size,
+                                       float* __restrict__ boxes, float* __restrict__ scores, uint8_t* __restrict__ valid) {
+  const int K = C - 1;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= R * K) return;
+  const int r = j / K, k = j - r * K + 1;
+  const bool real = (r % S) < (int)counts[r / S];
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  float p = 0.f;
+  bool v = false;
+  if (real) {
+    const float* lr = logits + (size_t)r * C;
+    float mx = lr[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lr[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(lr[c] - mx);
+    p = expf(lr[k] - mx) / se;
+    o = decode_clip_dev(codes + ((size_t)r * C + k) * 4, rois + (size_t)r * roi_stride, wx, wy, ww, wh, xclip, img_h, img_w);
+    v = (p > score_thresh) && ((o.z - o.x) >= min_size) && ((o.w - o.y) >= min_size);
+  }
+  *reinterpret_cast<float4*>(boxes + (size_t)j * 4) = o;
+  scores[j] = p;
+  valid[j] = v;
+}
+
 // ---- RoI sampling tail + FPN level mapping -------------------------------------------------------------------------------
 // RoIHeads.select_training_samples after the sampler [EXT]: for the r-th selected candidate (flat index sel[r] into [N][T]):
 // rois[r] = (image, box), labels[r], regression target = BoxCoder.encode(matched GT (zeros for GT-less images), box).
@@ -1012,6 +1042,66 @@ __global__ void roi_samples_finish_kernel(const int64_t* __restrict__ sel, int R
   t.z = ww * logf(gw / ew);
   t.w = wh * logf(gh / eh);
   *reinterpret_cast<float4*>(reg_t + (size_t)r * 4) = t;
+}
+
+// Fixed-size form of the above, compaction included: one block per image scans its T candidates (selected = pos | neg), the r-th
+// selected candidate (ascending candidate index: the order torchvision's torch.where gives) becomes row n*S + r, rows from the
+// image's count up to S are padding (empty box, label -1, zero target); counts[n] = number of real rows.
+__device__ __forceinline__ void roi_row_write(int r, int n, float4 b, int64_t label, float4 t, float* __restrict__ rois,
+                                              int64_t* __restrict__ labels, float* __restrict__ reg_t) {
+  rois[(size_t)r * 5 + 0] = (float)n;
+  rois[(size_t)r * 5 + 1] = b.x;
+  rois[(size_t)r * 5 + 2] = b.y;
+  rois[(size_t)r * 5 + 3] = b.z;
+  rois[(size_t)r * 5 + 4] = b.w;
+  labels[r] = label;
+  *reinterpret_cast<float4*>(reg_t + (size_t)r * 4) = t;
+}
+
+__global__ __launch_bounds__(256) void roi_samples_padded_kernel(const uint8_t* __restrict__ pos_sel, const uint8_t* __restrict__ neg_sel,
+                                                                 const float* __restrict__ comb, const int64_t* __restrict__ lab,
+                                                                 const int64_t* __restrict__ matched, const float* __restrict__ gt,
+                                                                 const uint8_t* __restrict__ gvalid, int T, int G, int S, float wx, float wy,
+                                                                 float ww, float wh, float* __restrict__ rois, int64_t* __restrict__ labels,
+                                                                 float* __restrict__ reg_t, int64_t* __restrict__ counts) {
+  __shared__ int wsum[4];
+  __shared__ int carry;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  bool has_gt = false;
+  for (int g = 0; g < G; ++g) has_gt = has_gt || gvalid[(size_t)n * G + g];
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 256) {
+    const int t = t0 + tid;
+    const size_t s = (size_t)n * T + t;
+    const bool on = t < T && (pos_sel[s] | neg_sel[s]);
+    const unsigned long long bal = __ballot(on);
+    const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int before = carry;
+    for (int k = 0; k < w; ++k) before += wsum[k];
+    const int r = before + in_wave;
+    if (on && r < S) {
+      const float4 b = *reinterpret_cast<const float4*>(comb + s * 4);
+      const int64_t m = matched[s];
+      float4 rg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (has_gt) rg = *reinterpret_cast<const float4*>(gt + ((size_t)n * G + (m > 0 ? m : 0)) * 4);
+      const float ew = b.z - b.x, eh = b.w - b.y;
+      const float ecx = b.x + 0.5f * ew, ecy = b.y + 0.5f * eh;
+      const float gw = rg.z - rg.x, gh = rg.w - rg.y;
+      const float gcx = rg.x + 0.5f * gw, gcy = rg.y + 0.5f * gh;
+      roi_row_write(n * S + r, n, b, lab[s], make_float4(wx * (gcx - ecx) / ew, wy * (gcy - ecy) / eh, ww * logf(gw / ew), wh * logf(gh / eh)), rois,
+                    labels, reg_t);
+    }
+    __syncthreads();
+    if (tid == 0) carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  const int cnt = carry < S ? carry : S;
+  for (int r = cnt + tid; r < S; r += 256)
+    roi_row_write(n * S + r, n, make_float4(0.f, 0.f, 0.f, 0.f), -1, make_float4(0.f, 0.f, 0.f, 0.f), rois, labels, reg_t);
+  if (tid == 0) counts[n] = cnt;
 }
 
 // torchvision LevelMapper [EXT]: level = clamp(floor(k0 + log2(sqrt(area) / s0) + eps), k_min, k_max) - k_min
@@ -1249,6 +1339,20 @@ extern "C" int hd_roi_decode_clip(const float* codes, const float* rois, long ro
   return HD_OK;
 }
 
+extern "C" int hd_roi_postprocess(const float* class_logits, const float* box_regression, const float* rois, long roi_stride, const int64_t* counts,
+                                  int R, int C, int S, const float* coder_weights, float bbox_xform_clip, float img_h, float img_w, float score_thresh,
+                                  float min_size, float* boxes, float* scores, uint8_t* valid, void* stream) {
+  HD_CHECK_ARG(class_logits && box_regression && rois && counts && coder_weights && boxes && scores && valid && R >= 0 && C >= 2 && S > 0 &&
+               roi_stride >= 4, "hd_roi_postprocess: bad args");
+  if (R == 0) return HD_OK;
+  const int total = R * (C - 1);
+  hipLaunchKernelGGL(roi_postprocess_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, class_logits, box_regression, rois,
+                     roi_stride, counts, R, C, S, 1.0f / coder_weights[0], 1.0f / coder_weights[1], 1.0f / coder_weights[2], 1.0f / coder_weights[3],
+                     bbox_xform_clip, img_h, img_w, score_thresh, min_size, boxes, scores, valid);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
 extern "C" int hd_roi_samples_finish(const int64_t* sel, int R, const float* comb, const int64_t* lab, const int64_t* matched, const float* gt,
                                      const uint8_t* gvalid, int T, int G, const float* coder_weights, float* rois, int64_t* labels, float* reg_t,
                                      void* stream) {
@@ -1257,6 +1361,17 @@ extern "C" int hd_roi_samples_finish(const int64_t* sel, int R, const float* com
   HD_CHECK_ARG(sel && comb && lab && matched && gt && gvalid && rois && labels && reg_t, "hd_roi_samples_finish: null pointer");
   hipLaunchKernelGGL(roi_samples_finish_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, sel, R, comb, lab, matched, gt, gvalid, T,
                      G, coder_weights[0], coder_weights[1], coder_weights[2], coder_weights[3], rois, labels, reg_t);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_roi_samples_padded(const uint8_t* pos_sel, const uint8_t* neg_sel, const float* comb, const int64_t* lab, const int64_t* matched,
+                                     const float* gt, const uint8_t* gvalid, int N, int T, int G, int S, const float* coder_weights, float* rois,
+                                     int64_t* labels, float* reg_t, int64_t* counts, void* stream) {
+  HD_CHECK_ARG(pos_sel && neg_sel && comb && lab && matched && gt && gvalid && coder_weights && rois && labels && reg_t && counts && N > 0 &&
+               T > 0 && G > 0 && S > 0, "hd_roi_samples_padded: bad args");
+  hipLaunchKernelGGL(roi_samples_padded_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, pos_sel, neg_sel, comb, lab, matched, gt, gvalid, T, G, S,
+                     coder_weights[0], coder_weights[1], coder_weights[2], coder_weights[3], rois, labels, reg_t, counts);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -1529,33 +1529,27 @@ def select_training_samples_padded(rh, props, pcounts, gt, glabels, gvalid):
     T = comb.shape[1]
     m, lab, _ = ops.match_targets(gt, gvalid, glabels, comb, rh.proposal_matcher.high_threshold, rh.proposal_matcher.low_threshold, False)
     lab = torch.where(cvalid, lab, torch.full_like(lab, -1))
-    pos_sel, neg_sel, counts = _sample_batched(rh.fg_bg_sampler, lab, host_counts=False)
-    S = rh.fg_bg_sampler.batch_size_per_image
-    mask = (pos_sel | neg_sel).bool()
-    rank = torch.cumsum(mask, dim=1) - 1
-    tgt = torch.where(mask, rank, torch.full_like(rank, S))          # unselected candidates all land in the spare column S
-    base = torch.arange(N, device=dev, dtype=torch.int64)[:, None]
-    out = (-(base + 1)).expand(N, S + 1).contiguous()                # padding code -(image + 1): hd_roi_samples_finish writes an empty row
-    out.scatter_(1, tgt, base * T + torch.arange(T, device=dev, dtype=torch.int64)[None, :])
-    sel = out[:, :S].reshape(-1)
-    rois, labels, reg_t = ops.roi_samples_finish(sel, comb, lab, m, gt, gvalid, rh.box_coder.weights)
-    return rois, labels, reg_t, counts.sum(dim=1)
+    pos_sel, neg_sel, _ = _sample_batched(rh.fg_bg_sampler, lab, host_counts=False)
+    # compaction (r-th selected candidate of image n -> row n*S + r), padding rows, box targets and the counts in one launch
+    return ops.roi_samples_padded(pos_sel, neg_sel, comb, lab, m, gt, gvalid, rh.fg_bg_sampler.batch_size_per_image, rh.box_coder.weights)
+
+
+_LABEL_GRID = {}
 
 
 def postprocess_detections_padded_rois(rh, class_logits, box_regression, rois, per_dev, S, image_shape):
-    """postprocess_detections_flat for the fixed-size RoI list (rows [i*S, i*S + per_dev[i]) of image i are real)."""
+    """postprocess_detections_flat for the fixed-size RoI list (rows [i*S, i*S + per_dev[i]) of image i are real): softmax, decode,
+    clip and the candidate tests in one launch (hd_roi_postprocess), then the batched NMS."""
     device = class_logits.device
     num_classes = class_logits.shape[-1]
     n_img, K = per_dev.shape[0], num_classes - 1
-    s = F.softmax(class_logits.detach(), -1)[:, 1:]
-    b = ops.roi_decode_clip(box_regression.detach(), rois, rh.box_coder.weights, rh.box_coder.bbox_xform_clip, image_shape)[:, 1:]
-    real = (torch.arange(S, device=device)[None, :] < per_dev[:, None]).reshape(-1, 1)
-    ws, hs = b[..., 2] - b[..., 0], b[..., 3] - b[..., 1]
-    V = (s > rh.score_thresh) & (ws >= 1e-2) & (hs >= 1e-2) & real
-    B = torch.where(real[:, :, None], b, torch.zeros_like(b)).reshape(n_img, S * K, 4)
-    Sx = torch.where(real, s, torch.zeros_like(s)).reshape(n_img, S * K)
-    V = V.reshape(n_img, S * K)
-    Lb = torch.arange(1, num_classes, device=device).view(1, 1, K).expand(n_img, S, K).reshape(n_img, S * K)
+    b, s, v = ops.roi_postprocess(class_logits.detach(), box_regression.detach(), rois, per_dev, S, rh.box_coder.weights,
+                                  rh.box_coder.bbox_xform_clip, image_shape, rh.score_thresh)
+    B, Sx, V = b.view(n_img, S * K, 4), s.view(n_img, S * K), v.view(n_img, S * K)
+    key = (n_img, S, K, str(device))
+    Lb = _LABEL_GRID.get(key)
+    if Lb is None:                       # class id of every (row, class) slot: constant per shape
+        Lb = _LABEL_GRID[key] = torch.arange(1, num_classes, device=device).view(1, 1, K).expand(n_img, S, K).reshape(n_img, S * K).contiguous()
     pick, counts = _batched_nms_pick(B, Sx, Lb, V, rh.nms_thresh, rh.detections_per_img)
     return torch.gather(B, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(Sx, 1, pick), torch.gather(Lb, 1, pick), counts
 

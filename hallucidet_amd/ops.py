@@ -513,6 +513,41 @@ def roi_samples_finish(sel, comb, lab, matched, gt, gvalid, coder_weights):
     return rois, labels, reg_t
 
 
+def roi_samples_padded(pos_sel, neg_sel, comb, lab, matched, gt, gvalid, S, coder_weights):
+    """Fixed-size RoI sampling tail in one launch: (rois [N*S,5], labels [N*S] (-1 = padding), targets [N*S,4], counts [N] int64)."""
+    _need_cuda(pos_sel, neg_sel, comb, lab, matched, gt, gvalid)
+    N, T, _ = comb.shape
+    G = gt.shape[1]
+    dev = comb.device
+    rois = torch.empty((N * S, 5), dtype=torch.float32, device=dev)
+    labels = torch.empty((N * S,), dtype=torch.int64, device=dev)
+    reg_t = torch.empty((N * S, 4), dtype=torch.float32, device=dev)
+    counts = torch.empty((N,), dtype=torch.int64, device=dev)
+    u8 = lambda t: t.contiguous().view(torch.uint8) if t.dtype == torch.bool else t.to(torch.uint8).contiguous()
+    w = (C.c_float * 4)(*[float(x) for x in coder_weights])
+    check(_abi.load().hd_roi_samples_padded(ptr(u8(pos_sel)), ptr(u8(neg_sel)), ptr(comb.contiguous().float()), ptr(lab.contiguous()),
+                                            ptr(matched.contiguous()), ptr(gt.contiguous().float()), ptr(u8(gvalid)), N, T, G, int(S),
+                                            C.cast(w, C.c_void_p), ptr(rois), ptr(labels), ptr(reg_t), ptr(counts), _stream()),
+          "hd_roi_samples_padded")
+    return rois, labels, reg_t, counts
+
+
+def roi_postprocess(class_logits, box_regression, rois, counts, S, coder_weights, bbox_xform_clip, image_shape, score_thresh, min_size=1e-2):
+    """Fixed-size RoI list -> foreground boxes [R, C-1, 4], scores [R, C-1], valid [R, C-1] bool (softmax + decode + clip + tests)."""
+    _need_cuda(class_logits, box_regression, rois, counts)
+    R, C_ = class_logits.shape
+    dev = class_logits.device
+    lg, br, ro = class_logits.contiguous().float(), box_regression.contiguous().float(), rois.contiguous().float()
+    boxes = torch.empty((R, C_ - 1, 4), dtype=torch.float32, device=dev)
+    scores = torch.empty((R, C_ - 1), dtype=torch.float32, device=dev)
+    valid = torch.empty((R, C_ - 1), dtype=torch.bool, device=dev)
+    w = (C.c_float * 4)(*[float(x) for x in coder_weights])
+    check(_abi.load().hd_roi_postprocess(ptr(lg), ptr(br), ro.data_ptr() + (ro.shape[1] - 4) * 4, ro.shape[1], ptr(counts.contiguous().to(torch.int64)),
+                                         R, C_, int(S), C.cast(w, C.c_void_p), float(bbox_xform_clip), float(image_shape[0]), float(image_shape[1]),
+                                         float(score_thresh), float(min_size), ptr(boxes), ptr(scores), ptr(valid), _stream()), "hd_roi_postprocess")
+    return boxes, scores, valid
+
+
 def roi_levels(rois, canonical_scale, canonical_level, eps, k_min, k_max):
     """rois [R, 4 or 5] f32 (box in the last four columns) -> FPN level index [R] int32 (LevelMapper)."""
     _need_cuda(rois)

@@ -337,9 +337,21 @@ int hd_sample_pos_neg(const int64_t* labels, const int32_t* keys, int N, int A, 
  * sampled candidate, sel[r] = flat index into the [N][T] candidate arrays: rois[r] = (image, box) [R][5], labels[r] = lab[sel],
  * reg_t[r] = BoxCoder(coder_weights).encode(gt[image][max(matched[sel], 0)] or zeros for an image without GT, box).
  * comb [N*T][4] f32, lab / matched [N*T] i64, gt [N][G][4] f32, gvalid [N][G] u8, coder_weights host float[4]. */
+/* RoIHeads.postprocess_detections up to the NMS, for the fixed-size RoI list (row r is real iff r % S < counts[r / S]): softmax over the C
+ * class logits, decode + clip of the C - 1 foreground boxes (rois: box in the last four columns of a roi_stride-wide row), candidate
+ * test (score > score_thresh, both sides >= min_size) -> boxes [R][C-1][4], scores [R][C-1], valid [R][C-1] u8; padding rows are zero. */
+int hd_roi_postprocess(const float* class_logits, const float* box_regression, const float* rois, long roi_stride, const int64_t* counts,
+                       int R, int C, int S, const float* coder_weights, float bbox_xform_clip, float img_h, float img_w, float score_thresh,
+                       float min_size, float* boxes, float* scores, uint8_t* valid, void* stream);
 int hd_roi_samples_finish(const int64_t* sel, int R, const float* comb, const int64_t* lab, const int64_t* matched, const float* gt,
                           const uint8_t* gvalid, int T, int G, const float* coder_weights, float* rois, int64_t* labels, float* reg_t,
                           void* stream);
+/* fixed-size form with the compaction included: image n owns rows [n*S, (n+1)*S) of the outputs -- its selected candidates (pos_sel |
+ * neg_sel over [N][T], ascending candidate index) first, then padding rows (empty box, label -1, zero target); counts[n] = real rows.
+ * Nothing is sized on the host (no synchronisation). */
+int hd_roi_samples_padded(const uint8_t* pos_sel, const uint8_t* neg_sel, const float* comb, const int64_t* lab, const int64_t* matched,
+                          const float* gt, const uint8_t* gvalid, int N, int T, int G, int S, const float* coder_weights, float* rois,
+                          int64_t* labels, float* reg_t, int64_t* counts, void* stream);
 /* torchvision.ops.poolers.LevelMapper [EXT]: levels[r] = clamp(floor(canonical_level + log2(sqrt(area_r) / canonical_scale) +
  * eps), k_min, k_max) - k_min; boxes = pointer to x1 of the first box, `stride` floats between boxes. */
 int hd_roi_levels(const float* boxes, long stride, int R, float canonical_scale, float canonical_level, float eps, int k_min, int k_max,

@@ -475,8 +475,8 @@ def test_fixed_size_roi_stage_equals_variable_size(dev, case, monkeypatch):
     for k in l0:
         assert torch.allclose(l0[k], l1[k], rtol=2e-6, atol=1e-7), (k, float(l0[k]), float(l1[k]))
     for p in range(3):
-        for x, y in zip(d0[p], d1[p]):
-            assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["boxes"], y["boxes"]) and torch.equal(x["scores"], y["scores"])
+        for x, y in zip(d0[p], d1[p]):      # scores: torch's softmax vs the fused kernel's (same formula, one ulp at most)
+            assert torch.equal(x["labels"], y["labels"]) and torch.equal(x["boxes"], y["boxes"]) and torch.allclose(x["scores"], y["scores"], rtol=1e-6, atol=0)
     assert torch.allclose(g0, g1, rtol=1e-3, atol=1e-6 + 1e-3 * float(g0.abs().max()))
     # padded sampling primitive on a case where one image is SHORT of RoIs (fewer candidates than S)
     rh = det.roi_heads
