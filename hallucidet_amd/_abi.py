@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HD_HIP_LIB") or os.path.join(_HERE, "lib", "libhallucidet_hip.so")
 
 HD_ACT_NONE, HD_ACT_RELU, HD_ACT_SIGMOID = 0, 1, 2
-HD_OUT_NHWC_F16, HD_OUT_NCHW_F32 = 0, 1
+HD_OUT_NHWC_F16, HD_OUT_NCHW_F32, HD_OUT_NHWC_F32 = 0, 1, 2
 
 c_i32 = C.c_int32
 c_i64 = C.c_int64
@@ -98,6 +98,7 @@ PROTOTYPES = {
     "hd_relu_bwd": (C.c_int, [vp, vp, vp, c_i64, vp]),
     "hd_f32_to_f16": (C.c_int, [vp, vp, c_i64, c_f, vp]),
     "hd_f16_to_f32": (C.c_int, [vp, vp, c_i64, c_f, vp]),
+    "hd_pad_cast_f32_f16": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
     "hd_channel_sum_f16": (C.c_int, [vp, c_i64, C.c_int, vp, C.c_int, vp]),
     "hd_scale_store": (C.c_int, [vp, vp, C.c_int, c_f, C.c_int, vp]),
     "hd_nms_sorted_batched": (C.c_int, [vp, vp, C.c_int, C.c_int, c_f, vp, vp, vp]),

@@ -210,6 +210,7 @@ bool hd_conv_small_eligible(const ConvP& p) {
   if (!(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.in_dil == 1 && p.C2 == 0 && p.x2 == nullptr &&
         (p.C1 == 8 || p.C1 == 16 || p.C1 == 32) && !p.res && !p.mask && p.Ho == p.Hin && p.Wo == p.Win))
     return false;
+  if (p.out_mode == HD_OUT_NHWC_F32) return false;
   if (p.out_mode == HD_OUT_NCHW_F32) return p.Cout <= 16 && !p.stats;                       // head: bias + activation allowed
   return (p.Cout == 16 || p.Cout == 32) && !p.bias && p.act == HD_ACT_NONE;                   // conv -> BN units, data gradients
 }

@@ -38,6 +38,7 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW;
   p.stride = a->stride; p.pad = a->pad; p.up1 = a->up1; p.in_dil = a->in_dil < 1 ? 1 : a->in_dil;
   p.act = a->act; p.out_mode = a->out_mode;
+  HD_CHECK_ARG(p.out_mode >= HD_OUT_NHWC_F16 && p.out_mode <= HD_OUT_NHWC_F32, "hd_conv2d: out_mode %d", p.out_mode);
   p.M = a->N * a->Ho * a->Wo;
   p.cin8 = p.Cin / 8;
   p.nchunks = a->KH * a->KW * p.cin8;

@@ -185,6 +185,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, f32x16 (&acc)[BM /
           else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + __expf(-v));
           if (p.out_mode == HD_OUT_NHWC_F16) {
             reinterpret_cast<f16*>(p.y)[(size_t)pix * p.Cout + co] = (f16)v;
+          } else if (p.out_mode == HD_OUT_NHWC_F32) {
+            reinterpret_cast<float*>(p.y)[(size_t)pix * p.Cout + co] = v;
           } else {
             int n = pix / HoWo;
             int rem = pix - n * HoWo;

@@ -129,8 +129,22 @@ def _conv_entry(conv, bn=None, cin_pad=None):
 
 
 def _fwd(e, x, *, act=ACT_NONE, res=None, f32=False):
+    """f32: False -> NHWC fp16; True -> NCHW fp32; "nhwc" -> NHWC fp32 (returned as its NCHW VIEW: torchvision's
+    `permute_and_flatten` of such a tensor is a free view instead of a copy)."""
+    if f32 == "nhwc":
+        return ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
+                          out_nhwc_f32=True, cout=e["cout"]).permute(0, 3, 1, 2)
     return ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
                       out_nchw_f32=f32, cout=e["cout"])
+
+
+def _head_grad_nhwc16(g, H, W, cout_p):
+    """Gradient of a head output [n, C, H, W] fp32 -> NHWC fp16 with cout_p channels.  When the gradient is the NCHW view of NHWC
+    memory (what autograd hands back for `_fwd(..., f32="nhwc")` outputs) this is one pad-and-cast launch."""
+    v = g.permute(0, 2, 3, 1)
+    if g.dtype == torch.float32 and v.is_contiguous():
+        return ops.pad_cast_f32_f16(v, cout_p)
+    return ops.nchw_to_nhwc_resize(g.contiguous().float(), H, W, cout_p)
 
 
 def _dgrad(e, dy, in_hw, *, res=None, mask=None):
@@ -633,8 +647,8 @@ class _RPNHeadFn(torch.autograd.Function):
         for f in feats:
             t = _fwd(P["conv"], f, act=ACT_RELU)
             ts.append(t[:n_active])
-            outs.append(_fwd(P["cls"], t, f32=True))
-            outs.append(_fwd(P["box"], t, f32=True))
+            outs.append(_fwd(P["cls"], t, f32="nhwc"))
+            outs.append(_fwd(P["box"], t, f32="nhwc"))
         ctx.head, ctx.ts, ctx.na, ctx.n = head, ts, n_active, feats[0].shape[0]
         ctx.feats = [f[:n_active] for f in feats] if head.train_params else None
         return tuple(outs)
@@ -653,13 +667,13 @@ class _RPNHeadFn(torch.autograd.Function):
             dt = None
             tp, inv = ctx.head.train_params, 1.0 / ctx.head.grad_scale
             if dl is not None:
-                gl = ops.nchw_to_nhwc_resize(dl.contiguous().float(), H, W, P["cls"]["cout_p"])
+                gl = _head_grad_nhwc16(dl, H, W, P["cls"]["cout_p"])
                 dt = _dgrad(P["cls"], gl, hw)
                 if tp:
                     _wgrad_into(ctx.head.cls_logits.weight, P["cls"], t, gl, inv)
                     _bgrad_into(ctx.head.cls_logits.bias, gl, inv)
             if dr is not None:
-                gr = ops.nchw_to_nhwc_resize(dr.contiguous().float(), H, W, P["box"]["cout_p"])
+                gr = _head_grad_nhwc16(dr, H, W, P["box"]["cout_p"])
                 dt = _dgrad(P["box"], gr, hw, res=dt, mask=t)
                 if tp:
                     _wgrad_into(ctx.head.bbox_pred.weight, P["box"], t, gr, inv)

@@ -72,7 +72,7 @@ class _HeadFn(torch.autograd.Function):
                     acts.append((t[:n_active], c[:n_active], z[:n_active], stat[:n_active]))
                     t = z
                 for last in lasts:
-                    outs.append(_fwd(last, t, f32=True))
+                    outs.append(_fwd(last, t, f32="nhwc"))
                 lv.append(acts)
             saved.append(lv)
         ctx.head, ctx.saved, ctx.na, ctx.n = head, saved, n_active, feats[0].shape[0]
@@ -96,7 +96,7 @@ class _HeadFn(torch.autograd.Function):
                 for last, g, conv in lasts:
                     if g is None:
                         continue
-                    gl = ops.nchw_to_nhwc_resize(g[:na].contiguous().float(), H, W, last["cout_p"])
+                    gl = D._head_grad_nhwc16(g[:na], H, W, last["cout_p"])
                     if tp:                               # the towers and their output convs are shared by the 5 levels: accumulate
                         D._wgrad_into(conv.weight, last, acts[3][2], gl, inv)
                         D._bgrad_into(conv.bias, gl, inv)

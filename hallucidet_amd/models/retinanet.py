@@ -47,7 +47,7 @@ class _HeadFn(torch.autograd.Function):
                 for e in tower:
                     t = _fwd(e, t, act=ACT_RELU)
                     acts.append(t[:n_active])
-                outs.append(_fwd(last, t, f32=True))
+                outs.append(_fwd(last, t, f32="nhwc"))
                 lv.append(acts)
             saved.append(lv)
         ctx.head, ctx.saved, ctx.na, ctx.n = head, saved, n_active, feats[0].shape[0]
@@ -71,7 +71,7 @@ class _HeadFn(torch.autograd.Function):
                 acts = lv[j]
                 H, W = acts[0].shape[1], acts[0].shape[2]
                 convs = [l for l in mods[j][0].conv if isinstance(l, nn.Conv2d)]
-                d = ops.nchw_to_nhwc_resize(g[:na].contiguous().float(), H, W, last["cout_p"])
+                d = D._head_grad_nhwc16(g[:na], H, W, last["cout_p"])
                 if tp:                                   # the towers share their weights over the 5 levels: accumulate
                     D._wgrad_into(mods[j][1].weight, last, acts[3], d, inv)
                     D._bgrad_into(mods[j][1].bias, d, inv)

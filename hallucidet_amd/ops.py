@@ -47,7 +47,7 @@ def _ensure_workspace(lib, device):
 
 
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
-           out_nchw_f32=False, want_stats=False, out_hw=None, cout=None, out=None, patch_kernel=False):
+           out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None, patch_kernel=False):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
@@ -77,11 +77,13 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
         y = out
     elif out_nchw_f32:
         y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    elif out_nhwc_f32:
+        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     else:
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
     a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(mask), ptr(y), None,
                  N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
-                 1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else 0)
+                 1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0))
     stats = None
     if want_stats:
         rows = (lib.hd_conv2d_patch_stats_rows if patch_kernel else lib.hd_conv2d_stats_rows)(C.byref(a))
@@ -309,6 +311,15 @@ def groupnorm8_param_grad(dy, x, y, stat, dgamma, dbeta, scale=1.0, *, relu=True
     N, H, W, C_ = x.shape
     check(_abi.load().hd_groupnorm8_param_grad(ptr(dy), ptr(x), ptr(y), ptr(stat), ptr(dgamma), ptr(dbeta), N, H * W, C_, 1 if relu else 0,
                                                float(scale), 1 if accumulate else 0, _stream()), "hd_groupnorm8_param_grad")
+
+
+def pad_cast_f32_f16(x, cp):
+    """[..., C] fp32 contiguous -> [..., cp] fp16, extra channels zero (one launch)."""
+    _need_cuda(x)
+    C_ = x.shape[-1]
+    y = torch.empty(tuple(x.shape[:-1]) + (cp,), dtype=torch.float16, device=x.device)
+    check(_abi.load().hd_pad_cast_f32_f16(ptr(x), ptr(y), x.numel() // C_, C_, cp, _stream()), "hd_pad_cast_f32_f16")
+    return y
 
 
 def maxpool3x3s2(x):

@@ -37,6 +37,7 @@ extern "C" {
 
 #define HD_OUT_NHWC_F16 0
 #define HD_OUT_NCHW_F32 1
+#define HD_OUT_NHWC_F32 2 /* [N][Ho][Wo][Cout] fp32 (any Cout): head outputs whose [N, HWA, C] view must be free */
 
 /* library identity / diagnostics */
 int hd_abi_version(void);
@@ -223,6 +224,8 @@ int hd_sigmoid_bwd_nchw_to_nhwc(const float* dy, const float* s, void* dlogit, i
 int hd_relu_bwd(const void* dy, const void* z, void* dx, int64_t n, void* stream);
 int hd_f32_to_f16(const float* x, void* y, int64_t n, float scale, void* stream);
 int hd_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream);
+/* x [P][C] fp32 -> y [P][Cp] fp16 with zero channels C..Cp-1 (gradient of an HD_OUT_NHWC_F32 head output entering a data-gradient conv) */
+int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, int Cp, void* stream);
 /* per-channel sums of an NHWC f16 tensor -> part[rows][C] (bias gradients); reduce with hd_colsum */
 int hd_channel_sum_f16(const void* x, int64_t npix, int C, float* part, int rows, void* stream);
 /* out[i] (=|+=) in[i]*scale, small fp32 vectors */
