@@ -98,7 +98,7 @@ PROTOTYPES = {
     "hd_relu_bwd": (C.c_int, [vp, vp, vp, c_i64, vp]),
     "hd_f32_to_f16": (C.c_int, [vp, vp, c_i64, c_f, vp]),
     "hd_f16_to_f32": (C.c_int, [vp, vp, c_i64, c_f, vp]),
-    "hd_pad_cast_f32_f16": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, vp]),
+    "hd_pad_cast_f32_f16": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, vp]),
     "hd_channel_sum_f16": (C.c_int, [vp, c_i64, C.c_int, vp, C.c_int, vp]),
     "hd_scale_store": (C.c_int, [vp, vp, C.c_int, c_f, C.c_int, vp]),
     "hd_nms_sorted_batched": (C.c_int, [vp, vp, C.c_int, C.c_int, c_f, vp, vp, vp]),

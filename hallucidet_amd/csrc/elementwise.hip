@@ -752,13 +752,16 @@ __global__ void f16_to_f32_kernel(const f16* __restrict__ x, float* __restrict__
 }
 
 // per-channel sum of an NHWC f16 tensor -> part[rows][C]  (bias gradients)
-// [P][C] fp32 -> [P][Cp] fp16, channels >= C zero (gradients of the small fp32 head outputs on their way into a data-gradient conv)
-__global__ void pad_cast_kernel(const float* __restrict__ x, f16* __restrict__ y, int64_t P, int C, int Cp) {
+// [P][C] fp32 -> [P][Cp] fp16, channels >= C zero (gradients of the small fp32 head outputs on their way into a data-gradient conv).
+// The source may be a slice of a larger buffer: row p lives at (p / rows_per_image) * image_stride + (p % rows_per_image) * C.
+__global__ void pad_cast_kernel(const float* __restrict__ x, f16* __restrict__ y, int64_t P, int C, int Cp, int64_t rows_per_image,
+                                int64_t image_stride) {
   const int64_t total = P * Cp;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t p = i / Cp;
     const int c = (int)(i - p * Cp);
-    y[i] = c < C ? (f16)x[p * C + c] : (f16)0.f;
+    const int64_t n = p / rows_per_image;
+    y[i] = c < C ? (f16)x[n * image_stride + (p - n * rows_per_image) * C + c] : (f16)0.f;
   }
 }
 
@@ -1006,10 +1009,10 @@ extern "C" int hd_f16_to_f32(const void* x, float* y, int64_t n, float scale, vo
   return HD_OK;
 }
 
-extern "C" int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, int Cp, void* stream) {
-  HD_CHECK_ARG(x && y && P >= 0 && C > 0 && Cp >= C, "hd_pad_cast_f32_f16: bad args");
+extern "C" int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, int Cp, int64_t rows_per_image, int64_t image_stride, void* stream) {
+  HD_CHECK_ARG(x && y && P >= 0 && C > 0 && Cp >= C && rows_per_image > 0 && image_stride >= rows_per_image * C, "hd_pad_cast_f32_f16: bad args");
   if (P == 0) return HD_OK;
-  hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for(P * Cp)), dim3(TB), 0, S_, x, (f16*)y, P, C, Cp);
+  hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for(P * Cp)), dim3(TB), 0, S_, x, (f16*)y, P, C, Cp, rows_per_image, image_stride);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -142,7 +142,7 @@ def _head_grad_nhwc16(g, H, W, cout_p):
     """Gradient of a head output [n, C, H, W] fp32 -> NHWC fp16 with cout_p channels.  When the gradient is the NCHW view of NHWC
     memory (what autograd hands back for `_fwd(..., f32="nhwc")` outputs) this is one pad-and-cast launch."""
     v = g.permute(0, 2, 3, 1)
-    if g.dtype == torch.float32 and v.is_contiguous():
+    if g.dtype == torch.float32 and v.stride()[1:] == (v.shape[2] * v.shape[3], v.shape[3], 1):     # dense images (slices of the flat [N, HWA, C] gradient)
         return ops.pad_cast_f32_f16(v, cout_p)
     return ops.nchw_to_nhwc_resize(g.contiguous().float(), H, W, cout_p)
 

@@ -326,28 +326,21 @@ class FCOS(nn.Module):
     def postprocess_detections_padded(self, head_outputs, anchors0, napl, image_shape):
         """Same selection on padded tensors.  Returns boxes [B, D, 4], scores [B, D], labels [B, D], counts [B]."""
         cls_logits, bbox_regression, ctr = head_outputs["cls_logits"], head_outputs["bbox_regression"], head_outputs["bbox_ctrness"]
-        B, _, K = cls_logits.shape
-        cb, cs, cl, cv = [], [], [], []
-        lo = 0
-        for n in napl:
-            scores = torch.sqrt(torch.sigmoid(cls_logits[:, lo:lo + n].detach()) * torch.sigmoid(ctr[:, lo:lo + n].detach())).reshape(B, n * K)
-            keep = scores > self.score_thresh
-            k = min(self.topk_candidates, n * K)
-            key = torch.where(keep, scores, torch.full_like(scores, float("-inf")))
-            skey, idx = torch.sort(key, dim=1, descending=True, stable=True)
-            idx, sc = idx[:, :k], skey[:, :k]
-            valid = sc > float("-inf")
-            aidx = torch.div(idx, K, rounding_mode="floor")
-            breg = torch.gather(bbox_regression[:, lo:lo + n].detach(), 1, aidx[:, :, None].expand(-1, -1, 4))
-            anc = anchors0[lo:lo + n][aidx]
-            boxes = self.box_coder.decode_single(breg.reshape(-1, 4), anc.reshape(-1, 4)).reshape(B, k, 4)
-            cb.append(D.clip_boxes_to_image(boxes, image_shape))
-            cs.append(torch.where(valid, sc, torch.zeros_like(sc)))
-            cl.append(idx % K)
-            cv.append(valid)
-            lo += n
-        cb, cs, cl, cv = torch.cat(cb, 1), torch.cat(cs, 1), torch.cat(cl, 1), torch.cat(cv, 1)
-        pick, counts = D._batched_nms_pick(cb, cs, cl, cv, self.nms_thresh, self.detections_per_img)
+        B, A, K = cls_logits.shape
+        # all levels at once (as RetinaNet.postprocess_detections_padded): threshold, per-level top-k in one hd_topk_select_rows launch,
+        # one gather / decode / clip over the selected candidates
+        scores = torch.sqrt(torch.sigmoid(cls_logits.detach()) * torch.sigmoid(ctr.detach())).reshape(B, A * K)
+        key = torch.where(scores > self.score_thresh, scores, torch.full_like(scores, float("-inf")))
+        idx = ops.topk_rows_segments(key, [n * K for n in napl], self.topk_candidates)
+        sc = torch.gather(key, 1, idx)
+        valid = sc > float("-inf")
+        aidx = torch.div(idx, K, rounding_mode="floor")
+        breg = torch.gather(bbox_regression.detach(), 1, aidx[:, :, None].expand(-1, -1, 4))
+        boxes = self.box_coder.decode_single(breg.reshape(-1, 4), anchors0[aidx].reshape(-1, 4)).reshape(B, -1, 4)
+        cb = D.clip_boxes_to_image(boxes, image_shape)
+        cs = torch.where(valid, sc, torch.zeros_like(sc))
+        cl = idx % K
+        pick, counts = D._batched_nms_pick(cb, cs, cl, valid, self.nms_thresh, self.detections_per_img)
         return (torch.gather(cb, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(cs, 1, pick), torch.gather(cl, 1, pick), counts)
 
 

@@ -314,11 +314,14 @@ def groupnorm8_param_grad(dy, x, y, stat, dgamma, dbeta, scale=1.0, *, relu=True
 
 
 def pad_cast_f32_f16(x, cp):
-    """[..., C] fp32 contiguous -> [..., cp] fp16, extra channels zero (one launch)."""
+    """x [n, H, W, C] fp32 whose images are dense (strides (*, W*C, C, 1); the image stride may be larger: a slice of a bigger
+    buffer) -> [n, H, W, cp] fp16, extra channels zero (one launch)."""
     _need_cuda(x)
-    C_ = x.shape[-1]
-    y = torch.empty(tuple(x.shape[:-1]) + (cp,), dtype=torch.float16, device=x.device)
-    check(_abi.load().hd_pad_cast_f32_f16(ptr(x), ptr(y), x.numel() // C_, C_, cp, _stream()), "hd_pad_cast_f32_f16")
+    n, H, W, C_ = x.shape
+    assert x.stride()[1:] == (W * C_, C_, 1) or n * H * W == 0
+    y = torch.empty((n, H, W, cp), dtype=torch.float16, device=x.device)
+    img_stride = x.stride(0) if n > 1 else H * W * C_
+    check(_abi.load().hd_pad_cast_f32_f16(ptr(x), ptr(y), n * H * W, C_, cp, H * W, max(img_stride, H * W * C_), _stream()), "hd_pad_cast_f32_f16")
     return y
 
 

@@ -224,8 +224,10 @@ int hd_sigmoid_bwd_nchw_to_nhwc(const float* dy, const float* s, void* dlogit, i
 int hd_relu_bwd(const void* dy, const void* z, void* dx, int64_t n, void* stream);
 int hd_f32_to_f16(const float* x, void* y, int64_t n, float scale, void* stream);
 int hd_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream);
-/* x [P][C] fp32 -> y [P][Cp] fp16 with zero channels C..Cp-1 (gradient of an HD_OUT_NHWC_F32 head output entering a data-gradient conv) */
-int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, int Cp, void* stream);
+/* x fp32 rows of C channels -> y [P][Cp] fp16 with zero channels C..Cp-1 (gradient of an HD_OUT_NHWC_F32 head output entering a
+ * data-gradient conv); row p of x lives at (p / rows_per_image) * image_stride + (p % rows_per_image) * C floats (a slice of a larger
+ * buffer; image_stride == rows_per_image * C for a dense source) */
+int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, int Cp, int64_t rows_per_image, int64_t image_stride, void* stream);
 /* per-channel sums of an NHWC f16 tensor -> part[rows][C] (bias gradients); reduce with hd_colsum */
 int hd_channel_sum_f16(const void* x, int64_t npix, int C, float* part, int rows, void* stream);
 /* out[i] (=|+=) in[i]*scale, small fp32 vectors */
