@@ -590,7 +590,13 @@ def _batched_nms_pick(boxes, scores, idxs, valid, iou_thr, top_n):
         order, sel, counts = _batched_nms_padded(boxes, scores, idxs, valid, iou_thr, top_n)
         return torch.gather(order, 1, _front(sel, top_n)), counts
     key = torch.where(valid, scores, torch.full_like(scores, float("-inf")))
-    order = torch.sort(key, dim=1, descending=True, stable=True)[1]
+    n = key.shape[1]
+    if n <= 4096 and key.dtype == torch.float32:
+        # full descending stable order of every row by the radix-select + in-LDS sort kernel (one launch; rocprim's segmented radix sort
+        # behind torch.sort is 2-3 launches of 17-25 us at these sizes); same order: equal keys by ascending index
+        order = ops.topk_rows_segments(key.contiguous(), [n], n)
+    else:
+        order = torch.sort(key, dim=1, descending=True, stable=True)[1]
     return ops.batched_nms_pick(boxes, idxs, valid, order, iou_thr, top_n)
 
 

@@ -375,11 +375,16 @@ def subsample2_bwd(dy, dx, accumulate=True):
     return dx
 
 
-def nchw_to_nhwc_resize(x, Ho, Wo, Cp=8):
+def nchw_to_nhwc_resize(x, Ho, Wo, Cp=8, out=None):
+    """`out`: write into this [N, Ho, Wo, Cp] fp16 tensor (e.g. a slice along dim 0 of a larger batch buffer) instead of a new one."""
     _need_cuda(x)
     N, Cr, H, W = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous()
-    y = torch.empty((N, Ho, Wo, Cp), dtype=torch.float16, device=x.device)
+    if out is None:
+        y = torch.empty((N, Ho, Wo, Cp), dtype=torch.float16, device=x.device)
+    else:
+        y = out
+        assert y.shape == (N, Ho, Wo, Cp) and y.dtype == torch.float16 and y.is_contiguous()
     check(_abi.load().hd_nchw_to_nhwc_resize(ptr(x), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()), "hd_nchw_to_nhwc_resize")
     return y
 

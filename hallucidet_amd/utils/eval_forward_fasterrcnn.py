@@ -101,9 +101,8 @@ def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name
         _check_targets(t)
     sizes = [[(img.shape[-2], img.shape[-1]) for img in b] for b in image_batches]
     nb = [len(s) for s in sizes]
-    x = torch.cat([b if isinstance(b, torch.Tensor) else torch.stack(list(b)) for b in image_batches], dim=0)
     flat_targets = [t for tl in target_lists for t in tl]
-    il, flat_targets = model.transform(x, flat_targets)
+    il, flat_targets = model.transform.forward_batches(image_batches, flat_targets)       # every batch resized into its slice: no fp32 concat
     fused = getattr(model, "fused_passes", False) if fused is None else fused
     if fused and getattr(model, "batched_heads", False):
         return _multi_fused(model, il, flat_targets, nb, sizes, image_batches[0].requires_grad)

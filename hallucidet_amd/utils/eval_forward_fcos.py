@@ -69,9 +69,8 @@ def eval_forward_fcos_multi(model, image_batches, target_lists, model_name='fcos
         _check_targets(t)
     sizes = [[(img.shape[-2], img.shape[-1]) for img in b] for b in image_batches]
     nb = [len(s) for s in sizes]
-    x = torch.cat([b if isinstance(b, torch.Tensor) else torch.stack(list(b)) for b in image_batches], dim=0)
     flat_targets = [t for tl in target_lists for t in tl]
-    il, flat_targets = model.transform(x, flat_targets)
+    il, flat_targets = model.transform.forward_batches(image_batches, flat_targets)       # every batch resized into its slice: no fp32 concat
     check_degenerate_deferred(model, flat_targets)          # no host synchronisation inside the step
     n0 = nb[0]
     if image_batches[0].requires_grad:
