@@ -45,21 +45,27 @@ def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in two separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py) committed under profiles/ for this round.
     bench.py itself cannot collect PMCs (they need rocprofv3 around the process): null if the file is absent."""
-    j = _profile_json(["r02_conv_traffic.json", "r01_conv_traffic.json"])
-    try:
-        return round(j["traffic_bytes_per_launch"])
-    except Exception:
-        return None
+    for name in ("r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
+        j = _profile_json([name])
+        try:
+            return round(j["traffic_bytes_per_launch"]), {"static": True, "source": "profiles/" + name, "commit": j.get("commit"),
+                                                          "note": "PMC counters need rocprofv3 around the process: collected by tools/collect_profiles.sh, NOT measured in this run"}
+        except Exception:
+            continue
+    return None, None
 
 
 def _pmc_mfma_util():
     """MFMA-pipe utilisation of the conv kernels in a training step (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy
     clocks), tools/pmc_mfma.py on a `rocprofv3 --pmc` run of tools/bench_step.py), committed under profiles/."""
-    j = _profile_json(["r02_conv_mfma_util.json"])
-    try:
-        return {"value": j["mfma_util"], "by_kernel": j.get("by_kernel"), "source": "profiles/r02_conv_mfma_util.json"}
-    except Exception:
-        return None
+    for name in ("r03_conv_mfma_util.json", "r02_conv_mfma_util.json"):
+        j = _profile_json([name])
+        try:
+            return {"value": j["mfma_util"], "by_kernel": j.get("by_kernel"), "static": True, "source": "profiles/" + name, "commit": j.get("commit"),
+                    "note": "NOT measured in this run (PMC pass of tools/collect_profiles.sh)"}
+        except Exception:
+            continue
+    return None
 
 
 def _cpu_model():
@@ -224,7 +230,7 @@ def conv_roofline(lit, batch, reps=5):
             "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "frac_isolated": round(iso / MFMA_F16_PEAK_TFLOPS, 4),
             "timing": "step-order replay: the 257 hd_conv2d launches of one training step, each once, in step order, captured in one hipGraph and "
                       "replayed between HIP events on the launch stream (3 passes); `*_isolated`: each launch 5x back to back",
-            "mfma_util": _pmc_mfma_util(), "traffic": _pmc_traffic(), "traffic_unit": "HBM bytes per launch (PMC)",
+            "mfma_util": _pmc_mfma_util(), "traffic": _pmc_traffic()[0], "traffic_provenance": _pmc_traffic()[1], "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
             "kernel": "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + "
                       "conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
@@ -304,9 +310,9 @@ def cpu_baseline(protocol):
                           "(`value`; best of the sweep, %d CPUs usable) and at the reference's 8 threads; U-Net forward+backward alone "
                           "likewise; host: %s" % (best, usable, host))
     else:
-        v = timed_steps(8, best, 1, 1, warm_n=2)
+        v = timed_steps(8, best, 1, 3, warm_n=2)
         res.update(value=round(v, 4), cores=best, unet_only_8_threads=round(unet_only(2, 8, 1, net), 4),
-                   sample="bounded: ONE timed full training step of the CPU oracle (oracle/step.py, fp32 torch) on batch 8 x 512x640 at %d "
+                   sample="bounded: THREE timed full training steps of the CPU oracle (oracle/step.py, fp32 torch) on batch 8 x 512x640 at %d "
                           "threads (best of a sweep over %s; %d CPUs usable) after one warm-up step on batch 2; U-Net forward+backward alone "
                           "on batch 2 at the reference's 8 threads (src/config/config.py:10-11); the full SURVEY 8d protocol is "
                           "`--cpu-protocol full`; host: %s" % (best, cand, usable, host))
@@ -383,6 +389,15 @@ def main():
     if args.batch:
         BATCH_PER_GPU = args.batch
 
+    # `python bench.py --gpus N` started plainly: become the launcher -- N children (one per GPU, the torch.distributed.run
+    # environment), rank 0's JSON line relayed.  Nothing in this process has touched the GPU yet, and nothing will.
+    from hallucidet_amd import launch
+    if launch.need_self_launch(args.gpus):
+        n_vis = torch.cuda.device_count()            # counting devices does not create a HIP context
+        if n_vis < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_vis))
+        raise SystemExit(launch.launch_ranks(args.gpus))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -398,7 +413,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it plainly (it starts its own ranks) or with "
+                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
 
     from hallucidet_amd import synthetic
     dev = "cuda:%d" % local
@@ -407,12 +424,44 @@ def main():
     lit = synthetic.make_module(seed=123, device=dev, precision=16, detector_name=args.detector)
     batch = synthetic.make_batch(BATCH_PER_GPU, H, W, seed=123 + rank, device=dev)   # per-rank shard, resident in HBM
 
+    overlap_note = None
+    if dist.is_initialized() and os.environ.get("HD_OVERLAP_ALLREDUCE", "") != "":
+        lit.overlap_allreduce = os.environ["HD_OVERLAP_ALLREDUCE"] != "0"
+    elif dist.is_initialized() and world > 1:
+        # Safety net for the overlapped exchange (bucketed all-reduces issued between the segmented backward graphs): before
+        # anything is timed, one step is taken from the same parameters with and without the overlap; the averaged gradients
+        # must agree (the reduction order inside RCCL may differ between bucketings: 1e-5 relative), on every rank.  If they
+        # do not, the run falls back to the un-overlapped exchange and says so in its line.
+        r = lit.encoder_decoder.runner
+        p0, m0, v0 = r.flat_params.clone(), lit.optimizer.exp_avg.clone(), lit.optimizer.exp_avg_sq.clone()
+        bufs0 = [b.clone() for b in lit.encoder_decoder.buffers()]
+        sc0, st0 = lit.optimizer.step_count, lit.scaler.scale_value
+        grads = []
+        for ov in (False, True):
+            lit.overlap_allreduce = ov
+            torch.manual_seed(1000 + rank)
+            lit.fit_step(batch)
+            torch.cuda.synchronize()
+            grads.append(r.flat_grads.clone())
+            r.flat_params.copy_(p0); lit.optimizer.exp_avg.copy_(m0); lit.optimizer.exp_avg_sq.copy_(v0)
+            for b, b0 in zip(lit.encoder_decoder.buffers(), bufs0):
+                b.copy_(b0)
+            lit.optimizer.resolve_found_inf()
+            lit.optimizer.step_count, lit.scaler.scale_value = sc0, st0
+        err = (grads[0] - grads[1]).norm() / grads[0].norm().clamp(min=1e-30)
+        bad = torch.tensor([float(not (err <= 1e-4))], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        lit.overlap_allreduce = not bool(bad.item())
+        overlap_note = "self-check: overlapped vs un-overlapped averaged gradient rel-L2 %.2e -> overlap %s" % (float(err), "on" if lit.overlap_allreduce else "OFF (fallback)")
+        del grads, p0, m0, v0, bufs0
+
     for _ in range(args.warmup):
         lit.fit_step(batch)
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
+    lit.averager.timing = dist.is_initialized()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = lit.fit_step(batch)
@@ -421,12 +470,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    lit.averager.timing = False
+    rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
     if not torch.isfinite(loss):
         raise SystemExit("non-finite loss in the timed region")
+    lit.optimizer.resolve_found_inf()          # the last timed step's overflow flag (skipped_steps below must include it)
 
     if rank == 0:
         # everything below is rank-0-only measurement: no collective may be issued from here on (the other ranks are
@@ -453,7 +505,14 @@ def main():
                        "step_alg_tflops": round(428.5e9 * value / 1e12, 1) if args.detector == "fasterrcnn" else None},
             "final_loss": round(float(loss), 5),
             "skipped_steps": lit.optimizer.skipped_steps,       # overflow-skipped optimizer steps in the whole run (must be 0)
+            "rccl_ranks": rccl_ranks,                           # dist.get_world_size() of the process group the exchange ran on
         }
+        if dist.is_initialized():
+            out["allreduce"] = {"payload_bytes": int(lit.encoder_decoder.runner.flat_grads.numel()) * 4, "overlap": bool(lit.overlap_allreduce),
+                                "note": overlap_note,
+                                # per bucket, issue order: the part of its all-reduce the backward pass did not hide (HIP events on
+                                # the compute stream around the wait), mean over the timed steps of rank 0
+                                "exposed_wait_per_bucket": lit.averager.exposed_wait_ms()}
         if world == 1:
             # PCIe-inclusive rate (never `value`): every step's batch comes from host memory through the product's input path
             # (hallucidet_amd.dataloader.DevicePrefetcher: uint8 images stacked into pinned memory, copied on a side HIP stream

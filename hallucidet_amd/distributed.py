@@ -36,6 +36,8 @@ class GradientAverager:
         self._flat = None
         self._covered = []
         self.issued = []          # [(lo, hi)] of the current step, in issue order (tests / diagnostics)
+        self.timing = False       # bench.py: HIP events around every bucket's wait -> exposed (un-overlapped) communication time
+        self._events = []         # [[(e0, e1, nbytes)] per step]
 
     def begin(self, flat_grads):
         """Start of a step's backward pass: buckets will arrive through bucket_ready()."""
@@ -76,9 +78,32 @@ class GradientAverager:
         work, self._work, self._flat = self._work, [], None
         if not is_dist():
             return
-        for w in work:
-            w.wait()
+        if self.timing and flat_grads.is_cuda:
+            # w.wait() makes the CURRENT stream wait for the collective (the host does not block): the time between two events
+            # recorded on that stream around it is the part of the bucket's all-reduce that the backward pass did not hide
+            ev = []
+            for w, (lo, hi) in zip(work, self.issued):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                w.wait()
+                e1.record()
+                ev.append((e0, e1, (hi - lo) * 4))
+            self._events.append(ev)
+        else:
+            for w in work:
+                w.wait()
         flat_grads.mul_(1.0 / dist.get_world_size())
+
+    def exposed_wait_ms(self):
+        """Mean exposed wait per bucket (issue order) over the steps timed so far: [{'bytes', 'ms'}]; call after a synchronize."""
+        if not self._events:
+            return []
+        n = min(len(e) for e in self._events)
+        out = []
+        for k in range(n):
+            ms = [e[k][0].elapsed_time(e[k][1]) for e in self._events]
+            out.append({"bytes": self._events[0][k][2], "ms": round(sum(ms) / len(ms), 4)})
+        return out
 
 
 def exchange_and_step(averager, flat_grads, scaler, optimizer):

@@ -128,14 +128,26 @@ def _conv_entry(conv, bn=None, cin_pad=None):
                 cin_p=cin_p, cout_p=cout_p)
 
 
-def _fwd(e, x, *, act=ACT_NONE, res=None, f32=False):
+# Parity instrumentation (tests only): when `_TAP` is a dict, every activation whose sign pattern is a DISCRETE decision of the
+# forward pass (post-ReLU tensors, the max-pool winner bytes) is recorded under a tag, so that a test can hand the same decisions
+# to the CPU oracle (oracle.detection.Pins) and compare gradients of the same piecewise-linear function.  None in production.
+_TAP = None
+
+
+def _tap(tag, t):
+    if _TAP is not None and tag is not None:
+        _TAP[tag] = t
+    return t
+
+
+def _fwd(e, x, *, act=ACT_NONE, res=None, f32=False, tag=None):
     """f32: False -> NHWC fp16; True -> NCHW fp32; "nhwc" -> NHWC fp32 (returned as its NCHW VIEW: torchvision's
     `permute_and_flatten` of such a tensor is a free view instead of a copy)."""
     if f32 == "nhwc":
         return ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
                           out_nhwc_f32=True, cout=e["cout"]).permute(0, 3, 1, 2)
-    return ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
-                      out_nchw_f32=f32, cout=e["cout"])
+    return _tap(tag, ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
+                                out_nchw_f32=f32, cout=e["cout"]))
 
 
 def _head_grad_nhwc16(g, H, W, cout_p):
@@ -274,17 +286,18 @@ class BackboneWithFPN(nn.Module):
         P = self.pack()
         na = x.shape[0] if n_active is None else n_active
         rec = {"x": x[:na], "blocks": []} if save else None
-        s = _fwd(P["stem"], x, act=ACT_RELU)
+        s = _fwd(P["stem"], x, act=ACT_RELU, tag=("stem",))
         p, pidx = ops.maxpool3x3s2_idx(s) if save else (ops.maxpool3x3s2(s), None)
+        _tap(("pool",), pidx)
         cur = p
         C = []
-        for stage in P["blocks"]:
+        for si, stage in enumerate(P["blocks"]):
             srec = []
-            for e in stage:
-                o1 = _fwd(e["c1"], cur, act=ACT_RELU)
-                o2 = _fwd(e["c2"], o1, act=ACT_RELU)
+            for bi, e in enumerate(stage):
+                o1 = _fwd(e["c1"], cur, act=ACT_RELU, tag=("b", si, bi, 1))
+                o2 = _fwd(e["c2"], o1, act=ACT_RELU, tag=("b", si, bi, 2))
                 idt = cur if e["ds"] is None else _fwd(e["ds"], cur)
-                out = _fwd(e["c3"], o2, act=ACT_RELU, res=idt)
+                out = _fwd(e["c3"], o2, act=ACT_RELU, res=idt, tag=("b", si, bi, 3))
                 if save:
                     srec.append((cur[:na], o1[:na], o2[:na], out[:na]))
                 cur = out
@@ -303,7 +316,7 @@ class BackboneWithFPN(nn.Module):
             outs[i] = _fwd(P["layer"][i], inner[i])
         if self.p6p7:
             p6 = _fwd(P["p6"], outs[L - 1])
-            extra = [p6, _fwd(P["p7"], torch.relu(p6))]
+            extra = [p6, _fwd(P["p7"], _tap(("p7in",), torch.relu(p6)))]
         else:
             extra = [ops.subsample2(outs[L - 1])]
         if save:
@@ -650,8 +663,8 @@ class _RPNHeadFn(torch.autograd.Function):
         feats = feats[:nlev]
         P = head.pack()
         ts, outs = [], []
-        for f in feats:
-            t = _fwd(P["conv"], f, act=ACT_RELU)
+        for li, f in enumerate(feats):
+            t = _fwd(P["conv"], f, act=ACT_RELU, tag=("rpn", li))
             ts.append(t[:n_active])
             outs.append(_fwd(P["cls"], t, f32="nhwc"))
             outs.append(_fwd(P["box"], t, f32="nhwc"))
@@ -901,8 +914,8 @@ class _MLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, head):
         P = head.pack()
-        h6 = _fwd(P["fc6"], x, act=ACT_RELU)
-        h7 = _fwd(P["fc7"], h6, act=ACT_RELU)
+        h6 = _fwd(P["fc6"], x, act=ACT_RELU, tag=("fc6",))
+        h7 = _fwd(P["fc7"], h6, act=ACT_RELU, tag=("fc7",))
         ctx.head, ctx.h6, ctx.h7, ctx.xshape = head, h6, h7, tuple(x.shape)
         ctx.x = x if head.train_params else None
         ctx.need_dx = x.requires_grad

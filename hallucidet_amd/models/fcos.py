@@ -62,13 +62,14 @@ class _HeadFn(torch.autograd.Function):
         feats = feats[:nlev]
         P = head.pack()
         outs, saved = [], []
-        for f in feats:
+        for li, f in enumerate(feats):
             lv = []
-            for tower, lasts in ((P["cls_tower"], (P["cls_out"],)), (P["reg_tower"], (P["reg_out"], P["ctr_out"]))):
+            for name, tower, lasts in (("cls", P["cls_tower"], (P["cls_out"],)), ("reg", P["reg_tower"], (P["reg_out"], P["ctr_out"]))):
                 t, acts = f, []
-                for e, (ga, be, eps) in tower:
+                for k, (e, (ga, be, eps)) in enumerate(tower):
                     c = _fwd(e, t)                                       # conv + bias, NHWC f16
                     z, stat = ops.groupnorm8_relu(c, ga, be, eps)
+                    D._tap((name, li, k), z)
                     acts.append((t[:n_active], c[:n_active], z[:n_active], stat[:n_active]))
                     t = z
                 for last in lasts:
@@ -195,6 +196,8 @@ class FCOSHead(nn.Module):
         acts = D._active_views(feats, na) if na < feats[0].shape[0] else None
         outs = _HeadFn.apply(self._hook, self, na, len(feats), *feats, *(acts or ()))
         K = self.classification_head.cls_logits.out_channels // self.classification_head.num_anchors
+        for li, r in enumerate(outs[1::3]):
+            D._tap(("reg_out", li), r)
 
         def flat(t, k):
             N, _, H, W = t.shape

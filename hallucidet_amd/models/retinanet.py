@@ -40,12 +40,12 @@ class _HeadFn(torch.autograd.Function):
         feats = feats[:nlev]
         P = head.pack()
         outs, saved = [], []
-        for f in feats:
+        for li, f in enumerate(feats):
             lv = []
-            for tower, last in ((P["cls_tower"], P["cls_out"]), (P["reg_tower"], P["reg_out"])):
+            for name, tower, last in (("cls", P["cls_tower"], P["cls_out"]), ("reg", P["reg_tower"], P["reg_out"])):
                 t, acts = f, []
-                for e in tower:
-                    t = _fwd(e, t, act=ACT_RELU)
+                for k, e in enumerate(tower):
+                    t = _fwd(e, t, act=ACT_RELU, tag=(name, li, k))
                     acts.append(t[:n_active])
                 outs.append(_fwd(last, t, f32="nhwc"))
                 lv.append(acts)

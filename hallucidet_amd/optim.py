@@ -79,6 +79,8 @@ class FusedAdam(torch.optim.Optimizer):
         r = self.runner
         r.flatten_parameters()
         g = self.param_groups[0]
+        if self._inf_pending:               # the previous step's skip flag must be accounted for before it is overwritten
+            self.resolve_found_inf()
         if check_inf:
             self.found_inf.zero_()
             ops.check_finite(r.flat_grads, self.found_inf)

@@ -259,7 +259,9 @@ class UnetRunner:
             torch.cuda.current_stream().wait_stream(side)
             g["pool"] = torch.cuda.graph_pool_handle()
             g["fwd"] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g["fwd"], pool=g["pool"]):
+            # thread_local: the input pipeline's helper thread (DevicePrefetcher) allocates pinned / device memory while this thread
+            # captures; in the default 'global' mode such a call from ANOTHER thread invalidates the capture
+            with torch.cuda.graph(g["fwd"], pool=g["pool"], capture_error_mode="thread_local"):
                 g["out"] = self.forward(g["x"], training=True, save=True)
             g["saved"] = self.saved
             # the capture itself did not execute: restore the BatchNorm buffers the warm-up touched, then replay
@@ -301,11 +303,11 @@ class UnetRunner:
             g["dout"] = torch.empty(g["out"].shape, dtype=torch.float32, device=g["dev"])
             g["dout"].copy_(dout)
             self.saved = g["saved"]
-            g["scale"], g["segmented"] = S, segmented
+            g["bwd"] = None                 # a failed capture must not leave graphs of another (scale, segmentation) behind
             torch.cuda.synchronize()
             if not segmented:
-                g["bwd"] = [torch.cuda.CUDAGraph()]
-                with torch.cuda.graph(g["bwd"][0], pool=g["pool"]):
+                graphs = [torch.cuda.CUDAGraph()]
+                with torch.cuda.graph(graphs[0], pool=g["pool"], capture_error_mode="thread_local"):
                     self.backward(g["dout"], keep_saved=True)
             else:
                 # one graph per bucket: end the running capture at every boundary and begin the next one in the same pool
@@ -314,22 +316,31 @@ class UnetRunner:
                 side.wait_stream(torch.cuda.current_stream())
                 hook, self.bucket_hook = self.bucket_hook, None
                 with torch.cuda.stream(side):
-                    graphs[0].capture_begin(pool=g["pool"])
+                    graphs[0].capture_begin(pool=g["pool"], capture_error_mode="thread_local")
 
                     def cut(k):
                         if k < 4:
                             graphs[-1].capture_end()
                             graphs.append(torch.cuda.CUDAGraph())
-                            graphs[-1].capture_begin(pool=g["pool"])
+                            graphs[-1].capture_begin(pool=g["pool"], capture_error_mode="thread_local")
                     self._cut = cut
+                    err = None
                     try:
                         self.backward(g["dout"], keep_saved=True)
+                    except BaseException as e:          # keep the ORIGINAL error: ending an invalidated capture raises its own
+                        err = e
                     finally:
                         self._cut = None
-                        graphs[-1].capture_end()
                         self.bucket_hook = hook
+                        try:
+                            graphs[-1].capture_end()
+                        except Exception:
+                            if err is None:
+                                raise
+                    if err is not None:
+                        raise err
                 torch.cuda.current_stream().wait_stream(side)
-                g["bwd"] = graphs
+            g["bwd"], g["scale"], g["segmented"] = graphs, S, segmented       # only a complete capture is remembered
         g["dout"].copy_(dout)
         if not segmented:
             g["bwd"][0].replay()

@@ -14,7 +14,7 @@ from .models.detector import Detector
 from .models.encoder_decoder import EncoderDecoder
 from .optim import LossScaler
 from .utils.utils import Utils
-from .utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn_multi
+from .utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn_multi, flush_degenerate
 from .utils.eval_forward_retinanet import eval_forward_retinanet_multi
 from .utils.eval_forward_fcos import eval_forward_fcos_multi
 
@@ -240,5 +240,6 @@ class EncoderDecoderLit(nn.Module):
         for d in (self._last_detections or {}).values():       # deferred detector post-processing: queue it behind the backward pass
             if hasattr(d, "flush"):
                 d.flush()
+        flush_degenerate(self.detector, block=False)      # the reference's degenerate-box assertion, before the update when it is known by now
         exchange_and_step(self.averager, g, self.scaler, self.optimizer)
         return loss.detach()

@@ -72,7 +72,44 @@ class Trainer:
         dist.all_reduce(t)
         return float(t[0]) / max(float(t[1]), 1.0)
 
+    @staticmethod
+    def _nanmean_over_ranks(metrics):
+        """All monitored scalars in ONE unconditional all-reduce: per key a (sum, count) pair, NaN / 'no data' (-1 from the mAP
+        accumulators) entries contribute (0, 0).  Every rank issues the same collective whatever its local values are -- a
+        per-key reduce guarded by a local NaN test would pair up differently on ranks whose values differ."""
+        from .distributed import is_dist
+        keys = sorted(metrics)
+        pairs = []
+        for k in keys:
+            v = metrics[k]
+            s, c = (float(v[0]), float(v[1])) if isinstance(v, tuple) else (float(v), 1.0)
+            if math.isnan(s) or (k.startswith("map") and s == -1.0):
+                s, c = 0.0, 0.0
+            pairs += [s, c]
+        if is_dist():
+            import torch.distributed as dist
+            t = torch.tensor(pairs, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t)
+            pairs = t.tolist()
+        out = {}
+        for i, k in enumerate(keys):
+            s, c = pairs[2 * i], pairs[2 * i + 1]
+            if c > 0:
+                out[k] = s / c
+            else:
+                v = metrics[k]
+                out[k] = float("nan") if isinstance(v, tuple) else float(v)      # nobody had data: keep the local sentinel
+        return out
+
+    @staticmethod
+    def _flush_deferred_checks(model):
+        det = getattr(model, "detector", None)
+        if det is not None:
+            from .utils.eval_forward_fasterrcnn import flush_degenerate
+            flush_degenerate(det, block=True)
+
     def validate(self, model, loader):
+        self._flush_deferred_checks(model)          # the last training batch's degenerate-box flag is read here, not during validation
         state = self._set_eval(model)
         try:
             tot, n = 0.0, 0
@@ -81,12 +118,10 @@ class Trainer:
                 tot += float(r[0] if isinstance(r, tuple) else r)
                 n += 1
             m = self._flat(model.on_validation_epoch_end())
+            self._flush_deferred_checks(model)
         finally:
             self._restore(state)
-        m["val_loss"] = self._mean_over_ranks(tot, n)
-        for k in list(m):
-            if k != "val_loss" and not math.isnan(m[k]):
-                m[k] = self._mean_over_ranks(m[k], 1)
+        m.update(self._nanmean_over_ranks(dict(m, val_loss=(tot, n))))
         # Lightning logs `val_map` = the hallucinated stream's mAP (train_hallucidet.py:357) / the detector's mAP
         m["val_map"] = m.get("map_hall/map", m.get("map", float("nan")))
         return m
@@ -137,6 +172,7 @@ class Trainer:
         try:
             for i, batch in enumerate(DevicePrefetcher(datamodule.test_dataloader(), self.device)):
                 model.test_step(batch, i)
+            self._flush_deferred_checks(model)
             return model.on_test_epoch_end()
         finally:
             self._restore(state)

@@ -42,6 +42,16 @@ def check_degenerate_deferred(model, targets):
             _raise_if_degenerate(flag, targets)
 
 
+def flush_degenerate(model, block=True):
+    """Read the degenerate-box flag the last deferred check left behind (fit_step: right before the optimizer step, without
+    waiting -- a bad batch whose flag has already arrived never updates the parameters; epoch ends / validation: blocking, so the
+    flag of a run's last batch is never lost).  Raises the reference's assertion (:41-53) if it is set."""
+    pend = model.__dict__.get("_pending_degenerate")
+    if pend is not None and (block or pend.ready()):
+        model.__dict__.pop("_pending_degenerate", None)
+        pend.raise_if_set()
+
+
 _PAD_ROIS = os.environ.get("HD_PAD_ROIS", "1") != "0"      # fixed-size RoI stage of the fused three-pass evaluation (A/B knob)
 
 
@@ -55,6 +65,9 @@ class _AsyncFlag:
         self.host.copy_(flag.reshape(1).to(torch.uint8), non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
+
+    def ready(self):
+        return self.event.query()
 
     def raise_if_set(self):
         self.event.synchronize()
@@ -320,6 +333,7 @@ def _heads_batched(model, images, features, objectness, deltas, targets):
     obj, dl = concat_box_prediction_layers(objectness, deltas)
     shape = images.image_sizes[0]
     pb, _, pc = D.filter_proposals_padded(model.rpn, None, obj, shape, napl, deltas=dl, anchors0=anchors[0])
+    D._tap(("proposals",), (pb, pc))
     if targets is None:
         raise ValueError("targets should not be None")
     for t in targets:
@@ -352,6 +366,8 @@ def rpn_eval(model, images, features, targets, head_out=None):
     proposals = model.rpn.box_coder.decode(pred_bbox_deltas.detach(), anchors)
     proposals = proposals.view(num_images, -1, 4)
     boxes, scores = model.rpn.filter_proposals(proposals, objectness, images.image_sizes, num_anchors_per_level)
+    from ..models.detection import _tap
+    _tap(("proposals",), boxes)
 
     if targets is None:
         raise ValueError("targets should not be None")

@@ -32,6 +32,38 @@ from . import kernels as ok
 NMS_VANILLA_NUMEL = 20000
 
 
+class Pins:
+    """Test aid: take the DISCRETE decisions of the forward pass (ReLU on/off per element, the winning position of every
+    max-pool window, optionally the post-NMS proposals) from recorded tensors instead of from this restatement's own
+    activations.  The product stores activations in fp16, so its values differ from an fp32 evaluation by ~1e-3 relative and a
+    ReLU whose input is within that noise of zero flips; each flip re-routes the gradient of everything behind it.  With the
+    decisions pinned both sides evaluate the SAME piecewise-linear function and differ by rounding / summation order only, which
+    is what a tight gradient comparison needs.  `masks`: {tag: float tensor (1 = pass) shaped like the oracle's activation};
+    `pool`: int64 [N, C, Ho, Wo] in 0..8 (row-major position inside the 3x3 window); missing tags fall back to the plain op."""
+
+    def __init__(self, masks=None, pool=None, proposals=None):
+        self.masks, self.pool, self.proposals = masks or {}, pool, proposals
+        self.used = set()
+
+    def relu(self, tag, x):
+        m = self.masks.get(tag)
+        if m is None:
+            return F.relu(x)
+        self.used.add(tag)
+        return x * m.reshape(x.shape)
+
+    def maxpool3x3s2(self, x):
+        if self.pool is None:
+            return F.max_pool2d(x, 3, 2, 1)
+        xp = F.pad(x, (1, 1, 1, 1), value=float("-inf"))
+        win = xp.unfold(2, 3, 2).unfold(3, 3, 2)                       # [N, C, Ho, Wo, 3, 3]
+        win = win.reshape(win.shape[:4] + (9,))
+        return win.gather(4, self.pool.reshape(win.shape[:4] + (1,))).squeeze(4)
+
+
+NO_PINS = Pins()
+
+
 # ----------------------------------------------------------------------------- box utilities
 def box_area(b):
     return (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
@@ -243,11 +275,11 @@ class Bottleneck(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), FrozenBatchNorm2d(cout))
 
-    def forward(self, x, q):
+    def forward(self, x, q, pins=NO_PINS, tag=()):
         idt = x if self.downsample is None else q(self.downsample[1](self.downsample[0](x)))
-        o = q(F.relu(self.bn1(self.conv1(x))))
-        o = q(F.relu(self.bn2(self.conv2(o))))
-        return q(F.relu(self.bn3(self.conv3(o)) + idt))
+        o = q(pins.relu(tag + (1,), self.bn1(self.conv1(x))))
+        o = q(pins.relu(tag + (2,), self.bn2(self.conv2(o))))
+        return q(pins.relu(tag + (3,), self.bn3(self.conv3(o)) + idt))
 
 
 class ResNet50Body(nn.Module):
@@ -266,13 +298,13 @@ class ResNet50Body(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
-    def forward(self, x, q):
-        x = q(F.relu(self.bn1(self.conv1(x))))
-        x = q(F.max_pool2d(x, 3, 2, 1))
+    def forward(self, x, q, pins=NO_PINS):
+        x = q(pins.relu(("stem",), self.bn1(self.conv1(x))))
+        x = q(pins.maxpool3x3s2(x))
         out = OrderedDict()
         for i, name in enumerate(("layer1", "layer2", "layer3", "layer4")):
-            for blk in getattr(self, name):
-                x = blk(x, q)
+            for bi, blk in enumerate(getattr(self, name)):
+                x = blk(x, q, pins, ("b", i, bi))
             out[str(i)] = x
         return out
 
@@ -308,9 +340,10 @@ class BackboneWithFPN(nn.Module):
         self.body = ResNet50Body()
         self.fpn = FeaturePyramidNetwork()
         self.q = lambda t: t
+        self.pins = NO_PINS
 
     def forward(self, x):
-        return self.fpn(self.body(self.q(x), self.q), self.q)
+        return self.fpn(self.body(self.q(x), self.q, self.pins), self.q)
 
 
 # ----------------------------------------------------------------------------- RPN
@@ -358,11 +391,12 @@ class RPNHead(nn.Module):
             nn.init.normal_(layer.weight, std=0.01)
             nn.init.constant_(layer.bias, 0)
         self.q = lambda t: t
+        self.pins = NO_PINS
 
     def forward(self, x):
         logits, regs = [], []
-        for f in x:
-            t = self.q(F.relu(self.conv(f)))
+        for li, f in enumerate(x):
+            t = self.q(self.pins.relu(("rpn", li), self.conv(f)))
             logits.append(self.cls_logits(t))
             regs.append(self.bbox_pred(t))
         return logits, regs
@@ -394,6 +428,7 @@ class RegionProposalNetwork(nn.Module):
         self._pre_nms_top_n = dict(training=2000, testing=1000)
         self._post_nms_top_n = dict(training=2000, testing=1000)
         self.nms_thresh, self.score_thresh, self.min_size = 0.7, 0.0, 1e-3
+        self.pinned_proposals = None
 
     def pre_nms_top_n(self):
         return self._pre_nms_top_n["training" if self.training else "testing"]
@@ -428,6 +463,9 @@ class RegionProposalNetwork(nn.Module):
         return torch.cat(r, dim=1)
 
     def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
+        if self.pinned_proposals is not None:        # tests: the product's post-NMS proposal sets (Pins docstring)
+            fb = [b.clone() for b in self.pinned_proposals]
+            return fb, [torch.zeros(b.shape[0]) for b in fb]
         n_img = proposals.shape[0]
         objectness = objectness.detach().reshape(n_img, -1)
         levels = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(num_anchors_per_level)], 0)
@@ -549,10 +587,12 @@ class TwoMLPHead(nn.Module):
         self.fc6 = nn.Linear(in_channels, rep)
         self.fc7 = nn.Linear(rep, rep)
         self.q = lambda t: t
+        self.pins = NO_PINS
 
     def forward(self, x):
         x = self.q(x).flatten(start_dim=1)
-        return self.q(F.relu(self.fc7(self.q(F.relu(self.fc6(x))))))
+        h6 = self.q(self.pins.relu(("fc6",), self.fc6(x)))
+        return self.q(self.pins.relu(("fc7",), self.fc7(h6)))
 
 
 class FastRCNNPredictor(nn.Module):
@@ -658,6 +698,12 @@ class FasterRCNN(nn.Module):
         self.backbone.q = q
         self.rpn.head.q = q
         self.roi_heads.box_head.q = q
+
+    def set_pins(self, pins):
+        """See `Pins`.  `None` restores the plain operations."""
+        pins = pins or NO_PINS
+        self.backbone.pins = self.rpn.head.pins = self.roi_heads.box_head.pins = pins
+        self.rpn.pinned_proposals = pins.proposals
 
 
 def eval_forward_fasterrcnn(model, images, targets, train_det=False):

@@ -89,10 +89,16 @@ class _GNTower(nn.Module):
                 nn.init.normal_(l.weight, std=0.01)
                 nn.init.constant_(l.bias, 0)
         self.q = lambda t: t
+        self.pins, self.pin_name = od.NO_PINS, "reg"
 
-    def tower(self, x):
+    def tower(self, x, level=0):
+        k = 0
         for l in self.conv:
-            x = l(x)
+            if isinstance(l, nn.ReLU):
+                x = self.pins.relu((self.pin_name, level, k), x)
+                k += 1
+            else:
+                x = l(x)
             if not isinstance(l, nn.GroupNorm):      # the product stores the conv output and the ReLU output in fp16
                 x = self.q(x)
         return x
@@ -106,13 +112,14 @@ def _flat(t, k):
 class FCOSClassificationHead(_GNTower):
     def __init__(self, in_channels, num_anchors, num_classes, prior_probability=0.01):
         super().__init__(in_channels)
+        self.pin_name = "cls"
         self.num_classes, self.num_anchors = num_classes, num_anchors
         self.cls_logits = nn.Conv2d(in_channels, num_anchors * num_classes, 3, padding=1)
         nn.init.normal_(self.cls_logits.weight, std=0.01)
         nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_probability) / prior_probability))
 
     def forward(self, x):
-        return torch.cat([_flat(self.cls_logits(self.tower(f)), self.num_classes) for f in x], dim=1)
+        return torch.cat([_flat(self.cls_logits(self.tower(f, li)), self.num_classes) for li, f in enumerate(x)], dim=1)
 
 
 class FCOSRegressionHead(_GNTower):
@@ -126,9 +133,9 @@ class FCOSRegressionHead(_GNTower):
 
     def forward(self, x):
         reg, ctr = [], []
-        for f in x:
-            t = self.tower(f)
-            reg.append(_flat(F.relu(self.bbox_reg(t)), 4))
+        for li, f in enumerate(x):
+            t = self.tower(f, li)
+            reg.append(_flat(self.pins.relu(("reg_out", li), self.bbox_reg(t)), 4))
             ctr.append(_flat(self.bbox_ctrness(t), 1))
         return torch.cat(reg, dim=1), torch.cat(ctr, dim=1)
 
@@ -202,6 +209,11 @@ class FCOS(nn.Module):
         self.backbone.q = q
         self.head.classification_head.q = q
         self.head.regression_head.q = q
+
+    def set_pins(self, pins):
+        """oracle.detection.Pins: ReLU / max-pool decisions taken from recorded tensors (tests)."""
+        pins = pins or od.NO_PINS
+        self.backbone.pins = self.head.classification_head.pins = self.head.regression_head.pins = pins
 
     def match(self, anchors_per_image, targets_per_image, num_anchors_per_level):
         if targets_per_image["boxes"].numel() == 0:

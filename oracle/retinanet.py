@@ -46,7 +46,7 @@ class FPN3(nn.Module):
                 nn.init.constant_(m.bias, 0)
         self.extra_blocks = LastLevelP6P7(out_channels, out_channels)
 
-    def forward(self, xs, q):
+    def forward(self, xs, q, pins=od.NO_PINS):
         last = q(self.inner_blocks[-1](xs[-1]))
         results = [q(self.layer_blocks[-1](last))]
         for i in range(len(xs) - 2, -1, -1):
@@ -54,7 +54,7 @@ class FPN3(nn.Module):
             last = q(lat + F.interpolate(last, size=lat.shape[-2:], mode="nearest"))
             results.insert(0, q(self.layer_blocks[i](last)))
         p6 = q(self.extra_blocks.p6(results[-1]))
-        p7 = q(self.extra_blocks.p7(q(F.relu(p6))))
+        p7 = q(self.extra_blocks.p7(q(pins.relu(("p7in",), p6))))
         return OrderedDict(zip(("0", "1", "2", "p6", "p7"), results + [p6, p7]))
 
 
@@ -66,10 +66,11 @@ class RetinaBackbone(nn.Module):
         self.body = od.ResNet50Body()
         self.fpn = FPN3()
         self.q = lambda t: t
+        self.pins = od.NO_PINS
 
     def forward(self, x):
-        feats = self.body(self.q(x), self.q)          # '0'..'3' = layer1..4
-        return self.fpn([feats["1"], feats["2"], feats["3"]], self.q)
+        feats = self.body(self.q(x), self.q, self.pins)          # '0'..'3' = layer1..4
+        return self.fpn([feats["1"], feats["2"], feats["3"]], self.q, self.pins)
 
 
 class _Tower(nn.Module):
@@ -86,10 +87,16 @@ class _Tower(nn.Module):
         setattr(self, out_name, nn.Conv2d(in_channels, out_channels, 3, padding=1))
         self._out = out_name
         self.q = lambda t: t
+        self.pins, self.pin_name = od.NO_PINS, "cls" if out_name == "cls_logits" else "reg"
 
-    def tower(self, x):
+    def tower(self, x, level=0):
+        k = 0
         for l in self.conv:
-            x = self.q(l(x)) if isinstance(l, nn.ReLU) else l(x)
+            if isinstance(l, nn.ReLU):
+                x = self.q(self.pins.relu((self.pin_name, level, k), x))
+                k += 1
+            else:
+                x = l(x)
         return x
 
 
@@ -104,8 +111,8 @@ class RetinaNetClassificationHead(_Tower):
 
     def forward(self, x):
         out = []
-        for f in x:
-            t = self.cls_logits(self.tower(f))
+        for li, f in enumerate(x):
+            t = self.cls_logits(self.tower(f, li))
             N, _, H, W = t.shape
             out.append(t.view(N, -1, self.num_classes, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, self.num_classes))
         return torch.cat(out, dim=1)
@@ -119,8 +126,8 @@ class RetinaNetRegressionHead(_Tower):
 
     def forward(self, x):
         out = []
-        for f in x:
-            t = self.bbox_reg(self.tower(f))
+        for li, f in enumerate(x):
+            t = self.bbox_reg(self.tower(f, li))
             N, _, H, W = t.shape
             out.append(t.view(N, -1, 4, H, W).permute(0, 3, 4, 1, 2).reshape(N, -1, 4))
         return torch.cat(out, dim=1)
@@ -164,6 +171,11 @@ class RetinaNet(nn.Module):
         self.backbone.q = q
         self.head.classification_head.q = q
         self.head.regression_head.q = q
+
+    def set_pins(self, pins):
+        """oracle.detection.Pins: ReLU / max-pool decisions taken from recorded tensors (tests)."""
+        pins = pins or od.NO_PINS
+        self.backbone.pins = self.head.classification_head.pins = self.head.regression_head.pins = pins
 
     def postprocess_detections(self, head_outputs, anchors, image_shapes):
         class_logits, box_regression = head_outputs["cls_logits"], head_outputs["bbox_regression"]

@@ -27,12 +27,21 @@ class OracleTrainer:
         self.clip = clip
         self.unet_q = None          # optional activation rounding schedule (tests: oracle.unet.fp16_round)
 
-    def forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir):
+    def forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir, det_pins=None):
+        """`det_pins` (tests, oracle.detection.Pins): discrete decisions of the HALLUCINATED pass -- the only one that carries a
+        gradient -- taken from a recording of the product; the RGB / IR passes always run plain."""
         ir3 = imgs_ir.repeat(1, 3, 1, 1) if imgs_ir.shape[1] == 1 else imgs_ir
         hall = self.unet(ir3) if self.unet_q is None else self.unet(ir3, q=self.unet_q)
+        self.last_hall = hall.detach()
         retina = isinstance(self.det, orn.RetinaNet)
         fwd = orn.eval_forward_retinanet if retina else od.eval_forward_fasterrcnn
-        losses, det_h = fwd(self.det, hall, targets_ir)
+        if det_pins is not None:
+            self.det.set_pins(det_pins)
+        try:
+            losses, det_h = fwd(self.det, hall, targets_ir)
+        finally:
+            if det_pins is not None:
+                self.det.set_pins(None)
         with torch.no_grad():
             _, det_rgb = fwd(self.det, imgs_rgb, targets_rgb)
             _, det_ir = fwd(self.det, ir3, targets_ir)

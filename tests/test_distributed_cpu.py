@@ -170,3 +170,39 @@ def test_single_process_is_a_noop():
     av.start(g)
     av.finish(g)
     assert torch.equal(g, torch.arange(5.0))
+
+
+def test_self_launcher_starts_one_rank_per_gpu_and_relays_rank0(tmp_path):
+    """`python bench.py --gpus N` without torchrun: hallucidet_amd.launch re-runs the command N times with the torch.distributed.run
+    environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR 127.0.0.1 / a free MASTER_PORT) and relays rank 0's output.  Driven
+    here with a two-rank gloo child (what bench.py does with RCCL): the ranks rendezvous, all-reduce, rank 0's JSON line comes
+    back through the launcher; a failing rank's exit code is the launcher's and the surviving rank is not left behind."""
+    import io
+    import json
+    import sys
+    from hallucidet_amd import launch
+    child = tmp_path / "child.py"
+    child.write_text(
+        "import json, os, sys, time\n"
+        "import torch, torch.distributed as dist\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "assert os.environ['LOCAL_RANK'] == os.environ['RANK'] and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+        "if len(sys.argv) > 1 and sys.argv[1] == 'fail' and rank == 1:\n"
+        "    sys.exit(3)\n"
+        "dist.init_process_group('gloo', rank=rank, world_size=world)\n"
+        "t = torch.tensor([float(rank + 1)])\n"
+        "dist.all_reduce(t)\n"
+        "print('noise from rank %d' % rank) if rank else print(json.dumps({'sum': float(t), 'rccl_ranks': dist.get_world_size()}), flush=True)\n"
+        "dist.barrier()\n"
+        "dist.destroy_process_group()\n")
+    assert launch.need_self_launch(1) is False
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    buf = io.StringIO()
+    rc = launch.launch_ranks(2, [sys.executable, str(child)], env=env, timeout=120, out=buf)
+    assert rc == 0, buf.getvalue()
+    lines = [l for l in buf.getvalue().splitlines() if l.strip() and not l.startswith("[Gloo]")]      # gloo's own connection banner
+    assert len(lines) == 1 and json.loads(lines[0]) == {"sum": 3.0, "rccl_ranks": 2}      # rank 1's stdout is not relayed
+    assert "noise from rank 1" not in buf.getvalue()
+    buf = io.StringIO()
+    rc = launch.launch_ranks(2, [sys.executable, str(child), "fail"], env=env, timeout=120, out=buf)
+    assert rc == 3

@@ -239,25 +239,35 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
     """Detector.calculate_loss(model_name='fcos') vs the oracle end to end, and the data gradient w.r.t. the input images against
     the oracle's autograd with shared rounding (fp16 storage => statistical tolerance, as for the other two detectors)."""
     from hallucidet_amd.models.detector import Detector
+    from _pins import record, grad_agreement
     det, oracle, images, targets = case
     x = images.to(dev).requires_grad_(True)
-    losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="fcos")
+    with record() as rec:
+        losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="fcos")
     assert set(losses) == {"classification", "bbox_regression", "bbox_ctrness"}
     (losses["classification"] + losses["bbox_regression"] + losses["bbox_ctrness"]).backward()
-    ox = images.clone().requires_grad_(True)
-    olosses, odets = ofc.eval_forward_fcos(oracle, ox, targets, train_det=False)
+    # decisions (ReLU after GroupNorm / in the trunk, ReLU on the regression outputs, max-pool winners) shared with the oracle
+    pins = rec.pins()
+    assert len(pins.masks) == 1 + 3 * 16 + 1 + 2 * 5 * 4 + 5
+    oracle.set_pins(pins)
+    try:
+        ox = images.clone().requires_grad_(True)
+        olosses, odets = ofc.eval_forward_fcos(oracle, ox, targets, train_det=False)
+    finally:
+        oracle.set_pins(None)
+    assert pins.used == set(pins.masks)
     (olosses["classification"] + olosses["bbox_regression"] + olosses["bbox_ctrness"]).backward()
     for k in losses:
-        assert abs(float(losses[k]) - float(olosses[k])) < 2e-2 * abs(float(olosses[k])) + 1e-4, (k, float(losses[k]), float(olosses[k]))
+        print("fcos %s: product %.6f oracle %.6f" % (k, float(losses[k]), float(olosses[k])))
+        assert abs(float(losses[k]) - float(olosses[k])) < 5e-3 * abs(float(olosses[k])) + 1e-5, (k, float(losses[k]), float(olosses[k]))
     assert len(dets) == 3 and all(d["boxes"].shape[0] <= 100 for d in dets)
     for d in dets:
         assert d["boxes"].shape[1] == 4 and d["labels"].dtype == torch.int64 and float(d["boxes"].max()) <= 128.0 + 1e-3
     g, og = x.grad.cpu(), ox.grad
     assert torch.isfinite(g).all() and float(og.abs().max()) > 0
-    rel = float((g - og).norm() / og.norm())
-    cos = float((g * og).sum() / (g.norm() * og.norm()))
-    print("fcos image gradient: rel-L2 %.3f cosine %.3f" % (rel, cos))
-    assert cos > 0.7 and rel < 0.8, (rel, cos)
+    cos, rel = grad_agreement(g, og)
+    print("fcos image gradient: rel-L2 %.4f cosine %.5f" % (rel, cos))
+    assert cos >= 0.999 and rel <= 0.03, (rel, cos)
     det.batched_heads = False                      # list-based (reference-shaped) route gives the same numbers
     try:
         with torch.no_grad():
@@ -343,6 +353,8 @@ def test_fcos_parameter_gradients_and_fit_step(dev):
     det.backbone.calibrate_(il.tensors)
     oracle = ofc.FCOS(num_classes=2, size=300)
     oracle.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    from _pins import product_weight_numerics_
+    product_weight_numerics_(oracle)
     oracle.set_quant(ou.fp16_round)
 
     S = 256.0
@@ -350,8 +362,10 @@ def test_fcos_parameter_gradients_and_fit_step(dev):
     det.set_trainable(True, grad_scale=S)
     arena = ParamArena(det.trainable_parameters())
     det.invalidate_packs()
-    feats = list(det.backbone(il.tensors).values())
-    ho = det.head(feats)
+    from _pins import record
+    with record() as rec:
+        feats = list(det.backbone(il.tensors).values())
+        ho = det.head(feats)
     g = torch.Generator().manual_seed(6)
     ws = {k: torch.randn(v.shape, generator=g) for k, v in ho.items()}
     arena.flat_grads.zero_()
@@ -369,22 +383,30 @@ def test_fcos_parameter_gradients_and_fit_step(dev):
             a, b = got[n].flatten().double(), p.grad.flatten().double()
             cos, rel = float((a * b).sum() / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
             assert cos > 0.999 and rel < 0.05, (n, cos, rel)
+    # end to end with the product's ReLU / max-pool decisions (tests/_pins.py): every trainable tensor tight
     for p in oracle.parameters():
         p.grad = None
-    ol, _ = oracle.transform(rgb.cpu(), None)
-    oho = oracle.head(list(oracle.backbone(ol.tensors).values()))
+    pins = rec.pins()
+    oracle.set_pins(pins)
+    try:
+        ol, _ = oracle.transform(rgb.cpu(), None)
+        oho = oracle.head(list(oracle.backbone(ol.tensors).values()))
+    finally:
+        oracle.set_pins(None)
+    assert pins.used == set(pins.masks)
     sum((oho[k] * ws[k]).sum() for k in oho).backward()
     worst = {}
     for n, p in oracle.named_parameters():
         if p.grad is None:
             continue
         a, b = got[n].flatten().double(), p.grad.flatten().double()
-        cos = float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+        cos, rel = float((a * b).sum() / (a.norm() * b.norm() + 1e-30)), float((a - b).norm() / (b.norm() + 1e-30))
         grp = "head" if n.startswith("head") else ("extra" if "extra_blocks" in n else "fpn" if "fpn" in n else n.split(".")[2])
-        worst[grp] = min(worst.get(grp, 1.0), cos)
-    print({k: round(v, 4) for k, v in worst.items()})
-    assert worst["head"] > 0.9 and worst["fpn"] > 0.9 and worst["extra"] > 0.9, worst
-    assert min(worst["layer4"], worst["layer3"], worst["layer2"]) > 0.8, worst
+        if rel > worst.get(grp, (1.0, 0.0))[1]:
+            worst[grp] = (cos, rel, n)
+        assert cos >= 0.999 and rel <= 0.03, (n, cos, rel)
+    print({k: (round(v[0], 5), round(v[1], 4), v[2]) for k, v in worst.items()})
+    assert set(worst) == {"head", "fpn", "extra", "layer4", "layer3", "layer2"}
     det.set_trainable(False)
 
     lit = DetectorLit(batch_size=2, lr=1e-4, detector_name="fcos", pretrained=False, detector=det, device=str(dev)).prepare()

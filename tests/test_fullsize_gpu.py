@@ -174,3 +174,42 @@ def test_full_size_detector16_training_step_is_reproducible(dev):
         assert len(dets) == 16 and all(d["boxes"].shape[0] <= 100 for d in dets)
         outs.append((float(loss), g.clone()))
     assert outs[0][0] == outs[1][0] and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_config0_eval_batch_one_full_size(dev):
+    """BASELINE configs[0] (eval_hallucidet.py:135-182: Faster R-CNN, LLVIP geometry, batch = 1) through the HIP path at full size:
+    one 512x640 IR / RGB pair per test_step, eval-mode U-Net (running statistics) and detector.  Size-independent properties: the
+    hallucinated image and the detector's FPN features of the image evaluated ALONE equal, bit for bit, those of the same image
+    as member 1 of a batch of two (batch invariance of every kernel on the path); the three detection lists obey the reference's
+    contract (<= 100 per image, boxes inside 640x512, scores descending); the mAP hook returns the three streams."""
+    from hallucidet_amd import synthetic
+    lit = synthetic.make_module(seed=77)
+    with torch.no_grad():
+        lit.detector.roi_heads.box_predictor.cls_score.weight.mul_(30.0)      # spread the random-init class scores
+    lit.detector.invalidate_packs()
+    lit.eval()
+    rgb, trgb, ir, tir = synthetic.make_batch(2, device=dev, seed=78)
+    one = (rgb[1:2].contiguous(), trgb[1:2], ir[1:2].contiguous(), tir[1:2])
+    with torch.no_grad():
+        out2 = lit.forward_step(rgb, trgb, ir, tir, 0, step="test")
+        h2 = out2["output"]["imgs_hallucinated"].clone()
+        il2, _ = lit.detector.transform(h2, None)
+        f2 = {k: v.clone() for k, v in lit.detector.backbone(il2.tensors).items()}
+        out1 = lit.forward_step(*one, 0, step="test")
+        h1 = out1["output"]["imgs_hallucinated"]
+        il1, _ = lit.detector.transform(h1, None)
+        f1 = lit.detector.backbone(il1.tensors)
+    assert h1.shape == (1, 3, 512, 640) and torch.equal(h1[0], h2[1])
+    for k in f1:
+        assert torch.equal(f1[k][0], f2[k][1]), k
+    loss, dets = lit.test_step(one, 0)
+    assert torch.isfinite(loss) and set(dets) == {"hall", "rgb", "ir"}
+    for k in dets:
+        assert len(dets[k]) == 1
+        d = dets[k][0]
+        assert d["boxes"].shape[0] <= 100 and d["labels"].dtype == torch.int64
+        if d["boxes"].numel():
+            assert float(d["boxes"][:, 0::2].max()) <= 640.0 + 1e-3 and float(d["boxes"][:, 1::2].max()) <= 512.0 + 1e-3 and float(d["boxes"].min()) >= 0.0
+            assert bool((d["scores"][:-1] >= d["scores"][1:]).all())
+    m = lit.on_test_epoch_end()
+    assert set(m) == {"map_rgb", "map_hall", "map_ir"}

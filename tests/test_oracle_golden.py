@@ -355,3 +355,55 @@ def test_fastrcnn_and_rpn_loss_shapes():
     assert torch.isclose(cls, want_cls)
     # smooth-l1 beta=1/9 on |0.5| = 0.5 - 0.5/9 ; / numel(labels)=3
     assert torch.isclose(box, torch.tensor((0.5 - 0.5 / 9) / 3))
+
+
+def test_pins_from_own_decisions_reproduce_the_plain_forward_and_gradient():
+    """oracle.detection.Pins (the test aid that shares the product's ReLU / max-pool decisions with the oracle): fed the oracle's
+    OWN decisions it must change nothing -- same features, same input gradient -- for all three trunks / heads, and a flipped
+    mask must change the result (the pins are really consumed)."""
+    import torch.nn.functional as F
+    from oracle import detection as od, retinanet as orn, fcos as ofc
+
+    class Rec(od.Pins):
+        def relu(self, tag, x):
+            y = F.relu(x)
+            self.masks[tag] = (y > 0).float()
+            return y
+
+        def maxpool3x3s2(self, x):
+            y, idx = F.max_pool2d(x, 3, 2, 1, return_indices=True)
+            W = x.shape[-1]
+            ho = torch.arange(y.shape[2]).view(1, 1, -1, 1)
+            wo = torch.arange(y.shape[3]).view(1, 1, 1, -1)
+            self.pool = (idx // W - (2 * ho - 1)) * 3 + (idx % W - (2 * wo - 1))
+            return y
+
+    torch.manual_seed(0)
+    x = torch.rand(2, 3, 64, 96)
+    for model, run in ((od.FasterRCNN(2, 300), lambda m, t: list(m.rpn.head(list(m.backbone(t).values()))[0])),
+                       (orn.RetinaNet(2, 300), lambda m, t: [m.head(list(m.backbone(t).values()))["cls_logits"]]),
+                       (ofc.FCOS(2, 300), lambda m, t: [m.head(list(m.backbone(t).values()))["bbox_regression"]])):
+        model.eval()
+        rec = Rec()
+        model.set_pins(rec)
+        xa = x.clone().requires_grad_(True)
+        ya = run(model, xa)
+        sum(t.sum() for t in ya).backward()
+        assert rec.pool is not None and int(rec.pool.min()) >= 0 and int(rec.pool.max()) <= 8
+        pins = od.Pins(dict(rec.masks), rec.pool)
+        model.set_pins(pins)
+        xb = x.clone().requires_grad_(True)
+        yb = run(model, xb)
+        sum(t.sum() for t in yb).backward()
+        assert pins.used == set(pins.masks) and len(pins.masks) >= 1 + 48 + 5
+        for a, b in zip(ya, yb):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-6)
+        assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xa.grad.abs().max())       # summation order of unfold / gather vs max_pool2d's backward
+        flipped = dict(rec.masks)
+        flipped[("b", 1, 0, 2)] = 1.0 - flipped[("b", 1, 0, 2)]
+        model.set_pins(od.Pins(flipped, rec.pool))
+        yc = run(model, x)
+        assert not torch.allclose(ya[0], yc[0], rtol=1e-3, atol=1e-3)
+        model.set_pins(None)
+        yd = run(model, x)
+        assert torch.allclose(ya[0], yd[0], rtol=1e-6, atol=1e-6)

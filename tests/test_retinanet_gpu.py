@@ -151,26 +151,36 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
     """eval_forward_retinanet (batched heads) vs the oracle end to end, and the data gradient w.r.t. the input images
     against the oracle's autograd with shared rounding (fp16 storage => statistical tolerance, see test_unet_gpu)."""
     from hallucidet_amd.models.detector import Detector
+    from _pins import record, grad_agreement
     det, oracle, images, targets = case
     x = images.to(dev).requires_grad_(True)
-    losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="retinanet")
+    with record() as rec:
+        losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="retinanet")
     assert set(losses) == {"classification", "bbox_regression"}
     (losses["classification"] + losses["bbox_regression"]).backward()
-    ox = images.clone().requires_grad_(True)
-    olosses, odets = orn.eval_forward_retinanet(oracle, ox, targets, train_det=False)
+    # the oracle takes every ReLU / max-pool decision from the product's activations (tests/_pins.py): same piecewise-linear
+    # network on both sides, so losses and the image gradient differ by fp16 storage and summation order only
+    pins = rec.pins()
+    assert len(pins.masks) == 1 + 3 * 16 + 1 + 2 * 5 * 4           # stem, bottlenecks, ReLU(P6), two towers x 5 levels x 4 convs
+    oracle.set_pins(pins)
+    try:
+        ox = images.clone().requires_grad_(True)
+        olosses, odets = orn.eval_forward_retinanet(oracle, ox, targets, train_det=False)
+    finally:
+        oracle.set_pins(None)
+    assert pins.used == set(pins.masks)
     (olosses["classification"] + olosses["bbox_regression"]).backward()
     for k in losses:
-        assert abs(float(losses[k]) - float(olosses[k])) < 2e-2 * abs(float(olosses[k])) + 1e-4, (k, float(losses[k]), float(olosses[k]))
+        print("retinanet %s: product %.6f oracle %.6f" % (k, float(losses[k]), float(olosses[k])))
+        assert abs(float(losses[k]) - float(olosses[k])) < 5e-3 * abs(float(olosses[k])) + 1e-5, (k, float(losses[k]), float(olosses[k]))
     assert len(dets) == 3 and all(d["boxes"].shape[0] <= 300 for d in dets)
     for d in dets:
         assert d["boxes"].shape[1] == 4 and d["labels"].dtype == torch.int64 and float(d["boxes"].max()) <= 128.0 + 1e-3
     g, og = x.grad.cpu(), ox.grad
     assert torch.isfinite(g).all() and float(og.abs().max()) > 0
-    rel = float((g - og).norm() / og.norm())
-    cos = float((g * og).sum() / (g.norm() * og.norm()))
-    # ReLU-mask flips between fp16 and fp32 activations decorrelate deep gradients (DESIGN.md "fp16 noise"); the
-    # Faster R-CNN image-gradient test uses the same yardstick
-    assert cos > 0.7 and rel < 0.8, (rel, cos)
+    cos, rel = grad_agreement(g, og)
+    print("retinanet image gradient: rel-L2 %.4f cosine %.5f" % (rel, cos))
+    assert cos >= 0.999 and rel <= 0.03, (rel, cos)
     # list-based (reference-shaped) path gives the same numbers as the batched one
     det.batched_heads = False
     try:

@@ -30,6 +30,13 @@ def test_train_eval_and_detector_scripts(dev, tmp_path, capsys, monkeypatch):
                                  "--hallucidet-path", ck, "--precision", "16"])
     out = capsys.readouterr().out
     assert out.count("AP@50") == 3 and set(maps) == {"map_rgb", "map_hall", "map_ir"}
+    # BASELINE configs[0] as written: eval_hallucidet.py, fasterrcnn, batch = 1 (eval_hallucidet.py:135-182)
+    maps1 = eval_hallucidet.main(["--dataset", "llvip", "--test", root, "--ext", ".jpg", "--batch", "1", "--num-workers", "0",
+                                  "--hallucidet-path", ck, "--precision", "16", "--detector", "fasterrcnn"])
+    out = capsys.readouterr().out
+    assert out.count("AP@50") == 3 and set(maps1) == {"map_rgb", "map_hall", "map_ir"}
+    for k in maps1:
+        assert set(maps1[k]) >= {"map_50"} and -1.0 <= float(maps1[k]["map_50"]) <= 1.0
     train_detector.main(common + ["--detector", "fasterrcnn", "--modality", "rgb", "--epochs", "1", "--wandb-name", "t2"])
     out = capsys.readouterr().out
     assert "test:" in out and "map_50" in out
