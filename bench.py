@@ -170,6 +170,21 @@ def conv_roofline(lit, batch, reps=5):
         ms = e0.elapsed_time(e1) / passes
         del g
         return ms
+    def iso(call):
+        """One launch `reps` times back to back, captured in a hipGraph (issued from Python a 5-us kernel is host-bound)."""
+        call()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                call()
+        g.replay()
+        e0.record()
+        g.replay()
+        e1.record()
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        del g
+        return ms
     conv_call = lambda it: orig(it[1][0], it[1][1], it[1][2], it[1][3], **it[0])
     grp_step = {k: replay([r_ for r_ in rec if r_[4] == k], conv_call) for k in ("unet", "detector")}
     step_conv_ms = replay(rec, conv_call)
@@ -182,13 +197,7 @@ def conv_roofline(lit, batch, reps=5):
         roof_ms += max(fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / 8e12) * 1e3
         hbm_bound += int(by / 8e12 > fl / (MFMA_F16_PEAK_TFLOPS * 1e12))
         kw = dict(kw)                                 # same epilogue (bias / res / mask / BN statistics) as in the step
-        orig(x, w, KH, KW, **kw)                      # warm
-        e0.record()
-        for _ in range(reps):
-            orig(x, w, KH, KW, **kw)
-        e1.record()
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        ms = iso(lambda: orig(x, w, KH, KW, **kw))
         tot_ms += ms
         tot_fl += fl
         grp[origin][0] += ms
@@ -207,13 +216,7 @@ def conv_roofline(lit, batch, reps=5):
     achieved = tot_fl / (step_conv_ms * 1e-3) / 1e12
     wg_ms = wg_fl = 0.0
     for (x, dy, KH, KW), kw, fl in wrec:
-        orig_wg(x, dy, KH, KW, **kw)
-        e0.record()
-        for _ in range(reps):
-            orig_wg(x, dy, KH, KW, **kw)
-        e1.record()
-        e1.synchronize()
-        wg_ms += e0.elapsed_time(e1) / reps
+        wg_ms += iso(lambda: orig_wg(x, dy, KH, KW, **kw))
         wg_fl += fl
     tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None
     # groups are IN-STEP times (isolated re-timing in *_isolated_ms)

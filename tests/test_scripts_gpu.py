@@ -73,3 +73,30 @@ def test_device_prefetcher_stages_batches_exactly(dev):
         seen += 1
         del burn
     assert seen == 5
+
+
+def test_published_key_checkpoint_loads_strict_and_runs(dev, tmp_path):
+    """a Lightning 1.5.10 checkpoint holding EXACTLY the keys and shapes torchvision 0.12 / smp publish for
+    fasterrcnn_resnet50_fpn (re-headed to 2 classes) and Unet('resnet34') (tests/golden/state_dict_layouts.json, written from the
+    published definitions) loads with strict=True through EncoderDecoderLit.load_from_checkpoint, and the loaded modules run one
+    Detector.calculate_loss / one evaluation step on the GPU -- i.e. a released checkpoint of the reference would drop in."""
+    from test_checkpoint import _published_checkpoint
+    from hallucidet_amd import synthetic
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.train_hallucidet import EncoderDecoderLit
+    p = str(tmp_path / "published.ckpt")
+    sd = _published_checkpoint(p)
+    lit = EncoderDecoderLit.load_from_checkpoint(p, strict=True, batch_size=2, device=str(dev))
+    lit.to(dev)
+    got = {"encoder_decoder." + k for k in lit.encoder_decoder.state_dict()} | {"detector." + k for k in lit.detector.state_dict()}
+    assert got == set(sd)
+    lit.eval()
+    rgb, trgb, ir, tir = synthetic.make_batch(2, 128, 160, seed=3, device=str(dev))
+    with torch.no_grad():
+        losses, dets = Detector.calculate_loss(lit.detector, rgb, trgb, train_det=False, model_name="fasterrcnn")
+        loss, d3 = lit.validation_step((rgb, trgb, ir, tir), 0)
+    assert set(losses) == {"loss_classifier", "loss_box_reg", "loss_objectness", "loss_rpn_box_reg"}
+    assert all(bool(torch.isfinite(v)) for v in losses.values()) and bool(torch.isfinite(loss))
+    # all-zero weights: the box head scores every RoI 0.5 / 0.5 and regresses nothing -> cross-entropy = ln 2 exactly
+    assert abs(float(losses["loss_classifier"]) - 0.6931472) < 1e-5 and float(losses["loss_box_reg"]) >= 0.0
+    assert len(dets) == 2 and set(d3) == {"hall", "rgb", "ir"}

@@ -205,3 +205,50 @@ def test_resnet50_backbone_forward_and_gradients(dev):
         # 0.995 holds for resnet18/34; the gradient of the first layers crosses ~70 conv+BN units here and collects more
         # fp16 rounding (measured worst: 0.990 at encoder.layer1.0.conv1)
         assert cos > 0.98, (n, cos)
+
+
+def test_graph_recapture_survives_allocations_from_another_thread(dev):
+    """The input pipeline's helper thread (DevicePrefetcher) pins host memory and allocates device memory while the main thread may
+    be inside a hipGraph capture -- the backward graph is re-captured whenever the loss scale changes.  Captures use
+    capture_error_mode='thread_local', so foreign-thread allocations must neither invalidate the capture nor change its result."""
+    import threading
+    from hallucidet_amd.models.encoder_decoder import EncoderDecoder
+    results = []
+    for hammer in (False, True):
+        torch.manual_seed(9)
+        net = EncoderDecoder(name="resnet34").encoder_decoder.to(dev).train()
+        net.runner.enable_graphs(True)
+        x = torch.rand(2, 3, 64, 96, device=dev)
+        g = torch.randn(2, 3, 64, 96, device=dev) * 1e-2
+        stop = threading.Event()
+        count = [0]
+
+        def stage():
+            side = torch.cuda.Stream(device=dev)
+            k = 0
+            while not stop.is_set():
+                k += 1
+                h = torch.empty(3, 64 + 8 * (k % 7), 96, dtype=torch.uint8).pin_memory()      # new shapes: fresh hipHostMalloc
+                with torch.cuda.stream(side):
+                    d = h.to(dev, non_blocking=True).float()                                   # fresh hipMalloc on a side stream
+                side.synchronize()
+                del d, h
+                count[0] += 1
+        th = threading.Thread(target=stage, daemon=True)
+        if hammer:
+            th.start()
+        try:
+            for scale in (128.0, 256.0, 64.0, 512.0):          # every change of the scale re-captures the backward graph
+                net.runner.grad_scale = scale
+                out = net(x)
+                out.backward(g * scale)
+            torch.cuda.synchronize()
+        finally:
+            stop.set()
+            if hammer:
+                th.join(timeout=30)
+        if hammer:
+            assert count[0] > 0, "the staging thread never ran"
+        results.append((out.detach().clone(), net.runner.flat_grads.clone()))
+    assert bool(torch.isfinite(results[0][1]).all()) and float(results[0][1].abs().sum()) > 0
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
