@@ -36,6 +36,7 @@ class ConvArgs(C.Structure):
         ("C1", c_i32), ("C2", c_i32), ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
         ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32),
         ("up1", c_i32), ("in_dil", c_i32), ("act", c_i32), ("out_mode", c_i32),
+        ("in_scale", vp), ("in_shift", vp), ("in_relu", c_i32), ("reserved0", c_i32),
     ]
 
 
@@ -51,6 +52,7 @@ class WgradArgs(C.Structure):
         ("C1", c_i32), ("C2", c_i32), ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
         ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32), ("up1", c_i32),
         ("nsplit", c_i32),
+        ("in_scale", vp), ("in_shift", vp), ("in_relu", c_i32), ("reserved0", c_i32),
     ]
 
 

@@ -10,6 +10,6 @@ void hd_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-extern "C" int hd_abi_version(void) { return 1; }
+extern "C" int hd_abi_version(void) { return 2; }      // 2: hd_conv_args / hd_wgrad_args carry in_scale / in_shift / in_relu
 extern "C" const char* hd_last_error(void) { return g_err; }
 extern "C" const char* hd_arch(void) { return "gfx950"; }

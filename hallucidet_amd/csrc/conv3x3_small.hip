@@ -50,7 +50,23 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
   constexpr int C8 = CIN / 8;
   constexpr int XL = (PH * PW * C8 + 255) / 256;
   f16x8 rx[XL];
+  // consumer-side BatchNorm (hd_conv_args.in_scale): a thread always stages the same 8 channels (256 % C8 == 0), so their coefficients
+  // live in registers; `vmask` remembers which staged vectors are real pixels -- zero padding must stay zero after the affine map
+  const bool fuse_bn = p.in_scale != nullptr;
+  float isc[8], ish[8];
+  if (fuse_bn) {
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(p.in_scale + (tid % C8) * 8), a1 = *reinterpret_cast<const f32x4_t*>(p.in_scale + (tid % C8) * 8 + 4);
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(p.in_shift + (tid % C8) * 8), b1 = *reinterpret_cast<const f32x4_t*>(p.in_shift + (tid % C8) * 8 + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      isc[k] = a0[k]; isc[4 + k] = a1[k];
+      ish[k] = b0[k]; ish[4 + k] = b1[k];
+    }
+  }
+  const bool in_relu = p.in_relu != 0;
+  unsigned vmask = 0;
   auto gload = [&](int tile) {
+    vmask = 0;
     const bool live = tile < tiles_total;
     int b = live ? tile : 0;
     const int tx = b % tiles_x;
@@ -68,6 +84,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
       if (live && e < PH * PW * C8 && (unsigned)hi < (unsigned)p.Hin && (unsigned)wi < (unsigned)p.Win) {
         const int hs = p.up1 ? (hi >> 1) : hi, ws = p.up1 ? (wi >> 1) : wi;
         v = *reinterpret_cast<const f16x8*>(xb + ((size_t)hs * p.Wsrc + ws) * CIN + c8 * 8);
+        vmask |= 1u << i;
       }
       rx[i] = v;
     }
@@ -86,7 +103,16 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int e = tid + i * 256;
-      if (e < PH * PW * C8) *reinterpret_cast<f16x8*>(s_patch + (e / C8) * CIN + (e % C8) * 8) = rx[i];
+      f16x8 v = rx[i];
+      if (fuse_bn && ((vmask >> i) & 1u)) {       // hd_bn_apply's arithmetic, applied on the way into LDS
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float f = hd_bn_affine((float)v[k], isc[k], ish[k]);
+          if (in_relu) f = fmaxf(f, 0.f);
+          v[k] = (f16)f;
+        }
+      }
+      if (e < PH * PW * C8) *reinterpret_cast<f16x8*>(s_patch + (e / C8) * CIN + (e % C8) * 8) = v;
     }
     __syncthreads();
     gload(tile + gridDim.x);

@@ -38,6 +38,8 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.Ho = a->Ho; p.Wo = a->Wo; p.Cout = a->Cout; p.KH = a->KH; p.KW = a->KW;
   p.stride = a->stride; p.pad = a->pad; p.up1 = a->up1; p.in_dil = a->in_dil < 1 ? 1 : a->in_dil;
   p.act = a->act; p.out_mode = a->out_mode;
+  HD_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "hd_conv2d: in_scale / in_shift must be given together");
+  p.in_scale = a->in_scale; p.in_shift = a->in_shift; p.in_relu = a->in_relu;
   HD_CHECK_ARG(p.out_mode >= HD_OUT_NHWC_F16 && p.out_mode <= HD_OUT_NHWC_F32, "hd_conv2d: out_mode %d", p.out_mode);
   p.M = a->N * a->Ho * a->Wo;
   p.cin8 = p.Cin / 8;
@@ -269,7 +271,7 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   int rc = fill_params(a, p);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (use_patch(p)) {
+  if (use_patch(p) && !p.in_scale) {
     hd_conv_launch_patch(p, s);
     HD_CHECK_LAUNCH();
     return HD_OK;
@@ -283,6 +285,8 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
     HD_CHECK_LAUNCH();
     return HD_OK;
   }
+  HD_CHECK_ARG(!p.in_scale, "hd_conv2d: consumer-side BatchNorm (in_scale / in_shift) is implemented by the small-channel 3x3 kernel only "
+                            "(3x3 / stride 1 / pad 1, one source, C1 in {8,16,32}, Cout in {16,32} or a <= 16-channel fp32 head)");
   // stride-2 data gradients: four output-parity classes, each walking only the taps that meet non-zero input (conv_params.h)
   static const int par_on = env_int("HD_CONV_PARITY", 1);
   const bool par = par_on && p.in_dil == 2 && !p.stats && p.stride == 1 && (p.cin8 % 4) == 0 && p.out_mode == HD_OUT_NHWC_F16 && g_small_ok &&

@@ -21,6 +21,9 @@ struct ConvP {
   // walks a quarter of the taps (none at all for three classes of a 1x1).  `par` is set by the dispatcher, the rest by the kernel.
   int par, ph, pw, Hc, Wc, t0h, t0w;
   int prio;            // 8-wave families: s_setprio policy (experiment knob HD_W8_PRIO: 0 none, 1 MFMA phase, 2 MEM phase)
+  const float* in_scale;   // consumer-side BatchNorm of the x operand (hd_conv_args.in_scale / in_shift / in_relu): small-channel kernel only
+  const float* in_shift;
+  int in_relu;
   float* ws;           // split-K slabs of the 8-wave family (hd_conv_set_workspace), fp32 [slice][M][Cout]
   int* tickets;        // per-tile arrival counters of the split-K reduction (zero between launches)
 #ifdef HD_CONV_TRACE

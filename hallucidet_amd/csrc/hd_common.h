@@ -35,3 +35,8 @@ void hd_set_error(const char* fmt, ...);
   } while (0)
 
 static inline int hd_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// BatchNorm's affine map as ONE fused multiply-add, spelled out so that every kernel that evaluates it (hd_bn_apply, the ReLU-mask
+// recomputation of the BatchNorm backward, the consumer-side BatchNorm of the small-channel kernels) rounds identically.
+__device__ __forceinline__ float hd_bn_affine(float y, float scale, float shift) { return __builtin_fmaf(y, scale, shift); }
+

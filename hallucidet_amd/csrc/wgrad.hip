@@ -484,15 +484,18 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->Cout % 8 == 0, "hd_wgrad: channels must be multiples of 8");
   HD_CHECK_ARG((a->C2 == 0) == (a->x2 == nullptr), "hd_wgrad: x2/C2 mismatch");
   HD_CHECK_ARG(a->nsplit >= 1, "hd_wgrad: nsplit");
+  HD_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "hd_wgrad: in_scale / in_shift must be given together");
   {
     static const char* env = getenv("HD_WGRAD_SMALL");
     static const bool small_on = !(env && env[0] == '0');
-    if (small_on && g_wg_tm < 0 && hd_wgrad_small_eligible(a)) {
+    if ((small_on || a->in_scale) && g_wg_tm < 0 && hd_wgrad_small_eligible(a)) {
       hd_wgrad_small_launch(a, (hipStream_t)stream);
       HD_CHECK_LAUNCH();
       return HD_OK;
     }
   }
+  HD_CHECK_ARG(!a->in_scale, "hd_wgrad: consumer-side BatchNorm (in_scale / in_shift) is implemented by the small-channel 3x3 kernel only "
+                             "(3x3 / stride 1 / pad 1, one source, C1 in {16,32}, Cout <= 32)");
   {
     static const char* env8 = getenv("HD_WGRAD_W8");
     static const bool w8_on = !(env8 && env8[0] == '0');

@@ -33,7 +33,8 @@ __device__ __forceinline__ f16x8 tr_frag8(const f16* row0_ptr) {
 template <int CIN, int MT>
 __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, float* __restrict__ slab,
                                                              int N, int Hsrc, int Wsrc, int H, int W, int Cout, int up1, int tiles_total,
-                                                             int tiles_x, int tiles_y) {
+                                                             int tiles_x, int tiles_y, const float* __restrict__ in_scale,
+                                                             const float* __restrict__ in_shift, int in_relu) {
   constexpr int CT = CIN / 16;
   constexpr int UNITS = 9 * CT;                 // (tap, 16-channel ci tile) pairs; a wave owns units wave, wave+4, ... for every cout tile
   constexpr int UPW = (UNITS + 3) / 4;
@@ -59,7 +60,21 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
   constexpr int XL = (PH * PW * C8 + 255) / 256;   // 16-byte input loads per thread per tile (3 / 6)
   constexpr int DL = 2 * MT;                       // dY loads per thread per tile (Cout / 8 <= 2 * MT)
   f16x8 rx[XL], rd[DL];
+  // consumer-side BatchNorm of the x operand (hd_wgrad_args.in_scale): see conv3x3_small.hip
+  const bool fuse_bn = in_scale != nullptr;
+  float isc[8], ish[8];
+  if (fuse_bn) {
+    const f32x4_t a0 = *reinterpret_cast<const f32x4_t*>(in_scale + (tid % C8) * 8), a1 = *reinterpret_cast<const f32x4_t*>(in_scale + (tid % C8) * 8 + 4);
+    const f32x4_t b0 = *reinterpret_cast<const f32x4_t*>(in_shift + (tid % C8) * 8), b1 = *reinterpret_cast<const f32x4_t*>(in_shift + (tid % C8) * 8 + 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      isc[k] = a0[k]; isc[4 + k] = a1[k];
+      ish[k] = b0[k]; ish[4 + k] = b1[k];
+    }
+  }
+  unsigned vmask = 0;
   auto gload = [&](int tile) {
+    vmask = 0;
     const bool live = tile < tiles_total;
     int b = live ? tile : 0;
     const int tx = b % tiles_x;
@@ -78,6 +93,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
       if (live && e < PH * PW * C8 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
         const int hs = up1 ? (hi >> 1) : hi, ws = up1 ? (wi >> 1) : wi;
         v = *reinterpret_cast<const f16x8*>(xb + ((size_t)hs * Wsrc + ws) * CIN + c8 * 8);
+        vmask |= 1u << i;
       }
       rx[i] = v;
     }
@@ -94,7 +110,16 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int e = tid + i * 256;
-      if (e < PH * PW * C8) *reinterpret_cast<f16x8*>(s_x + (e / C8) * PS + (e % C8) * 8) = rx[i];
+      f16x8 v = rx[i];
+      if (fuse_bn && ((vmask >> i) & 1u)) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float f = hd_bn_affine((float)v[k], isc[k], ish[k]);
+          if (in_relu) f = fmaxf(f, 0.f);
+          v[k] = (f16)f;
+        }
+      }
+      if (e < PH * PW * C8) *reinterpret_cast<f16x8*>(s_x + (e / C8) * PS + (e % C8) * 8) = v;
     }
 #pragma unroll
     for (int i = 0; i < DL; ++i)
@@ -161,7 +186,7 @@ void hd_wgrad_small_launch(const hd_wgrad_args* a, hipStream_t s) {
   const f16* dy = (const f16*)a->dy;
 #define LAUNCH(CI, M_)                                                                                                              \
   hipLaunchKernelGGL((wgrad3x3_small_kernel<CI, M_>), grid, dim3(256), 0, s, x, dy, a->slab, a->N, a->Hsrc, a->Wsrc, a->Hin, a->Win, \
-                     a->Cout, a->up1, total, tiles_x, tiles_y)
+                     a->Cout, a->up1, total, tiles_x, tiles_y, a->in_scale, a->in_shift, a->in_relu)
   if (a->C1 == 16) { if (a->Cout <= 16) LAUNCH(16, 1); else LAUNCH(16, 2); }
   else { if (a->Cout <= 16) LAUNCH(32, 1); else LAUNCH(32, 2); }
 #undef LAUNCH

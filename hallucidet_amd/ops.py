@@ -47,10 +47,13 @@ def _ensure_workspace(lib, device):
 
 
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
-           out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None, patch_kernel=False):
+           out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None, patch_kernel=False,
+           in_scale=None, in_shift=None, in_relu=True):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
+    ``in_scale`` / ``in_shift`` ([C1] fp32): consumer-side BatchNorm -- x holds the RAW output of the producing conv and the kernel
+    reads relu(fp16(x * scale + shift)) in its place (small-channel 3x3 kernel only; bit-identical to bn_apply + the plain call).
     Returns y or (y, stats_slab[rows,2,Cout]).
     """
     _need_cuda(x, w, x2, bias, res, mask)
@@ -83,7 +86,8 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
     a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(mask), ptr(y), None,
                  N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
-                 1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0))
+                 1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0),
+                 ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
     stats = None
     if want_stats:
         rows = (lib.hd_conv2d_patch_stats_rows if patch_kernel else lib.hd_conv2d_stats_rows)(C.byref(a))
@@ -97,8 +101,9 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
     return (y, stats) if want_stats else y
 
 
-def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None):
-    """Returns fp32 slab [nsplit, Cout, KH*KW*(C1+C2)] of partial weight gradients."""
+def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in_scale=None, in_shift=None, in_relu=True):
+    """Returns fp32 slab [nsplit, Cout, KH*KW*(C1+C2)] of partial weight gradients.  ``in_scale`` / ``in_shift``: as in conv2d
+    (x is the raw output of the producing conv; small-channel 3x3 kernel only)."""
     _need_cuda(x, dy, x2)
     lib = _abi.load()
     N, Hs, Ws, C1 = x.shape
@@ -120,7 +125,7 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None):
             nsplit = pick_nsplit(M, Cout, K)
     slab = torch.empty((nsplit, Cout, K), dtype=torch.float32, device=x.device)
     a = WgradArgs(ptr(x), ptr(x2), ptr(dy), ptr(slab), N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
-                  1 if up1 else 0, nsplit)
+                  1 if up1 else 0, nsplit, ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
     check(lib.hd_wgrad(C.byref(a), _stream()), "hd_wgrad")
     return slab
 

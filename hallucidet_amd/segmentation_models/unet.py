@@ -17,6 +17,8 @@ backward pass; weights are re-packed each step from the fp32 masters into [Cout]
 [Cin][KH][KW][Cout] copy the data-gradient consumes); BatchNorm statistics, parameter gradients and the optimizer run
 in fp32 on one flat arena (one all-reduce buffer for data parallelism).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -199,6 +201,37 @@ class _UnetFn(torch.autograd.Function):
         return None, None, None
 
 
+class _RawAct:
+    """The output of a Conv2dReLU unit BEFORE its BatchNorm + ReLU, together with the BatchNorm's (scale, shift): what a consumer
+    with consumer-side BatchNorm (ops.conv2d / ops.wgrad `in_scale`) reads instead of the normalised activation, which is then
+    never written to HBM (src/segmentation_models/base/modules.py:10-47 fused into the NEXT convolution's operand staging)."""
+    __slots__ = ("y", "scale", "shift", "relu")
+
+    def __init__(self, y, scale, shift, relu):
+        self.y, self.scale, self.shift, self.relu = y, scale, shift, relu
+
+    @property
+    def shape(self):
+        return self.y.shape
+
+    def materialize(self):
+        """The normalised activation as a tensor (hd_bn_apply): tests / diagnostics only, the training step never calls it."""
+        return ops.bn_apply(self.y, self.scale, self.shift, relu=self.relu)
+
+
+def _operand(t):
+    """-> (tensor, in_scale, in_shift, in_relu) of a conv / wgrad input that may be a _RawAct."""
+    if isinstance(t, _RawAct):
+        return t.y, t.scale, t.shift, t.relu
+    return t, None, None, True
+
+
+def _small_conv_ok(cin, cout, dual):
+    """Shapes hd_conv2d routes to the small-channel 3x3 kernel AND hd_wgrad to its small-channel kernel (conv3x3_small.hip /
+    wgrad3x3_small.hip): the only ones that implement consumer-side BatchNorm."""
+    return (not dual) and cin in (16, 32) and cout in (16, 32)
+
+
 class UnetRunner:
     """Explicit forward/backward schedule over the C ABI for one Unet module."""
 
@@ -234,6 +267,27 @@ class UnetRunner:
         self.head_conv = module.segmentation_head[0]
         self.units = [self.stem] + [u for st in self.stages for (us, ud) in st for u in us + ([ud] if ud is not None else [])] + [u for d in self.dec for u in d[:2]]
         self._wplan = {}
+        # Consumer-side BatchNorm: a decoder unit whose ONLY consumer is a small-channel 3x3 convolution (next conv of the decoder or
+        # the segmentation head) hands on its raw conv output + BatchNorm coefficients; hd_bn_apply is not launched for it and the
+        # four largest activations of the network (32 ch @ 256x320 x2, 16 ch @ 512x640 x2) are never written / re-read in normalised
+        # form.  HD_BN_FUSE=0: every unit materialises its activation (A/B knob; the two forms are bit-identical, tested).
+        self.fuse_bn = os.environ.get("HD_BN_FUSE", "1") != "0"
+        self._raw_units = set()
+        nd = len(self.dec)
+        for i, (u1, u2, cin, cskip) in enumerate(self.dec):
+            if _small_conv_ok(u1.cout, u2.cout, False):
+                self._raw_units.add(u1.name)                        # consumer: conv2 of the same block
+            if i + 1 < nd:
+                n1 = self.dec[i + 1]
+                if _small_conv_ok(u2.cout, n1[0].cout, n1[3] > 0):
+                    self._raw_units.add(u2.name)                    # consumer: conv1 of the next block (no skip source)
+            elif u2.cout == 16 and self.head_conv.out_channels <= 16:
+                self._raw_units.add(u2.name)                        # consumer: the segmentation head (16 -> <= 16 channels)
+
+    def saved_activations(self):
+        """{unit name: post-BatchNorm(+ReLU) activation, NHWC f16} of the last saved training forward (tests: ReLU decisions for the
+        oracle).  Units that hand on their raw output (consumer-side BatchNorm) are normalised here, on demand."""
+        return {k: (v["z"].materialize() if isinstance(v["z"], _RawAct) else v["z"]) for k, v in self.saved["rec"].items()}
 
     # ------------------------------------------------------------------ hipGraph replay
     def enable_graphs(self, on=True):
@@ -406,20 +460,28 @@ class UnetRunner:
 
     # ------------------------------------------------------------------ forward pieces
     def _conv_bn(self, u, x, W, training, rec, *, x2=None, up1=False, res=None):
-        """conv -> BatchNorm(train: batch statistics / eval: running statistics) (+res) (+ReLU).  Returns z."""
+        """conv -> BatchNorm(train: batch statistics / eval: running statistics) (+res) (+ReLU).  Returns z -- or, for the units
+        in `_raw_units`, a _RawAct (raw conv output + BatchNorm coefficients) that the consumer normalises on the fly.  `x` may
+        itself be a _RawAct."""
         wf = W[u.name][0]
+        xin = x
+        x, isc, ish, irelu = _operand(xin)
+        bnk = dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}
         if training:
-            y, stats = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1, want_stats=True)
+            y, stats = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1, want_stats=True, **bnk)
             npix = y.numel() // u.cout
             mean, invstd, scale, shift = ops.bn_finalize(stats, npix, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
                                                          u.bn.momentum, u.bn.eps)
         else:
-            y = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1)
+            y = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1, **bnk)
             scale, shift = ops.bn_eval_scale_shift(u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.bn.eps)
             mean = invstd = None
-        z = ops.bn_apply(y, scale, shift, res=res, relu=u.relu)
+        if self.fuse_bn and res is None and u.name in self._raw_units:
+            z = _RawAct(y, scale, shift, u.relu)
+        else:
+            z = ops.bn_apply(y, scale, shift, res=res, relu=u.relu)
         if rec is not None:
-            rec[u.name] = dict(x=x, x2=x2, up1=up1, y=y, z=z, mean=mean, invstd=invstd, has_res=res is not None)
+            rec[u.name] = dict(x=xin, x2=x2, up1=up1, y=y, z=z, mean=mean, invstd=invstd, has_res=res is not None)
         return z
 
     def forward(self, x, training, save):
@@ -453,7 +515,9 @@ class UnetRunner:
             z1 = self._conv_bn(u1, d, Wt, training, rec, x2=skip, up1=True)
             d = self._conv_bn(u2, z1, Wt, training, rec)
         hc = self.head_conv
-        out = ops.conv2d(d, Wt["head"][0], 3, 3, bias=hc.bias, pad=1, act=ACT_SIGMOID, out_nchw_f32=True, cout=hc.out_channels)
+        dt, isc, ish, irelu = _operand(d)
+        out = ops.conv2d(dt, Wt["head"][0], 3, 3, bias=hc.bias, pad=1, act=ACT_SIGMOID, out_nchw_f32=True, cout=hc.out_channels,
+                         **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
         if training:
             self._bump_batches_tracked()
         if save:
@@ -486,12 +550,14 @@ class UnetRunner:
         dy, dres, _, _ = ops.bn_backward(dz, r["z"] if r["has_res"] else None, r["y"], r["mean"], r["invstd"], u.bn.weight, u.bn.bias,
                                          relu=u.relu, want_dres=want_dres,
                                          gscale=inv, dgamma=u.bn.weight.grad, dbeta=u.bn.bias.grad)
-        slab = ops.wgrad(r["x"], dy, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"])
+        xt, isc, ish, irelu = _operand(r["x"])
+        slab = ops.wgrad(xt, dy, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"],
+                         **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
         ops.wgrad_reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
         dx = None
         if need_dx:
             wd = self.saved["W"][u.name][1]
-            x = r["x"]
+            x = xt
             if r["up1"]:
                 hw = (x.shape[1] * 2, x.shape[2] * 2)
             else:
@@ -511,7 +577,8 @@ class UnetRunner:
         dl = ops.sigmoid_bwd_nchw_to_nhwc(dout.float(), sv["out"], 8, 1.0)
         db = ops.channel_sum(dl)
         ops.scale_store(db, hc.bias.grad, inv, accumulate=False)
-        slab = ops.wgrad(sv["head_in"], dl, 3, 3, pad=1)
+        ht, isc, ish, irelu = _operand(sv["head_in"])
+        slab = ops.wgrad(ht, dl, 3, 3, pad=1, **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
         ops.wgrad_reduce(slab, hc.weight.grad, 3, 3, hc.in_channels, Cout=hc.out_channels, scale=inv)
         dz = ops.conv2d(dl, sv["W"]["head"][1], 3, 3, pad=1, cout=hc.in_channels)
         # decoder, last block first
@@ -522,7 +589,7 @@ class UnetRunner:
             u1, u2, cin, cskip = self.dec[i]
             dz1, _ = self._unit_bwd(u2, dz, S)
             dcat, _ = self._unit_bwd(u1, dz1, S)
-            xin = sv["rec"][u1.name]["x"]
+            xin = _operand(sv["rec"][u1.name]["x"])[0]
             dz = torch.empty_like(xin)
             ops.upsample2_bwd(dcat, dz, 0, accumulate=False)
             if cskip:

@@ -78,6 +78,14 @@ typedef struct hd_conv_args {
   int32_t KH, KW, stride, pad;
   int32_t up1, in_dil;
   int32_t act, out_mode;
+  /* Consumer-side BatchNorm (both NULL: off).  `x` then holds the RAW output y of the producing convolution and the kernel reads
+   * fp16(fma(y, in_scale[c], in_shift[c])) (+ ReLU when in_relu) in its place -- the Conv2dReLU unit's BatchNorm2d + ReLU
+   * (src/segmentation_models/base/modules.py:10-47) folded into the operand staging of the NEXT convolution, so that the normalised
+   * activation never makes a round trip through HBM; zero padding stays zero.  Bit-identical to hd_bn_apply followed by the plain call.
+   * Implemented where the operand passes through registers: the small-channel 3x3 kernel (C1 in {8,16,32}); other shapes -> HD_E_ARG. */
+  const float* in_scale; /* [C1] or NULL */
+  const float* in_shift; /* [C1] or NULL */
+  int32_t in_relu, reserved0;
 } hd_conv_args;
 
 int hd_conv2d(const hd_conv_args* a, void* stream);
@@ -118,6 +126,10 @@ typedef struct hd_wgrad_args {
   int32_t N, Hsrc, Wsrc, Hin, Win, C1, C2, Ho, Wo, Cout;
   int32_t KH, KW, stride, pad, up1;
   int32_t nsplit;
+  /* consumer-side BatchNorm of the x operand, as in hd_conv_args (small-channel 3x3 kernel only: C1 in {16,32}, Cout <= 32) */
+  const float* in_scale; /* [C1] or NULL */
+  const float* in_shift; /* [C1] or NULL */
+  int32_t in_relu, reserved0;
 } hd_wgrad_args;
 int hd_wgrad(const hd_wgrad_args* a, void* stream);
 /* blocks per pixel slice the 8-wave 3x3 weight-gradient kernel uses for this problem ((Cin/64) * (Cout/64)), 0 if hd_wgrad

@@ -40,17 +40,34 @@ def test_ctypes_table_matches_header():
 
 
 def test_identity(lib):
-    assert lib.hd_abi_version() == 1
+    assert lib.hd_abi_version() == 2
     assert lib.hd_arch() == b"gfx950"
 
 
-def test_struct_layout_matches_c():
-    """sizeof/offsetof of the ctypes mirrors equal what the C compiler lays out (natural alignment, LP64)."""
+def test_struct_layout_matches_c(tmp_path):
+    """sizeof / offsetof of the ctypes mirrors equal what the C compiler lays out for include/hallucidet_hip.h (gcc, LP64)."""
+    import os
+    import subprocess
     from hallucidet_amd._abi import ConvArgs, WgradArgs
-    assert ctypes.sizeof(ConvArgs) == 8 * 8 + 18 * 4
-    assert ConvArgs.N.offset == 64 and ConvArgs.out_mode.offset == 64 + 17 * 4
-    assert ctypes.sizeof(WgradArgs) == 4 * 8 + 16 * 4
-    assert WgradArgs.nsplit.offset == 32 + 15 * 4
+    fields = {"hd_conv_args": (ConvArgs, ["x", "y", "stats", "N", "out_mode", "in_scale", "in_shift", "in_relu"]),
+              "hd_wgrad_args": (WgradArgs, ["x", "slab", "N", "nsplit", "in_scale", "in_shift", "in_relu"])}
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "hallucidet_hip.h"\nint main(void) {\n'
+    for st, (_, fs) in fields.items():
+        src += '  printf("%s %%zu\\n", sizeof(%s));\n' % (st, st)
+        for f in fs:
+            src += '  printf("%s.%s %%zu\\n", offsetof(%s, %s));\n' % (st, f, st, f)
+    src += "  return 0;\n}\n"
+    c = tmp_path / "layout.c"
+    c.write_text(src)
+    exe = str(tmp_path / "layout")
+    inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include")
+    subprocess.run(["gcc", "-I", inc, "-o", exe, str(c)], check=True)
+    got = dict(l.split() for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())
+    for st, (cls, fs) in fields.items():
+        assert int(got[st]) == ctypes.sizeof(cls), st
+        for f in fs:
+            assert int(got["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
+    assert ctypes.sizeof(ConvArgs) == 8 * 8 + 18 * 4 + 2 * 8 + 2 * 4 and ConvArgs.N.offset == 64
 
 
 def test_bad_arguments_return_status_codes(lib):

@@ -868,3 +868,45 @@ def test_fused_detector_losses_equal_torch_ops(dev):
     g2 = torch.autograd.grad(rc * 0.4 + rbx * 1.1, (lg, br))
     assert torch.allclose(lc, rc, rtol=2e-6, atol=1e-7) and torch.allclose(lbx, rbx, rtol=2e-6, atol=1e-7)
     assert torch.allclose(g1[0], g2[0], rtol=1e-5, atol=1e-9) and torch.allclose(g1[1], g2[1], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("cin,cout,up,head", [(32, 32, False, False), (32, 16, True, False), (16, 16, False, False), (16, 3, False, True), (8, 16, False, False)])
+def test_consumer_side_batchnorm_is_bit_identical_to_bn_apply_then_conv(dev, cin, cout, up, head):
+    """hd_conv2d / hd_wgrad with in_scale / in_shift (the producer's BatchNorm + ReLU folded into the operand staging of the
+    small-channel 3x3 kernels, src/segmentation_models/base/modules.py:10-47) against hd_bn_apply followed by the plain call:
+    outputs, BatchNorm partial sums and weight-gradient slabs must be IDENTICAL bit for bit -- ragged tile edges (the zero padding
+    must stay zero after the affine map: shift != 0), the nearest-2x upsampled source and the fp32 NCHW head included."""
+    from hallucidet_amd import ops
+    g = torch.Generator().manual_seed(cin * 100 + cout)
+    N, H, W = 2, 21, 45                                  # not multiples of the 8 x 32 tile
+    y_raw = (torch.randn(N, H, W, cin, generator=g) * 2).half().to(dev)
+    scale = (torch.rand(cin, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(cin, generator=g) * 0.7 + 0.3).to(dev)          # relu(shift) != 0 at the padding if it were transformed
+    cp = (cout + 7) // 8 * 8
+    w = (torch.randn(cp, 9 * cin, generator=g) * 0.1).half().to(dev)
+    z = ops.bn_apply(y_raw, scale, shift, relu=True)
+    kw = dict(pad=1, up1=up)
+    if head:
+        bias = torch.randn(cout, generator=g).to(dev)
+        kw.update(bias=bias, act=ops.ACT_SIGMOID, out_nchw_f32=True, cout=cout)
+        a = ops.conv2d(z, w, 3, 3, **kw)
+        b = ops.conv2d(y_raw, w, 3, 3, in_scale=scale, in_shift=shift, **kw)
+        assert torch.equal(a, b)
+    else:
+        a, sa = ops.conv2d(z, w, 3, 3, want_stats=True, **kw)
+        b, sb = ops.conv2d(y_raw, w, 3, 3, want_stats=True, in_scale=scale, in_shift=shift, **kw)
+        assert torch.equal(a, b) and torch.equal(sa, sb)
+        # no ReLU variant
+        z2 = ops.bn_apply(y_raw, scale, shift, relu=False)
+        assert torch.equal(ops.conv2d(z2, w, 3, 3, **kw), ops.conv2d(y_raw, w, 3, 3, in_scale=scale, in_shift=shift, in_relu=False, **kw))
+    if cin >= 16:
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        dy = torch.randn(N, Ho, Wo, cp, generator=g).half().to(dev)
+        s0 = ops.wgrad(z, dy, 3, 3, pad=1, up1=up, nsplit=7)
+        s1 = ops.wgrad(y_raw, dy, 3, 3, pad=1, up1=up, nsplit=7, in_scale=scale, in_shift=shift)
+        assert torch.equal(s0, s1) and float(s0.abs().sum()) > 0
+    # shapes the small-channel kernels do not serve refuse the request instead of silently ignoring it
+    x64 = torch.randn(1, 8, 8, 64, device=dev).half()
+    w64 = torch.randn(64, 9 * 64, device=dev).half()
+    with pytest.raises(Exception, match="consumer-side BatchNorm"):
+        ops.conv2d(x64, w64, 3, 3, pad=1, in_scale=torch.ones(64, device=dev), in_shift=torch.zeros(64, device=dev))

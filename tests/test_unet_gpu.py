@@ -69,8 +69,7 @@ def _train_pair_run(dev, seed, N, H, W, S):
     gout = torch.randn(N, 3, H, W) * 1e-2
     net.runner.grad_scale = S
     out = net(x.to(dev))
-    rec = net.runner.saved["rec"]
-    masks = {k: (v["z"].permute(0, 3, 1, 2) > 0).float().cpu() for k, v in rec.items() if not k.endswith("downsample")}
+    masks = {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
     (out * (gout.to(dev) * S)).sum().backward()
     torch.cuda.synchronize()
     wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
@@ -166,8 +165,7 @@ def test_resnet18_backbone_forward_and_gradients(dev):
     gout = torch.randn(2, 3, 64, 96) * 1e-2
     net.runner.grad_scale = 256.0
     out = net(x.to(dev))
-    rec = net.runner.saved["rec"]
-    masks = {k: (v["z"].permute(0, 3, 1, 2) > 0).float().cpu() for k, v in rec.items() if not k.endswith("downsample")}
+    masks = {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
     (out * (gout.to(dev) * 256.0)).sum().backward()
     wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
     (wq * gout).sum().backward()
@@ -192,8 +190,7 @@ def test_resnet50_backbone_forward_and_gradients(dev):
     gout = torch.randn(2, 3, 64, 96) * 1e-2
     net.runner.grad_scale = 256.0
     out = net(x.to(dev))
-    rec = net.runner.saved["rec"]
-    masks = {k: (v["z"].permute(0, 3, 1, 2) > 0).float().cpu() for k, v in rec.items() if not k.endswith("downsample")}
+    masks = {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
     (out * (gout.to(dev) * 256.0)).sum().backward()
     wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
     (wq * gout).sum().backward()
@@ -252,3 +249,36 @@ def test_graph_recapture_survives_allocations_from_another_thread(dev):
         results.append((out.detach().clone(), net.runner.flat_grads.clone()))
     assert bool(torch.isfinite(results[0][1]).all()) and float(results[0][1].abs().sum()) > 0
     assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+
+
+def test_consumer_side_batchnorm_step_is_bit_identical_to_materialised_activations(dev):
+    """The runner's consumer-side BatchNorm (four decoder units hand their RAW conv output + BatchNorm coefficients to the next
+    small-channel convolution; hd_bn_apply is not launched for them) against the same network with every activation materialised:
+    output, every parameter gradient and every BatchNorm buffer bit for bit, over two training steps, eager and graph-replayed."""
+    from hallucidet_amd.models.encoder_decoder import EncoderDecoder
+    for graphs in (False, True):
+        outs = []
+        for fuse in (True, False):
+            torch.manual_seed(11)
+            net = EncoderDecoder(name="resnet34").encoder_decoder.to(dev).train()
+            net.runner.fuse_bn = fuse
+            net.runner.enable_graphs(graphs)
+            net.runner.grad_scale = 256.0
+            assert net.runner._raw_units == {"decoder.blocks.3.conv1", "decoder.blocks.3.conv2", "decoder.blocks.4.conv1", "decoder.blocks.4.conv2"}
+            x = torch.rand(2, 3, 64, 96, device=dev)
+            g = torch.randn(2, 3, 64, 96, device=dev) * 1e-2
+            for it in range(2):
+                out = net(x + 0.01 * it)
+                raw = [k for k, v in net.runner.saved["rec"].items() if not torch.is_tensor(v["z"])]
+                assert (len(raw) == 4) == fuse and (len(raw) == 0) == (not fuse)
+                out.backward(g * 256.0)
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), net.runner.flat_grads.clone(), {k: v.clone() for k, v in net.state_dict().items()}))
+            net.eval()
+            with torch.no_grad():
+                outs[-1] += (net(x).clone(),)             # eval mode (running statistics) takes the same route
+        (o0, g0, s0, e0), (o1, g1, s1, e1) = outs
+        assert torch.equal(o0, o1) and torch.equal(g0, g1) and torch.equal(e0, e1)
+        assert bool(torch.isfinite(g0).all()) and float(g0.abs().sum()) > 0
+        for k in s0:
+            assert torch.equal(s0[k], s1[k]), k

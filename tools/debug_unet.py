@@ -34,7 +34,7 @@ for n, m in ref.named_modules():
 r = net.runner
 out = net(x.to(dev))
 rec = dict(r.saved["rec"])
-masks = {k: (v["z"].permute(0, 3, 1, 2) > 0).float().cpu() for k, v in rec.items() if not k.endswith("downsample")}
+masks = {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
 wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
 (wq * gout).sum().backward()
 (out * (gout.to(dev) * S)).sum().backward()
