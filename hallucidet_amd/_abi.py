@@ -89,6 +89,7 @@ PROTOTYPES = {
     "hd_subsample2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_subsample2_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
     "hd_nchw_to_nhwc_resize": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
+    "hd_nchw_to_nhwc_resize_strided": (C.c_int, [vp, c_i64, c_i64, vp] + [C.c_int] * 7 + [vp]),
     "hd_nchw_to_nhwc_resize_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, vp]),
     "hd_nhwc_to_nchw": (C.c_int, [vp, vp] + [C.c_int] * 5 + [vp]),
     "hd_upsample_add": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),

@@ -548,8 +548,10 @@ __device__ __forceinline__ int nn_src(int dst, float scale, int in_size) {
   return s < in_size - 1 ? s : in_size - 1;
 }
 
+// `cstride` / `nstride` (elements): channel / image stride of x.  cstride == 0 reads every channel from plane 0: the reference's
+// `imgs_ir.repeat(1, 3, 1, 1)` (src/utils/utils.py:52-53) as a stride-0 view -- the three copies are never materialised.
 __global__ void nchw_to_nhwc_resize_kernel(const float* __restrict__ x, f16* __restrict__ y, int N, int Cr, int H, int W,
-                                           int Ho, int Wo, int Cp, float sh, float sw) {
+                                           int Ho, int Wo, int Cp, float sh, float sw, int64_t nstride, int64_t cstride) {
   const int64_t total = (int64_t)N * Ho * Wo;
   for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
     int wo = (int)(p % Wo);
@@ -561,7 +563,7 @@ __global__ void nchw_to_nhwc_resize_kernel(const float* __restrict__ x, f16* __r
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         int c = c0 + k;
-        o[k] = c < Cr ? (f16)x[((size_t)(n * Cr + c) * H + hs) * W + ws] : (f16)0.f;
+        o[k] = c < Cr ? (f16)x[(size_t)n * nstride + (size_t)c * cstride + (size_t)hs * W + ws] : (f16)0.f;
       }
       st8(y + (size_t)p * Cp + c0, o);
     }
@@ -948,7 +950,18 @@ extern "C" int hd_subsample2_bwd(const void* dy, void* dx, int N, int H, int W, 
 extern "C" int hd_nchw_to_nhwc_resize(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream) {
   HD_CHECK_ARG(x && y && Cp % 8 == 0 && Cr <= Cp && Cr > 0, "hd_nchw_to_nhwc_resize: bad args");
   float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
-  hipLaunchKernelGGL(nchw_to_nhwc_resize_kernel, dim3(grid_for((int64_t)N * Ho * Wo)), dim3(TB), 0, S_, x, (f16*)y, N, Cr, H, W, Ho, Wo, Cp, sh, sw);
+  hipLaunchKernelGGL(nchw_to_nhwc_resize_kernel, dim3(grid_for((int64_t)N * Ho * Wo)), dim3(TB), 0, S_, x, (f16*)y, N, Cr, H, W, Ho, Wo, Cp, sh, sw,
+                     (int64_t)Cr * H * W, (int64_t)H * W);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_nchw_to_nhwc_resize_strided(const float* x, int64_t nstride, int64_t cstride, void* y, int N, int Cr, int H, int W, int Ho,
+                                              int Wo, int Cp, void* stream) {
+  HD_CHECK_ARG(x && y && Cp % 8 == 0 && Cr <= Cp && Cr > 0 && nstride >= 0 && cstride >= 0, "hd_nchw_to_nhwc_resize_strided: bad args");
+  float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
+  hipLaunchKernelGGL(nchw_to_nhwc_resize_kernel, dim3(grid_for((int64_t)N * Ho * Wo)), dim3(TB), 0, S_, x, (f16*)y, N, Cr, H, W, Ho, Wo, Cp, sh, sw,
+                     nstride, cstride);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -157,7 +157,7 @@ class CustomGeneralizedRCNNTransform(nn.Module):
                 raise TypeError(f"Expected input images to be of floating type (in range [0, 1]), but found type {b.dtype} instead")
             if b.shape[1:] != (image_batches[0].shape[1:] if isinstance(image_batches[0], Tensor) else b.shape[1:]):
                 raise NotImplementedError("hallucidet_amd: fused transform needs equally sized images in a batch")
-            xs.append(b.float().contiguous())
+            xs.append(ops.as_dense_planes_f32(b))
         h, w = xs[0].shape[-2:]
         Wo, Ho = self.fixed_size[0], self.fixed_size[1]
         y = _ResizeManyFn.apply(Ho, Wo, *xs)

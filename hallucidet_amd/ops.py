@@ -384,14 +384,32 @@ def nchw_to_nhwc_resize(x, Ho, Wo, Cp=8, out=None):
     """`out`: write into this [N, Ho, Wo, Cp] fp16 tensor (e.g. a slice along dim 0 of a larger batch buffer) instead of a new one."""
     _need_cuda(x)
     N, Cr, H, W = x.shape
-    assert x.dtype == torch.float32 and x.is_contiguous()
+    assert x.dtype == torch.float32
     if out is None:
         y = torch.empty((N, Ho, Wo, Cp), dtype=torch.float16, device=x.device)
     else:
         y = out
         assert y.shape == (N, Ho, Wo, Cp) and y.dtype == torch.float16 and y.is_contiguous()
-    check(_abi.load().hd_nchw_to_nhwc_resize(ptr(x), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()), "hd_nchw_to_nhwc_resize")
+    if x.is_contiguous():
+        check(_abi.load().hd_nchw_to_nhwc_resize(ptr(x), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()), "hd_nchw_to_nhwc_resize")
+    else:
+        # dense planes with arbitrary image / channel strides: the stride-0 channel view of a 1 -> 3 channel `expand`
+        assert dense_planes(x), "nchw_to_nhwc_resize: rows of x must be dense (stride (.., .., W, 1))"
+        check(_abi.load().hd_nchw_to_nhwc_resize_strided(ptr(x), x.stride(0), x.stride(1), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()),
+              "hd_nchw_to_nhwc_resize_strided")
     return y
+
+
+def dense_planes(x):
+    """[N, C, H, W] tensor whose H x W planes are dense (any image / channel stride, e.g. `t.expand(-1, 3, -1, -1)`)."""
+    return x.dim() == 4 and x.stride(3) == 1 and x.stride(2) == x.shape[3]
+
+
+def as_dense_planes_f32(x):
+    """fp32 view / copy of an NCHW batch that hd_nchw_to_nhwc_resize can read: contiguous tensors and stride-0 channel views of a
+    dense single-channel batch pass through untouched; anything else is made contiguous."""
+    x = x if x.dtype == torch.float32 else x.float()
+    return x if (x.is_contiguous() or dense_planes(x)) else x.contiguous()
 
 
 def nchw_to_nhwc_resize_bwd(dy, N, Cr, H, W, gscale=1.0):

@@ -297,14 +297,26 @@ class UnetRunner:
         self.use_graphs = on
         self._g = None
 
+    @staticmethod
+    def _copy_input(static, x):
+        """x -> the forward graph's static input; a stride-0 channel view (1 -> 3 channel `expand`) holds ONE plane per image."""
+        if static.stride(1) == 0:
+            static[:, :1].copy_(x[:, :1])
+        else:
+            static.copy_(x)
+
     def run_forward_train(self, x):
         if not self.use_graphs:
             return self.forward(x, training=True, save=True)
         g = self._g
-        if g is None or g["xshape"] != tuple(x.shape) or g["dev"] != x.device:
+        if g is None or g["xshape"] != tuple(x.shape) or g["dev"] != x.device or g.get("xkind") != (x.stride(1) == 0):
             self.flatten_parameters()
-            g = self._g = dict(xshape=tuple(x.shape), dev=x.device, x=torch.empty_like(x, dtype=torch.float32), bwd=None, scale=None)
-            g["x"].copy_(x)
+            if x.stride(1) == 0 and ops.dense_planes(x):      # stride-0 channel view (IR image): the static input is ONE plane per image
+                x_static = torch.empty((x.shape[0], 1) + tuple(x.shape[2:]), dtype=torch.float32, device=x.device).expand(-1, x.shape[1], -1, -1)
+            else:
+                x_static = torch.empty(tuple(x.shape), dtype=torch.float32, device=x.device)
+            g = self._g = dict(xshape=tuple(x.shape), dev=x.device, x=x_static, bwd=None, scale=None, xkind=x.stride(1) == 0)
+            self._copy_input(g["x"], x)
             snap = [b.clone() for b in self.module.buffers()]   # the warm-up run must not count as a training step
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -321,7 +333,7 @@ class UnetRunner:
             # the capture itself did not execute: restore the BatchNorm buffers the warm-up touched, then replay
             for b, s0 in zip(self.module.buffers(), snap):
                 b.copy_(s0)
-        g["x"].copy_(x)
+        self._copy_input(g["x"], x)
         g["fwd"].replay()
         self.saved = g["saved"]
         return g["out"]
@@ -494,7 +506,7 @@ class UnetRunner:
         save = save and training
         rec = {} if save else None
         Wt = self._prep_weights(need_dgrad=save)
-        x = x.contiguous().float()
+        x = ops.as_dense_planes_f32(x)              # a 1 -> 3 channel `expand` view stays a view (read three times by the kernel below)
         a0 = ops.nchw_to_nhwc_resize(x, H, Wd, 8)
         f1 = self._conv_bn(self.stem, a0, Wt, training, rec)
         cur, pool_idx = ops.maxpool3x3s2_idx(f1) if save else (ops.maxpool3x3s2(f1), None)

@@ -3,6 +3,9 @@ Plotting / VOC-XML helpers of that class are outside the hot path (SURVEY #8).""
 import torch
 
 
+_IR_VIEW = __import__("os").environ.get("HD_IR_VIEW", "1") != "0"      # A/B knob: 0 = materialise the repeat
+
+
 class Utils():
 
     @staticmethod
@@ -35,6 +38,11 @@ class Utils():
 
     @staticmethod
     def expand_one_channel_to_output_channels(imgs, output_channels=3):
+        """utils.py:52-53 `imgs.repeat(1, C, 1, 1)`.  A single-channel batch is returned as its stride-0 channel VIEW (same shape, same
+        values, read-only use downstream): the U-Net's and the detector transform's first kernel read the one plane three times
+        instead of 31 MB being written and read back every step."""
+        if imgs.dim() == 4 and imgs.shape[1] == 1 and _IR_VIEW:
+            return imgs.expand(-1, output_channels, -1, -1)
         return imgs.repeat(1, output_channels, 1, 1)
 
     @staticmethod

@@ -214,6 +214,11 @@ int hd_subsample2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int 
  * (custom_generalized_transform.py:80-87: F.interpolate default mode) ; channels >= Cr zero-filled.
  * in_scale multiplies the value (normalize (x-0)/1 is identity: custom_generalized_transform.py:177-186). */
 int hd_nchw_to_nhwc_resize(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream);
+/* the same with explicit image / channel strides of x (in elements; rows stay dense).  cstride == 0 broadcasts plane 0 to every
+ * channel: the reference's 1 -> 3 channel repeat of the IR image (src/utils/utils.py:52-53, train_hallucidet.py:171) folded into
+ * the layout conversion, so that the repeated tensor is never materialised */
+int hd_nchw_to_nhwc_resize_strided(const float* x, int64_t nstride, int64_t cstride, void* y, int N, int Cr, int H, int W, int Ho,
+                                   int Wo, int Cp, void* stream);
 /* backward of the above: dx NCHW f32 (zero where no destination pixel selects the source) */
 int hd_nchw_to_nhwc_resize_bwd(const void* dy, float* dx, int N, int Cr, int H, int W, int Ho, int Wo, int Cp,
                                float gscale, void* stream);

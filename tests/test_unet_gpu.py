@@ -282,3 +282,35 @@ def test_consumer_side_batchnorm_step_is_bit_identical_to_materialised_activatio
         assert bool(torch.isfinite(g0).all()) and float(g0.abs().sum()) > 0
         for k in s0:
             assert torch.equal(s0[k], s1[k]), k
+
+
+def test_one_to_three_channel_repeat_is_a_view_and_bit_identical(dev):
+    """SURVEY K1 (src/utils/utils.py:52-53, train_hallucidet.py:171): `expand_one_channel_to_output_channels` hands the U-Net and the
+    detector transform a stride-0 channel view of the single-channel IR batch instead of a materialised `repeat`; the layout kernel
+    reads the plane three times.  Outputs, gradients and the detector's ImageList must equal the materialised form bit for bit,
+    eager and graph-replayed."""
+    from hallucidet_amd.models.encoder_decoder import EncoderDecoder
+    from hallucidet_amd.models.detector import Detector
+    from hallucidet_amd.utils.utils import Utils
+    ir = torch.rand(2, 1, 64, 96, device=dev)
+    view = Utils.expand_one_channel_to_output_channels(ir, 3)
+    full = ir.repeat(1, 3, 1, 1)
+    assert view.shape == full.shape and view.stride(1) == 0 and view.data_ptr() == ir.data_ptr() and torch.equal(view, full)
+    assert torch.equal(Utils.expand_one_channel_to_output_channels(full, 1), full)           # multi-channel input: plain repeat
+    for graphs in (False, True):
+        outs = []
+        for x in (view, full):
+            torch.manual_seed(13)
+            net = EncoderDecoder(name="resnet34").encoder_decoder.to(dev).train()
+            net.runner.enable_graphs(graphs)
+            net.runner.grad_scale = 64.0
+            g = torch.randn(2, 3, 64, 96, device=dev) * 1e-2
+            for it in range(2):
+                out = net(x)
+                out.backward(g * 64.0)
+            torch.cuda.synchronize()
+            outs.append((out.detach().clone(), net.runner.flat_grads.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector.to(dev).eval()
+    a, _ = det.transform.forward_batches([full, view], None)
+    assert torch.equal(a.tensors[:2], a.tensors[2:]) and a.tensors.shape == (4, 300, 300, 8)
