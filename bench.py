@@ -170,7 +170,7 @@ def conv_roofline(lit, batch, reps=5):
         ms = e0.elapsed_time(e1) / passes
         del g
         return ms
-    def iso(call):
+    def iso_time(call):
         """One launch `reps` times back to back, captured in a hipGraph (issued from Python a 5-us kernel is host-bound)."""
         call()
         g = torch.cuda.CUDAGraph()
@@ -197,7 +197,7 @@ def conv_roofline(lit, batch, reps=5):
         roof_ms += max(fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / 8e12) * 1e3
         hbm_bound += int(by / 8e12 > fl / (MFMA_F16_PEAK_TFLOPS * 1e12))
         kw = dict(kw)                                 # same epilogue (bias / res / mask / BN statistics) as in the step
-        ms = iso(lambda: orig(x, w, KH, KW, **kw))
+        ms = iso_time(lambda: orig(x, w, KH, KW, **kw))
         tot_ms += ms
         tot_fl += fl
         grp[origin][0] += ms
@@ -216,7 +216,7 @@ def conv_roofline(lit, batch, reps=5):
     achieved = tot_fl / (step_conv_ms * 1e-3) / 1e12
     wg_ms = wg_fl = 0.0
     for (x, dy, KH, KW), kw, fl in wrec:
-        wg_ms += iso(lambda: orig_wg(x, dy, KH, KW, **kw))
+        wg_ms += iso_time(lambda: orig_wg(x, dy, KH, KW, **kw))
         wg_fl += fl
     tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None
     # groups are IN-STEP times (isolated re-timing in *_isolated_ms)

@@ -1,6 +1,6 @@
 # Round profiles: kernel-trace summary of a training-step run and of the bench command, PMC passes (MFMA utilisation, HBM traffic).
 # Run on the GPU box from the repo root:  bash tools/collect_profiles.sh r02
-R=${1:-r02}
+R=${1:-r03}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -13,6 +13,8 @@ STEPS=3 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write --outp
 python3 tools/pmc_mfma.py gpurun_out/pmc_mfma gpurun_out/pmc_gui gpurun_out/${R}_conv_mfma_util.json > /dev/null
 F=$(ls gpurun_out/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls gpurun_out/pmc_write/*/*counter_collection.csv | head -1)
 python3 tools/pmc_traffic.py $F $W conv_igemm_kernel,conv3x3_small_kernel,conv3x3_w8_kernel,conv_w8_kernel gpurun_out/${R}_conv_traffic.json > /dev/null
+python3 bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
 cp $(ls gpurun_out/prof_step/*/*kernel_stats.csv | head -1) gpurun_out/${R}_train_step_kernel_stats.csv
 cp $(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_kernel_stats.csv
+rm -rf gpurun_out/prof_step gpurun_out/prof_bench gpurun_out/pmc_mfma gpurun_out/pmc_gui gpurun_out/pmc_fetch gpurun_out/pmc_write
 tail -2 gpurun_out/prof_step.log; tail -c 600 gpurun_out/prof_bench.log; cat gpurun_out/${R}_conv_mfma_util.json | head -40

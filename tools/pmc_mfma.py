@@ -59,5 +59,6 @@ for fam in FAMILIES:
         busy_all += busy
         wall_all += wall
 out["mfma_util"] = round(busy_all / 1024.0 / wall_all, 4) if wall_all else None
+out["commit"] = __import__("os").environ.get("HD_COMMIT")      # the tree this profile was taken on (the GPU box has no .git)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -23,5 +23,6 @@ out = {"kernel": sys.argv[3], "launches_sampled": [nf, nw], "fetch_bytes_per_lau
        "corrections": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies 16-B/lane streaming reads at half); WRITE_SIZE [KiB] x 1024",
        "command": "STEPS=3 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/bench_step.py (two separate passes)"}
 out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
+out["commit"] = __import__("os").environ.get("HD_COMMIT")
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out))
