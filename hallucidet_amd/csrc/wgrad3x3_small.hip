@@ -1,5 +1,6 @@
-// Weight gradient of the 3x3 / stride 1 / pad 1 convolutions with SMALL channel counts (Cin in {16,32}, Cout <= 32): the
-// U-Net decoder's 16/32-channel layers at 256x320 / 512x640 and the segmentation head.
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolutions with a THIN output (Cout <= 32): the U-Net decoder's 16/32-channel layers
+// at 256x320 / 512x640 and the segmentation head (Cin in {16,32}), and decoder block 3's first conv (Cin = 64 upsampled + 64 skip
+// channels -> 32, src/segmentation_models/decoders/unet/decoder.py:38-46: 209 us in the general kernel, the longest launch of the step).
 //
 // In the general wgrad_kernel these launches run at ~4x their HBM time: the im2col operand is refetched tap by tap in
 // 16-byte pieces of 32-byte pixels, and K = 144 fills 1.1 of its two 128-column tiles.  Here a block walks 8x32-pixel
@@ -19,27 +20,32 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
-constexpr int PS = 32;          // halves per staged pixel (64 B: an odd multiple of 64 B keeps the 4 k-rows of a transposed read apart)
+constexpr int PS = 32;          // halves per staged dY pixel (64 B: an odd multiple of 64 B keeps the 4 k-rows of a transposed read apart)
 
+template <int PITCH>
 __device__ __forceinline__ f16x8 tr_frag8(const f16* row0_ptr) {
-  // two transposed 4x16 block reads: reduction rows [0,4) and [4,8) relative to row0_ptr (rows are PS halves apart)
+  // two transposed 4x16 block reads: reduction rows [0,4) and [4,8) relative to row0_ptr (rows are PITCH halves apart)
   s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row0_ptr));
-  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row0_ptr + 4 * PS));
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(row0_ptr + 4 * PITCH));
   f16x4 fa = __builtin_bit_cast(f16x4, a), fb = __builtin_bit_cast(f16x4, b);
   f16x8 r = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
   return r;
 }
 
-template <int CIN, int MT>
-__global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restrict__ x, const f16* __restrict__ dy, float* __restrict__ slab,
+// DUAL: the decoder concat gathered in place -- channels [0, CIN/2) from the nearest-2x upsampled tensor x (pixel (y >> 1, x >> 1)),
+// channels [CIN/2, CIN) from the skip tensor x2.
+template <int CIN, int MT, bool DUAL>
+__global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restrict__ x, const f16* __restrict__ x2, const f16* __restrict__ dy,
+                                                             float* __restrict__ slab,
                                                              int N, int Hsrc, int Wsrc, int H, int W, int Cout, int up1, int tiles_total,
                                                              int tiles_x, int tiles_y, const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift, int in_relu) {
+  constexpr int PSX = CIN <= 32 ? 32 : CIN + 32;      // halves per staged input pixel: an odd multiple of 64 bytes
   constexpr int CT = CIN / 16;
   constexpr int UNITS = 9 * CT;                 // (tap, 16-channel ci tile) pairs; a wave owns units wave, wave+4, ... for every cout tile
   constexpr int UPW = (UNITS + 3) / 4;
   constexpr int KTOT = 9 * CIN;
-  __shared__ __attribute__((aligned(16))) f16 s_x[PH * PW * PS];       // [py][px][channel], 21.8 KB
+  __shared__ __attribute__((aligned(16))) f16 s_x[PH * PW * PSX];      // [py][px][channel], 21.8 KB (108.8 KB for the 128-channel concat)
   __shared__ __attribute__((aligned(16))) f16 s_dy[TH * TW * PS];      // [oy][ox][channel], 16 KB
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, g = lane >> 4;
@@ -82,7 +88,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
     const int ty = b % tiles_y;
     const int n = b / tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
-    const f16* xb = x + (size_t)n * Hsrc * Wsrc * CIN;
+    constexpr int CSRC = DUAL ? CIN / 2 : CIN;             // channels of each source tensor
+    const f16* xb = x + (size_t)n * Hsrc * Wsrc * CSRC;
+    const f16* x2b = DUAL ? x2 + (size_t)n * H * W * CSRC : nullptr;
 #pragma unroll
     for (int i = 0; i < XL; ++i) {
       const int e = tid + i * 256;
@@ -91,8 +99,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
       const int hi = y0 + py - 1, wi = x0 + px - 1;
       f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
       if (live && e < PH * PW * C8 && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
-        const int hs = up1 ? (hi >> 1) : hi, ws = up1 ? (wi >> 1) : wi;
-        v = *reinterpret_cast<const f16x8*>(xb + ((size_t)hs * Wsrc + ws) * CIN + c8 * 8);
+        if (DUAL && c8 >= C8 / 2) {
+          v = *reinterpret_cast<const f16x8*>(x2b + ((size_t)hi * W + wi) * CSRC + (c8 - C8 / 2) * 8);
+        } else {
+          const int hs = up1 ? (hi >> 1) : hi, ws = up1 ? (wi >> 1) : wi;
+          v = *reinterpret_cast<const f16x8*>(xb + ((size_t)hs * Wsrc + ws) * CSRC + c8 * 8);
+        }
         vmask |= 1u << i;
       }
       rx[i] = v;
@@ -119,7 +131,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
           v[k] = (f16)f;
         }
       }
-      if (e < PH * PW * C8) *reinterpret_cast<f16x8*>(s_x + (e / C8) * PS + (e % C8) * 8) = v;
+      if (e < PH * PW * C8) *reinterpret_cast<f16x8*>(s_x + (e / C8) * PSX + (e % C8) * 8) = v;
     }
 #pragma unroll
     for (int i = 0; i < DL; ++i)
@@ -140,13 +152,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
         const int c = u % CT, t = u / CT;
         const int kh = t / 3, kw = t - kh * 3;
         const f16* ap = s_dy + krow * PS + 4 * tp;
-        const f16* bp = s_x + (kh * PW + kw + krow) * PS + c * 16 + 4 * tp;
+        const f16* bp = s_x + (kh * PW + kw + krow) * PSX + c * 16 + 4 * tp;
 #pragma unroll
         for (int oy = 0; oy < TH; ++oy) {
-          const f16x8 bf = tr_frag8(bp + oy * PW * PS);
+          const f16x8 bf = tr_frag8<PSX>(bp + oy * PW * PSX);
 #pragma unroll
           for (int m = 0; m < MT; ++m) {
-            const f16x8 af = tr_frag8(ap + oy * TW * PS + m * 16);
+            const f16x8 af = tr_frag8<PS>(ap + oy * TW * PS + m * 16);
             acc[q][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf, acc[q][m], 0, 0, 0);
           }
         }
@@ -174,8 +186,9 @@ __global__ __launch_bounds__(256) void wgrad3x3_small_kernel(const f16* __restri
 }  // namespace
 
 bool hd_wgrad_small_eligible(const hd_wgrad_args* a) {
-  return a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->C2 == 0 && a->x2 == nullptr && (a->C1 == 16 || a->C1 == 32) &&
-         a->Cout % 8 == 0 && a->Cout <= 32 && a->Ho == a->Hin && a->Wo == a->Win;
+  if (!(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->Cout % 8 == 0 && a->Cout <= 32 && a->Ho == a->Hin && a->Wo == a->Win)) return false;
+  if (a->x2) return a->up1 && a->C1 == 64 && a->C2 == 64 && !a->in_scale;      // decoder concat 64 (upsampled) + 64 (skip) channels
+  return a->C2 == 0 && (a->C1 == 16 || a->C1 == 32);
 }
 
 void hd_wgrad_small_launch(const hd_wgrad_args* a, hipStream_t s) {
@@ -183,11 +196,13 @@ void hd_wgrad_small_launch(const hd_wgrad_args* a, hipStream_t s) {
   const int total = a->N * tiles_x * tiles_y;
   dim3 grid(a->nsplit);
   const f16* x = (const f16*)a->x;
+  const f16* x2 = (const f16*)a->x2;
   const f16* dy = (const f16*)a->dy;
-#define LAUNCH(CI, M_)                                                                                                              \
-  hipLaunchKernelGGL((wgrad3x3_small_kernel<CI, M_>), grid, dim3(256), 0, s, x, dy, a->slab, a->N, a->Hsrc, a->Wsrc, a->Hin, a->Win, \
+#define LAUNCH(CI, M_, DU)                                                                                                                  \
+  hipLaunchKernelGGL((wgrad3x3_small_kernel<CI, M_, DU>), grid, dim3(256), 0, s, x, x2, dy, a->slab, a->N, a->Hsrc, a->Wsrc, a->Hin, a->Win, \
                      a->Cout, a->up1, total, tiles_x, tiles_y, a->in_scale, a->in_shift, a->in_relu)
-  if (a->C1 == 16) { if (a->Cout <= 16) LAUNCH(16, 1); else LAUNCH(16, 2); }
-  else { if (a->Cout <= 16) LAUNCH(32, 1); else LAUNCH(32, 2); }
+  if (a->x2) { if (a->Cout <= 16) LAUNCH(128, 1, true); else LAUNCH(128, 2, true); }
+  else if (a->C1 == 16) { if (a->Cout <= 16) LAUNCH(16, 1, false); else LAUNCH(16, 2, false); }
+  else { if (a->Cout <= 16) LAUNCH(32, 1, false); else LAUNCH(32, 2, false); }
 #undef LAUNCH
 }

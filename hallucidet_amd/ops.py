@@ -121,6 +121,8 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in
             nsplit = max(1, min(_WGRAD8_BLOCKS // blocks8, tiles // 4))
             while nsplit > 1 and nsplit * Cout * K * 4 > (64 << 20):
                 nsplit //= 2
+        elif x2 is not None and up1 and KH == 3 and C1 == 64 and C2 == 64 and Cout <= 32 and stride == 1 and pad == 1:
+            nsplit = 256          # thin-output kernel on the decoder concat (wgrad3x3_small.hip): 125 KB of LDS, one persistent block per CU
         else:
             nsplit = pick_nsplit(M, Cout, K)
     slab = torch.empty((nsplit, Cout, K), dtype=torch.float32, device=x.device)

@@ -237,6 +237,8 @@ WGRAD_CASES = [
     (2, 8, 10, 32, 0, 16, 3, 1, 1, True, 2),        # nearest-2x upsampled source
     (1, 9, 33, 16, 0, 32, 3, 1, 1, False, 50),      # more blocks than tiles (empty partials)
     (3, 16, 64, 32, 0, 24, 3, 1, 1, False, 4),      # Cout not a multiple of 16
+    (2, 9, 21, 64, 64, 32, 3, 1, 1, True, 5),       # thin output on the decoder concat (64 upsampled + 64 skip channels -> 32), ragged tiles
+    (1, 8, 16, 64, 64, 16, 3, 1, 1, True, 300),     # the same with one cout tile and more blocks than tiles
     # 3x3 / s1 layers with >= 64 channels: the 8-wave patch-staged kernel (wgrad3x3_w8.hip; also the first and the 512-channel cases above)
     (2, 40, 24, 64, 0, 128, 3, 1, 1, False, 5),     # two cout chunks; 16x8 tiles exact in W, ragged in H
     (3, 19, 21, 128, 0, 64, 3, 1, 1, False, 4),     # ragged both ways, two ci chunks
