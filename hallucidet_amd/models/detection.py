@@ -1220,6 +1220,10 @@ def pad_targets(targets, device):
     One concatenation + one gather through a [N,G] row-index table (pad_sequence issues two device copies per target: 48
     launches for the 24 targets of a step).  The table depends on the box counts only: built on the host, cached per count
     tuple, uploaded from pinned memory without a stream synchronisation."""
+    if targets and "_rows" in targets[0]:
+        # staged targets (det_graph.py): G rows for every image already, zero rows as padding
+        gt = torch.stack([t["boxes"].to(torch.float32) for t in targets])
+        return gt, torch.stack([t["labels"] for t in targets]), gt[:, :, 2] > gt[:, :, 0]
     lens = tuple(int(t["boxes"].shape[0]) for t in targets)
     N, S = len(lens), sum(lens)
     G = max(1, max(lens))

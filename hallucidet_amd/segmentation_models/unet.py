@@ -407,7 +407,8 @@ class UnetRunner:
                         raise err
                 torch.cuda.current_stream().wait_stream(side)
             g["bwd"], g["scale"], g["segmented"] = graphs, S, segmented       # only a complete capture is remembered
-        g["dout"].copy_(dout)
+        if dout.data_ptr() != g["dout"].data_ptr():     # (det_graph.py writes the image gradient straight into the static input)
+            g["dout"].copy_(dout)
         if not segmented:
             g["bwd"][0].replay()
         else:

@@ -5,6 +5,8 @@ Kept: constructor keywords, `forward_step` (one U-Net pass, three detector passe
 batches, :161-240), `training_step / validation_step / test_step`, `configure_optimizers`.  The RGB and IR detector passes
 run without autograd (their losses are discarded by the reference, App. D.2 -- same results).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -57,6 +59,7 @@ class EncoderDecoderLit(nn.Module):
         self.optimizer = None
         self.averager = GradientAverager()
         self.overlap_allreduce = True        # False: one exchange after the whole backward (A/B knob)
+        self.use_detector_graph = os.environ.get("HD_DET_GRAPH", "1") != "0"
 
     # ------------------------------------------------------------------------------------------------------------
     def forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train'):
@@ -72,6 +75,34 @@ class EncoderDecoderLit(nn.Module):
         loss_pixel_rgb = loss_perceptual_rgb = loss_pixel_ir = loss_perceptual_ir = 0.0
 
         train_det = True if (self.train_det is True and step == 'train') else False
+        graph = self._detector_graph() if (step == 'train' and not train_det and imgs_hallucinated.requires_grad) else None
+        if graph is not None:
+            # the detector half of the step (three passes, losses, the backward pass down to the hallucinated image, the deferred
+            # post-processing) as ONE hipGraph replay (det_graph.py); the U-Net's backward continues from the image gradient
+            losses_det, loss_det_total, (detections_hall, detections_rgb, detections_ir) = graph.step(
+                imgs_hallucinated, imgs_rgb, imgs_ir_three_channel, targets_rgb, targets_ir)
+        else:
+            losses_det, loss_det_total, (detections_hall, detections_rgb, detections_ir) = self._detector_section(
+                imgs_hallucinated, imgs_rgb, imgs_ir_three_channel, targets_rgb, targets_ir, step, train_det)
+        total_loss = loss_det_total
+        for extra in (loss_pixel_rgb, loss_perceptual_rgb, loss_pixel_ir, loss_perceptual_ir):
+            if torch.is_tensor(extra) or extra != 0.0:
+                total_loss = total_loss + extra
+
+        self._last_detections = dict(hall=detections_hall, rgb=detections_rgb, ir=detections_ir)
+        return {
+            'loss': {'total': total_loss, 'pixel_rgb': loss_pixel_rgb, 'perceptual_rgb': loss_perceptual_rgb,
+                     'pixel_ir': loss_pixel_ir, 'perceptual_ir': loss_perceptual_ir,
+                     'det_regression': losses_det['bbox_regression'], 'det_classification': losses_det['classification'],
+                     'det_objectness': losses_det['loss_objectness'], 'det_rpn_box_reg': losses_det['loss_rpn_box_reg'],
+                     'det_bbox_ctrness': losses_det['bbox_ctrness'], 'det_total': loss_det_total},
+            # train_hallucidet.py:218 min-max normalises a detached clone for plotting only; kept lazy (SURVEY K23)
+            'output': {'imgs_rgb': imgs_rgb, 'imgs_ir': imgs_ir, 'imgs_hallucinated': imgs_hallucinated.detach()},
+        }
+
+    def _detector_section(self, imgs_hallucinated, imgs_rgb, imgs_ir_three_channel, targets_rgb, targets_ir, step, train_det):
+        """train_hallucidet.py:180-210: the three detector passes and the weighted detector losses.
+        -> (losses_det with the weighted keys, their sum, (detections_hall, detections_rgb, detections_ir))."""
         if step == 'train' and self.skip_unused_train_passes and not train_det:
             losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=False, model_name=self.detector_name)
             detections_rgb, detections_ir = [], []
@@ -99,10 +130,7 @@ class EncoderDecoderLit(nn.Module):
         # train_hallucidet.py:193-210: every detector loss times its weight, their sum, plus the (weight 0.0) pixel / perceptual terms.
         # One stack, one multiply by a cached weight vector, one sum (the per-key results are views of the product) instead of a
         # scalar kernel per key and per '+': each of those is a serialised ~3 us launch in a step that is GPU-bound.
-        frcnn, fcos_ = 'fasterrcnn' in self.detector_name, 'fcos' in self.detector_name
-        keys = [('bbox_regression', 'det_regression'), ('classification', 'det_classification')]
-        keys += [('loss_objectness', 'det_objectness'), ('loss_rpn_box_reg', 'det_rpn_box_reg')] if frcnn else []
-        keys += [('bbox_ctrness', 'det_bbox_ctrness')] if fcos_ else []
+        keys = self._loss_keys()
         vals = [losses_det[k] for k, _ in keys]
         wkey = (tuple(float(w[wk]) for _, wk in keys), str(vals[0].device))
         wvec = self._wvec_cache.get(wkey) if hasattr(self, "_wvec_cache") else None
@@ -114,22 +142,26 @@ class EncoderDecoderLit(nn.Module):
         for k in ('loss_objectness', 'loss_rpn_box_reg', 'bbox_ctrness'):
             if not any(k == kk for kk, _ in keys):
                 losses_det[k] = 0.0
-        loss_det_total = weighted.sum()
-        total_loss = loss_det_total
-        for extra in (loss_pixel_rgb, loss_perceptual_rgb, loss_pixel_ir, loss_perceptual_ir):
-            if torch.is_tensor(extra) or extra != 0.0:
-                total_loss = total_loss + extra
+        return losses_det, weighted.sum(), (detections_hall, detections_rgb, detections_ir)
 
-        self._last_detections = dict(hall=detections_hall, rgb=detections_rgb, ir=detections_ir)
-        return {
-            'loss': {'total': total_loss, 'pixel_rgb': loss_pixel_rgb, 'perceptual_rgb': loss_perceptual_rgb,
-                     'pixel_ir': loss_pixel_ir, 'perceptual_ir': loss_perceptual_ir,
-                     'det_regression': losses_det['bbox_regression'], 'det_classification': losses_det['classification'],
-                     'det_objectness': losses_det['loss_objectness'], 'det_rpn_box_reg': losses_det['loss_rpn_box_reg'],
-                     'det_bbox_ctrness': losses_det['bbox_ctrness'], 'det_total': loss_det_total},
-            # train_hallucidet.py:218 min-max normalises a detached clone for plotting only; kept lazy (SURVEY K23)
-            'output': {'imgs_rgb': imgs_rgb, 'imgs_ir': imgs_ir, 'imgs_hallucinated': imgs_hallucinated.detach()},
-        }
+    def _loss_keys(self):
+        frcnn, fcos_ = 'fasterrcnn' in self.detector_name, 'fcos' in self.detector_name
+        keys = [('bbox_regression', 'det_regression'), ('classification', 'det_classification')]
+        keys += [('loss_objectness', 'det_objectness'), ('loss_rpn_box_reg', 'det_rpn_box_reg')] if frcnn else []
+        keys += [('bbox_ctrness', 'det_bbox_ctrness')] if fcos_ else []
+        return keys
+
+    def _detector_graph(self):
+        """The captured detector half (det_graph.DetectorStepGraph) when it applies: graphs enabled, frozen detector, the fused
+        three-pass evaluation, device tensors.  HD_DET_GRAPH=0 keeps the eager issue order (A/B knob)."""
+        if not (self.use_graphs and self.use_detector_graph and self.batch_detector_passes and not self.skip_unused_train_passes
+                and self.dev.type == "cuda" and self.scaler is not None):
+            return None
+        g = self.__dict__.get("_det_graph")
+        if g is None:
+            from .det_graph import DetectorStepGraph
+            g = self.__dict__["_det_graph"] = DetectorStepGraph(self)
+        return g if g.usable else None
 
     def training_step(self, train_batch, batch_idx):
         imgs_rgb, targets_rgb, imgs_ir, targets_ir = train_batch

@@ -23,23 +23,46 @@ def _check_targets(targets):
 
 def _degenerate_flag(targets):
     """Device-side flag of the reference's degenerate-box check (:41-53); read at the step's first natural sync."""
+    if targets and "_rows" in targets[0]:
+        # staged targets (det_graph.py): every image carries the same number of rows, `_rows` marks the real ones (the rest is
+        # zero padding, which must not trip the check)
+        allb = torch.stack([t["boxes"] for t in targets])
+        live = torch.stack([t["_rows"] for t in targets])
+        return ((allb[..., 2:] <= allb[..., :2]).any(dim=-1) & live).any()
     allb = torch.cat([t["boxes"] for t in targets], dim=0)
     return (allb[:, 2:] <= allb[:, :2]).any() if allb.numel() else None
+
+
+# While det_graph.py captures the detector half this is a list: the batch's degenerate-box flag is appended to it (a uint8 [1]
+# tensor, an OUTPUT of the graph) instead of being sent to the host from inside the capture; its trip to pinned memory is issued
+# after every replay.
+_GRAPH_FLAGS = None
+
+
+def _defer_flag(model, flag, targets):
+    if _GRAPH_FLAGS is not None:
+        if flag is not None:
+            _GRAPH_FLAGS.append(flag.reshape(1).to(torch.uint8))
+        return
+    pend = model.__dict__.pop("_pending_degenerate", None)
+    if pend is not None:
+        pend.raise_if_set()
+    if flag is not None:
+        model.__dict__["_pending_degenerate"] = _AsyncFlag(flag, targets)
 
 
 def check_degenerate_deferred(model, targets):
     """The reference's degenerate-box check (:41-53) without a host synchronisation inside the step: this batch's device flag
     travels to pinned memory now and is read when the NEXT batch arrives (a bad box still raises, one call later, with the same
     message); the flag left by the previous call is read first."""
-    pend = model.__dict__.pop("_pending_degenerate", None)
-    if pend is not None:
-        pend.raise_if_set()
     flag = _degenerate_flag(targets)
-    if flag is not None:
-        if flag.is_cuda:
-            model.__dict__["_pending_degenerate"] = _AsyncFlag(flag, targets)
-        else:
-            _raise_if_degenerate(flag, targets)
+    if flag is not None and not flag.is_cuda:
+        pend = model.__dict__.pop("_pending_degenerate", None)
+        if pend is not None:
+            pend.raise_if_set()
+        _raise_if_degenerate(flag, targets)
+    else:
+        _defer_flag(model, flag, targets)
 
 
 def flush_degenerate(model, block=True):
@@ -62,7 +85,7 @@ class _AsyncFlag:
     def __init__(self, flag, targets):
         self.targets = targets
         self.host = torch.empty(1, dtype=torch.uint8).pin_memory()
-        self.host.copy_(flag.reshape(1).to(torch.uint8), non_blocking=True)
+        self.host.copy_(flag if flag.dtype == torch.uint8 else flag.reshape(1).to(torch.uint8), non_blocking=True)
         self.event = torch.cuda.Event()
         self.event.record()
 
@@ -200,11 +223,7 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     if padded:
         # Fixed-size RoI stage: S rows per image, padding rows carry label -1, counts stay on the device -> the step has NO host
         # synchronisation left (the degenerate-box flag of this batch is read, from pinned memory, when the next batch arrives).
-        pend = model.__dict__.pop("_pending_degenerate", None)
-        if pend is not None:
-            pend.raise_if_set()
-        if flag is not None:
-            model.__dict__["_pending_degenerate"] = _AsyncFlag(flag, targets)
+        _defer_flag(model, flag, targets)
         rois, labels, reg_t, per_dev = D.select_training_samples_padded(rh, pb, pc, gt, glab, gvalid)
         S = rh.fg_bg_sampler.batch_size_per_image
         r0 = S * n0

@@ -1,0 +1,128 @@
+"""The detector half of the training step as one hipGraph replay (hallucidet_amd/det_graph.py) against the same code issued eagerly
+on the same staged inputs: losses, the gradient handed to the U-Net, the U-Net's parameter gradients after the step's backward pass
+and the three passes' detections must agree BIT FOR BIT (the graph only changes how the launches are issued), for all three
+detectors; the samplers must keep drawing fresh permutations from replay to replay; ragged target counts that change from step to
+step must reuse one graph per G bucket; and the reference's degenerate-box assertion must still fire (one call later)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W = 128, 160
+
+
+def _lit(detector_name, seed=5):
+    from hallucidet_amd import synthetic
+    return synthetic.make_module(seed=seed, device="cuda", precision=16, detector_name=detector_name)
+
+
+def _step_outputs(lit, batch, graph):
+    """One forward_step + backward at a fixed generator state; -> comparable tensors."""
+    lit.use_detector_graph = graph
+    lit.encoder_decoder.train()
+    torch.manual_seed(77)
+    imgs_rgb, targets_rgb, imgs_ir, targets_ir = batch
+    out = lit.forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, 0, step='train')
+    r = lit.encoder_decoder.runner
+    r.flat_grads.zero_()
+    lit.scaler.scale(out['loss']['total']).backward()
+    dets = lit._last_detections
+    got = {"total": out['loss']['total'].detach().clone(), "grads": r.flat_grads.clone()}
+    for k in ('det_regression', 'det_classification', 'det_objectness', 'det_rpn_box_reg', 'det_bbox_ctrness'):
+        v = out['loss'][k]
+        got[k] = v.detach().clone() if torch.is_tensor(v) else torch.tensor(float(v))
+    for name in ("hall", "rgb", "ir"):
+        for i, d in enumerate(dets[name]):
+            for kk in ("boxes", "scores", "labels"):
+                got["%s%d_%s" % (name, i, kk)] = d[kk].clone()
+    torch.cuda.synchronize()
+    return got
+
+
+@pytest.mark.parametrize("detector_name", ["fasterrcnn", "retinanet", "fcos"])
+def test_replay_equals_eager_bit_for_bit(detector_name):
+    from hallucidet_amd import synthetic
+    lit = _lit(detector_name)
+    batch = synthetic.make_batch(2, H, W, seed=9, device="cuda")
+    _step_outputs(lit, batch, graph=True)               # captures (after two eager warm-up runs that advance the generator), then replays
+    g = lit._detector_graph()
+    assert g is not None and g.usable and g.captures == 1 and g.replays == 1
+    b = _step_outputs(lit, batch, graph=True)           # a pure replay from the seeded generator state
+    assert g.captures == 1 and g.replays == 2
+    # eager on the same staged targets: route the section through the graph's static inputs without replaying
+    e = next(iter(g.entries.values()))
+    lit.use_detector_graph = False
+    lit.encoder_decoder.train()
+    torch.manual_seed(77)
+    imgs_rgb, targets_rgb, imgs_ir, targets_ir = batch
+    ir3 = imgs_ir.expand(-1, 3, -1, -1)
+    hall = lit.encoder_decoder(ir3)
+    N = hall.shape[0]
+    t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i]} for i in range(2 * N)]
+    losses, total, dets = lit._detector_section(hall, imgs_rgb, ir3, t[N:], t[:N], 'train', False)
+    r = lit.encoder_decoder.runner
+    r.flat_grads.zero_()
+    lit.scaler.scale(total).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(total, b["total"]), (float(total), float(b["total"]))
+    assert torch.isfinite(r.flat_grads).all() and float(r.flat_grads.abs().max()) > 0
+    assert torch.equal(r.flat_grads, b["grads"])
+    for name, dd in zip(("hall", "rgb", "ir"), dets):
+        for i, d in enumerate(dd):
+            for kk in ("boxes", "scores", "labels"):
+                assert torch.equal(d[kk], b["%s%d_%s" % (name, i, kk)]), (name, i, kk)
+    for k, kk in (("bbox_regression", "det_regression"), ("classification", "det_classification")):
+        assert torch.equal(losses[k], b[kk])
+
+
+def test_sampler_draws_change_from_replay_to_replay_and_counts_share_a_graph():
+    from hallucidet_amd import synthetic
+    lit = _lit("fasterrcnn")
+    b1 = synthetic.make_batch(2, H, W, seed=9, device="cuda")
+    b2 = synthetic.make_batch(2, H, W, seed=10, device="cuda")          # other images, other box counts (1-8 per image: one G bucket)
+    lit.encoder_decoder.train()
+    lit.forward_step(b1[0], b1[1], b1[2], b1[3], 0, step='train')      # capture (its warm-up runs advance the generator)
+    torch.manual_seed(3)
+    tot = []
+    for b in (b1, b1, b2, b1):
+        out = lit.forward_step(b[0], b[1], b[2], b[3], 0, step='train')
+        tot.append(float(out['loss']['total'].detach()))
+    g = lit._detector_graph()
+    assert g.captures == 1 and g.replays == 5
+    # same batch, same weights, consecutive replays: the RoI / RPN samplers drew different subsets
+    assert tot[0] != tot[1] and tot[1] != tot[3]
+    # ... and a reseeded generator reproduces the sequence exactly
+    torch.manual_seed(3)
+    again = [float(lit.forward_step(b[0], b[1], b[2], b[3], 0, step='train')['loss']['total'].detach()) for b in (b1, b1, b2, b1)]
+    assert again == tot
+
+
+def test_more_boxes_than_the_bucket_captures_a_second_graph_and_loss_scale_changes_do_not():
+    from hallucidet_amd import synthetic
+    lit = _lit("fasterrcnn")
+    b = synthetic.make_batch(2, H, W, seed=9, device="cuda")
+    lit.fit_step(b)
+    g = lit._detector_graph()
+    assert g.captures == 1
+    lit.scaler.scale_value *= 0.5                      # what an overflow does
+    lit.fit_step(b)
+    assert g.captures == 1
+    many = [dict(t) for t in b[1]]
+    many[0] = {"boxes": torch.cat([many[0]["boxes"]] * 9)[:11], "labels": torch.ones(11, dtype=torch.int64, device="cuda")}
+    lit.fit_step((b[0], many, b[2], many))
+    assert g.captures == 2 and len(g.entries) == 2
+    torch.cuda.synchronize()
+
+
+def test_degenerate_box_still_raises_one_call_later():
+    from hallucidet_amd import synthetic
+    from hallucidet_amd.utils.eval_forward_fasterrcnn import flush_degenerate
+    lit = _lit("fasterrcnn")
+    b = synthetic.make_batch(2, H, W, seed=9, device="cuda")
+    lit.fit_step(b)
+    bad = [dict(t) for t in b[3]]
+    bad[1] = {"boxes": bad[1]["boxes"].clone(), "labels": bad[1]["labels"]}
+    bad[1]["boxes"][0, 2] = bad[1]["boxes"][0, 0]                      # x2 == x1
+    lit.forward_step(b[0], b[1], b[2], bad, 0, step='train')           # issued: the flag is on its way to the host
+    with pytest.raises(AssertionError, match="All bounding boxes should have positive height and width"):
+        flush_degenerate(lit.detector, block=True)
