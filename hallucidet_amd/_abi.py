@@ -45,6 +45,12 @@ class WprepDesc(C.Structure):
                [(n, C.c_int32) for n in ("Cout", "Cin", "KH", "KW", "Cin_pad", "Cout_pad")]
 
 
+class WredDesc(C.Structure):
+    _fields_ = [("slab", C.c_void_p), ("dw_oihw", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("nsplit", "Cout_slab", "Cout", "KH", "KW", "Cin", "Cin_real", "accumulate")] + \
+               [("scale", C.c_float)] + [(n, C.c_int32) for n in ("mode", "first_block", "reserved")]
+
+
 class WgradArgs(C.Structure):
     _fields_ = [
         ("x", vp), ("x2", vp), ("dy", vp), ("slab", vp),
@@ -73,6 +79,8 @@ PROTOTYPES = {
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "hd_wgrad_tune_override": (C.c_int, [C.c_int]),
     "hd_wgrad_reduce": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
+    "hd_wgrad_reduce_plan": (C.c_int, [vp, C.c_int]),
+    "hd_wgrad_reduce_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "hd_weight_prep": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_weight_prep_multi": (C.c_int, [vp, C.c_int, C.c_int, vp]),
     "hd_colsum": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),

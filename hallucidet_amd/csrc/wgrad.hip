@@ -211,121 +211,168 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab, int Cout,
-                                    int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
-  // one thread per 4 consecutive slab elements (co, kk..kk+3; kk = t*Cin + ci, Cin % 8 == 0 so the four share a tap):
-  // 16-byte coalesced slab reads (the bulk of the traffic: nsplit x |W|), four independent accumulators, strided OIHW
-  // writes (|W| once)
-  const int taps = KH * KW;
-  const int64_t Ktot = (int64_t)taps * Cin;
-  const int64_t total4 = (int64_t)Cout * Ktot / 4;
-  const size_t sstride = (size_t)Cout_slab * Ktot;
-  for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t i = i4 * 4;
-    const int co = (int)(i / Ktot);
-    const int kk = (int)(i - (int64_t)co * Ktot);
-    const int t = kk / Cin;
-    const int ci = kk - t * Cin;
-    const float* s = slab + i;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int k = 0;
-    for (; k + 4 <= nsplit; k += 4) {
-      f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 0) * sstride);
-      f32x4 a1 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 1) * sstride);
-      f32x4 a2 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 2) * sstride);
-      f32x4 a3 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 3) * sstride);
-      acc += (a0 + a1) + (a2 + a3);
-    }
-    for (; k < nsplit; ++k) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * sstride);
+// ---- slab reduction.  Geometry of one weight tensor (also one entry of hd_wgrad_reduce_multi's table):
+struct RedG {
+  const float* __restrict__ slab;
+  float* __restrict__ dw;
+  int nsplit, Cout, KH, KW, Cin, Cin_real, accumulate;
+  float scale;
+  int64_t Ktot, total4;
+  size_t sstride;
+};
+
+__device__ __forceinline__ RedG make_redg(const float* slab, float* dw, int nsplit, int Cout_slab, int Cout, int KH, int KW, int Cin, int Cin_real,
+                                          float scale, int accumulate) {
+  RedG g;
+  g.slab = slab; g.dw = dw; g.nsplit = nsplit; g.Cout = Cout; g.KH = KH; g.KW = KW; g.Cin = Cin; g.Cin_real = Cin_real;
+  g.accumulate = accumulate; g.scale = scale;
+  g.Ktot = (int64_t)KH * KW * Cin;
+  g.total4 = (int64_t)Cout * g.Ktot / 4;
+  g.sstride = (size_t)Cout_slab * g.Ktot;
+  return g;
+}
+
+// the four sums of quad i4 (slab elements (co, kk..kk+3); kk = t*Cin + ci, Cin % 8 == 0 so the four share a tap) -> OIHW
+__device__ __forceinline__ void red_store(const RedG& g, int64_t i4, f32x4 acc) {
+  const int64_t i = i4 * 4;
+  const int taps = g.KH * g.KW;
+  const int co = (int)(i / g.Ktot);
+  const int kk = (int)(i - (int64_t)co * g.Ktot);
+  const int t = kk / g.Cin;
+  const int ci = kk - t * g.Cin;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (ci + u >= Cin_real) continue;
-      const size_t o = ((size_t)co * Cin_real + ci + u) * taps + t;
-      const float v = acc[u] * scale;
-      dw[o] = accumulate ? dw[o] + v : v;
-    }
+  for (int u = 0; u < 4; ++u) {
+    if (ci + u >= g.Cin_real) continue;
+    const size_t o = ((size_t)co * g.Cin_real + ci + u) * taps + t;
+    const float v = acc[u] * g.scale;
+    g.dw[o] = g.accumulate ? g.dw[o] + v : v;
   }
 }
 
-// Same reduction for SMALL weight tensors with MANY splits (the 16/32-channel full-resolution layers: 2 304 - 9 216
-// weights, 128 - 768 pixel splits): one WAVE per 4 consecutive slab elements, lane l sums the splits l, l+64, ...,
-// then a shuffle tree (fixed order: deterministic).  The one-thread-per-element form above walks all the splits in
-// one dependent chain there: 45 - 67 us per launch for a few KB of output.
-__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab,
-                                                                int Cout, int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
-  const int taps = KH * KW;
-  const int64_t Ktot = (int64_t)taps * Cin;
-  const int64_t total4 = (int64_t)Cout * Ktot / 4;
-  const size_t sstride = (size_t)Cout_slab * Ktot;
-  const int lane = threadIdx.x & 63;
-  const int64_t i4 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i4 >= total4) return;
-  const int64_t i = i4 * 4;
-  const float* s = slab + i;
+// one thread per quad: 16-byte coalesced slab reads (the bulk of the traffic: nsplit x |W|), four independent accumulators,
+// strided OIHW writes (|W| once)
+__device__ __forceinline__ void red_plain(const RedG& g, int64_t i4) {
+  const float* s = g.slab + i4 * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = lane; k < nsplit; k += 64) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * sstride);
+  int k = 0;
+  for (; k + 4 <= g.nsplit; k += 4) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 0) * g.sstride);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 1) * g.sstride);
+    f32x4 a2 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 2) * g.sstride);
+    f32x4 a3 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 3) * g.sstride);
+    acc += (a0 + a1) + (a2 + a3);
+  }
+  for (; k < g.nsplit; ++k) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * g.sstride);
+  red_store(g, i4, acc);
+}
+
+// SMALL weight tensors with MANY splits (the 16/32-channel full-resolution layers: 2 304 - 9 216 weights, 128 - 768 pixel
+// splits): one WAVE per quad, lane l sums the splits l, l+64, ..., then a shuffle tree (fixed order: deterministic).  The
+// one-thread-per-quad form walks all the splits in one dependent chain there: 45 - 67 us per launch for a few KB of output.
+__device__ __forceinline__ void red_wave(const RedG& g, int64_t i4, int lane) {
+  const float* s = g.slab + i4 * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = lane; k < g.nsplit; k += 64) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * g.sstride);
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] += __shfl_xor(acc[u], d);
   }
-  if (lane == 0) {
-    const int co = (int)(i / Ktot);
-    const int kk = (int)(i - (int64_t)co * Ktot);
-    const int t = kk / Cin;
-    const int ci = kk - t * Cin;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      if (ci + u >= Cin_real) continue;
-      const size_t o = ((size_t)co * Cin_real + ci + u) * taps + t;
-      const float v = acc[u] * scale;
-      dw[o] = accumulate ? dw[o] + v : v;
-    }
-  }
+  if (lane == 0) red_store(g, i4, acc);
 }
 
 // Split-parallel form for weight tensors whose one-thread-per-quad grid is small while the split chains are long (the 64- and
-// 128-channel 3x3 layers behind the 8-wave weight gradient: 9 216 / 36 864 quads x 256 / 64 splits): a block owns 64
-// CONSECUTIVE quads (every wave-load is 1 KiB of one slice, contiguous) and its G waves each walk every G-th slice, four loads in
-// flight; the G partials are added through LDS in wave order (deterministic).
+// 128-channel 3x3 layers behind the 8-wave weight gradient: 9 216 / 36 864 quads x 256 / 64 splits): a group of G waves owns 64
+// CONSECUTIVE quads (every wave-load is 1 KiB of one slice, contiguous), wave w of the group walks the slices w, w+G, ..., four
+// loads in flight; the G partials are added through LDS in wave order (deterministic).  `part` = the group's [G][64] LDS rows;
+// contains a __syncthreads(): every thread of the block must call it.
 template <int G>
-__global__ __launch_bounds__(64 * G) void wgrad_reduce_split_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab,
-                                                                    int Cout, int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
-  __shared__ f32x4 part[G][64];
-  const int taps = KH * KW;
-  const int64_t Ktot = (int64_t)taps * Cin;
-  const int64_t total4 = (int64_t)Cout * Ktot / 4;
-  const size_t sstride = (size_t)Cout_slab * Ktot;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int64_t i4 = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = i4 < total4;
-  const int64_t i = (live ? i4 : 0) * 4;
-  const float* s = slab + i;
+__device__ __forceinline__ void red_split(const RedG& g, int64_t i4, bool live, int w, int lane, f32x4 (*part)[64]) {
+  const float* s = g.slab + (live ? i4 : 0) * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   int k = w;
-  for (; k + 3 * G < nsplit; k += 4 * G) {
-    f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 0 * G) * sstride);
-    f32x4 a1 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 1 * G) * sstride);
-    f32x4 a2 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 2 * G) * sstride);
-    f32x4 a3 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 3 * G) * sstride);
-    acc += (a0 + a1) + (a2 + a3);
+  if (live) {
+    for (; k + 3 * G < g.nsplit; k += 4 * G) {
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 0 * G) * g.sstride);
+      f32x4 a1 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 1 * G) * g.sstride);
+      f32x4 a2 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 2 * G) * g.sstride);
+      f32x4 a3 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 3 * G) * g.sstride);
+      acc += (a0 + a1) + (a2 + a3);
+    }
+    for (; k < g.nsplit; k += G) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * g.sstride);
   }
-  for (; k < nsplit; k += G) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * sstride);
   part[w][lane] = acc;
   __syncthreads();
   if (w != 0 || !live) return;
 #pragma unroll
-  for (int g = 1; g < G; ++g) acc += part[g][lane];
-  const int co = (int)(i / Ktot);
-  const int kk = (int)(i - (int64_t)co * Ktot);
-  const int t = kk / Cin;
-  const int ci = kk - t * Cin;
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    if (ci + u >= Cin_real) continue;
-    const size_t o = ((size_t)co * Cin_real + ci + u) * taps + t;
-    const float v = acc[u] * scale;
-    dw[o] = accumulate ? dw[o] + v : v;
+  for (int q = 1; q < G; ++q) acc += part[q][lane];
+  red_store(g, i4, acc);
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab, int Cout,
+                                    int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
+  const RedG g = make_redg(slab, dw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
+  for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < g.total4; i4 += (int64_t)gridDim.x * blockDim.x) red_plain(g, i4);
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_wave_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab,
+                                                                int Cout, int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
+  const RedG g = make_redg(slab, dw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
+  const int64_t i4 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i4 < g.total4) red_wave(g, i4, threadIdx.x & 63);
+}
+
+template <int G>
+__global__ __launch_bounds__(64 * G) void wgrad_reduce_split_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab,
+                                                                    int Cout, int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
+  __shared__ f32x4 part[G][64];
+  const RedG g = make_redg(slab, dw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t i4 = (int64_t)blockIdx.x * 64 + lane;
+  red_split<G>(g, i4, i4 < g.total4, w, lane, part);
+}
+
+// which form hd_wgrad_reduce picks for a tensor: 0 plain, 1 wave, 4 / 8 / 16 = split with that many waves per 64 quads
+__host__ __device__ inline int red_mode(int64_t total4, int nsplit, bool split_on) {
+  if (split_on && total4 >= 4096 && total4 <= 65536 && nsplit >= 16) {
+    const int64_t blocks = (total4 + 63) / 64;
+    return (nsplit >= 128 && blocks <= 256) ? 16 : (nsplit >= 32 && blocks <= 1024) ? 8 : 4;
+  }
+  return (total4 <= 16384 && nsplit >= 64) ? 1 : 0;
+}
+
+// Every weight tensor of a backward segment in ONE launch (hd_wgrad_reduce_multi): blocks [first_block, first_block + blocks) of
+// the 1-D grid belong to table entry e and run the SAME form, in the same summation order, as hd_wgrad_reduce would for that tensor
+// alone (bit-identical results).  1024 threads: 1024 quads (plain), 16 quads (wave) or 16 / G groups of 64 quads (split) per block.
+// 47 separate reductions per training step were 0.48 ms, much of it the ~4.5 us floor of a launch that moves a few KB.
+struct WredTab {
+  hd_wred_desc d[HD_WRED_MAX];       // by value in the kernel arguments (1 KB): no table in device memory, nothing to keep alive
+};
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const WredTab tab, int n) {
+  __shared__ f32x4 part[16][64];
+  int e = 0;
+  for (int i = 1; i < n; ++i)
+    if ((int)blockIdx.x >= tab.d[i].first_block) e = i;
+  const hd_wred_desc& d = tab.d[e];
+  const RedG g = make_redg(d.slab, d.dw_oihw, d.nsplit, d.Cout_slab, d.Cout, d.KH, d.KW, d.Cin, d.Cin_real, d.scale, d.accumulate);
+  const int64_t b = (int64_t)blockIdx.x - d.first_block;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (d.mode == 0) {
+    const int64_t i4 = b * 1024 + threadIdx.x;
+    if (i4 < g.total4) red_plain(g, i4);
+  } else if (d.mode == 1) {
+    const int64_t i4 = b * 16 + wave;
+    if (i4 < g.total4) red_wave(g, i4, lane);
+  } else if (d.mode == 16) {
+    const int64_t i4 = b * 64 + lane;
+    red_split<16>(g, i4, i4 < g.total4, wave, lane, part);
+  } else if (d.mode == 8) {
+    const int64_t i4 = (b * 2 + (wave >> 3)) * 64 + lane;
+    red_split<8>(g, i4, i4 < g.total4, wave & 7, lane, part + (wave >> 3) * 8);
+  } else {
+    const int64_t i4 = (b * 4 + (wave >> 2)) * 64 + lane;
+    red_split<4>(g, i4, i4 < g.total4, wave & 3, lane, part + (wave >> 2) * 4);
   }
 }
 
@@ -533,33 +580,62 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   return HD_OK;
 }
 
+static bool red_split_on() {
+  static const int on = getenv("HD_WGRAD_REDUCE_SPLIT") ? atoi(getenv("HD_WGRAD_REDUCE_SPLIT")) : 1;
+  return on != 0;
+}
+
 extern "C" int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW, int Cin,
                                int Cin_real, float scale, int accumulate, void* stream) {
   HD_CHECK_ARG(slab && dw_oihw && nsplit >= 1 && Cout <= Cout_slab && Cin_real <= Cin, "hd_wgrad_reduce: bad args");
   int64_t total = (int64_t)Cout * Cin * KH * KW / 4;
   int g = (int)((total + 255) / 256);
   if (g > 8192) g = 8192;
-  static const int split_on = getenv("HD_WGRAD_REDUCE_SPLIT") ? atoi(getenv("HD_WGRAD_REDUCE_SPLIT")) : 1;
-  if (split_on && total >= 4096 && total <= 65536 && nsplit >= 16) {      // see wgrad_reduce_split_kernel
+  hipStream_t st = (hipStream_t)stream;
+  const int mode = red_mode(total, nsplit, red_split_on());
+  if (mode >= 4) {
     const int blocks = (int)((total + 63) / 64);
-    hipStream_t st = (hipStream_t)stream;
-    if (nsplit >= 128 && blocks <= 256)
+    if (mode == 16)
       hipLaunchKernelGGL((wgrad_reduce_split_kernel<16>), dim3(blocks), dim3(1024), 0, st, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
-    else if (nsplit >= 32 && blocks <= 1024)
+    else if (mode == 8)
       hipLaunchKernelGGL((wgrad_reduce_split_kernel<8>), dim3(blocks), dim3(512), 0, st, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
     else
       hipLaunchKernelGGL((wgrad_reduce_split_kernel<4>), dim3(blocks), dim3(256), 0, st, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
-    HD_CHECK_LAUNCH();
-    return HD_OK;
-  }
-  if (total <= 16384 && nsplit >= 64) {      // few outputs, long split chains: one wave per float4 (see wgrad_reduce_wave_kernel)
-    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab,
+  } else if (mode == 1) {      // few outputs, long split chains: one wave per quad
+    hipLaunchKernelGGL(wgrad_reduce_wave_kernel, dim3((int)((total + 3) / 4)), dim3(256), 0, st, slab, dw_oihw, nsplit, Cout_slab,
                        Cout, KH, KW, Cin, Cin_real, scale, accumulate);
-    HD_CHECK_LAUNCH();
-    return HD_OK;
+  } else {
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, st, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
   }
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, slab, dw_oihw, nsplit, Cout_slab, Cout, KH, KW, Cin,
-                     Cin_real, scale, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_wgrad_reduce_plan(hd_wred_desc* table_host, int n) {
+  if (!table_host || n <= 0 || n > HD_WRED_MAX) { hd_set_error("hd_wgrad_reduce_plan: bad args"); return HD_E_ARG; }
+  int64_t first = 0;
+  for (int i = 0; i < n; ++i) {
+    hd_wred_desc& d = table_host[i];
+    if (!(d.slab && d.dw_oihw && d.nsplit >= 1 && d.Cout <= d.Cout_slab && d.Cin_real <= d.Cin && d.Cin % 8 == 0)) {
+      hd_set_error("hd_wgrad_reduce_plan: bad entry");
+      return HD_E_ARG;
+    }
+    const int64_t total = (int64_t)d.Cout * d.Cin * d.KH * d.KW / 4;
+    d.mode = red_mode(total, d.nsplit, red_split_on());
+    const int64_t per = d.mode == 0 ? 1024 : d.mode == 1 ? 16 : 64 * (16 / d.mode);
+    d.first_block = (int32_t)first;
+    first += (total + per - 1) / per;
+    if (first > 0x7fffffff) { hd_set_error("hd_wgrad_reduce_plan: grid too large"); return HD_E_ARG; }
+  }
+  return (int)first;
+}
+
+extern "C" int hd_wgrad_reduce_multi(const hd_wred_desc* table_host, int n, int total_blocks, void* stream) {
+  HD_CHECK_ARG(table_host && n > 0 && n <= HD_WRED_MAX && total_blocks > 0, "hd_wgrad_reduce_multi: bad args");
+  WredTab tab;
+  for (int i = 0; i < n; ++i) tab.d[i] = table_host[i];
+  for (int i = n; i < HD_WRED_MAX; ++i) tab.d[i] = table_host[n - 1];
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(total_blocks), dim3(1024), 0, (hipStream_t)stream, tab, n);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -175,6 +175,42 @@ def weight_prep(w_oihw, *, out_scale=None, cin_pad=None, cout_pad=None, want_fwd
     return wf, wd
 
 
+class WgradReduceBatch:
+    """Deferred hd_wgrad_reduce calls of one backward segment, issued as ONE launch per 16 tensors (hd_wgrad_reduce_multi): `add()`
+    has the signature of `wgrad_reduce` and keeps the slab alive until `flush()`, which plans the grid on the host and launches
+    (the descriptor table travels in the kernel arguments: capture-safe, nothing to keep alive afterwards).  Per-tensor summation
+    order = hd_wgrad_reduce's: bit-identical results."""
+    MAX = 16      # HD_WRED_MAX
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, slab, dw, KH, KW, Cin, Cin_real=None, Cout=None, scale=1.0, accumulate=False):
+        _need_cuda(slab, dw)
+        nsplit, Cout_slab, K = slab.shape
+        Cout = Cout_slab if Cout is None else Cout
+        Cin_real = Cin if Cin_real is None else Cin_real
+        assert dw.numel() == Cout * Cin_real * KH * KW and dw.dtype == torch.float32 and dw.is_contiguous()
+        self.items.append((slab, dw, (nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, 1 if accumulate else 0, float(scale))))
+
+    def flush(self):
+        from ._abi import WredDesc
+        lib = _abi.load()
+        items, self.items = self.items, []
+        for lo in range(0, len(items), self.MAX):
+            part = items[lo:lo + self.MAX]
+            n = len(part)
+            if n == 1:
+                slab, dw, a = part[0]
+                check(lib.hd_wgrad_reduce(ptr(slab), ptr(dw), *a[:7], a[8], a[7], _stream()), "hd_wgrad_reduce")
+                continue
+            arr = (WredDesc * n)(*[WredDesc(slab.data_ptr(), dw.data_ptr(), *a[:8], a[8], 0, 0, 0) for slab, dw, a in part])
+            blocks = lib.hd_wgrad_reduce_plan(C.cast(arr, C.c_void_p), n)
+            if blocks <= 0:
+                check(blocks if blocks < 0 else -1, "hd_wgrad_reduce_plan")
+            check(lib.hd_wgrad_reduce_multi(C.cast(arr, C.c_void_p), n, blocks, _stream()), "hd_wgrad_reduce_multi")
+
+
 class WeightPrepPlan:
     """All (fp32 master -> fp16 GEMM layouts) conversions of a network as ONE launch: persistent output buffers and a
     device-resident descriptor table built once; `run()` re-packs every layer (hd_weight_prep_multi)."""

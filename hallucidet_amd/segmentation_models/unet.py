@@ -164,6 +164,8 @@ def initialize_head(module):
                 nn.init.constant_(m.bias, 0)
 
 
+_WRED_MULTI = os.environ.get("HD_WRED_MULTI", "1") != "0"     # A/B knob: one slab-reduction launch per backward segment
+
 _ENCODERS = {
     "resnet18": dict(layers=(2, 2, 2, 2), out_channels=(3, 64, 64, 128, 256, 512)),
     "resnet34": dict(layers=(3, 4, 6, 3), out_channels=(3, 64, 64, 128, 256, 512)),
@@ -247,6 +249,7 @@ class UnetRunner:
         # overlaps the kernels of segment k+1).
         self.bucket_hook = None
         self._cut = None
+        self._red = None
         enc, dec = module.encoder, module.decoder
         self.stem = _Unit("encoder.conv1", enc.conv1, enc.bn1)
         self.stages = []
@@ -352,8 +355,18 @@ class UnetRunner:
             hi = lo
         return out
 
+    def _reduce(self, slab, dw, KH, KW, Cin, **kw):
+        """hd_wgrad_reduce of one conv's slab: deferred to the end of the backward segment, where all of the segment's weight
+        tensors are summed in ONE launch (ops.WgradReduceBatch; HD_WRED_MULTI=0: one launch per conv, as before)."""
+        if self._red is None:
+            ops.wgrad_reduce(slab, dw, KH, KW, Cin, **kw)
+        else:
+            self._red.add(slab, dw, KH, KW, Cin, **kw)
+
     def _segment_done(self, k):
         """Called by backward() at segment boundary k (0 = decoder + head done, 1..3 = layer4..layer2, 4 = everything)."""
+        if self._red is not None:
+            self._red.flush()                   # the segment's gradients are final only after this launch
         if self._cut is not None:
             self._cut(k)
         elif self.bucket_hook is not None:
@@ -566,7 +579,7 @@ class UnetRunner:
         xt, isc, ish, irelu = _operand(r["x"])
         slab = ops.wgrad(xt, dy, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"],
                          **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
-        ops.wgrad_reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
+        self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
         dx = None
         if need_dx:
             wd = self.saved["W"][u.name][1]
@@ -586,13 +599,14 @@ class UnetRunner:
         inv = 1.0 / S
         N, H, Wd = sv["shape"]
         hc = self.head_conv
+        self._red = ops.WgradReduceBatch() if _WRED_MULTI else None
         # head: sigmoid' then conv backward
         dl = ops.sigmoid_bwd_nchw_to_nhwc(dout.float(), sv["out"], 8, 1.0)
         db = ops.channel_sum(dl)
         ops.scale_store(db, hc.bias.grad, inv, accumulate=False)
         ht, isc, ish, irelu = _operand(sv["head_in"])
         slab = ops.wgrad(ht, dl, 3, 3, pad=1, **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
-        ops.wgrad_reduce(slab, hc.weight.grad, 3, 3, hc.in_channels, Cout=hc.out_channels, scale=inv)
+        self._reduce(slab, hc.weight.grad, 3, 3, hc.in_channels, Cout=hc.out_channels, scale=inv)
         dz = ops.conv2d(dl, sv["W"]["head"][1], 3, 3, pad=1, cout=hc.in_channels)
         # decoder, last block first
         feats = sv["feats"]

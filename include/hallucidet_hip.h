@@ -142,6 +142,22 @@ int hd_wgrad_tune_override(int tm);
 int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW,
                     int Cin, int Cin_real, float scale, int accumulate, void* stream);
 
+/* Every weight tensor of a backward segment reduced in ONE launch (src/segmentation_models: one hd_wgrad slab per conv of
+ * decoder / layer4 / ... / stem, 47 per training step).  Entries mean what hd_wgrad_reduce's arguments mean; `mode` and
+ * `first_block` are filled by hd_wgrad_reduce_plan (host side, no GPU work), which returns the grid size.  The table lives in
+ * HOST memory (n <= HD_WRED_MAX entries) and travels in the launch's kernel arguments.  Each tensor is summed in the same
+ * order as hd_wgrad_reduce would sum it alone: results are bit-identical. */
+#define HD_WRED_MAX 16
+typedef struct hd_wred_desc {
+  const float* slab;
+  float* dw_oihw;
+  int32_t nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, accumulate;
+  float scale;
+  int32_t mode, first_block, reserved;
+} hd_wred_desc;
+int hd_wgrad_reduce_plan(hd_wred_desc* table_host, int n);      /* -> total blocks (> 0) or a negative status */
+int hd_wgrad_reduce_multi(const hd_wred_desc* table_host, int n, int total_blocks, void* stream);
+
 /* one descriptor per layer for hd_weight_prep_multi (device-resident table; same meaning as hd_weight_prep's arguments,
  * no output scale) */
 typedef struct hd_wprep_desc {

@@ -912,3 +912,36 @@ def test_consumer_side_batchnorm_is_bit_identical_to_bn_apply_then_conv(dev, cin
     w64 = torch.randn(64, 9 * 64, device=dev).half()
     with pytest.raises(Exception, match="consumer-side BatchNorm"):
         ops.conv2d(x64, w64, 3, 3, pad=1, in_scale=torch.ones(64, device=dev), in_shift=torch.zeros(64, device=dev))
+
+
+def test_wgrad_reduce_multi_is_bit_identical_to_separate_reductions():
+    """hd_wgrad_reduce_multi (every weight tensor of a backward segment in one launch) against hd_wgrad_reduce per tensor: all five
+    reduction forms (plain, one wave per quad, split x4 / x8 / x16), channel padding dropped, Cout < Cout_slab, accumulate."""
+    from hallucidet_amd import ops
+    torch.manual_seed(0)
+    dev = "cuda"
+    # (nsplit, Cout_slab, Cout, k, Cin, Cin_real, accumulate)
+    shapes = [(3, 512, 512, 3, 512, 512, False),      # plain: few slices, large tensor
+              (768, 16, 16, 3, 16, 16, False),         # wave: 576 quads x 768 slices
+              (256, 64, 64, 3, 64, 64, False),         # split x16 (9 216 quads)
+              (64, 128, 128, 3, 128, 128, False),      # split x8 (36 864 quads)
+              (16, 128, 128, 3, 64, 64, False),        # split x4
+              (5, 64, 64, 7, 8, 3, False),             # stem: 3 real input channels of 8
+              (256, 32, 24, 3, 128, 128, True),        # Cout < Cout_slab, accumulate
+              (1, 8, 3, 3, 16, 16, False)]             # head: 3 of 8 rows, a single slice
+    slabs, outs_a, outs_b = [], [], []
+    batch = ops.WgradReduceBatch()
+    for ns, cs, co, k, ci, cir, acc in shapes:
+        slab = torch.randn(ns, cs, k * k * ci, device=dev)
+        base = torch.randn(co, cir, k, k, device=dev)
+        a, b = base.clone(), base.clone()
+        ops.wgrad_reduce(slab, a, k, k, ci, Cin_real=cir, Cout=co, scale=0.37, accumulate=acc)
+        batch.add(slab, b, k, k, ci, Cin_real=cir, Cout=co, scale=0.37, accumulate=acc)
+        slabs.append(slab); outs_a.append(a); outs_b.append(b)
+    batch.flush()
+    torch.cuda.synchronize()
+    for (ns, cs, co, k, ci, cir, acc), slab, a, b in zip(shapes, slabs, outs_a, outs_b):
+        assert torch.equal(a, b), (ns, cs, co, k, ci)
+        ref = slab.double().sum(0)[:co].reshape(co, k * k, ci)[:, :, :cir].permute(0, 2, 1).reshape(co, cir, k, k) * 0.37
+        if not acc:
+            assert torch.allclose(a.double(), ref, rtol=1e-4, atol=1e-3 * (ns ** 0.5))

@@ -8,7 +8,7 @@ import sys
 
 def main():
     path = sys.argv[1]
-    skip = float(sys.argv[2]) if len(sys.argv) > 2 else 0.5
+    skip = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 0.5
     rows = []
     for r in csv.DictReader(open(path)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
@@ -30,6 +30,29 @@ def main():
     names = ["<0.5us", "0.5-1", "1-2", "2-4", "4-10", ">10us"]
     for b in sorted(hist):
         print("  gap %-7s %6d launches  %8.3f ms" % (names[b], hist[b][0], hist[b][1] / 1e6))
+    # steady-state per-step table (the window holds whole steps only: from one adam_kernel to the last)
+    ends = [i for i, r in enumerate(rows) if "adam_kernel" in r[2]]
+    if len(ends) >= 2:
+        win = rows[ends[0] + 1:ends[-1] + 1]
+        nsteps = len(ends) - 1
+        per = {}
+        for s_, e_, n in win:
+            k = n.replace("(anonymous namespace)::", "").replace("void ", "")
+            per.setdefault(k, [0, 0])
+            per[k][0] += 1
+            per[k][1] += e_ - s_
+        tot = sum(v[1] for v in per.values())
+        aten = sum(v[1] for k, v in per.items() if "at::" in k or "rocclr" in k)
+        naten = sum(v[0] for k, v in per.items() if "at::" in k or "rocclr" in k)
+        print("steady state: %d steps, %.1f launches/step, kernel time %.3f ms/step, wall %.3f ms/step; ATen+copy %.1f launches, %.1f us per step"
+              % (nsteps, len(win) / nsteps, tot / nsteps / 1e6, (win[-1][1] - win[0][0]) / nsteps / 1e6, naten / nsteps, aten / nsteps / 1e3))
+        if "--aten" in sys.argv:
+            for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+                if "at::" in k or "rocclr" in k:
+                    print("  %7.1f us/step %6.1f x %7.1f us  %s" % (t / nsteps / 1e3, c / nsteps, t / c / 1e3, k[:230]))
+        if "--table" in sys.argv:
+            for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1])[:45]:
+                print("  %7.1f us/step %6.1f x %7.1f us  %s" % (t / nsteps / 1e3, c / nsteps, t / c / 1e3, k[:100]))
     agg = {}
     for g, n in gaps:
         if g >= 4000:
