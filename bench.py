@@ -510,6 +510,11 @@ def main():
             "skipped_steps": lit.optimizer.skipped_steps,       # overflow-skipped optimizer steps in the whole run (must be 0)
             "rccl_ranks": rccl_ranks,                           # dist.get_world_size() of the process group the exchange ran on
         }
+        dg = lit.__dict__.get("_det_graph")
+        # how the step was issued: the U-Net's forward / segmented backward graphs and the detector half (three passes, losses,
+        # backward to the image, post-processing) as hipGraph replays; `detector_replays` counts the timed + warm-up steps
+        out["graphs"] = {"unet": bool(lit.encoder_decoder.runner.use_graphs), "detector": bool(dg is not None and dg.usable and dg.replays > 0),
+                         "detector_captures": 0 if dg is None else dg.captures, "detector_replays": 0 if dg is None else dg.replays}
         if dist.is_initialized():
             out["allreduce"] = {"payload_bytes": int(lit.encoder_decoder.runner.flat_grads.numel()) * 4, "overlap": bool(lit.overlap_allreduce),
                                 "note": overlap_note,
