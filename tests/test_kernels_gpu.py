@@ -60,6 +60,10 @@ CONV_CASES = [
     (2, 10, 33, 8, 0, 16, 3, 1, 1, False, 0, False, False),       # Cin = 8: four taps per K step (head data gradient)
     (2, 8, 10, 32, 0, 16, 3, 1, 1, True, 0, False, False),        # nearest-2x upsampled source
     (3, 20, 64, 32, 0, 32, 3, 1, 1, False, 0, False, False),      # one tap per K step
+    # the detector's small-grid, long-K stages (56-184 tiles x 16-72 K tiles)
+    (8, 10, 10, 512, 0, 512, 3, 1, 1, False, 1, True, True),      # layer4 3x3, bias + residual + ReLU
+    (8, 10, 10, 2048, 0, 512, 1, 1, 0, False, 0, True, False),    # layer4 1x1
+    (2, 19, 19, 1024, 0, 256, 1, 1, 0, False, 1, False, False),   # layer3 1x1
 ]
 
 
@@ -945,3 +949,21 @@ def test_wgrad_reduce_multi_is_bit_identical_to_separate_reductions():
         ref = slab.double().sum(0)[:co].reshape(co, k * k, ci)[:, :, :cir].permute(0, 2, 1).reshape(co, cir, k, k) * 0.37
         if not acc:
             assert torch.allclose(a.double(), ref, rtol=1e-4, atol=1e-3 * (ns ** 0.5))
+
+
+def test_small_grid_conv_is_batch_invariant_and_run_to_run_identical(dev):
+    """Image n of a batched launch equals the same image alone, and two runs agree, bit for bit, on a small-grid long-K layer (the
+    property an in-launch split-K must keep; a ticketed split-K of the 64-deep family was built against this test, measured
+    slower on every such layer of the step -- DESIGN 6 -- and removed)."""
+    from hallucidet_amd import ops
+    x = rnd(8, 10, 10, 512, seed=1).to(dev)
+    w = rnd(512, 9 * 512, scale=1.0 / math.sqrt(9 * 512), seed=3).to(dev)
+    m = (rnd(8, 10, 10, 512, seed=7) > 0).half().to(dev)
+    a = ops.conv2d(x, w, 3, 3, pad=1, mask=m)
+    b = ops.conv2d(x, w, 3, 3, pad=1, mask=m)
+    one = ops.conv2d(x[5:6].contiguous(), w, 3, 3, pad=1, mask=m[5:6].contiguous())
+    big = ops.conv2d(torch.cat([x, x, x]), w, 3, 3, pad=1, mask=torch.cat([m, m, m]))
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    assert torch.equal(a[5:6], one)
+    assert torch.equal(big[8:16], a) and torch.equal(big[16:], a)
