@@ -13,6 +13,9 @@ STEPS=3 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write --outp
 python3 tools/pmc_mfma.py gpurun_out/pmc_mfma gpurun_out/pmc_gui gpurun_out/${R}_conv_mfma_util.json > /dev/null
 F=$(ls gpurun_out/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls gpurun_out/pmc_write/*/*counter_collection.csv | head -1)
 python3 tools/pmc_traffic.py $F $W conv_igemm_kernel,conv3x3_small_kernel,conv3x3_w8_kernel,conv_w8_kernel gpurun_out/${R}_conv_traffic.json > /dev/null
+STEPS=12 rocprofv3 --kernel-trace -d gpurun_out/trace_ss --output-format csv -- python3 tools/bench_step.py > gpurun_out/trace_ss.log 2>&1
+python3 tools/trace_gaps.py $(ls gpurun_out/trace_ss/*/*kernel_trace.csv | head -1) 0.5 --table --aten > gpurun_out/${R}_steady_state.txt 2>&1
+rm -rf gpurun_out/trace_ss
 python3 bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
 cp $(ls gpurun_out/prof_step/*/*kernel_stats.csv | head -1) gpurun_out/${R}_train_step_kernel_stats.csv
 cp $(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_kernel_stats.csv
