@@ -132,8 +132,9 @@ def conv_roofline(lit, batch, reps=5):
     import hallucidet_amd.models.detection as det_mod
     import hallucidet_amd.segmentation_models.unet as unet_mod
     r = lit.encoder_decoder.runner
-    was = r.use_graphs
+    was, was_det = r.use_graphs, lit.use_detector_graph
     r.enable_graphs(False)
+    lit.use_detector_graph = False          # the recording step is issued eagerly (a graph replay calls no Python wrapper)
     try:
         lit.fit_step(batch)
         torch.cuda.synchronize()
@@ -142,6 +143,7 @@ def conv_roofline(lit, batch, reps=5):
         ops.wgrad = orig_wg
         rr.forward, rr.backward = o_fwd, o_bwd
         r.enable_graphs(was)
+        lit.use_detector_graph = was_det
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     tot_ms, tot_fl, tot_by = 0.0, 0.0, 0.0
     roof_ms, hbm_bound = 0.0, 0                      # every launch at ITS binding roof (MFMA peak or 8 TB/s)

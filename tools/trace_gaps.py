@@ -46,6 +46,20 @@ def main():
         naten = sum(v[0] for k, v in per.items() if "at::" in k or "rocclr" in k)
         print("steady state: %d steps, %.1f launches/step, kernel time %.3f ms/step, wall %.3f ms/step; ATen+copy %.1f launches, %.1f us per step"
               % (nsteps, len(win) / nsteps, tot / nsteps / 1e6, (win[-1][1] - win[0][0]) / nsteps / 1e6, naten / nsteps, aten / nsteps / 1e3))
+        groups = [("hd_conv2d: conv_igemm", ("conv_igemm_kernel",)), ("hd_conv2d: conv3x3_w8", ("conv3x3_w8_kernel",)), ("hd_conv2d: conv3x3_small", ("conv3x3_small_kernel",)),
+                  ("weight gradients", ("wgrad_kernel", "wgrad3x3_w8_kernel", "wgrad3x3_small_kernel")), ("slab reductions", ("wgrad_reduce",)),
+                  ("BatchNorm reduce (bwd)", ("bn_bwd_reduce",)), ("BatchNorm apply (bwd)", ("bn_bwd_apply",)), ("BatchNorm apply (fwd)", ("bn_apply_kernel",)),
+                  ("BatchNorm finalize", ("bn_finalize",)), ("BatchNorm coefficients (bwd)", ("bn_bwd_coef",)),
+                  ("RoIAlign", ("roi_align",)), ("NMS", ("nms_",)), ("Adam", ("adam_kernel",)), ("weight repack", ("weight_prep",)),
+                  ("ATen + copies", ("at::", "rocclr"))]
+        print("  groups (us/step, launches/step):")
+        seen = 0.0
+        for name, pats in groups:
+            t = sum(v[1] for k, v in per.items() if any(p_ in k for p_ in pats))
+            c = sum(v[0] for k, v in per.items() if any(p_ in k for p_ in pats))
+            seen += t
+            print("    %-32s %8.1f %7.1f" % (name, t / nsteps / 1e3, c / nsteps))
+        print("    %-32s %8.1f" % ("everything else", (tot - seen) / nsteps / 1e3))
         if "--aten" in sys.argv:
             for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
                 if "at::" in k or "rocclr" in k:
