@@ -80,6 +80,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.w), 0, p.wbytes, 0x00020000);
 
   // ---- per-thread A rows
+  const bool fastdiv = p.N * HoWo < (1 << 24);          // (a parity class has fewer rows than the full output)
+  const float inv_howo = hd_rcp(HoWo), inv_wo = hd_rcp(p.Wo);
   int hb[A_LOADS], wb[A_LOADS];
   unsigned nb1[A_LOADS], nb2[A_LOADS];  // image base offsets (bytes) in x / x2
   bool rvalid[A_LOADS];
@@ -91,15 +93,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
     int n, ho, wo;
     if (p.par) {
       const int hw = p.Hc * p.Wc;
-      n = pp / hw;
+      n = fastdiv ? hd_fdiv(pp, hw, hd_rcp(hw)) : pp / hw;
       const int rem = pp - n * hw;
-      const int ii = rem / p.Wc;
+      const int ii = fastdiv ? hd_fdiv(rem, p.Wc, hd_rcp(p.Wc)) : rem / p.Wc;
       ho = 2 * ii + p.ph;
       wo = 2 * (rem - ii * p.Wc) + p.pw;
     } else {
-      n = pp / HoWo;
+      n = fastdiv ? hd_fdiv(pp, HoWo, inv_howo) : pp / HoWo;
       const int rem = pp - n * HoWo;
-      ho = rem / p.Wo;
+      ho = fastdiv ? hd_fdiv(rem, p.Wo, inv_wo) : rem / p.Wo;
       wo = rem - ho * p.Wo;
     }
     hb[i] = ho * p.stride - p.pad;

@@ -48,6 +48,19 @@ __device__ __forceinline__ unsigned long long hw_ids() {
 #define HD_TRACE(slot, expr) do {} while (0)
 #endif
 
+// a / d for 0 <= a < 2^24, d > 0 by a float reciprocal and one correction step (an integer division by a run-time divisor is ~40
+// VALU instructions; the kernels' prologue does two per operand row: 1 000-1 500 of the ~4 400 set-up clocks of a block whose whole
+// life is 20-25 k clocks on the short-K layers).  `inv` = hd_rcp(d).  Callers fall back to `/` when a may reach 2^24.
+__device__ __forceinline__ float hd_rcp(int d) { return __builtin_amdgcn_rcpf((float)d); }
+__device__ __forceinline__ int hd_fdiv(int a, int d, float inv) {
+  int q = (int)((float)a * inv);
+  int r = a - q * d;
+  q = r < 0 ? q - 1 : q;
+  r = r < 0 ? r + d : r;
+  q = r >= d ? q + 1 : q;
+  return q;
+}
+
 // Parity-class set-up (device): picks the class from blockIdx.y, shrinks M / nk to the class; returns false if this block has
 // no tile in its class.
 template <int BM, int CPT_>
@@ -67,9 +80,10 @@ __device__ __forceinline__ bool hd_par_setup(ConvP& p, int tile_m) {
 // output pixel index (in the full N x Ho x Wo image) of GEMM row `m` of this block's class
 __device__ __forceinline__ int hd_par_pixel(const ConvP& p, int m) {
   const int hw = p.Hc * p.Wc;
-  const int n = m / hw;
+  const bool fast = p.M < (1 << 24);
+  const int n = fast ? hd_fdiv(m, hw, hd_rcp(hw)) : m / hw;
   const int rem = m - n * hw;
-  const int i = rem / p.Wc;
+  const int i = fast ? hd_fdiv(rem, p.Wc, hd_rcp(p.Wc)) : rem / p.Wc;
   const int jj = rem - i * p.Wc;
   return (n * p.Ho + 2 * i + p.ph) * p.Wo + 2 * jj + p.pw;
 }

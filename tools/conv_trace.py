@@ -25,6 +25,11 @@ SHAPES = [   # name, N, H, W, Cin, Cout, KH, want_stats, override(bm,bn,bk,deep)
     ("layer4 512->512 @16x20", 8, 16, 20, 512, 512, 3, True, None),
     ("det 256->256 @75x75 x24", 24, 75, 75, 256, 256, 3, False, None),
     ("det 256->256 @38x38 x24", 24, 38, 38, 256, 256, 3, False, None),
+    ("det 64->64 3x3 @75x75 x24", 24, 75, 75, 64, 64, 3, False, None),
+    ("det 256->64 1x1 @75x75 x24", 24, 75, 75, 256, 64, 1, False, None),
+    ("det 64->256 1x1 @75x75 x24", 24, 75, 75, 64, 256, 1, False, None),
+    ("det 256->256 3x3 @19x19 x24", 24, 19, 19, 256, 256, 3, False, None),
+    ("det 1024->256 1x1 @19x19 x24", 24, 19, 19, 1024, 256, 1, False, None),
     ("layer1 as 128x64 deep", 8, 128, 160, 64, 64, 3, True, (128, 64, 64, 1)),
     ("layer1 as 64x64", 8, 128, 160, 64, 64, 3, True, (64, 64, 64, 0)),
 ]
