@@ -162,6 +162,9 @@ def load():
         raise HipLibraryMissing(
             "libhallucidet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `python hallucidet_amd/build.py`. There is no CPU fallback." % LIB_PATH)
+    # PyTorch ships its own libamdhip64: it must be the HIP runtime of the process.  Loading this library BEFORE torch would pull in
+    # the system copy, and torch's copy would then find no device ("no ROCm-capable device is detected" on the first launch).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
