@@ -21,6 +21,27 @@ from .utils.eval_forward_retinanet import eval_forward_retinanet_multi
 from .utils.eval_forward_fcos import eval_forward_fcos_multi
 
 
+class _WeightedLosses(torch.autograd.Function):
+    """(weighted = stack(losses) * w, total = weighted.sum()) with a ONE-launch backward: d total / d loss_i = w_i, so the incoming
+    gradients become one vector and the per-loss gradients are views of it.  Autograd's own backward of stack / mul / sum is seven
+    launches of ~5 us each inside a GPU-bound step (train_hallucidet.py:193-210 has one scalar kernel per key and per '+')."""
+
+    @staticmethod
+    def forward(ctx, wvec, *vals):
+        weighted = torch.stack(vals) * wvec
+        ctx.save_for_backward(wvec)
+        ctx.set_materialize_grads(False)          # an unused output arrives as None, not as a zero tensor to add
+        return weighted, weighted.sum()
+
+    @staticmethod
+    def backward(ctx, g_weighted, g_total):
+        wvec, = ctx.saved_tensors
+        if g_weighted is None and g_total is None:
+            return (None,) * (1 + wvec.shape[0])
+        g = wvec * g_total if g_weighted is None else (wvec * g_weighted if g_total is None else wvec * (g_weighted + g_total))
+        return (None,) + tuple(g[i] for i in range(g.shape[0]))
+
+
 class EncoderDecoderLit(nn.Module):
     def __init__(self, batch_size=4, wandb_logger=None, model_name='resnet34', in_channels=3, output_channels=3, lr=0.0001,
                  loss_pixel=None, loss_perceptual=None, detector_name='fasterrcnn', train_det=False, fuse_data='none',
@@ -136,13 +157,13 @@ class EncoderDecoderLit(nn.Module):
         wvec = self._wvec_cache.get(wkey) if hasattr(self, "_wvec_cache") else None
         if wvec is None:
             self.__dict__.setdefault("_wvec_cache", {})[wkey] = wvec = torch.tensor(wkey[0], dtype=torch.float32, device=vals[0].device)
-        weighted = torch.stack([v.reshape(()).float() for v in vals]) * wvec
+        weighted, total = _WeightedLosses.apply(wvec, *[v.reshape(()).float() for v in vals])
         for i, (k, _) in enumerate(keys):
             losses_det[k] = weighted[i]
         for k in ('loss_objectness', 'loss_rpn_box_reg', 'bbox_ctrness'):
             if not any(k == kk for kk, _ in keys):
                 losses_det[k] = 0.0
-        return losses_det, weighted.sum(), (detections_hall, detections_rgb, detections_ir)
+        return losses_det, total, (detections_hall, detections_rgb, detections_ir)
 
     def _loss_keys(self):
         frcnn, fcos_ = 'fasterrcnn' in self.detector_name, 'fcos' in self.detector_name
