@@ -602,7 +602,7 @@ def _batched_nms_pick(boxes, scores, idxs, valid, iou_thr, top_n):
     if not boxes.is_cuda:
         order, sel, counts = _batched_nms_padded(boxes, scores, idxs, valid, iou_thr, top_n)
         return torch.gather(order, 1, _front(sel, top_n)), counts
-    key = torch.where(valid, scores, torch.full_like(scores, float("-inf")))
+    key = torch.where(valid, scores, float("-inf"))            # (scalar `other`: one launch, no full_like)
     n = key.shape[1]
     if n <= 4096 and key.dtype == torch.float32:
         # full descending stable order of every row by the radix-select + in-LDS sort kernel (one launch; rocprim's segmented radix sort
@@ -1369,7 +1369,7 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
     # function is injected (parity tests), whose per-image loop needs the counts on the host anyway
     pos_sel, neg_sel, picked = _sample_batched(rpn.fg_bg_sampler, lab, host_counts=False)
     if n_loss is not None and n_loss < N:
-        keep_img = (torch.arange(N, device=labels.device) < n_loss)[:, None]
+        keep_img = _const_mask(N, n_loss, labels.device)
         pos_sel, neg_sel = pos_sel & keep_img, neg_sel & keep_img
         picked = picked[:n_loss]
     n_sampled = picked.sum() if torch.is_tensor(picked) else sum(a + b for a, b in picked)
@@ -1377,6 +1377,29 @@ def rpn_targets_sample_batched(rpn, anchors0, gt, gvalid, n_loss=None):
     samp_f = pos_f | neg_sel.reshape(-1)
     # regression targets are only ever read at sampled positives (elsewhere they may be inf for GT-less images)
     return dict(labels=labels.reshape(-1).clamp(min=0), reg_t=reg_t.reshape(-1, 4), pos_f=pos_f, samp_f=samp_f, n_sampled=n_sampled)
+
+
+_CONST_MASKS = {}
+
+
+def _const_mask(n, k, device):
+    """[n, 1] bool, True for the first k rows: constant per (n, k, device) -- built once instead of arange + compare per step."""
+    key = (int(n), int(k), str(device))
+    m = _CONST_MASKS.get(key)
+    if m is None:
+        m = _CONST_MASKS[key] = (torch.arange(n, device=device) < k)[:, None].contiguous()
+    return m
+
+
+_ARANGES = {}
+
+
+def _arange(n, device):
+    key = (int(n), str(device))
+    a = _ARANGES.get(key)
+    if a is None:
+        a = _ARANGES[key] = torch.arange(n, device=device)
+    return a
 
 
 def _u8(t):
@@ -1560,12 +1583,12 @@ def select_training_samples_padded(rh, props, pcounts, gt, glabels, gvalid):
     no host synchronisation sizes anything downstream (RoI pooling, box head, losses, post-processing)."""
     N, Pm, _ = props.shape
     dev = props.device
-    pvalid = torch.arange(Pm, device=dev)[None, :] < pcounts[:, None]
+    pvalid = _arange(Pm, dev)[None, :] < pcounts[:, None]
     comb = torch.cat([props, gt], dim=1)                     # torchvision order: proposals, then GT boxes
     cvalid = torch.cat([pvalid, gvalid], dim=1)
     T = comb.shape[1]
     m, lab, _ = ops.match_targets(gt, gvalid, glabels, comb, rh.proposal_matcher.high_threshold, rh.proposal_matcher.low_threshold, False)
-    lab = torch.where(cvalid, lab, torch.full_like(lab, -1))
+    lab = torch.where(cvalid, lab, -1)
     pos_sel, neg_sel, _ = _sample_batched(rh.fg_bg_sampler, lab, host_counts=False)
     # compaction (r-th selected candidate of image n -> row n*S + r), padding rows, box targets and the counts in one launch
     return ops.roi_samples_padded(pos_sel, neg_sel, comb, lab, m, gt, gvalid, rh.fg_bg_sampler.batch_size_per_image, rh.box_coder.weights)

@@ -333,7 +333,7 @@ class FCOS(nn.Module):
         # all levels at once (as RetinaNet.postprocess_detections_padded): threshold, per-level top-k in one hd_topk_select_rows launch,
         # one gather / decode / clip over the selected candidates
         scores = torch.sqrt(torch.sigmoid(cls_logits.detach()) * torch.sigmoid(ctr.detach())).reshape(B, A * K)
-        key = torch.where(scores > self.score_thresh, scores, torch.full_like(scores, float("-inf")))
+        key = torch.where(scores > self.score_thresh, scores, float("-inf"))
         idx = ops.topk_rows_segments(key, [n * K for n in napl], self.topk_candidates)
         sc = torch.gather(key, 1, idx)
         valid = sc > float("-inf")
@@ -341,7 +341,7 @@ class FCOS(nn.Module):
         breg = torch.gather(bbox_regression.detach(), 1, aidx[:, :, None].expand(-1, -1, 4))
         boxes = self.box_coder.decode_single(breg.reshape(-1, 4), anchors0[aidx].reshape(-1, 4)).reshape(B, -1, 4)
         cb = D.clip_boxes_to_image(boxes, image_shape)
-        cs = torch.where(valid, sc, torch.zeros_like(sc))
+        cs = torch.where(valid, sc, 0.0)
         cl = idx % K
         pick, counts = D._batched_nms_pick(cb, cs, cl, valid, self.nms_thresh, self.detections_per_img)
         return (torch.gather(cb, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(cs, 1, pick), torch.gather(cl, 1, pick), counts)

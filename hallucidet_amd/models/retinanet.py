@@ -268,7 +268,7 @@ class RetinaNet(nn.Module):
         # rows returns, per segment, the row indices of its largest entries in descending order, ties by ascending index -- what the
         # per-level `sort(descending, stable)[:k]` of the list form gives; candidates at or below the threshold carry -inf.
         scores = torch.sigmoid(cls_logits.detach().reshape(B, A * K))
-        key = torch.where(scores > self.score_thresh, scores, torch.full_like(scores, float("-inf")))
+        key = torch.where(scores > self.score_thresh, scores, float("-inf"))
         idx = ops.topk_rows_segments(key, [n * K for n in napl], self.topk_candidates)          # [B, sum(min(k, n*K))]
         sc = torch.gather(key, 1, idx)
         valid = sc > float("-inf")
@@ -278,7 +278,7 @@ class RetinaNet(nn.Module):
         # BoxCoder.decode_single + clip_boxes_to_image of the selected candidates in one launch (was ~25 elementwise launches per level)
         cb = ops.roi_decode_clip(breg.reshape(-1, 4), anc.reshape(-1, 4), self.box_coder.weights, self.box_coder.bbox_xform_clip,
                                  image_shape).reshape(B, -1, 4)
-        cs = torch.where(valid, sc, torch.zeros_like(sc))
+        cs = torch.where(valid, sc, 0.0)
         cl = idx % K
         pick, counts = D._batched_nms_pick(cb, cs, cl, valid, self.nms_thresh, self.detections_per_img)
         return (torch.gather(cb, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(cs, 1, pick), torch.gather(cl, 1, pick), counts)
