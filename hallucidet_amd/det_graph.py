@@ -98,10 +98,12 @@ class DetectorStepGraph:
     # -------------------------------------------------------------------------------------------------------- capture
     def _section(self, e, x):
         lit, N = self.lit, e.N
-        t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i]} for i in range(2 * N)]
-        t_ir, t_rgb = t[:N], t[N:]
+        # rows [0, N) = IR targets (hallucinated pass), [N, 2N) = RGB, [2N, 3N) = IR again: the order the fused evaluation
+        # concatenates the passes in, so that its stacks of these rows are views (detection.stack_rows), not copies
+        t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i]} for i in range(3 * N)]
+        t_ir, t_rgb, t_ir2 = t[:N], t[N:2 * N], t[2 * N:]
         ir3 = e.ir.expand(-1, e.x.shape[1], -1, -1) if e.ir.shape[1] == 1 and e.x.shape[1] != 1 else e.ir
-        return lit._detector_section(x, e.rgb, ir3, t_rgb, t_ir, 'train', False)
+        return lit._detector_section(x, e.rgb, ir3, t_rgb, t_ir, 'train', False, targets_ir_pass=t_ir2)
 
     def _aliased_runner(self, imgs_hallucinated):
         """The U-Net runner when `imgs_hallucinated` IS its forward graph's static output buffer, else None."""
@@ -133,9 +135,9 @@ class DetectorStepGraph:
         e.ir_one_plane = one_plane
         e.ir = torch.empty((imgs_ir.shape[0], 1) + tuple(imgs_ir.shape[2:]), dtype=imgs_ir.dtype, device=dev) if one_plane \
             else torch.empty_like(imgs_ir, memory_format=torch.contiguous_format)
-        e.tb = torch.zeros((2 * e.N, G, 4), dtype=torch.float32, device=dev)
-        e.tl = torch.zeros((2 * e.N, G), dtype=torch.int64, device=dev)
-        e.live = torch.zeros((2 * e.N, G), dtype=torch.bool, device=dev)
+        e.tb = torch.zeros((3 * e.N, G, 4), dtype=torch.float32, device=dev)
+        e.tl = torch.zeros((3 * e.N, G), dtype=torch.int64, device=dev)
+        e.live = torch.zeros((3 * e.N, G), dtype=torch.bool, device=dev)
         e.zero_box = torch.zeros((1, 4), dtype=torch.float32, device=dev)
         e.zero_label = torch.zeros((1,), dtype=torch.int64, device=dev)
         e.scale = torch.ones((), dtype=torch.float32, device=dev)
@@ -197,7 +199,7 @@ class DetectorStepGraph:
     def step(self, imgs_hallucinated, imgs_rgb, imgs_ir, targets_rgb, targets_ir):
         lit = self.lit
         N = imgs_hallucinated.shape[0]
-        targets = list(targets_ir) + list(targets_rgb)
+        targets = list(targets_ir) + list(targets_rgb) + list(targets_ir)
         for t in targets:
             _eff._check_targets([t])
         G = _bucket(max([1] + [int(t["boxes"].shape[0]) for t in targets]))

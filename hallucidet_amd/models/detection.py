@@ -1212,6 +1212,18 @@ def fasterrcnn_resnet50_fpn(pretrained=False, progress=True, num_classes=91, pre
 # list-based methods above (tests assert identical outputs); an order of magnitude fewer device launches and two host
 # synchronisations per detector pass (sampler population sizes, detection counts).
 # ======================================================================================================================
+def stack_rows(ts):
+    """torch.stack(ts) -- without the copy when `ts` are consecutive, equally shaped, contiguous views of ONE buffer (the staged
+    targets of det_graph.py, and what `resize_boxes_many` hands back: views of one scaled tensor)."""
+    t0 = ts[0]
+    base, n = t0._base, t0.numel()
+    if base is not None and n > 0 and t0.is_contiguous() and all(
+            t._base is base and t.shape == t0.shape and t.is_contiguous() and t.storage_offset() == t0.storage_offset() + i * n
+            for i, t in enumerate(ts)):
+        return base.as_strided((len(ts),) + tuple(t0.shape), (n,) + tuple(t0.stride()), t0.storage_offset())
+    return torch.stack(ts)
+
+
 _PAD_IDX_CACHE = {}
 
 
@@ -1222,8 +1234,8 @@ def pad_targets(targets, device):
     tuple, uploaded from pinned memory without a stream synchronisation."""
     if targets and "_rows" in targets[0]:
         # staged targets (det_graph.py): G rows for every image already, zero rows as padding
-        gt = torch.stack([t["boxes"].to(torch.float32) for t in targets])
-        return gt, torch.stack([t["labels"] for t in targets]), gt[:, :, 2] > gt[:, :, 0]
+        gt = stack_rows([t["boxes"].to(torch.float32) for t in targets])
+        return gt, stack_rows([t["labels"] for t in targets]), gt[:, :, 2] > gt[:, :, 0]
     lens = tuple(int(t["boxes"].shape[0]) for t in targets)
     N, S = len(lens), sum(lens)
     G = max(1, max(lens))

@@ -121,9 +121,13 @@ class EncoderDecoderLit(nn.Module):
             'output': {'imgs_rgb': imgs_rgb, 'imgs_ir': imgs_ir, 'imgs_hallucinated': imgs_hallucinated.detach()},
         }
 
-    def _detector_section(self, imgs_hallucinated, imgs_rgb, imgs_ir_three_channel, targets_rgb, targets_ir, step, train_det):
+    def _detector_section(self, imgs_hallucinated, imgs_rgb, imgs_ir_three_channel, targets_rgb, targets_ir, step, train_det,
+                          targets_ir_pass=None):
         """train_hallucidet.py:180-210: the three detector passes and the weighted detector losses.
-        -> (losses_det with the weighted keys, their sum, (detections_hall, detections_rgb, detections_ir))."""
+        -> (losses_det with the weighted keys, their sum, (detections_hall, detections_rgb, detections_ir)).
+        `targets_ir_pass`: the IR pass's own copy of the IR targets (det_graph.py stages one, so that the three passes' targets are
+        consecutive rows of one buffer); default: the same list as the hallucinated pass."""
+        t_ir3 = targets_ir if targets_ir_pass is None else targets_ir_pass
         if step == 'train' and self.skip_unused_train_passes and not train_det:
             losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=False, model_name=self.detector_name)
             detections_rgb, detections_ir = [], []
@@ -131,13 +135,13 @@ class EncoderDecoderLit(nn.Module):
             # one trunk evaluation for the three passes (frozen, eval-mode detector: images are independent); the RGB / IR
             # losses are discarded by the reference (train_hallucidet.py:183,186) and carry no gradient
             (losses_det, detections_hall), (_, detections_rgb), (_, detections_ir) = eval_forward_fasterrcnn_multi(
-                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, targets_ir])
+                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, t_ir3])
         elif self.batch_detector_passes and not train_det and 'retinanet' in self.detector_name:
             (losses_det, detections_hall), (_, detections_rgb), (_, detections_ir) = eval_forward_retinanet_multi(
-                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, targets_ir])
+                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, t_ir3])
         elif self.batch_detector_passes and not train_det and 'fcos' in self.detector_name:
             (losses_det, detections_hall), (_, detections_rgb), (_, detections_ir) = eval_forward_fcos_multi(
-                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, targets_ir])
+                self.detector, [imgs_hallucinated, imgs_rgb, imgs_ir_three_channel], [targets_ir, targets_rgb, t_ir3])
         else:
             losses_det, detections_hall = Detector.calculate_loss(self.detector, imgs_hallucinated, targets_ir, train_det=train_det, model_name=self.detector_name)
             with torch.no_grad():

@@ -26,8 +26,9 @@ def _degenerate_flag(targets):
     if targets and "_rows" in targets[0]:
         # staged targets (det_graph.py): every image carries the same number of rows, `_rows` marks the real ones (the rest is
         # zero padding, which must not trip the check)
-        allb = torch.stack([t["boxes"] for t in targets])
-        live = torch.stack([t["_rows"] for t in targets])
+        from ..models.detection import stack_rows
+        allb = stack_rows([t["boxes"] for t in targets])
+        live = stack_rows([t["_rows"] for t in targets])
         return ((allb[..., 2:] <= allb[..., :2]).any(dim=-1) & live).any()
     allb = torch.cat([t["boxes"] for t in targets], dim=0)
     return (allb[:, 2:] <= allb[:, :2]).any() if allb.numel() else None

@@ -58,8 +58,8 @@ def test_replay_equals_eager_bit_for_bit(detector_name):
     ir3 = imgs_ir.expand(-1, 3, -1, -1)
     hall = lit.encoder_decoder(ir3)
     N = hall.shape[0]
-    t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i]} for i in range(2 * N)]
-    losses, total, dets = lit._detector_section(hall, imgs_rgb, ir3, t[N:], t[:N], 'train', False)
+    t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i]} for i in range(3 * N)]        # rows: IR, RGB, IR again
+    losses, total, dets = lit._detector_section(hall, imgs_rgb, ir3, t[N:2 * N], t[:N], 'train', False, targets_ir_pass=t[2 * N:])
     r = lit.encoder_decoder.runner
     r.flat_grads.zero_()
     lit.scaler.scale(total).backward()
