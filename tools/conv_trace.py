@@ -83,6 +83,10 @@ for name, N, H, W, Cin, Cout, KH, stats, ov in SHAPES:
           (name, t_us, flops / t_us / 1e6, span_us, nb, len(uniq), cnt.min(), cnt.max(), nk))
     print("    median cycles: setup+prologue issue %5.0f | first tile lands %5.0f | K loop %6.0f (%4.0f per step) | epilogue %5.0f | block life %6.0f = %.2f us" %
           (med(c_pro - c0), med(c_land - c_pro), med(c_loop - c_land), med(c_loop - c_land) / nk, med(c_end - c_loop), med(life), med(life) / CLK_GHZ / 1e3))
+    if t.shape[1] >= 14 and (t[:, 10] != 0).any():
+        s10, s11, s12, s13 = [t[:, i] for i in (10, 11, 12, 13)]
+        print("    setup split: entry -> tile mapping / descriptors %5.0f | A rows %5.0f | B rows + acc init %5.0f | first pixel state %5.0f | prologue DMA issue %5.0f" %
+              (med(s10 - c0), med(s11 - s10), med(s12 - s11), med(s13 - s12), med(c_pro - s13)))
     print("    epilogue split: acc->LDS transpose + barrier %5.0f | row loop (LDS read, math, stores) %5.0f | BN partial sums %5.0f" %
           (med(c_tr - c_loop), med(c_rows - c_tr), med(c_end - c_rows)))
     if os.environ.get("TRACE_CU"):
