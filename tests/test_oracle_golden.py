@@ -407,3 +407,87 @@ def test_pins_from_own_decisions_reproduce_the_plain_forward_and_gradient():
         model.set_pins(None)
         yd = run(model, x)
         assert torch.allclose(ya[0], yd[0], rtol=1e-6, atol=1e-6)
+
+
+def test_roi_align_against_aten_grid_sample():
+    """An INDEPENDENT statement of RoIAlign(aligned=False, sampling_ratio=2) on top of ATen's own bilinear sampler: torchvision's
+    `bilinear_interpolate` puts pixel i at coordinate i and clamps to the border for samples in [-1, H], which is exactly
+    `F.grid_sample(mode='bilinear', padding_mode='border', align_corners=True)` at the normalised coordinate 2 y / (H - 1) - 1;
+    samples outside [-1, H] contribute zero.  The oracle's two RoIAlign forms (scalar loops, vectorised autograd form) must agree
+    with it -- this pins the sample-point geometry (bin size, the (i + .5) / 2 offsets, the max(., 1) of the RoI extent, the /4)."""
+    import torch.nn.functional as F
+    torch.manual_seed(3)
+    N, C, H, W, P, sr, scale = 2, 5, 19, 23, 7, 2, 1 / 16
+    feat = torch.randn(N, C, H, W)
+    g = torch.Generator().manual_seed(4)
+    x1 = torch.rand(40, generator=g) * 330 - 20
+    y1 = torch.rand(40, generator=g) * 280 - 20
+    w = torch.rand(40, generator=g) * 200 + 1
+    h = torch.rand(40, generator=g) * 160 + 1
+    idx = torch.randint(0, N, (40,), generator=g).float()
+    rois = torch.stack([idx, x1, y1, x1 + w, y1 + h], dim=1)
+    rois = torch.cat([rois, torch.tensor([[0, 5.0, 5.0, 5.5, 5.2], [1, 100.0, 90.0, 100.0, 90.0]])])     # extent below one feature pixel
+    out = torch.zeros(rois.shape[0], C, P, P)
+    for r in range(rois.shape[0]):
+        n = int(rois[r, 0])
+        rsw, rsh, rew, reh = [float(rois[r, k]) * scale for k in (1, 2, 3, 4)]
+        rw, rh = max(rew - rsw, 1.0), max(reh - rsh, 1.0)
+        bw, bh = rw / P, rh / P
+        ys = torch.tensor([rsh + ph * bh + (iy + 0.5) * bh / sr for ph in range(P) for iy in range(sr)])
+        xs = torch.tensor([rsw + pw * bw + (ix + 0.5) * bw / sr for pw in range(P) for ix in range(sr)])
+        gy, gx = torch.meshgrid(ys, xs, indexing="ij")
+        inside = ((gy >= -1.0) & (gy <= H) & (gx >= -1.0) & (gx <= W)).float()
+        grid = torch.stack([2 * gx / (W - 1) - 1, 2 * gy / (H - 1) - 1], dim=-1)[None]
+        s = F.grid_sample(feat[n:n + 1], grid, mode="bilinear", padding_mode="border", align_corners=True)[0] * inside
+        out[r] = s.reshape(C, P, sr, P, sr).mean(dim=(2, 4))
+    a = od.roi_align_autograd(feat, rois, P, scale, sr)
+    b = ok.roi_align_nchw(feat, rois, P, P, scale, sr)
+    assert torch.allclose(a, out, atol=2e-5), float((a - out).abs().max())
+    assert torch.allclose(b, out, atol=2e-5), float((b - out).abs().max())
+
+
+def test_nms_box_coder_matcher_properties():
+    """Properties that any correct statement of the torchvision pieces must have, checked on random inputs (independent of the
+    oracle's own arithmetic): NMS -- the kept set is independent (no two kept boxes overlap above the threshold), maximal (every
+    removed box overlaps a kept box of no lower score above the threshold) and greedy (the best-scoring box is kept); BoxCoder --
+    decode(encode(gt, anchors), anchors) == gt; Matcher -- a matched GT is the arg-max IoU of its anchor, BELOW / BETWEEN codes sit
+    in their IoU bands, and with low-quality matching every GT with any overlap keeps its best anchor(s)."""
+    g = torch.Generator().manual_seed(11)
+    for trial in range(5):
+        n = 200
+        xy = torch.rand(n, 2, generator=g) * 100
+        wh = torch.rand(n, 2, generator=g) * 40 + 2
+        boxes = torch.cat([xy, xy + wh], dim=1)
+        scores = torch.rand(n, generator=g)
+        thr = 0.3 + 0.1 * trial
+        keep = od.nms(boxes, scores, thr)
+        kept = torch.zeros(n, dtype=torch.bool)
+        kept[keep] = True
+        iou = ok.box_iou(boxes, boxes)
+        kk = iou[keep][:, keep]
+        assert float((kk - torch.eye(len(keep))).max()) <= thr + 1e-6            # independent
+        assert int(keep[0]) == int(scores.argmax())                               # greedy start, descending order
+        assert bool((scores[keep][:-1] >= scores[keep][1:]).all())
+        for i in (~kept).nonzero().flatten().tolist():                            # maximal
+            sup = (iou[i, keep] > thr) & (scores[keep] >= scores[i])
+            assert bool(sup.any()), i
+    coder = od.BoxCoder((10.0, 10.0, 5.0, 5.0))
+    a_xy = torch.rand(50, 2, generator=g) * 200
+    anchors = torch.cat([a_xy, a_xy + torch.rand(50, 2, generator=g) * 80 + 4], dim=1)
+    g_xy = torch.rand(50, 2, generator=g) * 200
+    gt = torch.cat([g_xy, g_xy + torch.rand(50, 2, generator=g) * 80 + 4], dim=1)
+    back = coder.decode_single(coder.encode_single(gt, anchors), anchors)
+    assert torch.allclose(back, gt, atol=1e-3)
+    m = od.Matcher(0.7, 0.3, allow_low_quality_matches=True)
+    iou = ok.box_iou(gt[:6], anchors)
+    res = m(iou)
+    vals, arg = iou.max(dim=0)
+    plain = od.Matcher(0.7, 0.3, allow_low_quality_matches=False)(iou)
+    assert bool((plain[vals >= 0.7] == arg[vals >= 0.7]).all())
+    assert bool((plain[vals < 0.3] == od.Matcher.BELOW_LOW_THRESHOLD).all())
+    assert bool((plain[(vals >= 0.3) & (vals < 0.7)] == od.Matcher.BETWEEN_THRESHOLDS).all())
+    best = iou.max(dim=1).values
+    for gi in range(6):
+        if best[gi] > 0:
+            cols = (iou[gi] == best[gi]).nonzero().flatten()
+            assert bool((res[cols] >= 0).all())                # low-quality rule: the best anchor(s) of every GT stay matched
