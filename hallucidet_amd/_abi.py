@@ -70,10 +70,7 @@ PROTOTYPES = {
     "hd_arch": (C.c_char_p, []),
     "hd_conv2d": (C.c_int, [C.POINTER(ConvArgs), vp]),
     "hd_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvArgs)]),
-    "hd_conv2d_patch": (C.c_int, [C.POINTER(ConvArgs), vp]),
     "hd_conv_tune_override": (C.c_int, [C.c_int] * 4),
-    "hd_conv2d_patch_stats_rows": (C.c_int, [C.POINTER(ConvArgs)]),
-    "hd_conv_set_workspace": (C.c_int, [vp, C.c_int64]),
     "hd_conv_tune_w8": (C.c_int, [C.c_int, C.c_int]),
     "hd_wgrad_w8_blocks": (C.c_int, [C.POINTER(WgradArgs)]),
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),

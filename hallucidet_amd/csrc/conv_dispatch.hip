@@ -46,8 +46,6 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.nchunks = a->KH * a->KW * p.cin8;
   p.nk = 0;
   p.Ktot = a->KH * a->KW * p.Cin;
-  p.ws = nullptr;
-  p.tickets = nullptr;
   p.prio = 0;
   p.par = p.ph = p.pw = p.Hc = p.Wc = p.t0h = p.t0w = 0;
   p.inv_cin8 = 1.0f / (float)p.cin8;
@@ -67,41 +65,13 @@ int env_int(const char* name, int dflt) {
 
 }  // namespace
 
-// 3x3 / s1 / p1 layers with >= 64 in/out channels CAN go to the input-patch kernel (conv3x3_patch.hip: 1.7-2.3x fewer bytes
-// filled per FLOP).  Measured on the hot path's layers it is 5-20 % SLOWER than the igemm family (launches of 9-72 K steps
-// are bound by per-block fixed costs and fill latency, not by fill volume), so it is opt-in (HD_CONV_PATCH=1 or
-// hd_conv2d_patch) until it keeps weights resident across tiles.
 static bool g_small_ok = true;   // cleared while a tuning override forces an igemm variant
-bool patch_eligible(const ConvP& p) {
-  return p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.in_dil == 1 && !p.up1 && p.C2 == 0 && p.C1 % 64 == 0 &&
-         p.out_mode == HD_OUT_NHWC_F16 && p.Cout % 8 == 0 && p.Cout >= 64 && p.Ho == p.Hin && p.Wo == p.Win;
-}
-bool use_patch(const ConvP& p) {
-  static const int on = env_int("HD_CONV_PATCH", 0);
-  return on && patch_eligible(p);
-}
 
 // the 16/32-channel 3x3 layers go to the direct small-channel kernel (conv3x3_small.hip); HD_CONV_SMALL=0 keeps them in the
 // igemm family (A/B)
 bool use_small(const ConvP& p) {
   static const int on = env_int("HD_CONV_SMALL", 1);
   return on && g_small_ok && hd_conv_small_eligible(p);
-}
-
-extern "C" int hd_conv2d_patch(const hd_conv_args* a, void* stream) {
-  ConvP p;
-  int rc = fill_params(a, p);
-  if (rc) return rc;
-  HD_CHECK_ARG(patch_eligible(p), "hd_conv2d_patch: needs 3x3 / stride 1 / pad 1, one source, Cin %% 64 == 0, Cout %% 8 == 0, Cout >= 64, NHWC f16 output");
-  hd_conv_launch_patch(p, (hipStream_t)stream);
-  HD_CHECK_LAUNCH();
-  return HD_OK;
-}
-
-extern "C" int hd_conv2d_patch_stats_rows(const hd_conv_args* a) {
-  ConvP p;
-  if (!a || fill_params(a, p) != HD_OK || !patch_eligible(p)) return HD_E_ARG;
-  return hd_conv_patch_tiles(p);
 }
 
 // tuning hook (tools/tune_conv.py): force the tile / K-depth / stage choice of the igemm family; -1 = heuristic
@@ -157,38 +127,16 @@ static int choose_p8(const ConvP& p) {
 struct TileChoice {
   int bm, bn;
   bool use64, deep;
-  int w8cfg, w8slices;   // w8cfg >= 0: the 8-wave family (conv_igemm_w8.hip) with that tile id / split-K factor
   int p8cfg;             // p8cfg >= 0: the 8-wave input-patch family (conv3x3_w8.hip) with that tile id
 };
 
-// Workspace of the 8-wave family's split-K path, owned by the caller (PyTorch): [HD_W8_TICKETS ints, zeroed once by the
-// caller][fp32 slabs].  Without one, split-K is never chosen.
-constexpr int HD_W8_TICKETS = 16384;
-static char* g_ws = nullptr;
-static int64_t g_ws_bytes = 0;
-extern "C" int hd_conv_set_workspace(void* ws, int64_t bytes) {
-  HD_CHECK_ARG(ws == nullptr || bytes > (int64_t)HD_W8_TICKETS * 4, "hd_conv_set_workspace: needs more than %d bytes", HD_W8_TICKETS * 4);
-  HD_CHECK_ARG(((uintptr_t)ws & 255) == 0, "hd_conv_set_workspace: 256-byte alignment");
-  g_ws = (char*)ws;
-  g_ws_bytes = ws ? bytes : 0;
-  return HD_OK;
-}
-static int max_slices(const ConvP& p, int bm, int bn) {
-  if (!g_ws) return 1;
-  const int64_t tiles = (int64_t)hd_cdiv(p.M, bm) * hd_cdiv(p.Cout, bn);
-  if (tiles > HD_W8_TICKETS) return 1;
-  const int64_t per = (int64_t)p.M * p.Cout * 4;
-  const int64_t n = (g_ws_bytes - (int64_t)HD_W8_TICKETS * 4) / per;
-  return n < 1 ? 1 : (n > 64 ? 64 : (int)n);
-}
-
-// tuning hook of the 8-wave family (tools/tune_conv.py): cfg -1 = heuristic, -2 = never, >= 0 = force that tile wherever
-// the family is eligible; nslices <= 0 = heuristic
-static int g_w8_cfg = -1, g_w8_slices = 0;
+// tuning hook of the 8-wave patch-staged family (tools/tune_w8.py): cfg -1 = cost model, -2 = never, 10..13 = force that tile
+// wherever the family is eligible
+static int g_w8_cfg = -1;
 extern "C" int hd_conv_tune_w8(int cfg, int nslices) {
-  HD_CHECK_ARG(cfg >= -2 && cfg <= 13 && !(cfg > 6 && cfg < 10) && nslices <= 64, "hd_conv_tune_w8: cfg in [-2, 6] or [10, 13], nslices <= 64");
+  (void)nslices;
+  HD_CHECK_ARG(cfg == -1 || cfg == -2 || (cfg >= 10 && cfg <= 13), "hd_conv_tune_w8: cfg in {-1, -2, 10..13}");
   g_w8_cfg = cfg;
-  g_w8_slices = nslices;
   return HD_OK;
 }
 
@@ -237,20 +185,9 @@ static TileChoice choose_tile(const ConvP& p) {
   if (g_ov_bk == 64) c.use64 = can64_ch;
   if (force_deep >= 0) c.deep = force_deep != 0;
   if (g_ov_deep >= 0) c.deep = g_ov_deep != 0;
-  c.w8cfg = -1;
-  c.w8slices = 1;
   c.p8cfg = -1;
   if (g_w8_cfg >= 10 && hd_conv_p8_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
   if (g_w8_cfg == -1 && g_small_ok && g_ov_bm < 0 && g_ov_bn < 0 && g_ov_bk < 0) c.p8cfg = choose_p8(p);
-  if (g_w8_cfg >= 0 && g_w8_cfg < 10 && hd_conv_w8_eligible(p) && g_small_ok) {
-    c.w8cfg = g_w8_cfg;
-    c.w8slices = g_w8_slices > 0 ? g_w8_slices : 1;
-  }
-  if (c.w8cfg >= 0) {
-    hd_conv_w8_tile(c.w8cfg, &c.bm, &c.bn);
-    const int cap = max_slices(p, c.bm, c.bn);
-    if (c.w8slices > cap) c.w8slices = cap;
-  }
   return c;
 }
 
@@ -259,7 +196,6 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   ConvP p;
   int rc = fill_params(a, p);
   if (rc) return rc;
-  if (use_patch(p)) return hd_conv_patch_tiles(p);
   if (use_small(p)) return hd_conv_small_tiles(p);
   const TileChoice c = choose_tile(p);
   if (c.p8cfg >= 0) return hd_conv_p8_tiles(p, c.p8cfg);
@@ -271,11 +207,6 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   int rc = fill_params(a, p);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (use_patch(p) && !p.in_scale) {
-    hd_conv_launch_patch(p, s);
-    HD_CHECK_LAUNCH();
-    return HD_OK;
-  }
 #ifdef HD_CONV_TRACE
   p.trace = g_trace;
   p.trace_tid = env_int("HD_TRACE_TID", 0);
@@ -298,17 +229,13 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   p.prio = w8_prio;
   const int bm = c.bm, bn = c.bn;
   const bool use64 = c.use64, deep = c.deep;
-  if (par && c.p8cfg < 0 && c.w8cfg < 0 && (c.use64 ? (p.cin8 % 8) == 0 : true)) {
+  if (par && c.p8cfg < 0 && (c.use64 ? (p.cin8 % 8) == 0 : true)) {
     p.par = 1;                     // the launchers add gridDim.y = 4
   } else {
     p.M = M_full;
   }
   if (c.p8cfg >= 0) {
     hd_conv_launch_p8(p, c.p8cfg, s);
-  } else if (c.w8cfg >= 0) {
-    p.tickets = (int*)g_ws;
-    p.ws = (float*)(g_ws + (size_t)HD_W8_TICKETS * 4);
-    hd_conv_launch_w8(p, c.w8cfg, c.w8slices, s);
   } else if (use64) hd_conv_launch_bk64(p, bm, bn, deep, s);
   else hd_conv_launch_bk32(p, bm, bn, deep, s);
   HD_CHECK_LAUNCH();

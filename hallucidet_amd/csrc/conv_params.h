@@ -24,8 +24,6 @@ struct ConvP {
   const float* in_scale;   // consumer-side BatchNorm of the x operand (hd_conv_args.in_scale / in_shift / in_relu): small-channel kernel only
   const float* in_shift;
   int in_relu;
-  float* ws;           // split-K slabs of the 8-wave family (hd_conv_set_workspace), fp32 [slice][M][Cout]
-  int* tickets;        // per-tile arrival counters of the split-K reduction (zero between launches)
 #ifdef HD_CONV_TRACE
   unsigned long long* trace;   // profiling builds only (tools/conv_trace.py): 16 stamps per block
   int trace_tid;               // which thread of the block stamps (HD_TRACE_TID, default 0)
@@ -90,13 +88,6 @@ __device__ __forceinline__ int hd_par_pixel(const ConvP& p, int m) {
 
 void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
-// conv3x3_patch.hip: 3x3 / stride 1 / pad 1, Cin % 64 == 0, NHWC f16 output, LDS-staged input patches
-void hd_conv_launch_patch(ConvP& p, hipStream_t s);
-int hd_conv_patch_tiles(const ConvP& p);
-// conv_igemm_w8.hip: 8-wave family (NHWC f16 output, Cout % 8 == 0); cfg = tile id, nslices = split-K factor
-bool hd_conv_w8_eligible(const ConvP& p);
-void hd_conv_w8_tile(int cfg, int* bm, int* bn);
-void hd_conv_launch_w8(ConvP& p, int cfg, int nslices, hipStream_t s);
 // conv3x3_w8.hip: 8-wave family with LDS-staged input patches (3x3 / s1 / p1, Cin % 64 == 0); cfg = tile id
 bool hd_conv_p8_eligible(const ConvP& p);
 int hd_conv_p8_tiles(const ConvP& p, int cfg);

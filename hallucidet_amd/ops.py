@@ -29,25 +29,8 @@ def conv_out_size(h, k, stride, pad):
     return (h + 2 * pad - k) // stride + 1
 
 
-_WS = {}
-_WS_BYTES = int(os.environ.get("HD_CONV_WS_MB", "96")) << 20
-
-
-def _ensure_workspace(lib, device):
-    """Scratch of hd_conv2d's split-K path: a torch-owned buffer registered once per process (the library allocates nothing).
-    The first 64 KiB are the per-tile arrival counters and start at zero; the kernels leave them at zero."""
-    key = (device.type, device.index)
-    if key not in _WS:
-        if _WS:
-            raise RuntimeError("hallucidet_amd: one GPU per process (hd_conv_set_workspace is process-wide)")
-        buf = torch.zeros(_WS_BYTES, dtype=torch.uint8, device=device)
-        check(lib.hd_conv_set_workspace(buf.data_ptr(), _WS_BYTES), "hd_conv_set_workspace")
-        _WS[key] = buf
-    return _WS[key]
-
-
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
-           out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None, patch_kernel=False,
+           out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None,
            in_scale=None, in_shift=None, in_relu=True):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
 
@@ -58,7 +41,6 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
     """
     _need_cuda(x, w, x2, bias, res, mask)
     lib = _abi.load()
-    _ensure_workspace(lib, x.device)
     N, Hs, Ws, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     Cout = w.shape[0] if cout is None else cout
@@ -90,14 +72,11 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
                  ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
     stats = None
     if want_stats:
-        rows = (lib.hd_conv2d_patch_stats_rows if patch_kernel else lib.hd_conv2d_stats_rows)(C.byref(a))
+        rows = lib.hd_conv2d_stats_rows(C.byref(a))
         check(0 if rows > 0 else rows, "hd_conv2d_stats_rows")
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         a.stats = ptr(stats)
-    if patch_kernel:      # explicit request for the LDS-staged-input-patch kernel (3x3 / s1 / p1, >= 64 channels)
-        check(lib.hd_conv2d_patch(C.byref(a), _stream()), "hd_conv2d_patch")
-    else:
-        check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
+    check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
     return (y, stats) if want_stats else y
 
 

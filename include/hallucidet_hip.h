@@ -91,24 +91,12 @@ typedef struct hd_conv_args {
 int hd_conv2d(const hd_conv_args* a, void* stream);
 /* number of M tiles (rows of `stats`) hd_conv2d will use for this problem */
 int hd_conv2d_stats_rows(const hd_conv_args* a);
-/* Same operator for the 3x3 / stride 1 / pad 1, single-source, Cin % 64 == 0, Cout >= 64, NHWC-f16 case through the
- * LDS-staged-input-patch kernel (each input pixel is filled into LDS once per channel chunk and read by the nine taps as
- * shifted windows; replaces the same Conv2d call sites as hd_conv2d: src/segmentation_models/base/modules.py:21-29,
- * torchvision Bottleneck.conv2 / FPN layer_blocks [EXT]).  Opt-in: see DESIGN.md 6.1 for the measured comparison.
- * BN partial-sum rows are per 8x16 output tile: hd_conv2d_patch_stats_rows. */
-int hd_conv2d_patch(const hd_conv_args* a, void* stream);
 /* tuning hook for hd_conv2d's tile choice (tools/tune_conv.py): bm in {64,128}, bn in {32,64,128}, bk in {32,64}, deep in {0,1};
  * -1 = the built-in heuristic.  Process-wide; not for production use. */
 int hd_conv_tune_override(int bm, int bn, int bk, int deep);
-int hd_conv2d_patch_stats_rows(const hd_conv_args* a);
-/* Caller-owned scratch of hd_conv2d's 8-wave family (split-K partial tiles): the first 65 536 bytes are per-tile arrival
- * counters and must be ZERO when registered (the kernels leave them zero), the rest holds fp32 slabs.  The library keeps the
- * pointer (nothing is allocated on its side, SURVEY 8b "Ownership"); NULL unregisters.  Launches that share it must be
- * stream-ordered (the boundary is not re-entrant, SURVEY 8b "Threading"). */
-int hd_conv_set_workspace(void* ws, int64_t bytes);
-/* tuning hook of the 8-wave families: cfg -1 heuristic, -2 never, 0..6 force the im2col tile {256x128, 128x128, 256x64, 128x64,
- * 128x256, 64x128, 64x256} wherever eligible (nslices > 0 forces the split-K factor), 10..13 force the input-patch kernel
- * (3x3 / stride 1) with tile {256x128, 128x128, 256x64, 128x64} wherever eligible */
+/* tuning hook of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip): cfg -1 = the built-in cost model, -2 = never, 10..13 = force
+ * tile {256x128, 128x128, 256x64, 128x64} wherever eligible.  `nslices` is ignored (kept for the call's shape: the im2col 8-wave
+ * family with split-K that used it was measured no faster than the 4-wave kernels on any shape and removed in round 3). */
 int hd_conv_tune_w8(int cfg, int nslices);
 
 /* ------------------------------------------------------------------------

@@ -47,7 +47,7 @@ CONV_CASES = [
     (4, 96, 96, 256, 0, 128, 1, 1, 0, False, 0, True, False),    # 128x128 tile, 64-deep, 2 stages (1x1: igemm family)
     (4, 96, 96, 256, 0, 64, 1, 1, 0, False, 1, False, False),     # 128x64 tile, 64-deep, 2 stages
     (4, 96, 96, 64, 0, 128, 3, 2, 1, False, 0, True, False),     # 3x3 stride 2 stays on the igemm family
-    # 3x3 / s1 / p1 with >= 64 channels: also run through the input-patch kernel (conv3x3_patch.hip) by test_conv2d_patch_kernel
+    # 3x3 / s1 / p1 with >= 64 channels
     (4, 96, 96, 64, 0, 128, 3, 1, 1, False, 0, True, False),     # BN=128, one channel chunk, full tiles
     (4, 96, 96, 64, 0, 64, 3, 1, 1, False, 1, False, False),      # BN=64
     (2, 13, 21, 128, 0, 192, 3, 1, 1, False, 1, True, True),      # ragged tiles in both directions, 2 chunks, partial N tile, residual
@@ -106,10 +106,11 @@ W8_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13])
 def test_conv2d_eight_wave_families(dev, cfg):
-    """Every tile of the 8-wave families (conv_igemm_w8.hip: cfg 0-6, incl. split-K over blocks; conv3x3_w8.hip: cfg 10-13),
-    forced through hd_conv_tune_w8, against the oracle: outputs, BN partial sums per tile, bias / residual / ReLU-mask / ReLU."""
+    """Every tile of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip: cfg 10-13), forced through hd_conv_tune_w8 wherever it is
+    eligible (the other cases fall through to the 4-wave family), against the oracle: outputs, BN partial sums per tile, bias /
+    residual / ReLU-mask / ReLU."""
     from hallucidet_amd import ops, _abi
     lib = _abi.load()
     try:
@@ -131,7 +132,7 @@ def test_conv2d_eight_wave_families(dev, cfg):
             if act == 1:
                 want = want.clamp_min(0)
             d = lambda t: None if t is None else t.to(dev)
-            for slices in ((1, 2, 3) if cfg < 10 else (1,)):
+            for slices in (1,):
                 lib.hd_conv_tune_w8(cfg, slices)
                 got, stats = ops.conv2d(d(x), d(w), K, K, x2=d(x2), bias=d(bias), res=d(res), mask=d(mask), stride=stride, pad=pad, up1=up1,
                                         act=act, want_stats=True)
@@ -142,36 +143,9 @@ def test_conv2d_eight_wave_families(dev, cfg):
                 assert torch.allclose(s_[1], wstats[1], rtol=3e-3, atol=1e-2), (cfg, slices, case)
                 again, _ = ops.conv2d(d(x), d(w), K, K, x2=d(x2), bias=d(bias), res=d(res), mask=d(mask), stride=stride, pad=pad, up1=up1,
                                       act=act, want_stats=True)
-                assert torch.equal(got, again), "split-K reduction must not depend on block arrival order"
+                assert torch.equal(got, again), "run-to-run identical"
     finally:
         lib.hd_conv_tune_w8(-1, 0)
-
-
-PATCH_CASES = [c for c in CONV_CASES if c[6] == 3 and c[7] == 1 and c[8] == 1 and not c[9] and c[4] == 0 and c[3] % 64 == 0 and c[5] >= 64]
-
-
-@pytest.mark.parametrize("case", PATCH_CASES)
-def test_conv2d_patch_kernel(dev, case):
-    """LDS-staged-input-patch kernel (opt-in): same results as the oracle / the igemm family, incl. BN partial sums per tile,
-    ragged tiles, multi-chunk K, partial N tiles, residual + ReLU epilogue."""
-    from hallucidet_amd import ops
-    N, H, W, C1, C2, Cout, K, stride, pad, up1, act, use_bias, use_res = case
-    x = rnd(N, H, W, C1, seed=1)
-    Kt = K * K * C1
-    w = rnd(Cout, Kt, scale=1.0 / math.sqrt(Kt), seed=3)
-    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(4)) if use_bias else None
-    res = rnd(N, H, W, Cout, seed=5) if use_res else None
-    want, wstats = ok.conv2d_nhwc(x, w, K, K, bias=bias, res=res, stride=1, pad=1, act=act)
-    d = lambda t: None if t is None else t.to(dev)
-    got, stats = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), stride=1, pad=1, act=act, want_stats=True, patch_kernel=True)
-    ref = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), stride=1, pad=1, act=act)
-    assert stats.shape[0] == N * ((H + 7) // 8) * ((W + 15) // 16)
-    close(got, want.half())
-    assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
-    s = stats.sum(dim=0).cpu()
-    assert torch.allclose(s[0], wstats[0], rtol=2e-3, atol=2e-3 * (N * H * W) ** 0.5 + 1e-2) and torch.allclose(s[1], wstats[1], rtol=3e-3, atol=1e-2)
-    with pytest.raises(Exception, match="hd_conv2d_patch"):
-        ops.conv2d(d(x), d(w[:, : 9 * C1]), 3, 3, stride=2, pad=1, patch_kernel=True)
 
 
 def test_conv2d_nchw_f32_output(dev):

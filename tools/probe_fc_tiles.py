@@ -31,20 +31,4 @@ for name, xs, ws, k, kw in cases:
     lib.hd_conv_tune_override(-1, -1, -1, -1)
     print(" | ".join(out))
 
-print("8-wave im2col family (hd_conv_tune_w8 cfg, slices):")
-for name, xs, ws, k, kw in cases:
-    x = torch.randn(*xs, device=dev, dtype=torch.float16) * 0.1
-    w = torch.randn(*ws, device=dev, dtype=torch.float16) * 0.02
-    lib.hd_conv_tune_w8(-1, 0)
-    for _ in range(2):
-        base = t(lambda: ops.conv2d(x, w, k, k, **kw))
-    out = ["%s: shipped %.1f" % (name, base)]
-    ref = ops.conv2d(x, w, k, k, **kw).float()
-    for cfg in (0, 1, 4, 6):
-        for sl in (1, 2):
-            lib.hd_conv_tune_w8(cfg, sl)
-            tt = t(lambda: ops.conv2d(x, w, k, k, **kw))
-            err = float((ops.conv2d(x, w, k, k, **kw).float() - ref).abs().max())
-            out.append("cfg%d/%d %.1f%s" % (cfg, sl, tt, "" if err < 0.05 else " (err %.2g)" % err))
-    lib.hd_conv_tune_w8(-1, 0)
-    print(" | ".join(out))
+# (the 8-wave im2col family that was probed here -- 166-270 us on the fc6 data gradient against 165 for the 128x64 4-wave tile -- was removed in round 3)

@@ -86,7 +86,7 @@ for s, lst in groups.items():
     best = (th, "4-wave")
     allt = {}
     eligible = (not kw.get("out_nchw_f32")) and cout % 8 == 0 and (kw.get("x2") is None or (C1 % 64 == 0 and kw["x2"].shape[3] % 64 == 0))
-    if eligible and th * n > (40.0 if quick else 0.0):
+    if False:      # (the im2col 8-wave family with split-K, cfg 0-6, was removed in round 3: no faster than the 4-wave kernels on any shape)
         for cfg, (bm, bn) in enumerate(TILES):
             if bn // 2 >= max(cout, 64) and bn > 64:
                 continue

@@ -21,7 +21,7 @@ SHAPES = [   # name, N, H, W, Cin, Cout, KH, want_stats
     ("layer2 128->128 @64x80", 8, 64, 80, 128, 128, 3, True),
     ("layer1 64->64 @128x160", 8, 128, 160, 64, 64, 3, True),
 ]
-CFGS = [int(v) for v in os.environ.get("CFGS", "0,1,4").split(",")]
+CFGS = [int(v) for v in os.environ.get("CFGS", "10,11,12").split(",")]     # tiles of the patch-staged family (conv3x3_w8.hip)
 TILES = [(256, 128), (128, 128), (256, 64), (128, 64), (128, 256), (64, 128), (64, 256), None, None, None, (256, 128), (128, 128), (256, 64), (128, 64)]
 med = lambda a: float(np.median(a))
 for name, N, H, W, Cin, Cout, KH, stats in SHAPES:
