@@ -126,3 +126,41 @@ def test_degenerate_box_still_raises_one_call_later():
     lit.forward_step(b[0], b[1], b[2], bad, 0, step='train')           # issued: the flag is on its way to the host
     with pytest.raises(AssertionError, match="All bounding boxes should have positive height and width"):
         flush_degenerate(lit.detector, block=True)
+
+
+def test_image_without_boxes_and_a_smaller_last_batch():
+    """An image with NO ground-truth boxes (all its staged rows are padding) and a last batch of another size (its own graph): the
+    replayed losses equal the eagerly issued ones on the same staged targets, bit for bit."""
+    from hallucidet_amd import synthetic
+    lit = _lit("fasterrcnn")
+    b = synthetic.make_batch(3, H, W, seed=21, device="cuda")
+    empty = {"boxes": torch.zeros((0, 4), device="cuda"), "labels": torch.zeros((0,), dtype=torch.int64, device="cuda")}
+    t_rgb, t_ir = [dict(t) for t in b[1]], [dict(t) for t in b[3]]
+    t_rgb[1], t_ir[1] = dict(empty), dict(empty)
+    batch = (b[0], t_rgb, b[2], t_ir)
+    lit.fit_step(batch)                                  # capture
+    g = lit._detector_graph()
+    assert g.captures == 1
+    lit.encoder_decoder.train()
+    torch.manual_seed(5)
+    out = lit.forward_step(batch[0], batch[1], batch[2], batch[3], 0, step='train')
+    got = {k: out['loss'][k].detach().clone() for k in ('total', 'det_regression', 'det_classification', 'det_objectness', 'det_rpn_box_reg')}
+    e = next(iter(g.entries.values()))
+    N = 3
+    t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i]} for i in range(3 * N)]
+    assert not bool(e.live[1].any()) and not bool(e.live[N + 1].any()) and bool(e.live[0].any())
+    lit.use_detector_graph = False
+    torch.manual_seed(5)
+    ir3 = batch[2].expand(-1, 3, -1, -1)
+    hall = lit.encoder_decoder(ir3)
+    losses, total, _ = lit._detector_section(hall, batch[0], ir3, t[N:2 * N], t[:N], 'train', False, targets_ir_pass=t[2 * N:])
+    torch.cuda.synchronize()
+    assert torch.isfinite(total) and torch.equal(total, got['total'])
+    assert torch.equal(losses['loss_objectness'], got['det_objectness']) and torch.equal(losses['loss_rpn_box_reg'], got['det_rpn_box_reg'])
+    # a smaller last batch: a second entry, replayed from then on
+    lit.use_detector_graph = True
+    small = synthetic.make_batch(2, H, W, seed=22, device="cuda")
+    lit.fit_step(small)
+    lit.fit_step(small)
+    assert g.captures == 2 and len(g.entries) == 2
+    torch.cuda.synchronize()
