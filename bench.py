@@ -101,7 +101,7 @@ def conv_roofline(lit, batch, reps=5):
         # algorithmic bytes: every operand once (x, x2, w, y, residual, mask)
         by = x.numel() * 2 + (0 if kw.get("x2") is None else kw["x2"].numel() * 2) + w.numel() * 2 + y.numel() * y.element_size()
         by += sum(t.numel() * 2 for t in (kw.get("res"), kw.get("mask")) if t is not None)
-        rec.append((dict(kw), (x, w, KH, KW), flops, by, where[0]))
+        rec.append(({k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, (x, w, KH, KW), flops, by, where[0]))
         return out
 
     # weight-gradient launches of the hallucination network (hd_wgrad): part of its "conv blocks" (BASELINE north_star)
@@ -111,7 +111,7 @@ def conv_roofline(lit, batch, reps=5):
     def spy_wg(x, dy, KH, KW, **kw):
         out = orig_wg(x, dy, KH, KW, **kw)
         C2 = 0 if kw.get("x2") is None else kw["x2"].shape[3]
-        wrec.append(((x, dy, KH, KW), dict(kw), 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * KH * KW * (x.shape[3] + C2)))
+        wrec.append(((x, dy, KH, KW), {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * KH * KW * (x.shape[3] + C2)))
         return out
 
     where = ["detector"]
@@ -198,7 +198,7 @@ def conv_roofline(lit, batch, reps=5):
         tot_by += by
         roof_ms += max(fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / 8e12) * 1e3
         hbm_bound += int(by / 8e12 > fl / (MFMA_F16_PEAK_TFLOPS * 1e12))
-        kw = dict(kw)                                 # same epilogue (bias / res / mask / BN statistics) as in the step
+        kw = {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}                                 # same epilogue (bias / res / mask / BN statistics) as in the step
         ms = iso_time(lambda: orig(x, w, KH, KW, **kw))
         tot_ms += ms
         tot_fl += fl

@@ -22,6 +22,7 @@
 //   * K order: channel chunk (outer) x tap (inner); the patch of chunk c+1 is fetched during taps 1-6 of chunk c.
 #include "hd_common.h"
 #include "conv_params.h"
+#include "wgrad3x3_w8_body.h"
 
 namespace {
 
@@ -37,8 +38,20 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, un
 
 __device__ __forceinline__ int swz_of(int y, int x) { return ((x >> 1) + 4 * y) & 7; }
 
+// LDS of one block, in halves: max(main-loop ring, epilogue tile)
+template <int TH, int WN, int WK>
+constexpr int p8_lds_halves() {
+  constexpr int BM = TH * TW, BN = WN * 64;
+  constexpr int NPIECE = ((TH + 2) * PW * 8 + 63) / 64;
+  constexpr int RING = 2 * NPIECE * 512 + 3 * BN * LDS_ROW;
+  constexpr int EPI = WK * BM * (BN + 4) * 2;
+  return RING > EPI ? RING : EPI;
+}
+
+// One output tile (block `bid_in` of a grid of `nwg_in` tiles); `lds`: p8_lds_halves<TH, WN, WK>() halves, 1 KiB aligned.  A device
+// function so that the fused data-gradient + weight-gradient launch below can run it in the leading blocks of its grid.
 template <int TH, int WN, int WK, bool DUAL>
-__global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
+__device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, int nwg_in) {
   constexpr int BM = TH * TW, BN = WN * 64, WM = TH / 8;
   static_assert(WM * WN * WK == 8, "eight waves");
   constexpr int KSP = 4 / WK;
@@ -52,7 +65,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
   constexpr int CP = BN + 4;                            // epilogue tile pitch in floats (16-byte LDS writes conflict-free)
   constexpr int EPI_HALVES = WK * BM * CP * 2;
   constexpr int LDS_HALVES = RING > EPI_HALVES ? RING : EPI_HALVES;
-  __shared__ __attribute__((aligned(1024))) f16 lds[LDS_HALVES];
+  static_assert(LDS_HALVES == p8_lds_halves<TH, WN, WK>(), "p8_lds_halves out of date");
   f16* const patch0 = lds;
   f16* const bst0 = lds + 2 * PSTAGE;
 
@@ -65,9 +78,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
   HD_TRACE(0, wall_clock64());
   HD_TRACE(1, clock64());
 
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {
-    const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int nwg = nwg_in, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   }
   const int tile_m = bid / p.gn, tile_n = bid - tile_m * p.gn;
@@ -421,6 +434,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
   HD_TRACE(7, hw_ids());
 }
 
+template <int TH, int WN, int WK, bool DUAL>
+__global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
+  __shared__ __attribute__((aligned(1024))) f16 lds[p8_lds_halves<TH, WN, WK>()];
+  conv3x3_w8_body<TH, WN, WK, DUAL>(p, lds, blockIdx.x, gridDim.x);
+}
+
+// Data gradient AND weight gradient of one layer as ONE grid: blocks [0, n_conv) run the convolution tiles, the blocks behind them
+// the 8-wave weight gradient (wgrad3x3_w8_body.h).  The deep U-Net layers have 160 convolution tiles for 256 CUs at batch 8 -- 37 % of
+// the chip idles through every one of those launches, and through the tail of the 256-block weight gradient that follows it; both
+// consume the same dY and are independent, so one grid of 160 + 256 blocks keeps every CU busy until the work of both is done.
+// Same code, same summation orders: results are bit-identical to the two separate launches.
+template <int TH, int WN, int WK>
+__global__ __launch_bounds__(512, 2) void conv3x3_w8_wgrad_kernel(ConvP p, hd_wg8::Wg8P q, int n_conv, int wg_gx) {
+  constexpr int L1 = p8_lds_halves<TH, WN, WK>(), L2 = hd_wg8::LDS_HALVES;
+  __shared__ __attribute__((aligned(1024))) f16 lds[L1 > L2 ? L1 : L2];
+  if ((int)blockIdx.x < n_conv) {
+    conv3x3_w8_body<TH, WN, WK, false>(p, lds, blockIdx.x, n_conv);
+  } else {
+    const int w = (int)blockIdx.x - n_conv;
+    hd_wg8::wgrad3x3_w8_body(q, lds, w % wg_gx, w / wg_gx);
+  }
+}
+
+template <int TH, int WN, int WK>
+void launch_p8_wgrad(ConvP& p, const hd_wg8::Wg8P& q, int wg_gx, int wg_gy, hipStream_t s) {
+  p.gm = p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW);
+  p.gn = hd_cdiv(p.Cout, WN * 64);
+  const int n_conv = p.gm * p.gn;
+  hipLaunchKernelGGL((conv3x3_w8_wgrad_kernel<TH, WN, WK>), dim3(n_conv + wg_gx * wg_gy), dim3(512), 0, s, p, q, n_conv, wg_gx);
+}
+
 template <int TH, int WN, int WK>
 void launch_p8(ConvP& p, hipStream_t s) {
   p.gm = p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW);
@@ -446,6 +490,19 @@ bool hd_conv_p8_eligible(const ConvP& p) {
 int hd_conv_p8_tiles(const ConvP& p, int cfg) {
   const int th = (cfg == 0 || cfg == 2) ? 32 : 16;
   return p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, TW);
+}
+
+// fused launch (see conv3x3_w8_wgrad_kernel): `p` is a single-source 3x3 conv eligible for tile `cfg`, `wa` an 8-wave weight gradient
+void hd_conv_launch_p8_wgrad(ConvP& p, int cfg, const hd_wgrad_args* wa, hipStream_t s) {
+  hd_wg8::Wg8P q;
+  int gx, gy;
+  hd_wg8::fill_params(wa, q, &gx, &gy);
+  switch (cfg) {
+    case 0: launch_p8_wgrad<32, 2, 1>(p, q, gx, gy, s); break;
+    case 1: launch_p8_wgrad<16, 2, 2>(p, q, gx, gy, s); break;
+    case 2: launch_p8_wgrad<32, 1, 2>(p, q, gx, gy, s); break;
+    default: launch_p8_wgrad<16, 1, 4>(p, q, gx, gy, s); break;
+  }
 }
 
 void hd_conv_launch_p8(ConvP& p, int cfg, hipStream_t s) {

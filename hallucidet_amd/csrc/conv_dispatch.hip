@@ -202,6 +202,37 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   return hd_cdiv(p.M, c.bm);
 }
 
+extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream);
+extern "C" int hd_conv2d(const hd_conv_args* a, void* stream);
+
+// Data gradient + weight gradient of one layer (both read the same dY): ONE grid when the convolution runs in the 8-wave
+// patch-staged family and the weight gradient in its 8-wave kernel (conv3x3_w8_wgrad_kernel), otherwise hd_conv2d then hd_wgrad.
+// Bit-identical to the two calls either way.  HD_FUSE_DGRAD_WGRAD=0: always two launches (A/B).
+extern "C" int hd_conv2d_wgrad(const hd_conv_args* a, const hd_wgrad_args* wa, void* stream) {
+  static const int fuse_on = env_int("HD_FUSE_DGRAD_WGRAD", 1);
+  HD_CHECK_ARG(a && wa, "hd_conv2d_wgrad: null pointer");
+  ConvP p;
+  int rc = fill_params(a, p);
+  if (rc) return rc;
+  if (fuse_on && !use_small(p) && !p.in_scale && !p.x2 && !p.stats && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
+    const TileChoice c = choose_tile(p);
+    if (c.p8cfg >= 0) {
+      static const int w8_prio = env_int("HD_W8_PRIO", 0);
+      p.prio = w8_prio;
+#ifdef HD_CONV_TRACE
+      p.trace = nullptr;
+      p.trace_tid = 0;
+#endif
+      hd_conv_launch_p8_wgrad(p, c.p8cfg, wa, (hipStream_t)stream);
+      HD_CHECK_LAUNCH();
+      return HD_OK;
+    }
+  }
+  rc = hd_conv2d(a, stream);
+  if (rc) return rc;
+  return hd_wgrad(wa, stream);
+}
+
 extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   ConvP p;
   int rc = fill_params(a, p);

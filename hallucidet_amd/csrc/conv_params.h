@@ -92,6 +92,10 @@ void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 bool hd_conv_p8_eligible(const ConvP& p);
 int hd_conv_p8_tiles(const ConvP& p, int cfg);
 void hd_conv_launch_p8(ConvP& p, int cfg, hipStream_t s);
+// the same tile grid with the blocks of an 8-wave weight gradient behind it (one launch; conv3x3_w8.hip)
+void hd_conv_launch_p8_wgrad(ConvP& p, int cfg, const hd_wgrad_args* wa, hipStream_t s);
+// wgrad.hip: would hd_wgrad run this weight gradient in the 8-wave patch-staged kernel?
+bool hd_wgrad_takes_w8(const hd_wgrad_args* a);
 // conv3x3_small.hip: 3x3 / stride 1 / pad 1, Cin in {8,16,32}, Cout in {16,32}, plain NHWC f16 output (+ BN partial sums)
 bool hd_conv_small_eligible(const ConvP& p);
 int hd_conv_small_tiles(const ConvP& p);

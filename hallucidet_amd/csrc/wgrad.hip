@@ -526,6 +526,14 @@ extern "C" int hd_wgrad_w8_blocks(const hd_wgrad_args* a) {
   return ((a->C1 + a->C2) / 64) * (a->Cout / 64);
 }
 
+bool hd_wgrad_takes_w8(const hd_wgrad_args* a) {
+  static const char* env8 = getenv("HD_WGRAD_W8");
+  static const bool w8_on = !(env8 && env8[0] == '0');
+  if (!a || !a->x || !a->dy || !a->slab || a->nsplit < 1 || a->in_scale) return false;
+  if (g_wg_tm >= 0 || hd_wgrad_small_eligible(a)) return false;
+  return w8_on && hd_wgrad_w8_eligible(a);
+}
+
 extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   HD_CHECK_ARG(a && a->x && a->dy && a->slab, "hd_wgrad: null pointer");
   HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->Cout % 8 == 0, "hd_wgrad: channels must be multiples of 8");

@@ -1,191 +1,11 @@
-// Weight gradient of the 3x3 / stride 1 / pad 1 layers with >= 64 channels on both sides, 8-wave family with LDS-STAGED INPUT
-// PATCHES:   dW[co][tap][ci] = sum_pixels dY[pixel][co] * X[pixel + tap][ci]
-//
-// The general kernel (wgrad.hip) stages 32-pixel reduction tiles through registers (4 global loads + 4 LDS stores per thread
-// for 8 MFMAs) and re-gathers the input once per tap: 13-17 % MFMA-pipe utilisation (profiles/r02_conv_mfma_util.json).  Here a
-// block owns one 64 (co) x 64 (ci) weight tile for ALL nine taps and walks a range of 16 x 8-pixel tiles:
-//   * per pixel tile it stages, by LDS-DMA in their natural [pixel][channel] layout, the 128 x 64 dY tile (16 KiB) and the
-//     (16+2) x (8+2) input patch of the 64-channel chunk (23 KiB) ONCE -- the nine taps read shifted windows of the patch;
-//     decoder layers gather the patch from the nearest-2x upsampled tensor or the skip tensor in place (decoder.py:38-41);
-//   * MFMA fragments need 8 consecutive PIXELS per lane (the reduction index is the slow axis of both operands): produced by the
-//     transposing LDS read ds_read_b64_tr_b16 (four pixel rows x 16 channels per 16-lane group); bank swizzle on the DMA source
-//     side: 16-byte slot s of pixel p holds channel group s ^ (4 * ((p >> 1) & 1)), which puts the four pixel rows of a 32-lane
-//     half into the four 64-byte quarters of the 256-byte bank row (conflict-free);
-//   * 8 waves = 2 (co halves) x 2 (ci halves) x 2 (pixel halves of the tile); a wave keeps its nine 32 x 32 fp32 accumulators (144
-//     registers) across the whole tile range, the two pixel halves meet once, in LDS, at the end;
-//   * one fp32 partial per block -> slab[slice][co][tap*Cin + ci], summed by hd_wgrad_reduce (deterministic, as before).
-#include "hd_common.h"
+// 8-wave patch-staged weight gradient: kernel wrapper and launch (the kernel body lives in wgrad3x3_w8_body.h)
+#include "wgrad3x3_w8_body.h"
 
 namespace {
 
-constexpr int TH = 16, TW = 8, PW = 10, PH = TH + 2;
-constexpr int PPX = PH * PW;                    // 180 patch pixels
-constexpr int XPIECES = (PPX * 8 + 63) / 64;    // 23 one-KiB pieces
-constexpr int YPIECES = TH * TW * 8 / 64;       // 16
-constexpr int XSTAGE = XPIECES * 512;           // halves
-constexpr int YSTAGE = YPIECES * 512;
-constexpr int STAGE = XSTAGE + YSTAGE;
-constexpr int NPIECES = XPIECES + YPIECES;      // 39 per tile
-constexpr int PPWV = (NPIECES + 7) / 8;         // 5 per wave
-constexpr unsigned OOBB = 0x80000000u;
-
-struct Wg8P {
-  const f16* x;
-  const f16* x2;
-  const f16* dy;
-  float* slab;
-  int N, Hsrc, Wsrc, H, W, C1, C2, Cin, Cout, Ktot;
-  int tiles_x, tiles_y, ntiles, per_split, dual;
-  unsigned xbytes, x2bytes, dybytes;
-};
-
-typedef __attribute__((address_space(3))) void lds_void;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_dst, 16, voff, 0, 0, 0);
-}
-__device__ __forceinline__ f16x8 tr_pair(const char* p0, const char* p1) {
-  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0));
-  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p1));
-  f16x4 fa = __builtin_bit_cast(f16x4, a), fb = __builtin_bit_cast(f16x4, b);
-  f16x8 r = {fa[0], fa[1], fa[2], fa[3], fb[0], fb[1], fb[2], fb[3]};
-  return r;
-}
-__device__ __forceinline__ int swz4(int p) { return ((p >> 1) & 1) << 2; }
-
-__global__ __launch_bounds__(512, 2) void wgrad3x3_w8_kernel(Wg8P p) {
-  __shared__ __attribute__((aligned(1024))) f16 lds[2 * STAGE > 9 * 4 * 1024 * 2 ? 2 * STAGE : 9 * 4 * 1024 * 2];   // ring / final half-sum
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave & 1, wci = (wave >> 1) & 1, wpx = wave >> 2;      // co half, ci half, pixel half of the tile
-  const int ci_chunks = p.Cin >> 6;
-  const int cchunk = blockIdx.y % ci_chunks, ochunk = blockIdx.y / ci_chunks;
-  const int ci0 = cchunk * 64, co0 = ochunk * 64;
-  const bool second = p.dual && ci0 >= p.C1;           // this ci chunk lives in the skip tensor
-
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(second ? p.x2 : p.x), 0, second ? p.x2bytes : p.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.dy), 0, p.dybytes, 0x00020000);
-
-  // ---- this wave's DMA pieces of a tile: piece q = k*8 + wave; q < XPIECES: input patch, else dY tile
-  int upix[PPWV];               // patch / tile pixel of this lane's unit
-  unsigned ucol[PPWV];          // byte offset of its channel group within the pixel's source row
-#pragma unroll
-  for (int k = 0; k < PPWV; ++k) {
-    const int q = k * 8 + wave;
-    const int u = (q < XPIECES ? q : q - XPIECES) * 64 + lane;
-    const int px = u >> 3, slot = u & 7;
-    upix[k] = px;
-    const int cg = (slot ^ swz4(px)) & 7;
-    ucol[k] = q < XPIECES ? (unsigned)((second ? ci0 - p.C1 : ci0) + cg * 8) * 2u : (unsigned)(co0 + cg * 8) * 2u;
-  }
-  const int srcC = second ? p.C2 : p.C1;
-  auto issue_tile = [&](int t, int stage) {
-    const bool live = t < p.ntiles;
-    const int tt = live ? t : 0;
-    const int n = tt / (p.tiles_x * p.tiles_y);
-    const int rem = tt - n * p.tiles_x * p.tiles_y;
-    const int tyi = rem / p.tiles_x;
-    const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
-    f16* sx = lds + stage * STAGE;
-    f16* sy = sx + XSTAGE;
-#pragma unroll
-    for (int k = 0; k < PPWV; ++k) {
-      const int q = k * 8 + wave;
-      if (q >= NPIECES) break;
-      if (q < XPIECES) {
-        const int pp = upix[k];
-        const int y = (pp * 6554) >> 16, x = pp - y * PW;
-        const int iy = ty0 - 1 + y, ix = tx0 - 1 + x;
-        const bool v = live && pp < PPX && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-        unsigned off;
-        if (p.dual && !second) off = (unsigned)(((n * p.Hsrc + (iy >> 1)) * p.Wsrc + (ix >> 1)) * srcC) * 2u;
-        else off = (unsigned)(((n * p.H + iy) * p.W + ix) * srcC) * 2u;
-        dma16(rx, sx + q * 512, v ? off + ucol[k] : OOBB);
-      } else {
-        const int pix = upix[k];
-        const int oy = ty0 + (pix >> 3), ox = tx0 + (pix & 7);
-        const bool v = live && oy < p.H && ox < p.W;
-        dma16(rdy, sy + (q - XPIECES) * 512, v ? (unsigned)(((n * p.H + oy) * p.W + ox) * p.Cout) * 2u + ucol[k] : OOBB);
-      }
-    }
-  };
-
-  // ---- transposed-read geometry: 16-lane group g = lane >> 4 -> k half th = g >> 1 (pixel row of the 2 x 8 block), column half
-  //      g & 1; within the group lane 4q+p addresses pixel q (x = q, second read x = q + 4), columns 4p .. 4p+3
-  const int li = lane & 15, g = lane >> 4;
-  const int tq = li >> 2, tp = li & 3, th = g >> 1, thalf = g & 1;
-  // byte offsets (within a stage) for K step 0 of this wave's pixel half; K step s adds s * 2 rows
-  unsigned ya[2], xa[9][2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int y = wpx * (TH / 2) + th, x = tq + 4 * r;
-    const int pix = y * 8 + x;
-    const int cb = wco * 64 + thalf * 32 + tp * 8;                 // byte column within the 128-byte dY row (co half, 16-col half, 4-col group)
-    ya[r] = (unsigned)(XSTAGE * 2 + pix * 128 + (((cb >> 4) ^ swz4(pix)) << 4) + (cb & 15));
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int pp = (y + t / 3) * PW + x + t % 3;
-      const int cx = wci * 64 + thalf * 32 + tp * 8;
-      xa[t][r] = (unsigned)(pp * 128 + (((cx >> 4) ^ swz4(pp)) << 4) + (cx & 15));
-    }
-  }
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  const int t_begin = blockIdx.x * p.per_split;
-  int t_end = t_begin + p.per_split;
-  if (t_end > p.ntiles) t_end = p.ntiles;
-  const char* lb = reinterpret_cast<const char*>(lds);
-
-  if (t_begin < t_end) issue_tile(t_begin, 0);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int st = (t - t_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // tile t landed everywhere; everyone is done with the other stage
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < t_end) issue_tile(t + 1, st ^ 1);
-    const unsigned sb = (unsigned)(st * STAGE * 2);
-    // K steps of this wave's pixel half: 2 pixel rows (16 pixels) each; row step = 8 dY pixels (1 KiB) / 10 patch pixels (1 280 B)
-#pragma unroll
-    for (int s = 0; s < TH / 4; ++s) {
-      const f16x8 a = tr_pair(lb + sb + ya[0] + s * 2048, lb + sb + ya[1] + s * 2048);
-#pragma unroll
-      for (int tp9 = 0; tp9 < 9; ++tp9) {
-        const f16x8 b = tr_pair(lb + sb + xa[tp9][0] + s * 2560, lb + sb + xa[tp9][1] + s * 2560);
-        acc[tp9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tp9], 0, 0, 0);
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- the two pixel halves meet in LDS (9 x 4 wave tiles of 32 x 32 fp32 = 147 KiB), then one coalesced slab write
-  float* red = reinterpret_cast<float*>(lds);
-  const int wt = wave & 3;
-  if (wpx == 1) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((t * 4 + wt) * 16 + r) * 64 + lane] = acc[t][r];
-  }
-  __syncthreads();
-  if (wpx == 0) {
-    float* out = p.slab + (size_t)blockIdx.x * p.Cout * p.Ktot;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = acc[t][r] + red[((t * 4 + wt) * 16 + r) * 64 + lane];
-        const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int ci = ci0 + wci * 32 + (lane & 31);
-        out[(size_t)co * p.Ktot + t * p.Cin + ci] = v;
-      }
-  }
+__global__ __launch_bounds__(512, 2) void wgrad3x3_w8_kernel(hd_wg8::Wg8P p) {
+  __shared__ __attribute__((aligned(1024))) f16 lds[hd_wg8::LDS_HALVES];
+  hd_wg8::wgrad3x3_w8_body(p, lds, blockIdx.x, blockIdx.y);
 }
 
 }  // namespace
@@ -201,17 +21,8 @@ bool hd_wgrad_w8_eligible(const hd_wgrad_args* a) {
 }
 
 void hd_wgrad_w8_launch(const hd_wgrad_args* a, hipStream_t s) {
-  Wg8P p;
-  p.x = (const f16*)a->x; p.x2 = (const f16*)a->x2; p.dy = (const f16*)a->dy; p.slab = a->slab;
-  p.N = a->N; p.Hsrc = a->Hsrc; p.Wsrc = a->Wsrc; p.H = a->Hin; p.W = a->Win; p.C1 = a->C1; p.C2 = a->C2;
-  p.Cin = a->C1 + a->C2; p.Cout = a->Cout; p.Ktot = 9 * p.Cin;
-  p.tiles_x = hd_cdiv(p.W, TW); p.tiles_y = hd_cdiv(p.H, TH);
-  p.ntiles = p.N * p.tiles_x * p.tiles_y;
-  p.per_split = hd_cdiv(p.ntiles, a->nsplit);
-  p.dual = a->x2 != nullptr;
-  p.xbytes = (unsigned)((int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2);
-  p.x2bytes = a->x2 ? (unsigned)((int64_t)a->N * a->Hin * a->Win * a->C2 * 2) : 0u;
-  p.dybytes = (unsigned)((int64_t)a->N * a->Ho * a->Wo * a->Cout * 2);
-  dim3 grid(a->nsplit, (p.Cin / 64) * (p.Cout / 64));
-  hipLaunchKernelGGL(wgrad3x3_w8_kernel, grid, dim3(512), 0, s, p);
+  hd_wg8::Wg8P p;
+  int gx, gy;
+  hd_wg8::fill_params(a, p, &gx, &gy);
+  hipLaunchKernelGGL(wgrad3x3_w8_kernel, dim3(gx, gy), dim3(512), 0, s, p);
 }

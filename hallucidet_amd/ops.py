@@ -31,7 +31,7 @@ def conv_out_size(h, k, stride, pad):
 
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
            out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None,
-           in_scale=None, in_shift=None, in_relu=True):
+           in_scale=None, in_shift=None, in_relu=True, _defer=None):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
@@ -76,11 +76,14 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
         check(0 if rows > 0 else rows, "hd_conv2d_stats_rows")
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         a.stats = ptr(stats)
-    check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
+    if _defer is not None:          # wgrad_dgrad: the caller launches (the argument block and its tensors are kept by the list)
+        _defer.append((a, (x, x2, w, bias, res, mask, y, stats, in_scale, in_shift)))
+    else:
+        check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
     return (y, stats) if want_stats else y
 
 
-def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in_scale=None, in_shift=None, in_relu=True):
+def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in_scale=None, in_shift=None, in_relu=True, _defer=None):
     """Returns fp32 slab [nsplit, Cout, KH*KW*(C1+C2)] of partial weight gradients.  ``in_scale`` / ``in_shift``: as in conv2d
     (x is the raw output of the producing conv; small-channel 3x3 kernel only)."""
     _need_cuda(x, dy, x2)
@@ -107,8 +110,21 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in
     slab = torch.empty((nsplit, Cout, K), dtype=torch.float32, device=x.device)
     a = WgradArgs(ptr(x), ptr(x2), ptr(dy), ptr(slab), N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
                   1 if up1 else 0, nsplit, ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
-    check(lib.hd_wgrad(C.byref(a), _stream()), "hd_wgrad")
+    if _defer is not None:
+        _defer.append((a, (x, x2, dy, slab, in_scale, in_shift)))
+    else:
+        check(lib.hd_wgrad(C.byref(a), _stream()), "hd_wgrad")
     return slab
+
+
+def wgrad_dgrad(x, dy, KH, KW, wd, *, x2=None, stride=1, pad=0, up1=False, in_scale=None, in_shift=None, in_relu=True, dgrad=None):
+    """The two consumers of a layer's dY in one call (hd_conv2d_wgrad): -> (slab as `wgrad(x, dy, ...)`, dx as `conv2d(dy, wd, KH, KW,
+    **dgrad)`).  One grid when both run in the 8-wave kernels, two launches otherwise; bit-identical to the separate calls."""
+    hold = []
+    slab = wgrad(x, dy, KH, KW, x2=x2, stride=stride, pad=pad, up1=up1, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, _defer=hold)
+    dx = conv2d(dy, wd, KH, KW, _defer=hold, **(dgrad or {}))
+    check(_abi.load().hd_conv2d_wgrad(C.byref(hold[1][0]), C.byref(hold[0][0]), _stream()), "hd_conv2d_wgrad")
+    return slab, dx
 
 
 _WGRAD_BLOCKS = int(os.environ.get("HD_WGRAD_BLOCKS", "0"))   # 0: per-class targets below

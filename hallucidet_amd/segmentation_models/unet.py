@@ -577,18 +577,21 @@ class UnetRunner:
                                          relu=u.relu, want_dres=want_dres,
                                          gscale=inv, dgamma=u.bn.weight.grad, dbeta=u.bn.bias.grad)
         xt, isc, ish, irelu = _operand(r["x"])
-        slab = ops.wgrad(xt, dy, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"],
-                         **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
-        self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
+        wkw = dict(x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"], **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
         dx = None
         if need_dx:
+            # weight gradient and data gradient read the same dY and are independent: one call, ONE grid where both run in the 8-wave
+            # kernels (ops.wgrad_dgrad / hd_conv2d_wgrad: the deep layers' 160-tile data gradients leave 96 CUs idle on their own)
             wd = self.saved["W"][u.name][1]
             x = xt
             if r["up1"]:
                 hw = (x.shape[1] * 2, x.shape[2] * 2)
             else:
                 hw = (x.shape[1], x.shape[2])
-            dx = ops.conv2d(dy, wd, u.k, u.k, stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res)
+            slab, dx = ops.wgrad_dgrad(xt, dy, u.k, u.k, wd, dgrad=dict(stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res), **wkw)
+        else:
+            slab = ops.wgrad(xt, dy, u.k, u.k, **wkw)
+        self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
         return dx, dres
 
     def backward(self, dout, need_dx=False, keep_saved=False):

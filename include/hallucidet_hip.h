@@ -125,6 +125,12 @@ int hd_wgrad(const hd_wgrad_args* a, void* stream);
 int hd_wgrad_w8_blocks(const hd_wgrad_args* a);
 /* tuning hook (tools/tune_wgrad.py): force hd_wgrad's Cout tile (32 / 64 / 128 rows); -1 = by channel count. Process-wide. */
 int hd_wgrad_tune_override(int tm);
+/* The data gradient (an hd_conv2d over dY with the flipped weights) and the weight gradient of ONE layer -- the two consumers of the
+ * same dY in the backward pass of every trainable Conv2d (train_hallucidet.py:448-451 -> autograd) -- issued together: one grid when
+ * both run in the 8-wave kernels (the conv tiles first, the weight-gradient blocks behind them: the 160-tile data gradients of the deep
+ * layers leave 96 of the 256 CUs idle on their own), two launches otherwise.  Results are bit-identical to hd_conv2d + hd_wgrad. */
+int hd_conv2d_wgrad(const hd_conv_args* dgrad, const hd_wgrad_args* wgrad, void* stream);
+
 /* dw_oihw[co][ci][kh][kw] (=|+=) scale * sum_s slab[s][co][(kh,kw,ci)] ; Cin_real <= Cin, Cout <= Cout_slab
  * (slab rows/channels beyond the real extents are layout padding and are dropped) */
 int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW,

@@ -941,3 +941,23 @@ def test_small_grid_conv_is_batch_invariant_and_run_to_run_identical(dev):
     assert torch.equal(a, b)
     assert torch.equal(a[5:6], one)
     assert torch.equal(big[8:16], a) and torch.equal(big[16:], a)
+
+
+@pytest.mark.parametrize("case", [(8, 16, 24, 128, 128), (3, 19, 21, 256, 256), (8, 16, 20, 512, 512), (2, 40, 24, 128, 256), (2, 24, 24, 64, 64)])
+def test_fused_dgrad_wgrad_launch_is_bit_identical_to_the_two_launches(dev, case):
+    """ops.wgrad_dgrad (hd_conv2d_wgrad: the data-gradient conv tiles and the 8-wave weight-gradient blocks of a layer as one grid)
+    against ops.wgrad + ops.conv2d: same slab, same dx, bit for bit -- incl. a residual in the data-gradient epilogue, a shape whose
+    convolution stays on the 4-wave family (64 -> 64: two launches inside the call) and ragged tiles."""
+    from hallucidet_amd import ops
+    N, H, W, Cin, Cout = case
+    x = rnd(N, H, W, Cin, seed=1).to(dev)
+    dy = rnd(N, H, W, Cout, seed=2).to(dev)
+    wd = rnd(Cin, 9 * Cout, scale=1.0 / math.sqrt(9 * Cout), seed=3).to(dev)       # flipped / transposed layout: [Cin][tap][Cout]
+    res = rnd(N, H, W, Cin, seed=4).to(dev)
+    slab_a = ops.wgrad(x, dy, 3, 3, pad=1)
+    dx_a = ops.conv2d(dy, wd, 3, 3, pad=1, cout=Cin, res=res)
+    slab_b, dx_b = ops.wgrad_dgrad(x, dy, 3, 3, wd, pad=1, dgrad=dict(pad=1, cout=Cin, res=res))
+    torch.cuda.synchronize()
+    assert slab_a.shape == slab_b.shape and torch.equal(slab_a, slab_b)
+    assert torch.equal(dx_a, dx_b)
+    assert torch.isfinite(dx_b.float()).all() and float(slab_b.abs().max()) > 0

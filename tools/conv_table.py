@@ -22,7 +22,7 @@ orig = ops.conv2d
 
 def spy(x, w, KH, KW, **kw):
     out = orig(x, w, KH, KW, **kw)
-    rec.append((x, w, KH, KW, dict(kw), out[0] if isinstance(out, tuple) else out, where[0]))
+    rec.append((x, w, KH, KW, {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, out[0] if isinstance(out, tuple) else out, where[0]))
     return out
 
 

@@ -15,7 +15,7 @@ orig = ops.conv2d
 
 def spy(x, w, KH, KW, **kw):
     out = orig(x, w, KH, KW, **kw)
-    rec.append((x, w, KH, KW, dict(kw)))
+    rec.append((x, w, KH, KW, {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}))
     return out
 
 

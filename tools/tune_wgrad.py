@@ -13,7 +13,7 @@ o_w = ops.wgrad
 
 def spy_w(x, dy, KH, KW, **kw):
     out = o_w(x, dy, KH, KW, **kw)
-    rec.append((x, dy, KH, KW, dict(kw), out.shape))
+    rec.append((x, dy, KH, KW, {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, out.shape))
     return out
 
 
@@ -43,7 +43,7 @@ for (x, dy, KH, KW, kw, shp) in rec:
             ns = max(1, min(int(round(ns0 * f * tm0 / tm)) if tm != tm0 else int(round(ns0 * f)), M // 64))
             if (tm, ns) in res or ns * Cout * K * 4 > (256 << 20):
                 continue
-            k2 = dict(kw); k2["nsplit"] = ns
+            k2 = {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}; k2["nsplit"] = ns
             lib.hd_wgrad_tune_override(tm)
 
             def run():
