@@ -75,6 +75,7 @@ PROTOTYPES = {
     "hd_wgrad_w8_blocks": (C.c_int, [C.POINTER(WgradArgs)]),
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
     "hd_conv2d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(WgradArgs), vp]),
+    "hd_conv2d_multi": (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
     "hd_wgrad_tune_override": (C.c_int, [C.c_int]),
     "hd_wgrad_reduce": (C.c_int, [vp, vp] + [C.c_int] * 7 + [c_f, C.c_int, vp]),
     "hd_wgrad_reduce_plan": (C.c_int, [vp, C.c_int]),

@@ -233,6 +233,46 @@ extern "C" int hd_conv2d_wgrad(const hd_conv_args* a, const hd_wgrad_args* wa, v
   return hd_wgrad(wa, stream);
 }
 
+// n independent convolutions in ONE grid when they all resolve to the same 4-wave igemm variant (single source, no parity classes,
+// none of them claimed by the small-channel or the 8-wave kernels); otherwise n hd_conv2d calls.  The tile of the FIRST problem
+// (callers put the largest first) serves all of them: in this family the tile shape does not change a single output bit.
+// HD_CONV_MULTI=0: always separate launches (A/B).
+extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
+  static const int multi_on = env_int("HD_CONV_MULTI", 1);
+  HD_CHECK_ARG(args && n >= 1, "hd_conv2d_multi: bad args");
+  bool ok = multi_on && n >= 2 && n <= HD_CONV_MULTI_MAX && g_small_ok && g_w8_cfg < 0;
+  static ConvMulti mp;          // 3.3 KB: not on the stack of a ctypes call; the boundary is not re-entrant (SURVEY 8b "Threading")
+  TileChoice c0 = {};
+  for (int i = 0; ok && i < n; ++i) {
+    ConvP& p = mp.p[i];
+    int rc = fill_params(&args[i], p);
+    if (rc) return rc;
+    if (use_small(p) || p.in_scale || p.x2 || p.in_dil != 1) { ok = false; break; }
+    const TileChoice c = choose_tile(p);
+    if (c.p8cfg >= 0) { ok = false; break; }
+    if (i == 0) c0 = c;
+    else if (c.use64 != c0.use64) { ok = false; break; }
+#ifdef HD_CONV_TRACE
+    p.trace = nullptr;
+    p.trace_tid = 0;
+#endif
+  }
+  if (ok) {
+    mp.n = n;
+    const bool launched = c0.use64 ? hd_conv_launch_bk64_multi(mp, c0.bm, c0.bn, c0.deep, (hipStream_t)stream)
+                                   : hd_conv_launch_bk32_multi(mp, c0.bm, c0.bn, c0.deep, (hipStream_t)stream);
+    if (launched) {
+      HD_CHECK_LAUNCH();
+      return HD_OK;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    int rc = hd_conv2d(&args[i], stream);
+    if (rc) return rc;
+  }
+  return HD_OK;
+}
+
 extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   ConvP p;
   int rc = fill_params(a, p);

@@ -44,7 +44,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, un
 }
 
 template <int BM, int BN, int WM, int WN, bool DUAL, bool KGEN, int NSTAGE>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+__device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in) {
   constexpr int MT = BM / (WM * 32);
   constexpr int NT = BN / (WN * 32);
   constexpr int A_LOADS = BM * CPT / 256;               // 4 or 2
@@ -64,9 +64,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 
   // ---- XCD-aware tile mapping: blocks are dealt round-robin over the 8 XCDs, so give XCD x the x-th contiguous
   //      eighth of the (n-tile fastest) tile list.  Bijective for any grid size.
-  int bid = blockIdx.x;
+  int bid = bid_in;
   {
-    const int nwg = gridDim.x, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+    const int nwg = nwg_in, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   }
   const int tile_m = bid / p.gn, tile_n = bid - tile_m * p.gn;
@@ -264,6 +264,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
 }
 
 
+template <int BM, int BN, int WM, int WN, bool DUAL, bool KGEN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvP p) {
+  conv_igemm_body<BM, BN, WM, WN, DUAL, KGEN, NSTAGE>(p, blockIdx.x, gridDim.x);
+}
+
+// several problems in one grid (ConvMulti, conv_params.h): the block picks its problem, then runs the same body
+template <int BM, int BN, int WM, int WN, bool KGEN, int NSTAGE>
+__global__ __launch_bounds__(256) void conv_igemm_multi_kernel(ConvMulti mp) {
+  int pi = 0;
+  for (int i = 1; i < mp.n; ++i)
+    if ((int)blockIdx.x >= mp.first[i]) pi = i;
+  ConvP p = mp.p[pi];
+  conv_igemm_body<BM, BN, WM, WN, false, KGEN, NSTAGE>(p, (int)blockIdx.x - mp.first[pi], mp.first[pi + 1] - mp.first[pi]);
+}
+
 }  // namespace
 
 template <int BM, int BN, int WM, int WN, int NS>
@@ -293,4 +308,33 @@ void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s) {
     if (bn == 128) { if (deep) launch_variant_bk64<64, 128, 2, 2, 3>(p, s); else launch_variant_bk64<64, 128, 2, 2, 2>(p, s); }
     else { if (deep) launch_variant_bk64<64, 64, 2, 2, 3>(p, s); else launch_variant_bk64<64, 64, 2, 2, 2>(p, s); }
   }
+}
+
+template <int BM, int BN, int WM, int WN, int NS>
+static bool launch_multi_bk64(ConvMulti& mp, hipStream_t s) {
+  const bool kgen = (mp.p[0].cin8 % (64 / 8)) != 0;
+  int total = 0;
+  for (int i = 0; i < mp.n; ++i) {
+    ConvP& p = mp.p[i];
+    if (p.x2 || p.par || ((p.cin8 % (64 / 8)) != 0) != kgen) return false;
+    p.nk = (p.nchunks + 64 / 8 - 1) / (64 / 8);
+    p.gm = hd_cdiv(p.M, BM);
+    p.gn = hd_cdiv(p.Cout, BN);
+    mp.first[i] = total;
+    total += p.gm * p.gn;
+  }
+  mp.first[mp.n] = total;
+  if (kgen) hipLaunchKernelGGL((conv_igemm_multi_kernel<BM, BN, WM, WN, true, NS>), dim3(total), dim3(256), 0, s, mp);
+  else hipLaunchKernelGGL((conv_igemm_multi_kernel<BM, BN, WM, WN, false, NS>), dim3(total), dim3(256), 0, s, mp);
+  return true;
+}
+
+bool hd_conv_launch_bk64_multi(ConvMulti& mp, int bm, int bn, bool deep, hipStream_t s) {
+  if (bn == 32) return launch_multi_bk64<128, 32, 4, 1, 2>(mp, s);
+  if (bm == 128) {
+    if (bn == 128) return deep ? launch_multi_bk64<128, 128, 2, 2, 3>(mp, s) : launch_multi_bk64<128, 128, 2, 2, 2>(mp, s);
+    return deep ? launch_multi_bk64<128, 64, 2, 2, 3>(mp, s) : launch_multi_bk64<128, 64, 2, 2, 2>(mp, s);
+  }
+  if (bn == 128) return deep ? launch_multi_bk64<64, 128, 2, 2, 3>(mp, s) : launch_multi_bk64<64, 128, 2, 2, 2>(mp, s);
+  return deep ? launch_multi_bk64<64, 64, 2, 2, 3>(mp, s) : launch_multi_bk64<64, 64, 2, 2, 2>(mp, s);
 }

@@ -30,6 +30,17 @@ struct ConvP {
 #endif
 };
 
+// Several independent convolutions of ONE kernel variant in one grid (hd_conv2d_multi): the per-level convolutions of the FPN and of
+// the RPN / RetinaNet / FCOS heads (same layer type on 4-5 feature maps, the small ones 16-150 tiles) ride in the tail of the largest
+// level's launch instead of each paying a launch of their own.  Blocks [first[i], first[i+1]) belong to problem i.
+constexpr int HD_CONV_MULTI_MAX = 10;
+struct ConvMulti {
+  ConvP p[HD_CONV_MULTI_MAX];
+  int first[HD_CONV_MULTI_MAX + 1];
+  int n;
+};
+static_assert(sizeof(ConvMulti) <= 3968, "ConvMulti travels in the kernel arguments (4 KiB)");
+
 // per-block timeline stamps, compiled only into the profiling build (build.py --trace, tools/conv_trace.py)
 #ifdef HD_CONV_TRACE
 __device__ __forceinline__ unsigned long long hw_ids() {
@@ -88,6 +99,9 @@ __device__ __forceinline__ int hd_par_pixel(const ConvP& p, int m) {
 
 void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
 void hd_conv_launch_bk64(ConvP& p, int bm, int bn, bool deep, hipStream_t s);
+// multi-problem forms: every problem single-source, no parity classes, the same (per-lane tap) addressing mode; false = not launched
+bool hd_conv_launch_bk32_multi(ConvMulti& mp, int bm, int bn, bool deep, hipStream_t s);
+bool hd_conv_launch_bk64_multi(ConvMulti& mp, int bm, int bn, bool deep, hipStream_t s);
 // conv3x3_w8.hip: 8-wave family with LDS-staged input patches (3x3 / s1 / p1, Cin % 64 == 0); cfg = tile id
 bool hd_conv_p8_eligible(const ConvP& p);
 int hd_conv_p8_tiles(const ConvP& p, int cfg);

@@ -150,6 +150,32 @@ def _fwd(e, x, *, act=ACT_NONE, res=None, f32=False, tag=None):
                                 out_nchw_f32=f32, cout=e["cout"]))
 
 
+def _fwd_many(es, xs, *, act=ACT_NONE, f32=False, tags=None):
+    """`_fwd(e, x, ...)` for several independent (entry, input) pairs -- the same layer type on every feature level -- as ONE grid
+    where the kernels allow it (ops.conv2d_multi; put the largest level first).  Same outputs as the per-level calls, bit for bit."""
+    calls = []
+    for e, x in zip(es, xs):
+        kw = dict(bias=e["bias"], stride=e["stride"], pad=e["pad"], act=act, cout=e["cout"])
+        if f32 == "nhwc":
+            kw["out_nhwc_f32"] = True
+        elif f32:
+            kw["out_nchw_f32"] = True
+        calls.append((x, e["wf"], e["k"], e["k"], kw))
+    outs = ops.conv2d_multi(calls)
+    if f32 == "nhwc":
+        return [o.permute(0, 3, 1, 2) for o in outs]
+    return [_tap(None if tags is None else tags[i], o) for i, o in enumerate(outs)]
+
+
+def _dgrad_many(es, dys, hws, *, ress=None, masks=None):
+    """`_dgrad` for several independent (entry, gradient) pairs as one grid (see _fwd_many)."""
+    calls = []
+    for i, (e, dy, hw) in enumerate(zip(es, dys, hws)):
+        calls.append((dy, e["wd"], e["k"], e["k"], dict(stride=1, pad=e["k"] - 1 - e["pad"], in_dil=e["stride"], out_hw=hw, cout=e["cin_p"],
+                                                        res=None if ress is None else ress[i], mask=None if masks is None else masks[i])))
+    return ops.conv2d_multi(calls)
+
+
 def _head_grad_nhwc16(g, H, W, cout_p):
     """Gradient of a head output [n, C, H, W] fp32 -> NHWC fp16 with cout_p channels.  When the gradient is the NCHW view of NHWC
     memory (what autograd hands back for `_fwd(..., f32="nhwc")` outputs) this is one pad-and-cast launch."""
@@ -306,14 +332,12 @@ class BackboneWithFPN(nn.Module):
                 rec["blocks"].append(srec)
         L = len(self.returned_layers)
         Cr = [C[l - 1] for l in self.returned_layers]
-        inner = [None] * L
-        inner[L - 1] = _fwd(P["inner"][L - 1], Cr[L - 1])
-        outs = [None] * L
-        outs[L - 1] = _fwd(P["layer"][L - 1], inner[L - 1])
+        # the lateral 1x1 convs of all levels as one grid, the top-down additions, then the 3x3 output convs of all levels as one
+        # grid (the 19x19 / 10x10 levels are 16-150 tiles each: they ride in the tail of the largest level's launch)
+        inner = _fwd_many(P["inner"], Cr)
         for i in range(L - 2, -1, -1):
-            lat = _fwd(P["inner"][i], Cr[i])
-            inner[i] = ops.upsample_add(lat, inner[i + 1])
-            outs[i] = _fwd(P["layer"][i], inner[i])
+            inner[i] = ops.upsample_add(inner[i], inner[i + 1])
+        outs = _fwd_many(P["layer"], inner)
         if self.p6p7:
             p6 = _fwd(P["p6"], outs[L - 1])
             extra = [p6, _fwd(P["p7"], _tap(("p7in",), torch.relu(p6)))]
@@ -360,12 +384,9 @@ class BackboneWithFPN(nn.Module):
             ops.subsample2_bwd(grads[L].contiguous(), dP[L - 1], accumulate=True)
         C = rec["C"]
         Cr = [C[l - 1] for l in self.returned_layers]
-        d_li = [None] * L
-        for i in range(L):
-            hw = (shapes[i][1], shapes[i][2])
-            d_li[i] = _dgrad(P["layer"][i], dP[i], hw)
-            if i > 0:
-                ops.upsample_add_bwd(d_li[i - 1], d_li[i], accumulate=True)
+        d_li = _dgrad_many(P["layer"], dP, [(shapes[i][1], shapes[i][2]) for i in range(L)])
+        for i in range(1, L):
+            ops.upsample_add_bwd(d_li[i - 1], d_li[i], accumulate=True)
         if tp:
             for i in range(L):
                 lb, ib = self.fpn.layer_blocks[i], self.fpn.inner_blocks[i]
@@ -375,9 +396,9 @@ class BackboneWithFPN(nn.Module):
                 _bgrad_into(ib.bias, d_li[i], inv)
         # lateral 1x1 convs -> gradients w.r.t. the returned C levels (C5's carries the ReLU mask of layer4's output)
         dC = [None] * 4
+        dlat = _dgrad_many(P["inner"], d_li, [(Cr[i].shape[1], Cr[i].shape[2]) for i in range(L)], masks=[Cr[i] if i == L - 1 else None for i in range(L)])
         for i, l in enumerate(self.returned_layers):
-            hw = (Cr[i].shape[1], Cr[i].shape[2])
-            dC[l - 1] = _dgrad(P["inner"][i], d_li[i], hw, mask=Cr[i] if i == L - 1 else None)
+            dC[l - 1] = dlat[i]
         gm = dC[3]
         for si in (3, 2, 1, 0):
             stage, srec = P["blocks"][si], rec["blocks"][si]
@@ -662,12 +683,14 @@ class _RPNHeadFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         feats = feats[:nlev]
         P = head.pack()
-        ts, outs = [], []
-        for li, f in enumerate(feats):
-            t = _fwd(P["conv"], f, act=ACT_RELU, tag=("rpn", li))
-            ts.append(t[:n_active])
-            outs.append(_fwd(P["cls"], t, f32="nhwc"))
-            outs.append(_fwd(P["box"], t, f32="nhwc"))
+        nl = len(feats)
+        tfull = _fwd_many([P["conv"]] * nl, feats, act=ACT_RELU, tags=[("rpn", li) for li in range(nl)])
+        ts = [t[:n_active] for t in tfull]
+        heads = _fwd_many([P["cls"]] * nl + [P["box"]] * nl, list(tfull) + list(tfull), f32="nhwc")      # 2 x levels 1x1 convs, one grid
+        outs = []
+        for li in range(nl):
+            outs.append(heads[li])
+            outs.append(heads[nl + li])
         ctx.head, ctx.ts, ctx.na, ctx.n = head, ts, n_active, feats[0].shape[0]
         ctx.feats = [f[:n_active] for f in feats] if head.train_params else None
         return tuple(outs)
@@ -677,6 +700,20 @@ class _RPNHeadFn(torch.autograd.Function):
         P = ctx.head.pack()
         dfeats = []
         na = ctx.na
+        nl = len(ctx.ts)
+        if (not ctx.head.train_params and all(g is not None for g in grads[:2 * nl]) and (na == ctx.n or ctx.has_acts)):
+            # frozen head, every level has both gradients (the training step): the three data-gradient convs of ALL levels as three
+            # grids -- cls, then box (+ cls result as residual, ReLU mask), then the shared 3x3 conv -- instead of 3 x levels launches
+            hws = [(t.shape[1], t.shape[2]) for t in ctx.ts]
+            gls = [_head_grad_nhwc16(grads[2 * i][:na], hws[i][0], hws[i][1], P["cls"]["cout_p"]) for i in range(nl)]
+            grs = [_head_grad_nhwc16(grads[2 * i + 1][:na], hws[i][0], hws[i][1], P["box"]["cout_p"]) for i in range(nl)]
+            dts = _dgrad_many([P["cls"]] * nl, gls, hws)
+            dts = _dgrad_many([P["box"]] * nl, grs, hws, ress=dts, masks=list(ctx.ts))
+            dfeats = _dgrad_many([P["conv"]] * nl, dts, hws)
+            ctx.ts = None
+            if ctx.has_acts:
+                return (None, None, None, None) + (None,) * len(dfeats) + tuple(dfeats)
+            return (None, None, None, None) + tuple(dfeats)
         for i, t in enumerate(ctx.ts):
             N, H, W, _ = t.shape
             dl, dr = grads[2 * i], grads[2 * i + 1]

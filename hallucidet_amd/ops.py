@@ -117,6 +117,21 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in
     return slab
 
 
+def conv2d_multi(calls):
+    """calls: [(x, w, KH, KW, kwargs)] -- the arguments of independent `conv2d` calls -> their outputs, issued as ONE grid when all
+    of them run in the same 4-wave implicit-GEMM variant (hd_conv2d_multi: the per-level convolutions of an FPN / a detection head),
+    else one after the other.  Put the largest problem first (its tile serves all).  Bit-identical to the separate calls."""
+    if len(calls) == 1:
+        x, w, KH, KW, kw = calls[0]
+        return [conv2d(x, w, KH, KW, **kw)]
+    hold, outs = [], []
+    for x, w, KH, KW, kw in calls:
+        outs.append(conv2d(x, w, KH, KW, _defer=hold, **kw))
+    arr = (ConvArgs * len(hold))(*[h[0] for h in hold])
+    check(_abi.load().hd_conv2d_multi(arr, len(hold), _stream()), "hd_conv2d_multi")
+    return outs
+
+
 def wgrad_dgrad(x, dy, KH, KW, wd, *, x2=None, stride=1, pad=0, up1=False, in_scale=None, in_shift=None, in_relu=True, dgrad=None):
     """The two consumers of a layer's dY in one call (hd_conv2d_wgrad): -> (slab as `wgrad(x, dy, ...)`, dx as `conv2d(dy, wd, KH, KW,
     **dgrad)`).  One grid when both run in the 8-wave kernels, two launches otherwise; bit-identical to the separate calls."""

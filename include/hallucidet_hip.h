@@ -125,6 +125,13 @@ int hd_wgrad(const hd_wgrad_args* a, void* stream);
 int hd_wgrad_w8_blocks(const hd_wgrad_args* a);
 /* tuning hook (tools/tune_wgrad.py): force hd_wgrad's Cout tile (32 / 64 / 128 rows); -1 = by channel count. Process-wide. */
 int hd_wgrad_tune_override(int tm);
+/* n independent hd_conv2d problems (an array of argument blocks) as ONE grid where they all run in the same 4-wave implicit-GEMM
+ * variant, n separate launches otherwise: the same Conv2d applied per feature level -- torchvision FeaturePyramidNetwork inner_blocks /
+ * layer_blocks, RPNHead.conv / cls_logits / bbox_pred, the RetinaNet / FCOS towers [EXT], called per level from
+ * src/utils/eval_forward_*.py via model.backbone / model.rpn.head / model.head -- and their data gradients.  Results are bit-identical to
+ * n hd_conv2d calls.  n <= 10 for the single grid. */
+int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream);
+
 /* The data gradient (an hd_conv2d over dY with the flipped weights) and the weight gradient of ONE layer -- the two consumers of the
  * same dY in the backward pass of every trainable Conv2d (train_hallucidet.py:448-451 -> autograd) -- issued together: one grid when
  * both run in the 8-wave kernels (the conv tiles first, the weight-gradient blocks behind them: the 160-tile data gradients of the deep

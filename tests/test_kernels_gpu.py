@@ -961,3 +961,44 @@ def test_fused_dgrad_wgrad_launch_is_bit_identical_to_the_two_launches(dev, case
     assert slab_a.shape == slab_b.shape and torch.equal(slab_a, slab_b)
     assert torch.equal(dx_a, dx_b)
     assert torch.isfinite(dx_b.float()).all() and float(slab_b.abs().max()) > 0
+
+
+def test_conv2d_multi_equals_separate_calls(dev):
+    """hd_conv2d_multi: the per-level convolutions of a detection head / FPN as one grid -- bit-identical to one hd_conv2d per level:
+    a shared 3x3 conv over five feature levels (75^2 ... 5^2), its 1x1 heads with fp32 NHWC outputs and ragged channel counts,
+    1x1 lateral convs with a different Cin per level, and data-gradient calls with residual + ReLU mask; plus a list the single
+    grid cannot take (one member on the 8-wave family), which must fall back to separate launches with the same results."""
+    from hallucidet_amd import ops
+    g = lambda *s, seed: rnd(*s, seed=seed).to(dev)
+    sizes = [(3, 75, 75), (3, 38, 38), (3, 19, 19), (3, 10, 10), (3, 5, 5)]
+    feats = [g(n, h, w, 256, seed=10 + i) for i, (n, h, w) in enumerate(sizes)]
+    w3 = g(256, 9 * 256, seed=1) * (1.0 / 48.0)
+    bias = torch.randn(256, generator=torch.Generator().manual_seed(2)).to(dev)
+    calls = [(f, w3, 3, 3, dict(bias=bias, pad=1, act=1)) for f in feats]
+    sep = [ops.conv2d(x, w, kh, kw, **kw_) for x, w, kh, kw, kw_ in calls]
+    got = ops.conv2d_multi(calls)
+    for a, b in zip(sep, got):
+        assert torch.equal(a, b)
+    w1 = g(16, 256, seed=3) * (1.0 / 16.0)                         # 12 real output channels of 16 stored rows
+    b1 = torch.randn(12, generator=torch.Generator().manual_seed(4)).to(dev)
+    calls = [(t, w1, 1, 1, dict(bias=b1, out_nhwc_f32=True, cout=12)) for t in sep]
+    for a, b in zip([ops.conv2d(x, w, kh, kw, **kw_) for x, w, kh, kw, kw_ in calls], ops.conv2d_multi(calls)):
+        assert a.dtype == torch.float32 and torch.equal(a, b)
+    cins = [256, 512, 1024, 2048]                                   # FPN lateral convs: another Cin on every level
+    xs = [g(2, 40 >> i, 40 >> i, c, seed=20 + i) for i, c in enumerate(cins)]
+    ws = [g(256, c, seed=30 + i) * (1.0 / math.sqrt(c)) for i, c in enumerate(cins)]
+    calls = [(x, w, 1, 1, dict(bias=bias)) for x, w in zip(xs, ws)]
+    for a, b in zip([ops.conv2d(x, w, kh, kw, **kw_) for x, w, kh, kw, kw_ in calls], ops.conv2d_multi(calls)):
+        assert torch.equal(a, b)
+    wd = g(256, 9 * 256, seed=5) * (1.0 / 48.0)                     # data gradients of the shared 3x3 conv, residual + ReLU mask
+    dys = [g(*f.shape, seed=40 + i) for i, f in enumerate(feats)]
+    masks = [(g(*f.shape, seed=50 + i) > 0).half() for i, f in enumerate(feats)]
+    calls = [(d, wd, 3, 3, dict(pad=1, cout=256, res=f, mask=m, out_hw=(f.shape[1], f.shape[2]))) for d, f, m in zip(dys, feats, masks)]
+    for a, b in zip([ops.conv2d(x, w, kh, kw, **kw_) for x, w, kh, kw, kw_ in calls], ops.conv2d_multi(calls)):
+        assert torch.equal(a, b)
+    big = g(8, 64, 80, 128, seed=60)                                # 128 -> 128 @64x80 runs in the 8-wave family: no single grid
+    wb = g(128, 9 * 128, seed=61) * (1.0 / 34.0)
+    calls = [(big, wb, 3, 3, dict(pad=1)), (g(2, 16, 16, 128, seed=62), wb, 3, 3, dict(pad=1))]
+    for a, b in zip([ops.conv2d(x, w, kh, kw, **kw_) for x, w, kh, kw, kw_ in calls], ops.conv2d_multi(calls)):
+        assert torch.equal(a, b)
+    torch.cuda.synchronize()
