@@ -39,17 +39,22 @@ class _HeadFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # unused outputs arrive as None in backward, not as zero-filled maps
         feats = feats[:nlev]
         P = head.pack()
-        outs, saved = [], []
-        for li, f in enumerate(feats):
-            lv = []
-            for name, tower, last in (("cls", P["cls_tower"], P["cls_out"]), ("reg", P["reg_tower"], P["reg_out"])):
-                t, acts = f, []
-                for k, e in enumerate(tower):
-                    t = _fwd(e, t, act=ACT_RELU, tag=(name, li, k))
-                    acts.append(t[:n_active])
-                outs.append(_fwd(last, t, f32="nhwc"))
-                lv.append(acts)
-            saved.append(lv)
+        # layer k of BOTH towers on ALL levels is one grid (2 x levels independent 3x3 convs; D._fwd_many / hd_conv2d_multi): 5 launches
+        # for the head instead of 50, the 10x10 / 5x5 levels riding in the tail of the 38x38 level's tiles
+        nl = len(feats)
+        cur = list(feats) + list(feats)
+        saved = [[[], []] for _ in range(nl)]
+        for k in range(4):
+            cur = D._fwd_many([P["cls_tower"][k]] * nl + [P["reg_tower"][k]] * nl, cur, act=ACT_RELU,
+                              tags=[("cls", li, k) for li in range(nl)] + [("reg", li, k) for li in range(nl)])
+            for li in range(nl):
+                saved[li][0].append(cur[li][:n_active])
+                saved[li][1].append(cur[nl + li][:n_active])
+        heads = D._fwd_many([P["cls_out"]] * nl + [P["reg_out"]] * nl, cur, f32="nhwc")
+        outs = []
+        for li in range(nl):
+            outs.append(heads[li])
+            outs.append(heads[nl + li])
         ctx.head, ctx.saved, ctx.na, ctx.n = head, saved, n_active, feats[0].shape[0]
         ctx.feats = [f[:n_active] for f in feats] if head.train_params else None
         return tuple(outs)
@@ -62,6 +67,23 @@ class _HeadFn(torch.autograd.Function):
         tp, inv = head.train_params, 1.0 / head.grad_scale
         mods = ((head.classification_head, head.classification_head.cls_logits), (head.regression_head, head.regression_head.bbox_reg))
         dfeats = []
+        nl = len(ctx.saved)
+        if not tp and all(g is not None for g in grads[:2 * nl]) and (na == ctx.n or ctx.has_acts):
+            # frozen head, every output has a gradient (the training step): the data-gradient conv of layer k of both towers on all
+            # levels as one grid, walking the towers backwards; the two towers' first layers meet in the residual of the second
+            hws = [(lv[0][0].shape[1], lv[0][0].shape[2]) for lv in ctx.saved]
+            d = [D._head_grad_nhwc16(grads[2 * i][:na], hws[i][0], hws[i][1], P["cls_out"]["cout_p"]) for i in range(nl)] + \
+                [D._head_grad_nhwc16(grads[2 * i + 1][:na], hws[i][0], hws[i][1], P["reg_out"]["cout_p"]) for i in range(nl)]
+            acts = lambda k: [ctx.saved[i][0][k] for i in range(nl)] + [ctx.saved[i][1][k] for i in range(nl)]
+            d = D._dgrad_many([P["cls_out"]] * nl + [P["reg_out"]] * nl, d, hws + hws, masks=acts(3))
+            for k in (3, 2, 1):
+                d = D._dgrad_many([P["cls_tower"][k]] * nl + [P["reg_tower"][k]] * nl, d, hws + hws, masks=acts(k - 1))
+            df = D._dgrad_many([P["cls_tower"][0]] * nl, d[:nl], hws)
+            dfeats = D._dgrad_many([P["reg_tower"][0]] * nl, d[nl:], hws, ress=df)
+            ctx.saved = None
+            if ctx.has_acts:
+                return (None, None, None, None) + (None,) * len(dfeats) + tuple(dfeats)
+            return (None, None, None, None) + tuple(dfeats)
         for i, lv in enumerate(ctx.saved):
             df = None
             for j, (tower, last) in enumerate(((P["cls_tower"], P["cls_out"]), (P["reg_tower"], P["reg_out"]))):
