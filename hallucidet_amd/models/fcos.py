@@ -61,21 +61,26 @@ class _HeadFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)          # unused outputs arrive as None in backward, not as zero-filled maps
         feats = feats[:nlev]
         P = head.pack()
-        outs, saved = [], []
-        for li, f in enumerate(feats):
-            lv = []
-            for name, tower, lasts in (("cls", P["cls_tower"], (P["cls_out"],)), ("reg", P["reg_tower"], (P["reg_out"], P["ctr_out"]))):
-                t, acts = f, []
-                for k, (e, (ga, be, eps)) in enumerate(tower):
-                    c = _fwd(e, t)                                       # conv + bias, NHWC f16
-                    z, stat = ops.groupnorm8_relu(c, ga, be, eps)
-                    D._tap((name, li, k), z)
-                    acts.append((t[:n_active], c[:n_active], z[:n_active], stat[:n_active]))
-                    t = z
-                for last in lasts:
-                    outs.append(_fwd(last, t, f32="nhwc"))
-                lv.append(acts)
-            saved.append(lv)
+        # the 3x3 conv of layer k of BOTH towers on ALL levels is one grid (D._fwd_many / hd_conv2d_multi); GroupNorm + ReLU per tensor
+        nl = len(feats)
+        cur = list(feats) + list(feats)
+        saved = [[[], []] for _ in range(nl)]
+        for k in range(4):
+            cs = D._fwd_many([P["cls_tower"][k][0]] * nl + [P["reg_tower"][k][0]] * nl, cur)          # conv + bias, NHWC f16
+            nxt = []
+            for idx, c in enumerate(cs):
+                j, li = (0, idx) if idx < nl else (1, idx - nl)
+                ga, be, eps = (P["cls_tower"] if j == 0 else P["reg_tower"])[k][1]
+                z, stat = ops.groupnorm8_relu(c, ga, be, eps)
+                D._tap(("cls" if j == 0 else "reg", li, k), z)
+                saved[li][j].append((cur[idx][:n_active], c[:n_active], z[:n_active], stat[:n_active]))
+                nxt.append(z)
+            cur = nxt
+        h1 = D._fwd_many([P["cls_out"]] * nl + [P["reg_out"]] * nl, cur, f32="nhwc")
+        h2 = D._fwd_many([P["ctr_out"]] * nl, cur[nl:], f32="nhwc")
+        outs = []
+        for li in range(nl):
+            outs += [h1[li], h1[nl + li], h2[li]]
         ctx.head, ctx.saved, ctx.na, ctx.n = head, saved, n_active, feats[0].shape[0]
         return tuple(outs)
 
