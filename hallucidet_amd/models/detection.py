@@ -1021,7 +1021,8 @@ class _PredictorFn(torch.autograd.Function):
         ctx.pred = pred
         ctx.x = x if pred.train_params else None
         R = x.shape[0]
-        return _fwd(P["cls"], x, f32=True).view(R, -1), _fwd(P["box"], x, f32=True).view(R, -1)
+        cls, box = _fwd_many([P["cls"], P["box"]], [x, x], f32=True)          # the two tiny-N GEMMs (1024 -> K, 1024 -> 4K) as one grid
+        return cls.view(R, -1), box.view(R, -1)
 
     @staticmethod
     def backward(ctx, dc, db):
@@ -1076,7 +1077,8 @@ class FastRCNNPredictor(nn.Module):
             return _PredictorFn.apply(x, self)
         P = self.pack()
         R = x.shape[0]
-        return _fwd(P["cls"], x, f32=True).view(R, -1), _fwd(P["box"], x, f32=True).view(R, -1)
+        cls, box = _fwd_many([P["cls"], P["box"]], [x, x], f32=True)          # the two tiny-N GEMMs (1024 -> K, 1024 -> 4K) as one grid
+        return cls.view(R, -1), box.view(R, -1)
 
 
 def fastrcnn_loss(class_logits, box_regression, labels, regression_targets):
