@@ -174,6 +174,93 @@ __global__ __launch_bounds__(256) void nms_prepare_kernel(const float* __restric
   }
 }
 
+// ---- batched NMS over SEGMENTS (hd_batched_nms_pick_segments).  torchvision's batched_nms shifts the boxes of category c by
+// c * (max coordinate + 1): boxes of different categories never suppress each other, so the greedy scan decomposes into one
+// independent scan per (image, category).  The RPN's candidates arrive level by level (<= 1000 per level, already in descending
+// score order inside a level: rpn._get_top_n_idx): 24 x 5 scans of <= 16 chunks instead of 24 scans of 53 chunks whose blocks
+// occupied 24 of 256 CUs for 200 us, and a fifth of the pair tests.  The shift is still applied (per-image maximum, as
+// torchvision computes it), so every IoU is the bit pattern the one-list form produces.
+struct NmsSegs {
+  int off[9];      // segment l = candidates [off[l], off[l+1]) of every row
+  int L, S;        // number of segments (<= 8), largest segment (the per-segment stride of the work arrays)
+};
+
+// one block per image: per-image maximum coordinate, then per segment the valid candidates, in their given order, compacted to
+// the front of the segment's slot: shifted boxes, candidate indices, count
+__global__ __launch_bounds__(256) void nms_seg_prepare_kernel(const float* __restrict__ boxes, const uint8_t* __restrict__ valid, int n, NmsSegs sg,
+                                                              float* __restrict__ sorted, int64_t* __restrict__ order, int* __restrict__ counts) {
+  __shared__ float s_max[4];
+  __shared__ int s_cnt[4];
+  __shared__ int s_wsum[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* bb = boxes + (size_t)b * n * 4;
+  const uint8_t* vb = valid + (size_t)b * n;
+  float m = -INFINITY;
+  int cnt = 0;
+  for (int i = tid; i < n; i += 256)
+    if (vb[i]) {
+      const float4 v = *reinterpret_cast<const float4*>(bb + (size_t)i * 4);
+      m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+      ++cnt;
+    }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, d));
+    cnt += __shfl_xor(cnt, d);
+  }
+  if (lane == 0) {
+    s_max[wave] = m;
+    s_cnt[wave] = cnt;
+  }
+  __syncthreads();
+  cnt = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+  m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+  const float scale = (cnt > 0 ? m : 0.f) + 1.f;
+  for (int l = 0; l < sg.L; ++l) {
+    const int lo = sg.off[l], hi = sg.off[l + 1];
+    const float off = (float)l * scale;
+    float* so = sorted + ((size_t)b * sg.L + l) * sg.S * 4;
+    int64_t* oo = order + ((size_t)b * sg.L + l) * sg.S;
+    int base = 0;
+    for (int c0 = lo; c0 < hi; c0 += 256) {
+      const int i = c0 + tid;
+      const bool v = i < hi && vb[i];
+      const uint64_t bal = __ballot(v);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      __syncthreads();                       // s_wsum of the previous round has been read
+      if (lane == 0) s_wsum[wave] = __popcll(bal);
+      __syncthreads();
+      int wbase = 0;
+      for (int w = 0; w < wave; ++w) wbase += s_wsum[w];
+      if (v) {
+        const int r = base + wbase + before;
+        float4 bx = *reinterpret_cast<const float4*>(bb + (size_t)i * 4);
+        bx.x += off; bx.y += off; bx.z += off; bx.w += off;
+        *reinterpret_cast<float4*>(so + (size_t)r * 4) = bx;
+        oo[r] = i;
+      }
+      base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    }
+    if (tid == 0) counts[b * sg.L + l] = base;
+  }
+}
+
+// one block per (image, segment): key[b][segment] = -inf, then the score of every survivor of the segment at its candidate index
+__global__ __launch_bounds__(256) void nms_seg_key_kernel(const float* __restrict__ scores, const int64_t* __restrict__ pick, const int64_t* __restrict__ picked,
+                                                          int n, int pick_n, NmsSegs sg, float* __restrict__ key) {
+  const int b = blockIdx.x / sg.L, l = blockIdx.x % sg.L;
+  const int lo = sg.off[l], hi = sg.off[l + 1];
+  float* kb = key + (size_t)b * n;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) kb[i] = -INFINITY;
+  __syncthreads();
+  const int np = (int)picked[blockIdx.x];
+  const int64_t* pk = pick + (size_t)blockIdx.x * pick_n;
+  for (int r = threadIdx.x; r < np; r += 256) {
+    const int64_t i = pk[r];
+    kb[i] = scores[(size_t)b * n + i];
+  }
+}
+
 // ------------------------------------------------------------------ RoIAlign
 struct Bilin {
   int yl, xl, yh, xh;
@@ -1464,6 +1551,34 @@ extern "C" int hd_batched_nms_pick(const float* boxes, const int64_t* idxs, cons
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B), dim3(64), 0, s, (const float*)sorted_ws, (const int*)counts_ws, n, iou_thr, mask_ws);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(256), 0, s, (const uint64_t*)mask_ws, (const int*)counts_ws, n, keep_ws, top_n, order, pick,
                      top_n < n ? top_n : n, picked);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int hd_batched_nms_pick_segments(const float* boxes, const float* scores, const uint8_t* valid, int B, int n, const int* seg_sizes,
+                                            int L, float iou_thr, int top_n, float* sorted_ws, int64_t* order_ws, int* counts_ws,
+                                            uint64_t* mask_ws, uint8_t* keep_ws, int64_t* pick_ws, int64_t* picked_seg, float* key_out,
+                                            void* stream) {
+  HD_CHECK_ARG(boxes && scores && valid && seg_sizes && sorted_ws && order_ws && counts_ws && mask_ws && keep_ws && pick_ws && picked_seg && key_out &&
+               B > 0 && n > 0 && L >= 1 && L <= 8 && top_n > 0, "hd_batched_nms_pick_segments: bad args (<= 8 segments)");
+  NmsSegs sg;
+  sg.L = L;
+  sg.S = 1;
+  sg.off[0] = 0;
+  for (int l = 0; l < L; ++l) {
+    HD_CHECK_ARG(seg_sizes[l] > 0, "hd_batched_nms_pick_segments: empty segment");
+    sg.off[l + 1] = sg.off[l] + seg_sizes[l];
+    if (seg_sizes[l] > sg.S) sg.S = seg_sizes[l];
+  }
+  for (int l = L + 1; l < 9; ++l) sg.off[l] = sg.off[L];
+  HD_CHECK_ARG(sg.off[L] == n && sg.S <= 16384, "hd_batched_nms_pick_segments: segment sizes must add up to n");
+  hipStream_t s = (hipStream_t)stream;
+  const int S = sg.S, cb = (S + 63) / 64, pick_n = top_n < S ? top_n : S;
+  hipLaunchKernelGGL(nms_seg_prepare_kernel, dim3(B), dim3(256), 0, s, boxes, valid, n, sg, sorted_ws, order_ws, counts_ws);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B * L), dim3(64), 0, s, (const float*)sorted_ws, (const int*)counts_ws, S, iou_thr, mask_ws);
+  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B * L), dim3(256), 0, s, (const uint64_t*)mask_ws, (const int*)counts_ws, S, keep_ws, top_n,
+                     (const int64_t*)order_ws, pick_ws, pick_n, picked_seg);
+  hipLaunchKernelGGL(nms_seg_key_kernel, dim3(B * L), dim3(256), 0, s, scores, (const int64_t*)pick_ws, (const int64_t*)picked_seg, n, pick_n, sg, key_out);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -634,6 +634,22 @@ def _batched_nms_pick(boxes, scores, idxs, valid, iou_thr, top_n):
     return ops.batched_nms_pick(boxes, idxs, valid, order, iou_thr, top_n)
 
 
+_NMS_SEGMENTS = os.environ.get("HD_NMS_SEGMENTS", "1") != "0"      # A/B knob: 0 = one scan per image over all levels
+
+
+def _batched_nms_pick_segments(boxes, scores, seg_sizes, valid, iou_thr, top_n):
+    """`_batched_nms_pick` for candidates whose NMS categories are the SEGMENTS `seg_sizes` of every row, each segment already in
+    descending score order (what the RPN hands over: per-level top-k lists).  Same (pick, counts): the survivors of the
+    category-shifted NMS in global descending-score order -- but one greedy scan per (image, level) instead of one per image."""
+    B, n = scores.shape
+    key, picked = ops.batched_nms_pick_segments(boxes, scores, valid, seg_sizes, iou_thr, top_n)
+    k = min(int(top_n), n)
+    pick = ops.topk_rows_segments(key, [n], k)                         # survivors by descending score, equal scores by ascending index
+    counts = picked.sum(dim=1).clamp(max=k)
+    pick = torch.where(_arange(k, scores.device)[None, :] < counts[:, None], pick, pick[:, :1])     # padding = the best candidate, as before
+    return pick, counts
+
+
 # ======================================================================================================================
 # RPN
 # ======================================================================================================================
@@ -1589,7 +1605,12 @@ def filter_proposals_padded(rpn, proposals, objectness, image_shape, num_anchors
         valid = (ws >= rpn.min_size) & (hs >= rpn.min_size) & (prob >= rpn.score_thresh)
     post = rpn.post_nms_top_n()
     # survivors in score order at the front; rows past counts[i] are padding
-    pick, counts = _batched_nms_pick(boxes, prob, levels, valid, rpn.nms_thresh, post)
+    seg = [min(k, n) for n in num_anchors_per_level]
+    if _NMS_SEGMENTS and boxes.is_cuda and prob.dtype == torch.float32 and len(seg) <= 8 and sum(seg) == prob.shape[1]:
+        # the levels are the NMS categories and `top` lists every level in descending score order: one scan per (image, level)
+        pick, counts = _batched_nms_pick_segments(boxes, prob, seg, valid, rpn.nms_thresh, post)
+    else:
+        pick, counts = _batched_nms_pick(boxes, prob, levels, valid, rpn.nms_thresh, post)
     out_b = torch.gather(boxes, 1, pick[:, :, None].expand(-1, -1, 4))
     out_s = torch.gather(prob, 1, pick)
     return out_b, out_s, counts

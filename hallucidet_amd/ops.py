@@ -672,6 +672,34 @@ def batched_nms_pick(boxes, idxs, valid, order, iou_thr, top_n):
     return pick, picked
 
 
+def batched_nms_pick_segments(boxes, scores, valid, seg_sizes, iou_thr, top_n):
+    """Coordinate-offset batched NMS whose categories are SEGMENTS of the candidate list (the RPN's feature levels), each already in
+    descending score order: boxes [B,n,4] f32, scores [B,n] f32, valid [B,n] bool, seg_sizes (python ints, sum n, <= 8).
+    -> key [B,n] f32 (score of every survivor at its candidate index, -inf elsewhere), picked [B,L] int64 (survivors per segment)."""
+    _need_cuda(boxes, scores, valid)
+    B, n, _ = boxes.shape
+    dev = boxes.device
+    seg_sizes = [int(v) for v in seg_sizes]
+    L, S = len(seg_sizes), max(seg_sizes)
+    assert sum(seg_sizes) == n and scores.dtype == torch.float32
+    boxes, scores = boxes.contiguous().float(), scores.contiguous()
+    v8 = valid.contiguous().view(torch.uint8) if valid.dtype == torch.bool else valid.to(torch.uint8).contiguous()
+    cb = (S + 63) // 64
+    sorted_ws = torch.empty((B * L, S, 4), dtype=torch.float32, device=dev)
+    order_ws = torch.empty((B * L, S), dtype=torch.int64, device=dev)
+    counts_ws = torch.empty((B * L,), dtype=torch.int32, device=dev)
+    mask_ws = torch.empty((B * L, S, cb), dtype=torch.int64, device=dev)
+    keep_ws = torch.empty((B * L, S), dtype=torch.uint8, device=dev)
+    pick_ws = torch.empty((B * L, min(int(top_n), S)), dtype=torch.int64, device=dev)
+    picked = torch.empty((B, L), dtype=torch.int64, device=dev)
+    key = torch.empty((B, n), dtype=torch.float32, device=dev)
+    segs = (C.c_int * L)(*seg_sizes)
+    check(_abi.load().hd_batched_nms_pick_segments(ptr(boxes), ptr(scores), ptr(v8), B, n, C.cast(segs, C.c_void_p), L, float(iou_thr), int(top_n),
+                                                   ptr(sorted_ws), ptr(order_ws), ptr(counts_ws), ptr(mask_ws), ptr(keep_ws), ptr(pick_ws), ptr(picked),
+                                                   ptr(key), _stream()), "hd_batched_nms_pick_segments")
+    return key, picked
+
+
 def roi_align(feat, rois, PH, PW, spatial_scale, sampling_ratio):
     N, H, W, C_ = feat.shape
     R = rois.shape[0]

@@ -1002,3 +1002,33 @@ def test_conv2d_multi_equals_separate_calls(dev):
     for a, b in zip([ops.conv2d(x, w, kh, kw, **kw_) for x, w, kh, kw, kw_ in calls], ops.conv2d_multi(calls)):
         assert torch.equal(a, b)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("top_n", [1000, 150])
+def test_batched_nms_over_segments_equals_the_one_list_form(dev, top_n):
+    """hd_batched_nms_pick_segments (one greedy scan per (image, level), levels pre-sorted) against hd_batched_nms_pick (one scan per image
+    over the globally sorted, category-shifted list): the same survivors in the same order, the same counts, the same padding -- with
+    tied scores, invalid candidates inside the segments, an image whose candidates are all invalid and one truncated by top_n."""
+    from hallucidet_amd.models import detection as D
+    g = torch.Generator().manual_seed(5)
+    seg = [1000, 1000, 700, 300, 75]
+    B, n = 6, sum(seg)
+    xy = torch.rand(B, n, 2, generator=g) * 260
+    wh = torch.rand(B, n, 2, generator=g) * 90 + 4
+    boxes = torch.cat([xy, xy + wh], dim=2)
+    scores = torch.empty(B, n)
+    lo = 0
+    for s_ in seg:                                            # descending inside every segment, with runs of equal scores
+        v = (torch.rand(B, s_, generator=g) * 64).floor() / 64
+        scores[:, lo:lo + s_] = torch.sort(v, dim=1, descending=True)[0]
+        lo += s_
+    valid = torch.rand(B, n, generator=g) > 0.15
+    valid[3] = False
+    levels = torch.cat([torch.full((s_,), i, dtype=torch.int64) for i, s_ in enumerate(seg)])[None].expand(B, -1).contiguous()
+    boxes, scores, valid, levels = boxes.to(dev), scores.to(dev), valid.to(dev), levels.to(dev)
+    p0, c0 = D._batched_nms_pick(boxes, scores, levels, valid, 0.7, top_n)
+    p1, c1 = D._batched_nms_pick_segments(boxes, scores, seg, valid, 0.7, top_n)
+    torch.cuda.synchronize()
+    assert torch.equal(c0.to(torch.int64), c1.to(torch.int64)), (c0, c1)
+    assert int(c0[3]) == 0 and int(c0.max()) == min(top_n, int(c0.max()))
+    assert torch.equal(p0, p1)

@@ -11,13 +11,19 @@ def main():
     skip = float(sys.argv[2]) if len(sys.argv) > 2 and not sys.argv[2].startswith('-') else 0.5
     rows = []
     for r in csv.DictReader(open(path)):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        wg = 0
+        try:
+            wg = (int(r.get("Grid_Size_X", r.get("Grid_Size", 0))) // max(1, int(r.get("Workgroup_Size_X", r.get("Workgroup_Size", 1))))) * \
+                 max(1, int(r.get("Grid_Size_Y", 1)) // max(1, int(r.get("Workgroup_Size_Y", 1)))) * max(1, int(r.get("Grid_Size_Z", 1)) // max(1, int(r.get("Workgroup_Size_Z", 1))))
+        except (TypeError, ValueError):
+            pass
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], wg))
     rows.sort()
     rows = rows[int(len(rows) * skip):]
     span = rows[-1][1] - rows[0][0]
-    busy = sum(e - s for s, e, _ in rows)
+    busy = sum(r_[1] - r_[0] for r_ in rows)
     gaps = []
-    for (s0, e0, n0), (s1, e1, n1) in zip(rows, rows[1:]):
+    for (s0, e0, n0, _w0), (s1, e1, n1, _w1) in zip(rows, rows[1:]):
         gaps.append((max(0, s1 - e0), n0[:60] + "  ->  " + n1[:60]))
     tot_gap = sum(g for g, _ in gaps)
     print("launches %d  span %.3f ms  kernel time %.3f ms (%.1f %%)  gaps %.3f ms" % (len(rows), span / 1e6, busy / 1e6, 100.0 * busy / span, tot_gap / 1e6))
@@ -36,7 +42,7 @@ def main():
         win = rows[ends[0] + 1:ends[-1] + 1]
         nsteps = len(ends) - 1
         per = {}
-        for s_, e_, n in win:
+        for s_, e_, n, _wg in win:
             k = n.replace("(anonymous namespace)::", "").replace("void ", "")
             per.setdefault(k, [0, 0])
             per[k][0] += 1
@@ -60,6 +66,14 @@ def main():
             seen += t
             print("    %-32s %8.1f %7.1f" % (name, t / nsteps / 1e3, c / nsteps))
         print("    %-32s %8.1f" % ("everything else", (tot - seen) / nsteps / 1e3))
+        if "--small" in sys.argv:          # one step's launches that cannot fill the chip: candidates for one-grid fusion with a neighbour
+            one = rows[ends[0] + 1:ends[1] + 1]
+            tot_small = 0.0
+            for s_, e_, n, wg in one:
+                if 0 < wg < 230 and e_ - s_ >= 6000:
+                    tot_small += e_ - s_
+                    print("  %4d blocks %7.1f us  %s" % (wg, (e_ - s_) / 1e3, n.replace("(anonymous namespace)::", "")[:110]))
+            print("  launches with < 230 blocks and >= 6 us: %.1f us per step" % (tot_small / 1e3))
         if "--aten" in sys.argv:
             for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
                 if "at::" in k or "rocclr" in k:
