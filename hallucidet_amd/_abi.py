@@ -141,7 +141,7 @@ PROTOTYPES = {
     "hd_roi_samples_finish": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]),
     "hd_roi_levels": (C.c_int, [vp, C.c_long, C.c_int, C.c_float, C.c_float, C.c_float, C.c_int, C.c_int, vp, vp]),
     "hd_batched_nms_pick": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
-    "hd_batched_nms_pick_segments": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hd_batched_nms_pick_segments": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, C.c_float, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hd_rpn_decode_filter": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, vp, vp, vp, vp]),
     "hd_roi_decode_clip": (C.c_int, [vp, vp, C.c_long, C.c_int, C.c_int, vp, C.c_float, C.c_float, C.c_float, vp, vp]),
     "hd_topk_select_rows": (C.c_int, [vp, C.c_int, C.c_long, vp, C.c_int, C.c_int, vp, C.c_long, vp]),

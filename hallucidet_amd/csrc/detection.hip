@@ -245,19 +245,57 @@ __global__ __launch_bounds__(256) void nms_seg_prepare_kernel(const float* __res
   }
 }
 
-// one block per (image, segment): key[b][segment] = -inf, then the score of every survivor of the segment at its candidate index
-__global__ __launch_bounds__(256) void nms_seg_key_kernel(const float* __restrict__ scores, const int64_t* __restrict__ pick, const int64_t* __restrict__ picked,
-                                                          int n, int pick_n, NmsSegs sg, float* __restrict__ key) {
+// one block per (image, segment): merge of the segments' survivor lists (each in descending score order) into the row's global order --
+// descending score, equal scores by ascending candidate index, i.e. the stable sort the one-list form starts from.  The global rank of a
+// survivor = its rank in its own list + for every other segment the number of ITS survivors that sort before it (binary search over
+// that segment's scores, staged in LDS; lower segments hold lower candidate indices, so they win ties).  pick[b][rank] = candidate;
+// ranks >= top_n are dropped; positions past the total are padding = the best candidate (as hd_batched_nms_pick pads); picked[b] = total.
+__global__ __launch_bounds__(256) void nms_seg_merge_kernel(const float* __restrict__ scores, const int64_t* __restrict__ pick_seg,
+                                                            const int64_t* __restrict__ picked_seg, int n, int pick_n_seg, NmsSegs sg, int top_k,
+                                                            int64_t* __restrict__ pick, int64_t* __restrict__ picked) {
+  extern __shared__ float s_sc[];                 // [L][pick_n_seg] survivor scores of every segment of this row
   const int b = blockIdx.x / sg.L, l = blockIdx.x % sg.L;
-  const int lo = sg.off[l], hi = sg.off[l + 1];
-  float* kb = key + (size_t)b * n;
-  for (int i = lo + threadIdx.x; i < hi; i += 256) kb[i] = -INFINITY;
+  const float* sb = scores + (size_t)b * n;
+  int cnt[8], total = 0;
+  for (int q = 0; q < sg.L; ++q) {
+    cnt[q] = (int)picked_seg[b * sg.L + q];
+    total += cnt[q];
+    const int64_t* pq = pick_seg + ((size_t)b * sg.L + q) * pick_n_seg;
+    for (int r = threadIdx.x; r < cnt[q]; r += 256) s_sc[q * pick_n_seg + r] = sb[pq[r]];
+  }
   __syncthreads();
-  const int np = (int)picked[blockIdx.x];
-  const int64_t* pk = pick + (size_t)blockIdx.x * pick_n;
-  for (int r = threadIdx.x; r < np; r += 256) {
-    const int64_t i = pk[r];
-    kb[i] = scores[(size_t)b * n + i];
+  const int64_t* pk = pick_seg + (size_t)blockIdx.x * pick_n_seg;
+  for (int r = threadIdx.x; r < cnt[l]; r += 256) {
+    const float sc = s_sc[l * pick_n_seg + r];
+    int rank = r;
+    for (int q = 0; q < sg.L; ++q) {
+      if (q == l) continue;
+      const float* a = s_sc + q * pick_n_seg;     // non-increasing
+      int lo = 0, hi = cnt[q];
+      if (q < l) {                                // entries with score >= sc come first
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] >= sc) lo = mid + 1; else hi = mid; }
+      } else {                                    // entries with score > sc come first
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] > sc) lo = mid + 1; else hi = mid; }
+      }
+      rank += lo;
+    }
+    if (rank < top_k) pick[(size_t)b * top_k + rank] = pk[r];
+  }
+  if (l == 0) {
+    // padding: the best candidate of the row = the best first survivor over the segments (ties: the lower segment); an empty row pads
+    // with candidate 0 (what a stable sort of an all -inf key row puts first)
+    int64_t best = 0;
+    float bs = -INFINITY;
+    bool any = false;
+    for (int q = 0; q < sg.L; ++q)
+      if (cnt[q] > 0 && (!any || s_sc[q * pick_n_seg] > bs)) {
+        any = true;
+        bs = s_sc[q * pick_n_seg];
+        best = pick_seg[((size_t)b * sg.L + q) * pick_n_seg];
+      }
+    const int have = total < top_k ? total : top_k;
+    for (int r = have + threadIdx.x; r < top_k; r += 256) pick[(size_t)b * top_k + r] = best;
+    if (threadIdx.x == 0) picked[b] = have;
   }
 }
 
@@ -1557,9 +1595,9 @@ extern "C" int hd_batched_nms_pick(const float* boxes, const int64_t* idxs, cons
 
 extern "C" int hd_batched_nms_pick_segments(const float* boxes, const float* scores, const uint8_t* valid, int B, int n, const int* seg_sizes,
                                             int L, float iou_thr, int top_n, float* sorted_ws, int64_t* order_ws, int* counts_ws,
-                                            uint64_t* mask_ws, uint8_t* keep_ws, int64_t* pick_ws, int64_t* picked_seg, float* key_out,
-                                            void* stream) {
-  HD_CHECK_ARG(boxes && scores && valid && seg_sizes && sorted_ws && order_ws && counts_ws && mask_ws && keep_ws && pick_ws && picked_seg && key_out &&
+                                            uint64_t* mask_ws, uint8_t* keep_ws, int64_t* pick_ws, int64_t* picked_seg, int64_t* pick,
+                                            int64_t* picked, void* stream) {
+  HD_CHECK_ARG(boxes && scores && valid && seg_sizes && sorted_ws && order_ws && counts_ws && mask_ws && keep_ws && pick_ws && picked_seg && pick && picked &&
                B > 0 && n > 0 && L >= 1 && L <= 8 && top_n > 0, "hd_batched_nms_pick_segments: bad args (<= 8 segments)");
   NmsSegs sg;
   sg.L = L;
@@ -1578,7 +1616,9 @@ extern "C" int hd_batched_nms_pick_segments(const float* boxes, const float* sco
   hipLaunchKernelGGL(nms_mask_kernel, dim3(cb, cb, B * L), dim3(64), 0, s, (const float*)sorted_ws, (const int*)counts_ws, S, iou_thr, mask_ws);
   hipLaunchKernelGGL(nms_reduce_kernel, dim3(B * L), dim3(256), 0, s, (const uint64_t*)mask_ws, (const int*)counts_ws, S, keep_ws, top_n,
                      (const int64_t*)order_ws, pick_ws, pick_n, picked_seg);
-  hipLaunchKernelGGL(nms_seg_key_kernel, dim3(B * L), dim3(256), 0, s, scores, (const int64_t*)pick_ws, (const int64_t*)picked_seg, n, pick_n, sg, key_out);
+  const int top_k = top_n < n ? top_n : n;
+  hipLaunchKernelGGL(nms_seg_merge_kernel, dim3(B * L), dim3(256), (size_t)L * pick_n * sizeof(float), s, scores, (const int64_t*)pick_ws,
+                     (const int64_t*)picked_seg, n, pick_n, sg, top_k, pick, picked);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

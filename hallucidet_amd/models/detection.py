@@ -641,13 +641,7 @@ def _batched_nms_pick_segments(boxes, scores, seg_sizes, valid, iou_thr, top_n):
     """`_batched_nms_pick` for candidates whose NMS categories are the SEGMENTS `seg_sizes` of every row, each segment already in
     descending score order (what the RPN hands over: per-level top-k lists).  Same (pick, counts): the survivors of the
     category-shifted NMS in global descending-score order -- but one greedy scan per (image, level) instead of one per image."""
-    B, n = scores.shape
-    key, picked = ops.batched_nms_pick_segments(boxes, scores, valid, seg_sizes, iou_thr, top_n)
-    k = min(int(top_n), n)
-    pick = ops.topk_rows_segments(key, [n], k)                         # survivors by descending score, equal scores by ascending index
-    counts = picked.sum(dim=1).clamp(max=k)
-    pick = torch.where(_arange(k, scores.device)[None, :] < counts[:, None], pick, pick[:, :1])     # padding = the best candidate, as before
-    return pick, counts
+    return ops.batched_nms_pick_segments(boxes, scores, valid, seg_sizes, iou_thr, top_n)
 
 
 # ======================================================================================================================

@@ -675,7 +675,7 @@ def batched_nms_pick(boxes, idxs, valid, order, iou_thr, top_n):
 def batched_nms_pick_segments(boxes, scores, valid, seg_sizes, iou_thr, top_n):
     """Coordinate-offset batched NMS whose categories are SEGMENTS of the candidate list (the RPN's feature levels), each already in
     descending score order: boxes [B,n,4] f32, scores [B,n] f32, valid [B,n] bool, seg_sizes (python ints, sum n, <= 8).
-    -> key [B,n] f32 (score of every survivor at its candidate index, -inf elsewhere), picked [B,L] int64 (survivors per segment)."""
+    -> pick [B, min(top_n, n)] int64, picked [B] int64 -- what `batched_nms_pick` returns for the same candidates."""
     _need_cuda(boxes, scores, valid)
     B, n, _ = boxes.shape
     dev = boxes.device
@@ -691,13 +691,14 @@ def batched_nms_pick_segments(boxes, scores, valid, seg_sizes, iou_thr, top_n):
     mask_ws = torch.empty((B * L, S, cb), dtype=torch.int64, device=dev)
     keep_ws = torch.empty((B * L, S), dtype=torch.uint8, device=dev)
     pick_ws = torch.empty((B * L, min(int(top_n), S)), dtype=torch.int64, device=dev)
-    picked = torch.empty((B, L), dtype=torch.int64, device=dev)
-    key = torch.empty((B, n), dtype=torch.float32, device=dev)
+    picked_seg = torch.empty((B, L), dtype=torch.int64, device=dev)
+    pick = torch.empty((B, min(int(top_n), n)), dtype=torch.int64, device=dev)
+    picked = torch.empty((B,), dtype=torch.int64, device=dev)
     segs = (C.c_int * L)(*seg_sizes)
     check(_abi.load().hd_batched_nms_pick_segments(ptr(boxes), ptr(scores), ptr(v8), B, n, C.cast(segs, C.c_void_p), L, float(iou_thr), int(top_n),
-                                                   ptr(sorted_ws), ptr(order_ws), ptr(counts_ws), ptr(mask_ws), ptr(keep_ws), ptr(pick_ws), ptr(picked),
-                                                   ptr(key), _stream()), "hd_batched_nms_pick_segments")
-    return key, picked
+                                                   ptr(sorted_ws), ptr(order_ws), ptr(counts_ws), ptr(mask_ws), ptr(keep_ws), ptr(pick_ws), ptr(picked_seg),
+                                                   ptr(pick), ptr(picked), _stream()), "hd_batched_nms_pick_segments")
+    return pick, picked
 
 
 def roi_align(feat, rois, PH, PW, spatial_scale, sampling_ratio):

@@ -315,13 +315,13 @@ int hd_batched_nms_pick(const float* boxes, const int64_t* idxs, const uint8_t* 
 /* The same selection when the candidates of a row come in SEGMENTS that are the categories of the NMS (the RPN's feature levels:
  * rpn.filter_proposals -> batched_nms(boxes, scores, lvl, ...), torchvision [EXT], reached from src/utils/eval_forward_fasterrcnn.py:86)
  * and are already in descending score order inside each segment (rpn._get_top_n_idx): one independent greedy scan per (row, segment)
- * instead of one per row.  seg_sizes (HOST) add up to n, <= 8 segments.  Work arrays: S = the largest segment, sorted_ws [B*L*S*4] f32,
- * order_ws / pick_ws [B*L*S] i64, counts_ws [B*L] i32, mask_ws [B*L*S*ceil(S/64)] u64, keep_ws [B*L*S] u8.  Outputs: picked_seg [B*L] (survivors
- * per segment) and key_out [B*n] = the score of every survivor at its candidate index, -inf elsewhere: the caller's top-k of key_out is
- * the ordered survivor list hd_batched_nms_pick returns.  Same survivors, bit for bit. */
+ * instead of one per row, then a merge of the segments' survivor lists by (score descending, candidate index ascending).  seg_sizes
+ * (HOST) add up to n, <= 8 segments.  Work arrays: S = the largest segment, sorted_ws [B*L*S*4] f32, order_ws / pick_ws [B*L*S] i64,
+ * counts_ws [B*L] i32, mask_ws [B*L*S*ceil(S/64)] u64, keep_ws [B*L*S] u8, picked_seg [B*L] i64.  Outputs as hd_batched_nms_pick:
+ * pick [B, min(top_n, n)] and picked [B].  Same survivors, same order, same padding, bit for bit. */
 int hd_batched_nms_pick_segments(const float* boxes, const float* scores, const uint8_t* valid, int B, int n, const int* seg_sizes, int L,
                                  float iou_thr, int top_n, float* sorted_ws, int64_t* order_ws, int* counts_ws, uint64_t* mask_ws,
-                                 uint8_t* keep_ws, int64_t* pick_ws, int64_t* picked_seg, float* key_out, void* stream);
+                                 uint8_t* keep_ws, int64_t* pick_ws, int64_t* picked_seg, int64_t* pick, int64_t* picked, void* stream);
 /* RPN proposals of the selected anchors only (RegionProposalNetwork.filter_proposals [EXT], reached from
  * src/utils/eval_forward_fasterrcnn.py:86): for image n, candidate t, a = top[n][t]:
  *   boxes[n][t] = clip_boxes_to_image(BoxCoder(1,1,1,1).decode(deltas[n][a], anchors[a]), (img_h, img_w));
