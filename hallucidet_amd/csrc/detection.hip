@@ -82,14 +82,21 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
     if (wave == 0) {
       const int i = c * 64 + lane;
       const uint64_t diag = (i < n) ? mb[(size_t)i * cb + c] : 0;
+      // greedy resolve of the chunk on the SCALAR unit: `alive` is wave-uniform, only the boxes still alive are visited, and box j's
+      // diagonal word comes from lane j by v_readlane (the __shfl form of this loop compiled to two ds_bpermute per step: ~6 us per
+      // 64-box chunk, the whole cost of the scan)
+      const unsigned dlo = (unsigned)diag, dhi = (unsigned)(diag >> 32);
       uint64_t alive = ~remv[c];
+      if (lim < 64) alive &= (1ull << lim) - 1ull;
+      alive = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(alive >> 32)) << 32) |
+              (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)alive);
       uint64_t keepbits = 0;
-      for (int j = 0; j < lim; ++j) {
-        const uint64_t dj = __shfl(diag, j);
-        if ((alive >> j) & 1ull) {
-          keepbits |= (1ull << j);
-          alive &= ~dj;
-        }
+      for (int it = 0; it < 64 && alive; ++it) {          // (bounded: at most one visit per box)
+        const int j = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+        keepbits |= (1ull << j);
+        const uint64_t dj = ((uint64_t)(unsigned)__builtin_amdgcn_readlane(dhi, j) << 32) | (uint64_t)(unsigned)__builtin_amdgcn_readlane(dlo, j);
+        alive &= ~dj;
+        alive &= ~(1ull << j);
       }
       if (i < n) kb[i] = (uint8_t)((keepbits >> lane) & 1ull);
       if (pick && ((keepbits >> lane) & 1ull)) {
