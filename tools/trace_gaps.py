@@ -52,8 +52,9 @@ def main():
         naten = sum(v[0] for k, v in per.items() if "at::" in k or "rocclr" in k)
         print("steady state: %d steps, %.1f launches/step, kernel time %.3f ms/step, wall %.3f ms/step; ATen+copy %.1f launches, %.1f us per step"
               % (nsteps, len(win) / nsteps, tot / nsteps / 1e6, (win[-1][1] - win[0][0]) / nsteps / 1e6, naten / nsteps, aten / nsteps / 1e3))
-        groups = [("hd_conv2d: conv_igemm", ("conv_igemm_kernel",)), ("hd_conv2d: conv3x3_w8", ("conv3x3_w8_kernel",)), ("hd_conv2d: conv3x3_small", ("conv3x3_small_kernel",)),
-                  ("weight gradients", ("wgrad_kernel", "wgrad3x3_w8_kernel", "wgrad3x3_small_kernel")), ("slab reductions", ("wgrad_reduce",)),
+        groups = [("hd_conv2d: conv_igemm (+ multi)", ("conv_igemm_kernel", "conv_igemm_multi_kernel")), ("hd_conv2d: conv3x3_w8", ("conv3x3_w8_kernel",)),
+                  ("hd_conv2d: conv3x3_small", ("conv3x3_small_kernel",)), ("data + weight gradient, one grid", ("conv3x3_w8_wgrad_kernel",)),
+                  ("weight gradients", ("::wgrad_kernel", "wgrad3x3_w8_kernel", "wgrad3x3_small_kernel")), ("slab reductions", ("wgrad_reduce",)),
                   ("BatchNorm reduce (bwd)", ("bn_bwd_reduce",)), ("BatchNorm apply (bwd)", ("bn_bwd_apply",)), ("BatchNorm apply (fwd)", ("bn_apply_kernel",)),
                   ("BatchNorm finalize", ("bn_finalize",)), ("BatchNorm coefficients (bwd)", ("bn_bwd_coef",)),
                   ("RoIAlign", ("roi_align",)), ("NMS", ("nms_",)), ("Adam", ("adam_kernel",)), ("weight repack", ("weight_prep",)),
@@ -61,8 +62,9 @@ def main():
         print("  groups (us/step, launches/step):")
         seen = 0.0
         for name, pats in groups:
-            t = sum(v[1] for k, v in per.items() if any(p_ in k for p_ in pats))
-            c = sum(v[0] for k, v in per.items() if any(p_ in k for p_ in pats))
+            hit = lambda k: any((p_[2:] in k and "conv3x3_w8_wgrad" not in k) if p_.startswith("::") else p_ in k for p_ in pats)
+            t = sum(v[1] for k, v in per.items() if hit(k))
+            c = sum(v[0] for k, v in per.items() if hit(k))
             seen += t
             print("    %-32s %8.1f %7.1f" % (name, t / nsteps / 1e3, c / nsteps))
         print("    %-32s %8.1f" % ("everything else", (tot - seen) / nsteps / 1e3))
