@@ -1254,11 +1254,19 @@ __global__ void roi_levels_kernel(const float* __restrict__ rois, long stride, i
 // A uniformly random subset of size k = the k smallest of iid random keys: `keys` holds one random int32 >= 0 per
 // candidate (torch.randint, so the generator stream is the framework's); a block radix-selects the k-th smallest key of
 // each class and marks the members (equal keys at the cut: lowest index first).
+// `lds_keys` / `lds_cls` (optional): the row's keys and classes (1 positive, 0 negative, 2 neither) staged in LDS by the caller -- the
+// four radix passes and the marking pass then read LDS instead of streaming 12 bytes per anchor from L2 five times.
 __device__ __forceinline__ void select_smallest_marked(const int32_t* __restrict__ keys, const int64_t* __restrict__ labels, int A, bool want_pos,
                                                        int k, int population, uint8_t* __restrict__ out, int* hist, uint32_t* s_prefix,
-                                                       int* s_remaining, int* s_wave_l, int* s_wave_e) {
+                                                       int* s_remaining, int* s_wave_l, int* s_wave_e, const uint32_t* lds_keys = nullptr,
+                                                       const uint8_t* lds_cls = nullptr) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  auto member = [&](int i) { const int64_t l = labels[i]; return want_pos ? (l >= 1) : (l == 0); };
+  auto member = [&](int i) {
+    if (lds_cls) return lds_cls[i] == (want_pos ? 1 : 0);
+    const int64_t l = labels[i];
+    return want_pos ? (l >= 1) : (l == 0);
+  };
+  auto key_of = [&](int i) { return lds_keys ? lds_keys[i] : (uint32_t)keys[i]; };
   if (k <= 0) {
     for (int i = tid; i < A; i += 1024) out[i] = 0;
     return;
@@ -1275,7 +1283,7 @@ __device__ __forceinline__ void select_smallest_marked(const int32_t* __restrict
     __syncthreads();
     for (int i = tid; i < A; i += 1024) {
       if (!member(i)) continue;
-      const uint32_t u = (uint32_t)keys[i];
+      const uint32_t u = key_of(i);
       if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255], 1);
     }
     __syncthreads();
@@ -1291,7 +1299,7 @@ __device__ __forceinline__ void select_smallest_marked(const int32_t* __restrict
   for (int i0 = 0; i0 < A; i0 += 1024) {
     const int i = i0 + tid;
     const bool mem = i < A && member(i);
-    const uint32_t u = mem ? (uint32_t)keys[i] : 0xFFFFFFFFu;
+    const uint32_t u = mem ? key_of(i) : 0xFFFFFFFFu;
     const bool lt = mem && u < T, eq = mem && u == T;
     const uint64_t be = __ballot(eq);
     if (lane == 0) s_wave_e[wave] = __popcll(be);
@@ -1311,15 +1319,18 @@ __device__ __forceinline__ void select_smallest_marked(const int32_t* __restrict
 
 __global__ __launch_bounds__(1024) void sample_pos_neg_kernel(const int64_t* __restrict__ labels, const int32_t* __restrict__ keys, int A,
                                                               int batch_size, int cap_pos, uint8_t* __restrict__ pos_sel,
-                                                              uint8_t* __restrict__ neg_sel, int64_t* __restrict__ counts) {
+                                                              uint8_t* __restrict__ neg_sel, int64_t* __restrict__ counts, int use_lds) {
   __shared__ int hist[256];
   __shared__ uint32_t s_prefix;
   __shared__ int s_remaining;
   __shared__ int s_wave_l[16], s_wave_e[16];
   __shared__ int s_P, s_N;
+  extern __shared__ uint32_t s_dyn[];          // [A] keys, then [A] class bytes -- when the launch was given the room (use_lds)
   const int n = blockIdx.x, tid = threadIdx.x;
   const int64_t* lb = labels + (size_t)n * A;
   const int32_t* kb = keys + (size_t)n * A;
+  uint32_t* lk = use_lds ? s_dyn : nullptr;
+  uint8_t* lc = use_lds ? reinterpret_cast<uint8_t*>(s_dyn + A) : nullptr;
   if (tid == 0) s_P = s_N = 0;
   __syncthreads();
   int p = 0, q = 0;
@@ -1327,6 +1338,10 @@ __global__ __launch_bounds__(1024) void sample_pos_neg_kernel(const int64_t* __r
     const int64_t l = lb[i];
     p += l >= 1;
     q += l == 0;
+    if (use_lds) {
+      lk[i] = (uint32_t)kb[i];
+      lc[i] = l >= 1 ? 1 : (l == 0 ? 0 : 2);
+    }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
@@ -1345,9 +1360,9 @@ __global__ __launch_bounds__(1024) void sample_pos_neg_kernel(const int64_t* __r
     counts[(size_t)n * 2 + 0] = num_pos;
     counts[(size_t)n * 2 + 1] = num_neg;
   }
-  select_smallest_marked(kb, lb, A, true, num_pos, P, pos_sel + (size_t)n * A, hist, &s_prefix, &s_remaining, s_wave_l, s_wave_e);
+  select_smallest_marked(kb, lb, A, true, num_pos, P, pos_sel + (size_t)n * A, hist, &s_prefix, &s_remaining, s_wave_l, s_wave_e, lk, lc);
   __syncthreads();
-  select_smallest_marked(kb, lb, A, false, num_neg, Nn, neg_sel + (size_t)n * A, hist, &s_prefix, &s_remaining, s_wave_l, s_wave_e);
+  select_smallest_marked(kb, lb, A, false, num_neg, Nn, neg_sel + (size_t)n * A, hist, &s_prefix, &s_remaining, s_wave_l, s_wave_e, lk, lc);
 }
 
 // ---- fused target assignment (box_iou + Matcher + label lookup + BoxCoder.encode), one thread per (image, box) ---------
@@ -1531,8 +1546,11 @@ extern "C" int hd_sample_pos_neg(const int64_t* labels, const int32_t* keys, int
   HD_CHECK_ARG(N >= 0 && A >= 0 && batch_size > 0 && cap_pos >= 0 && cap_pos <= batch_size, "hd_sample_pos_neg: bad args");
   if (N == 0 || A == 0) return HD_OK;
   HD_CHECK_ARG(labels && keys && pos_sel && neg_sel && counts, "hd_sample_pos_neg: null pointer");
-  hipLaunchKernelGGL(sample_pos_neg_kernel, dim3(N), dim3(1024), 0, (hipStream_t)stream, labels, keys, A, batch_size, cap_pos, pos_sel, neg_sel,
-                     counts);
+  // keys + classes of a row in LDS when they fit (5 bytes per anchor; the RPN's 22 743 anchors: 111 KB): the radix passes read LDS
+  const size_t need = (size_t)A * 4 + (((size_t)A + 3) & ~(size_t)3);
+  const int use_lds = need <= 150 * 1024 ? 1 : 0;
+  hipLaunchKernelGGL(sample_pos_neg_kernel, dim3(N), dim3(1024), use_lds ? need : 0, (hipStream_t)stream, labels, keys, A, batch_size, cap_pos,
+                     pos_sel, neg_sel, counts, use_lds);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
