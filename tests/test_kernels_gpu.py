@@ -1032,3 +1032,34 @@ def test_batched_nms_over_segments_equals_the_one_list_form(dev, top_n):
     assert torch.equal(c0.to(torch.int64), c1.to(torch.int64)), (c0, c1)
     assert int(c0[3]) == 0 and int(c0.max()) == min(top_n, int(c0.max()))
     assert torch.equal(p0, p1)
+
+
+def test_random_shapes_against_aten_fp32_convolution(dev):
+    """tools/fuzz_conv.py, a bounded slice: 60 shapes drawn from the dispatcher's whole domain (odd extents, ragged tiles, every kernel
+    size / stride on the path, upsample + concat, every epilogue) -- forward, data gradient, weight gradient against ATen's fp32
+    convolution on the GPU (not this repository's oracle), the fused and the multi-problem launches against their separate launches bit
+    for bit.  The full sweep (8 300 legs, 0 failures) is profiles/r03_fuzz_conv.txt."""
+    import importlib.util
+    import os
+    import random
+    spec = importlib.util.spec_from_file_location("fuzz_conv", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_conv.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    from hallucidet_amd import ops
+    ran = 0
+    for i in range(60):
+        seed = 7_000_003 + i
+        r = random.Random(seed)
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        c = fz.draw_case(r)
+        legs = [fz.run_forward(ops, c, gen), fz.run_dgrad(ops, c, gen), fz.run_wgrad(ops, c, gen, r), fz.run_fused(ops, c, gen)]
+        if i % 4 == 0:
+            legs.append(fz.run_multi(ops, r, gen))
+        if i % 4 == 1:
+            legs.append(fz.run_consumer_bn(ops, r, gen))
+        for msg in legs:
+            if msg is None:
+                continue
+            ran += 1
+            assert msg == "", (seed, c, msg)
+    assert ran > 150

@@ -1,0 +1,259 @@
+"""Randomised parity sweep of the convolution entry points (hd_conv2d forward / data gradient, hd_wgrad + hd_wgrad_reduce, hd_conv2d_wgrad,
+hd_conv2d_multi) against ATen's fp32 convolution ON THE GPU (an implementation this repository did not write), over shapes drawn from the
+whole domain the dispatcher accepts: odd extents, ragged tiles, every kernel size / stride on the path, channel counts on both sides of
+every tile boundary, the nearest-2x + concat gather, bias / residual / ReLU / sigmoid epilogues.  The fixed cases of
+tests/test_kernels_gpu.py pin the variants one by one; this looks for the combination nobody wrote down.
+
+    python tools/fuzz_conv.py [--cases 300] [--seed 0] [--max-seconds 600]
+
+Prints one line per failing case (with the seed that reproduces it) and a summary; exit code 1 if anything failed."""
+import argparse
+import math
+import os
+import random
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CH_IN = [8, 16, 24, 32, 40, 64, 72, 96, 128, 192, 256, 320, 512]
+CH_OUT = [3, 8, 16, 24, 32, 40, 64, 72, 128, 136, 192, 256, 512]
+
+
+def rnd(gen, *shape, scale=1.0):
+    return (torch.randn(*shape, generator=gen, device="cuda") * scale).half()
+
+
+def err_of(got, want, rtol, atol):
+    got, want = got.float(), want.float()
+    e = (got - want).abs()
+    tol = atol + rtol * want.abs()
+    bad = e > tol
+    return int(bad.sum()), float(e.max()) if e.numel() else 0.0
+
+
+def nchw(t):
+    return t.float().permute(0, 3, 1, 2)
+
+
+def gathered_input(x, x2, up1):
+    a = nchw(x)
+    if up1:
+        a = a.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    if x2 is not None:
+        a = torch.cat([a, nchw(x2)], dim=1)
+    return a
+
+
+def draw_case(r):
+    K, stride, pad = r.choice([(3, 1, 1)] * 6 + [(3, 2, 1)] * 2 + [(1, 1, 0)] * 3 + [(1, 2, 0), (7, 2, 3), (7, 1, 0), (3, 1, 0), (5, 1, 2)])
+    N = r.choice([1, 1, 2, 3, 4, 8])
+    if K == 7 and stride == 1:
+        H = W = 7
+    else:
+        H, W = r.randint(max(3, K), 70), r.randint(max(3, K), 90)
+    C1 = r.choice(CH_IN)
+    up1 = K == 3 and stride == 1 and pad == 1 and r.random() < 0.25
+    C2 = r.choice([0, 0, 32, 64, 128]) if up1 or r.random() < 0.1 else 0
+    if C2 and not up1 and not (K == 3 and stride == 1 and pad == 1):
+        C2 = 0
+    if C2 and C1 % 32:                      # the two-source gather takes multiples of 32 channels per source (a K tile holds one source)
+        C1 = (C1 + 31) // 32 * 32
+    if up1:
+        H, W = max(2, H // 2), max(2, W // 2)
+    Cout = r.choice(CH_OUT)
+    while N * H * W * (4 if up1 else 1) * max(C1 + C2, Cout) > 40_000_000:
+        H, W = max(K, H // 2), max(K, W // 2)
+    return dict(N=N, H=H, W=W, C1=C1, C2=C2, Cout=Cout, K=K, stride=stride, pad=pad, up1=up1,
+                act=r.choice([0, 1, 1, 2]), bias=r.random() < 0.5, res=r.random() < 0.3, stats=r.random() < 0.5)
+
+
+def run_forward(ops, c, gen):
+    N, H, W, C1, C2, Cout, K = c["N"], c["H"], c["W"], c["C1"], c["C2"], c["Cout"], c["K"]
+    Hin, Win = (2 * H, 2 * W) if c["up1"] else (H, W)
+    x = rnd(gen, N, H, W, C1)
+    x2 = rnd(gen, N, Hin, Win, C2) if C2 else None
+    Kt = K * K * (C1 + C2)
+    w = rnd(gen, Cout, Kt, scale=1.0 / math.sqrt(Kt))
+    bias = torch.randn(Cout, generator=gen, device="cuda") if c["bias"] else None
+    Ho, Wo = ops.conv_out_size(Hin, K, c["stride"], c["pad"]), ops.conv_out_size(Win, K, c["stride"], c["pad"])
+    res = rnd(gen, N, Ho, Wo, Cout) if c["res"] else None
+    w_oihw = w.float().view(Cout, K, K, C1 + C2).permute(0, 3, 1, 2).contiguous()
+    pre = F.conv2d(gathered_input(x, x2, c["up1"]), w_oihw, bias, stride=c["stride"], padding=c["pad"])
+    if res is not None:
+        pre = pre + nchw(res)
+    want = pre.clamp_min(0) if c["act"] == 1 else torch.sigmoid(pre) if c["act"] == 2 else pre
+    out = ops.conv2d(x, w, K, K, x2=x2, bias=bias, res=res, stride=c["stride"], pad=c["pad"], up1=c["up1"], act=c["act"],
+                     want_stats=c["stats"])
+    got, stats = out if c["stats"] else (out, None)
+    torch.cuda.synchronize()
+    nbad, emax = err_of(nchw(got), want, 4e-3, 2e-3 + 1e-3 * (1 if c["res"] or c["bias"] else 0))
+    msg = "" if nbad == 0 else "forward: %d elements off, max err %.4g" % (nbad, emax)
+    if stats is not None and not msg:
+        # BatchNorm partial sums are those of the fp16-rounded PRE-activation (bias and residual included)
+        s = stats.sum(dim=0)
+        g32 = got.float() if c["act"] == 0 else pre.permute(0, 2, 3, 1).half().float()
+        w1, w2 = g32.sum(dim=(0, 1, 2)), (g32 * g32).sum(dim=(0, 1, 2))
+        npix = N * Ho * Wo
+        if not torch.allclose(s[0], w1, rtol=2e-3, atol=2e-3 * npix ** 0.5 + 1e-2):
+            msg = "stats: sum off by %.4g" % float((s[0] - w1).abs().max())
+        elif not torch.allclose(s[1], w2, rtol=3e-3, atol=1e-2 + 1e-3 * npix ** 0.5):
+            msg = "stats: sum of squares off by %.4g" % float((s[1] - w2).abs().max())
+    return msg
+
+
+def run_dgrad(ops, c, gen):
+    if c["up1"] or c["C2"]:
+        return None
+    N, H, W, Cin, Cout, K, stride, pad = c["N"], c["H"], c["W"], c["C1"], c["Cout"], c["K"], c["stride"], c["pad"]
+    Cin = random.Random(c["N"] * 7 + H).choice([3, Cin, Cin])          # the stem's 3 input channels now and then
+    w_oihw = torch.randn(Cout, Cin, K, K, generator=gen, device="cuda") / math.sqrt(K * K * Cin)
+    Ho, Wo = ops.conv_out_size(H, K, stride, pad), ops.conv_out_size(W, K, stride, pad)
+    cout_p, cin_p = (Cout + 7) // 8 * 8, (Cin + 7) // 8 * 8
+    dy = torch.zeros(N, Ho, Wo, cout_p, dtype=torch.float16, device="cuda")
+    dy[..., :Cout] = rnd(gen, N, Ho, Wo, Cout)
+    _, wd = ops.weight_prep(w_oihw, want_fwd=True, want_dgrad=True)
+    want = torch.nn.grad.conv2d_input((N, Cin, H, W), w_oihw.half().float(), nchw(dy[..., :Cout]), stride=stride, padding=pad)
+    got = ops.conv2d(dy, wd, K, K, stride=1, pad=K - 1 - pad, in_dil=stride, out_hw=(H, W), cout=cin_p)
+    torch.cuda.synchronize()
+    nbad, emax = err_of(nchw(got[..., :Cin]), want, 4e-3, 2e-3)
+    if nbad:
+        return "dgrad (Cin %d): %d elements off, max err %.4g" % (Cin, nbad, emax)
+    if cin_p > Cin and bool((got[..., Cin:] != 0).any()):
+        return "dgrad: padding channels not zero"
+    return ""
+
+
+def run_wgrad(ops, c, gen, r):
+    N, H, W, C1, C2, Cout, K = c["N"], c["H"], c["W"], c["C1"], c["C2"], c["Cout"], c["K"]
+    if K == 7 and c["stride"] == 1:
+        return None
+    Cout = (Cout + 7) // 8 * 8              # hd_wgrad takes dY with its channels padded to 8 (the head's 3 are stored as 8)
+    Hin, Win = (2 * H, 2 * W) if c["up1"] else (H, W)
+    x = rnd(gen, N, H, W, C1)
+    x2 = rnd(gen, N, Hin, Win, C2) if C2 else None
+    Ho, Wo = ops.conv_out_size(Hin, K, c["stride"], c["pad"]), ops.conv_out_size(Win, K, c["stride"], c["pad"])
+    dy = rnd(gen, N, Ho, Wo, Cout)
+    Cin = C1 + C2
+    want = torch.nn.grad.conv2d_weight(gathered_input(x, x2, c["up1"]), (Cout, Cin, K, K), nchw(dy), stride=c["stride"], padding=c["pad"])
+    nsplit = r.choice([None, None, 1, 2, 3, 7, 40])
+    slab = ops.wgrad(x, dy, K, K, x2=x2, stride=c["stride"], pad=c["pad"], up1=c["up1"], nsplit=nsplit)
+    dw = torch.empty(Cout, Cin, K, K, device="cuda")
+    ops.wgrad_reduce(slab, dw, K, K, Cin, scale=1.0)
+    torch.cuda.synchronize()
+    npix = N * Ho * Wo
+    nbad, emax = err_of(dw, want, 2e-3, 2e-3 * math.sqrt(npix))
+    return "" if nbad == 0 else "wgrad (nsplit %s -> %d): %d elements off, max err %.4g" % (nsplit, slab.shape[0], nbad, emax)
+
+
+def run_fused(ops, c, gen):
+    """hd_conv2d_wgrad against its two separate launches: bit for bit."""
+    if not (c["K"] == 3 and c["stride"] == 1 and c["pad"] == 1 and not c["up1"] and not c["C2"]):
+        return None
+    N, H, W, Cin, Cout = c["N"], c["H"], c["W"], c["C1"], (c["Cout"] + 7) // 8 * 8
+    x, dy = rnd(gen, N, H, W, Cin), rnd(gen, N, H, W, Cout)
+    w_oihw = torch.randn(Cout, Cin, 3, 3, generator=gen, device="cuda") / math.sqrt(9 * Cin)
+    _, wd = ops.weight_prep(w_oihw, want_fwd=True, want_dgrad=True)
+    kw = dict(stride=1, pad=1, cout=Cin)
+    slab0 = ops.wgrad(x, dy, 3, 3, stride=1, pad=1)
+    dx0 = ops.conv2d(dy, wd, 3, 3, **kw)
+    slab1, dx1 = ops.wgrad_dgrad(x, dy, 3, 3, wd, stride=1, pad=1, dgrad=kw)
+    torch.cuda.synchronize()
+    if not torch.equal(dx0, dx1):
+        return "fused dgrad+wgrad: data gradient differs from the separate launch"
+    if slab0.shape != slab1.shape or not torch.equal(slab0, slab1):
+        return "fused dgrad+wgrad: slab differs from the separate launch"
+    return ""
+
+
+def run_consumer_bn(ops, r, gen):
+    """in_scale / in_shift (the producer's BatchNorm + ReLU applied while the small-channel kernels stage their operand) against
+    hd_bn_apply followed by the plain call: outputs, BatchNorm partial sums and weight-gradient slabs bit for bit."""
+    cin, cout, up = r.choice([8, 16, 32]), r.choice([16, 32]), r.random() < 0.3
+    N, H, W = r.choice([1, 2, 3]), r.randint(3, 60), r.randint(3, 90)
+    y_raw = rnd(gen, N, H, W, cin, scale=2.0)
+    scale = torch.rand(cin, generator=gen, device="cuda") + 0.5
+    shift = torch.randn(cin, generator=gen, device="cuda") * 0.7 + 0.3
+    w = rnd(gen, cout, 9 * cin, scale=0.1)
+    relu = r.random() < 0.8
+    z = ops.bn_apply(y_raw, scale, shift, relu=relu)
+    a, sa = ops.conv2d(z, w, 3, 3, pad=1, up1=up, want_stats=True)
+    b, sb = ops.conv2d(y_raw, w, 3, 3, pad=1, up1=up, want_stats=True, in_scale=scale, in_shift=shift, in_relu=relu)
+    torch.cuda.synchronize()
+    if not (torch.equal(a, b) and torch.equal(sa, sb)):
+        return "consumer-side BN: forward differs (%d->%d, up %s, N %d, %dx%d, relu %s)" % (cin, cout, up, N, H, W, relu)
+    if cin >= 16:
+        Ho, Wo = (2 * H, 2 * W) if up else (H, W)
+        dy = rnd(gen, N, Ho, Wo, cout)
+        ns = r.choice([1, 3, 7, 64])
+        s0 = ops.wgrad(z, dy, 3, 3, pad=1, up1=up, nsplit=ns)
+        s1 = ops.wgrad(y_raw, dy, 3, 3, pad=1, up1=up, nsplit=ns, in_scale=scale, in_shift=shift, in_relu=relu)
+        torch.cuda.synchronize()
+        if not torch.equal(s0, s1):
+            return "consumer-side BN: weight-gradient slab differs (%d->%d, up %s, N %d, %dx%d, nsplit %d)" % (cin, cout, up, N, H, W, ns)
+    return ""
+
+
+def run_multi(ops, r, gen):
+    """hd_conv2d_multi on 2-5 'pyramid levels' of one layer type against the separate calls: bit for bit."""
+    K, pad = r.choice([(3, 1), (1, 0)])
+    Cin, Cout = r.choice([64, 128, 256]), r.choice([12, 36, 64, 256])
+    N = r.choice([1, 2, 8])
+    H, W = r.randint(20, 64), r.randint(20, 80)
+    w = rnd(gen, Cout, K * K * Cin, scale=1.0 / math.sqrt(K * K * Cin))
+    bias = torch.randn(Cout, generator=gen, device="cuda")
+    calls = []
+    for lvl in range(r.randint(2, 5)):
+        calls.append((rnd(gen, N, max(1, H >> lvl), max(1, W >> lvl), Cin), w, K, K, dict(bias=bias, pad=pad, act=r.choice([0, 1]))))
+    sep = [ops.conv2d(x, w_, K, K, **kw) for x, w_, _, _, kw in calls]
+    got = ops.conv2d_multi(calls)
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(sep, got)):
+        if not torch.equal(a, b):
+            return "multi: level %d differs from its own launch (K %d, %d->%d, N %d, %dx%d)" % (i, K, Cin, Cout, N, H, W)
+    return ""
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=300)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--max-seconds", type=float, default=600.0)
+    args = ap.parse_args()
+    from hallucidet_amd import ops
+    torch.backends.cudnn.allow_tf32 = False
+    torch.backends.cuda.matmul.allow_tf32 = False
+    t0, fails, ran = time.time(), [], {"forward": 0, "dgrad": 0, "wgrad": 0, "fused": 0, "multi": 0, "consumer_bn": 0}
+    for i in range(args.cases):
+        if time.time() - t0 > args.max_seconds:
+            break
+        seed = args.seed * 1_000_003 + i
+        r = random.Random(seed)
+        gen = torch.Generator(device="cuda").manual_seed(seed)
+        c = draw_case(r)
+        legs = [("forward", lambda: run_forward(ops, c, gen)), ("dgrad", lambda: run_dgrad(ops, c, gen)),
+                ("wgrad", lambda: run_wgrad(ops, c, gen, r)), ("fused", lambda: run_fused(ops, c, gen))]
+        if i % 4 == 0:
+            legs.append(("multi", lambda: run_multi(ops, r, gen)))
+        if i % 4 == 1:
+            legs.append(("consumer_bn", lambda: run_consumer_bn(ops, r, gen)))
+        for name, leg in legs:
+            try:
+                msg = leg()
+            except Exception as e:            # a refused shape is a finding too
+                msg = "%s: %s" % (type(e).__name__, str(e)[:200])
+            if msg is None:
+                continue
+            ran[name] += 1
+            if msg:
+                fails.append((seed, name, c, msg))
+                print("FAIL seed %d %s %s :: %s" % (seed, name, c, msg), flush=True)
+    print("fuzz_conv: %s legs run in %.0f s, %d failures" % (ran, time.time() - t0, len(fails)), flush=True)
+    return 1 if fails else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
