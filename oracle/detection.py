@@ -11,7 +11,9 @@ What it follows
     algorithm is restated here.  PARITY UNPINNED against torchvision itself: the reference holds no
     tests or golden vectors for it.  What *is* pinned: the orchestration (tests drive the reference's own
     eval_forward_fasterrcnn.py over this object), the transform (golden from the reference file) and hand-worked
-    known answers for NMS / RoIAlign / matcher / box coder / anchors.
+    known answers for NMS / RoIAlign / matcher / box coder / anchors; and, against code held outside this repository: the frozen
+    ResNet-50 trunk against the ResNet of the installed `transformers` wheel (same weights: four stage outputs), box_iou against its
+    DETR utilities, RoIAlign against ATen's grid_sample (tests/test_oracle_golden.py).
 
 The attribute tree (`transform, backbone.body/fpn, rpn.{head,anchor_generator,box_coder,...}, roi_heads.{...}`) and the
 state_dict key names mirror torchvision 0.12 so that (a) the reference glue can call into it duck-typed and (b) weights

@@ -14,7 +14,8 @@ Follows
     centre-ness BCE sum, each / max(1, #foreground of the batch)), postprocess (score = sqrt(sigmoid(cls) * sigmoid(ctr)) >
     0.2, top-1000 per level, decode + clip, class-aware NMS 0.6, 100 detections).
     PARITY UNPINNED against torchvision itself (absent from this image); the ORCHESTRATION is pinned by driving the
-    reference's own eval_forward_fcos.py over this object (tests/golden/make_golden.py: glue_fcos.npz).
+    reference's own eval_forward_fcos.py over this object (tests/golden/make_golden.py: glue_fcos.npz); generalized_box_iou_loss also
+    against the DETR utility of the installed `transformers` wheel.
 State-dict keys follow torchvision (`head.classification_head.conv.{0,1,3,4,...}`, `head.regression_head.bbox_ctrness.weight`).
 """
 import math

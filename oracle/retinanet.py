@@ -10,7 +10,8 @@ Follows
     (x, int(x*2^(1/3)), int(x*2^(2/3))) for x in 32..512 and ratios (0.5,1,2) => 9 anchors per location, Matcher(0.5, 0.4,
     allow_low_quality=True), BoxCoder (1,1,1,1), postprocess (score>0.05, top-1000 per level, NMS 0.5, 300 detections).
     PARITY UNPINNED against torchvision itself (absent); the loss functions and the orchestration ARE pinned by driving the
-    reference's own eval_forward_retinanet.py over this object (tests/golden/make_golden.py: glue_retinanet.npz).
+    reference's own eval_forward_retinanet.py over this object (tests/golden/make_golden.py: glue_retinanet.npz); sigmoid_focal_loss
+    also against the DETR utility of the installed `transformers` wheel.
 State-dict keys follow torchvision 0.12 (`backbone.fpn.extra_blocks.p6.weight`, `head.classification_head.conv.0.weight`, ...).
 """
 import math

@@ -491,3 +491,126 @@ def test_nms_box_coder_matcher_properties():
         if best[gi] > 0:
             cols = (iou[gi] == best[gi]).nonzero().flatten()
             assert bool((res[cols] >= 0).all())                # low-quality rule: the best anchor(s) of every GT stay matched
+
+
+def test_box_iou_focal_loss_giou_against_the_detr_utilities_of_transformers():
+    """Three torchvision ops of the detector half restated in oracle/ (box_iou of the matchers, sigmoid_focal_loss of RetinaNet / FCOS,
+    generalized_box_iou_loss of FCOS) against implementations this repository did not write: the DETR loss utilities shipped in the
+    installed `transformers` wheel (transformers/loss/loss_for_object_detection.py: box_iou, generalized_box_iou, sigmoid_focal_loss,
+    descended from torchvision's).  torchvision itself cannot be installed here; this is the nearest externally held pin."""
+    T = pytest.importorskip("transformers.loss.loss_for_object_detection")
+    from oracle import fcos as ofc
+    from oracle import retinanet as orn
+    g = torch.Generator().manual_seed(11)
+
+    def boxes(n, size=400.0):
+        xy = torch.rand(n, 2, generator=g) * size
+        wh = torch.rand(n, 2, generator=g) * size * 0.4 + 1.0
+        return torch.cat([xy, xy + wh], dim=1)
+
+    a, b = boxes(37), boxes(211)
+    b[5] = a[3]                                          # an exact duplicate: IoU 1
+    b[6] = torch.tensor([1000.0, 1000.0, 1010.0, 1010.0])  # disjoint from everything: IoU 0
+    iou_t, _union = T.box_iou(a, b)
+    assert torch.allclose(ok.box_iou(a, b), iou_t, rtol=0, atol=1e-6)
+    assert float(ok.box_iou(a, b)[3, 5]) == 1.0 and float(ok.box_iou(a, b)[:, 6].max()) == 0.0
+    # GIoU loss = 1 - GIoU of matched pairs (torchvision adds eps = 1e-7 to both denominators)
+    p, q = boxes(300), boxes(300)
+    want = 1.0 - torch.diag(T.generalized_box_iou(p, q))
+    got = ofc.generalized_box_iou_loss(p, q, reduction="none")
+    assert torch.allclose(got, want, rtol=0, atol=2e-6)
+    assert abs(float(ofc.generalized_box_iou_loss(p, q, reduction="sum")) - float(want.sum())) < 1e-3
+    # focal loss, element-wise: transformers reduces as mean over dim 1, summed, / num_boxes -> recover the sum
+    x = torch.randn(1, 5000, generator=g) * 3
+    t = (torch.rand(1, 5000, generator=g) < 0.1).float()
+    for alpha, gamma in ((0.25, 2), (0.5, 2), (-1.0, 2), (0.25, 1)):
+        want_sum = float(T.sigmoid_focal_loss(x, t, 1, alpha=alpha, gamma=gamma)) * x.shape[1]
+        got_sum = float(orn.sigmoid_focal_loss(x, t, alpha=alpha, gamma=gamma, reduction="sum"))
+        assert abs(got_sum - want_sum) <= 1e-4 * abs(want_sum) + 1e-4, (alpha, gamma, got_sum, want_sum)
+
+
+def _hf_resnet(layer_type, hidden):
+    R = pytest.importorskip("transformers.models.resnet.modeling_resnet")
+    from transformers import ResNetConfig
+    cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=list(hidden), depths=[3, 4, 6, 3], layer_type=layer_type,
+                       hidden_act="relu", downsample_in_first_stage=False, downsample_in_bottleneck=False)
+    torch.manual_seed(3)
+    m = R.ResNetModel(cfg)
+    g = torch.Generator().manual_seed(4)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):          # non-trivial affine + running statistics
+            mod.weight.data = torch.rand(mod.num_features, generator=g) + 0.5
+            mod.bias.data = torch.randn(mod.num_features, generator=g) * 0.1
+            mod.running_mean.data = torch.randn(mod.num_features, generator=g) * 0.1
+            mod.running_var.data = torch.rand(mod.num_features, generator=g) + 0.5
+    return m
+
+
+def _copy_bn(dst, src):
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        getattr(dst, k).data.copy_(getattr(src, k).data)
+
+
+def _load_from_hf(oracle_net, hf, nconv):
+    """HF ResNetModel -> the oracle's torchvision-shaped module tree (conv1/bn1, layerN[j].convK/bnK/downsample)."""
+    oracle_net.conv1.weight.data.copy_(hf.embedder.embedder.convolution.weight.data)
+    _copy_bn(oracle_net.bn1, hf.embedder.embedder.normalization)
+    for i, stage in enumerate(hf.encoder.stages):
+        for j, lay in enumerate(stage.layers):
+            blk = getattr(oracle_net, "layer%d" % (i + 1))[j]
+            for k in range(nconv):
+                getattr(blk, "conv%d" % (k + 1)).weight.data.copy_(lay.layer[k].convolution.weight.data)
+                _copy_bn(getattr(blk, "bn%d" % (k + 1)), lay.layer[k].normalization)
+            has_sc = hasattr(lay.shortcut, "convolution")
+            assert has_sc == (blk.downsample is not None), (i, j)
+            if has_sc:
+                assert lay.shortcut.convolution.stride == blk.downsample[0].stride
+                blk.downsample[0].weight.data.copy_(lay.shortcut.convolution.weight.data)
+                _copy_bn(blk.downsample[1], lay.shortcut.normalization)
+
+
+@pytest.mark.parametrize("block", ["basic", "bottleneck"])
+def test_unet_encoder_against_the_resnet_of_transformers(block):
+    """The oracle's ResNet-34 / ResNet-50 encoder (oracle/unet.py; the reference takes it from torchvision through
+    src/segmentation_models/encoders/resnet.py:36-60) against an implementation held outside this repository: the ResNet of the installed
+    `transformers` wheel (torchvision's v1.5 architecture: stride on the 3x3 of a bottleneck, no stride in stage 1), same weights, in
+    eval mode (running statistics) and in training mode (batch statistics, as the hallucination net runs): the five feature maps and
+    the input gradient must agree to fp32 round-off."""
+    hf = _hf_resnet(block, (64, 128, 256, 512) if block == "basic" else (256, 512, 1024, 2048))
+    enc = ou.ResNet34Encoder(block=block)
+    _load_from_hf(enc, hf, 2 if block == "basic" else 3)
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(5))
+    for train in (False, True):
+        hf.train(train)
+        enc.train(train)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        stem = hf.embedder.embedder(xa)
+        hs = hf.encoder(hf.embedder.pooler(stem), output_hidden_states=True).hidden_states
+        feats = enc(xb)
+        assert len(feats) == 6 and torch.equal(feats[0], xb)
+        pairs = [(feats[1], stem)] + list(zip(feats[2:], hs[1:]))
+        for lvl, (a, b) in enumerate(pairs):
+            assert a.shape == b.shape, (lvl, a.shape, b.shape)
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.detach().abs().max())), (block, train, lvl, float((a - b).detach().abs().max()))
+        w = torch.randn(feats[-1].shape, generator=torch.Generator().manual_seed(6))
+        ga, = torch.autograd.grad((hs[-1] * w).sum(), xa)
+        gb, = torch.autograd.grad((feats[-1] * w).sum(), xb)
+        assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-4 * float(ga.abs().max())), (block, train)
+
+
+def test_detector_trunk_against_the_resnet_of_transformers():
+    """The oracle's frozen ResNet-50 trunk of the three detectors (oracle/detection.py ResNet50Body + FrozenBatchNorm2d; the reference
+    builds it with torchvision.models.detection.*_resnet50_fpn, src/models/detector.py:20-60) against transformers' ResNet-50 in eval
+    mode with the same weights and statistics: the four stage outputs (strides 4 / 8 / 16 / 32) agree to fp32 round-off."""
+    hf = _hf_resnet("bottleneck", (256, 512, 1024, 2048)).eval()
+    body = od.ResNet50Body()
+    _load_from_hf(body, hf, 3)
+    x = torch.randn(2, 3, 64, 96, generator=torch.Generator().manual_seed(7))
+    with torch.no_grad():
+        hs = hf(x, output_hidden_states=True).hidden_states
+        out = body(x, lambda t: t)
+    assert list(out.keys()) == ["0", "1", "2", "3"]
+    for i in range(4):
+        a, b = out[str(i)], hs[i + 1]
+        assert a.shape == b.shape == (2, 256 << i, 16 >> i, 24 >> i)
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * float(b.abs().max())), (i, float((a - b).abs().max()))
