@@ -493,7 +493,20 @@ def test_nms_box_coder_matcher_properties():
             assert bool((res[cols] >= 0).all())                # low-quality rule: the best anchor(s) of every GT stay matched
 
 
-def test_box_iou_focal_loss_giou_against_the_detr_utilities_of_transformers():
+@pytest.fixture
+def no_torchvision_stub():
+    """The live reference-glue tests above leave stand-in `torchvision*` modules (no __spec__) in sys.modules; transformers probes for
+    torchvision with importlib.util.find_spec, which raises on those.  Hidden for the duration of a test, restored afterwards."""
+    import sys
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules)
+              if (k == "torchvision" or k.startswith("torchvision.")) and getattr(sys.modules[k], "__spec__", None) is None}
+    try:
+        yield
+    finally:
+        sys.modules.update(hidden)
+
+
+def test_box_iou_focal_loss_giou_against_the_detr_utilities_of_transformers(no_torchvision_stub):
     """Three torchvision ops of the detector half restated in oracle/ (box_iou of the matchers, sigmoid_focal_loss of RetinaNet / FCOS,
     generalized_box_iou_loss of FCOS) against implementations this repository did not write: the DETR loss utilities shipped in the
     installed `transformers` wheel (transformers/loss/loss_for_object_detection.py: box_iou, generalized_box_iou, sigmoid_focal_loss,
@@ -570,7 +583,7 @@ def _load_from_hf(oracle_net, hf, nconv):
 
 
 @pytest.mark.parametrize("block", ["basic", "bottleneck"])
-def test_unet_encoder_against_the_resnet_of_transformers(block):
+def test_unet_encoder_against_the_resnet_of_transformers(block, no_torchvision_stub):
     """The oracle's ResNet-34 / ResNet-50 encoder (oracle/unet.py; the reference takes it from torchvision through
     src/segmentation_models/encoders/resnet.py:36-60) against an implementation held outside this repository: the ResNet of the installed
     `transformers` wheel (torchvision's v1.5 architecture: stride on the 3x3 of a bottleneck, no stride in stage 1), same weights, in
@@ -598,7 +611,7 @@ def test_unet_encoder_against_the_resnet_of_transformers(block):
         assert torch.allclose(ga, gb, rtol=1e-3, atol=1e-4 * float(ga.abs().max())), (block, train)
 
 
-def test_detector_trunk_against_the_resnet_of_transformers():
+def test_detector_trunk_against_the_resnet_of_transformers(no_torchvision_stub):
     """The oracle's frozen ResNet-50 trunk of the three detectors (oracle/detection.py ResNet50Body + FrozenBatchNorm2d; the reference
     builds it with torchvision.models.detection.*_resnet50_fpn, src/models/detector.py:20-60) against transformers' ResNet-50 in eval
     mode with the same weights and statistics: the four stage outputs (strides 4 / 8 / 16 / 32) agree to fp32 round-off."""
