@@ -615,6 +615,15 @@ def test_detector_trunk_against_the_resnet_of_transformers(no_torchvision_stub):
     """The oracle's frozen ResNet-50 trunk of the three detectors (oracle/detection.py ResNet50Body + FrozenBatchNorm2d; the reference
     builds it with torchvision.models.detection.*_resnet50_fpn, src/models/detector.py:20-60) against transformers' ResNet-50 in eval
     mode with the same weights and statistics: the four stage outputs (strides 4 / 8 / 16 / 32) agree to fp32 round-off."""
+    D = pytest.importorskip("transformers.models.detr.modeling_detr")
+    g = torch.Generator().manual_seed(1)
+    fa, fb = D.DetrFrozenBatchNorm2d(16), od.FrozenBatchNorm2d(16)      # torchvision's FrozenBatchNorm2d as DETR carries it (eps 1e-5 inside the rsqrt)
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        v = torch.rand(16, generator=g) + 0.3
+        getattr(fa, k).data.copy_(v)
+        getattr(fb, k).data.copy_(v)
+    xf = torch.randn(2, 16, 5, 7, generator=g)
+    assert torch.allclose(fa(xf), fb(xf), rtol=0, atol=1e-6)
     hf = _hf_resnet("bottleneck", (256, 512, 1024, 2048)).eval()
     body = od.ResNet50Body()
     _load_from_hf(body, hf, 3)
