@@ -142,3 +142,24 @@ def test_randomised_scenes_against_the_second_restatement(seed):
     for k, v in want.items():
         assert abs(float(got[k]) - v) < 1e-6, (k, float(got[k]), v)
     assert 0.0 < float(got["map"]) < 1.0 and float(got["mar_1"]) <= float(got["mar_10"]) <= float(got["mar_100"])
+
+
+def test_documentation_example_of_torchmetrics_mean_average_precision():
+    """The worked example in the documentation of torchmetrics.detection.MeanAveragePrecision (the class the reference wraps,
+    src/metrics/metrics.py:7-32): one prediction [258, 41, 606, 285] (score 0.536, label 0) against one box [214, 41, 562, 285].
+    Published result: map 0.6, map_50 1.0, map_75 1.0, map_large 0.6, mar_1 = mar_10 = mar_100 = 0.6, mar_large 0.6, every small /
+    medium figure -1 (IoU = 74176 / 95648 = 0.7755: a true positive at six of the ten thresholds 0.50 ... 0.95).  The evaluator here
+    and the second restatement (oracle/coco_map.py) must both reproduce it."""
+    from oracle import coco_map
+    pred = [{"boxes": T([258.0, 41.0, 606.0, 285.0]), "scores": torch.tensor([0.536]), "labels": torch.tensor([0])}]
+    target = [{"boxes": T([214.0, 41.0, 562.0, 285.0]), "labels": torch.tensor([0])}]
+    m = MeanAveragePrecision()
+    m.update(pred, target)
+    r = m.compute()
+    want = {"map": 0.6, "map_50": 1.0, "map_75": 1.0, "map_small": -1.0, "map_medium": -1.0, "map_large": 0.6,
+            "mar_1": 0.6, "mar_10": 0.6, "mar_100": 0.6, "mar_small": -1.0, "mar_medium": -1.0, "mar_large": 0.6}
+    for k, v in want.items():
+        assert abs(float(r[k]) - v) < 1e-6, (k, float(r[k]), v)
+    second = coco_map.evaluate(pred, target)
+    for k, v in want.items():
+        assert abs(float(second[k]) - v) < 1e-6, (k, float(second[k]), v)
