@@ -264,3 +264,42 @@ def test_full_size_unet_forward_backward_against_the_oracle_run_on_the_gpu(dev):
     for k in sd_w:
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert torch.allclose(sd_g[k], sd_w[k], rtol=3e-2, atol=3e-3), k
+
+
+def test_full_size_detector_trunk_and_fpn_against_the_oracle_run_on_the_gpu(dev):
+    """The frozen ResNet-50 + FPN trunk of configs[1]'s three detector passes at FULL size (24 images of 512x640 -> the transform's
+    24 x 300 x 300) against the oracle's module tree (oracle/detection.py BackboneWithFPN: nn.Conv2d + FrozenBatchNorm2d + max_pool2d +
+    nearest top-down, ATen fp32 operators) evaluated on the GPU with the same folded fp16 weights and the product's rounding schedule:
+    the five pyramid levels."""
+    from oracle import detection as od
+    from oracle import unet as ou
+    from test_detector_gpu import fold_oracle_
+    from hallucidet_amd.models.detector import Detector
+    torch.manual_seed(11)
+    det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector
+    with torch.no_grad():
+        for mod in det.modules():
+            if isinstance(mod, (torch.nn.Conv2d, torch.nn.Linear)) and mod.bias is not None:
+                mod.weight.copy_(mod.weight.half().float())
+    det = det.to(dev).eval()
+    images = torch.rand(24, 3, 512, 640, generator=torch.Generator().manual_seed(12)).to(dev)
+    il, _ = det.transform(images, None)
+    assert il.tensors.shape[:3] == (24, 300, 300)
+    det.backbone.calibrate_(il.tensors)
+    oracle = od.FasterRCNN(num_classes=2, size=300)
+    oracle.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    fold_oracle_(oracle)
+    oracle.eval()
+    oracle.set_quant(ou.fp16_round)
+    ob = oracle.backbone.to(dev)
+    with torch.no_grad():
+        f = det.backbone(il.tensors)
+        of = ob(il.tensors[..., :3].permute(0, 3, 1, 2).float().contiguous())
+    torch.cuda.synchronize()
+    assert list(f.keys()) == ["0", "1", "2", "3", "pool"] == list(of.keys())
+    for k in f:
+        a, b = f[k].permute(0, 3, 1, 2).float(), of[k]
+        assert a.shape == b.shape, k
+        e = (a - b).abs()
+        print("level %s: mean |err| / mean |ref| = %.2e, max |err| / max |ref| = %.2e" % (k, float(e.mean() / b.abs().mean()), float(e.max() / b.abs().max())))
+        assert e.mean() < 1.5e-2 * b.abs().mean() + 1e-4 and e.max() < 0.08 * b.abs().max() + 1e-2, (k, float(e.mean()), float(e.max()), float(b.abs().mean()))
