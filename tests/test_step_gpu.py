@@ -102,7 +102,7 @@ def _unet_masks(lit):
 # own end-to-end step.  Measured worst cases over the six parametrisations (two runs) in brackets.
 BOUNDS = {
     #                 loss e2e   U-Net grad e2e (rel, cos)   loss @cut   dL/dimage @cut (rel, cos)   U-Net grad @cut (rel, cos)
-    "retinanet":  dict(loss=2e-3, ugrad=(0.05, 0.999),   loss_cut=1e-3, dimg=(0.03, 0.999),        ugrad_cut=(0.03, 0.999)),    # [5.8e-4; 0.035 | 5.1e-5; 0.0015; 0.019]
+    "retinanet":  dict(loss=4e-3, ugrad=(0.05, 0.999),   loss_cut=1e-3, dimg=(0.03, 0.999),        ugrad_cut=(0.03, 0.999)),    # [5.8e-4 at 2x128x160, 2.2e-3 at 8x512x640; 0.035 | 5.1e-5; 0.0015; 0.019]
     "fasterrcnn": dict(loss=3e-2, ugrad=(0.25, 0.98),    loss_cut=3e-3, dimg=(0.03, 0.999),        ugrad_cut=(0.03, 0.999)),    # [1.6e-2; 0.139 | 1.3e-3; 0.0043; 0.026]
 }
 
@@ -110,7 +110,7 @@ BOUNDS = {
 @pytest.mark.parametrize("detector_name,seed,shape", [("retinanet", 5, (2, 128, 160)), ("retinanet", 6, (2, 128, 160)),
                                                       ("fasterrcnn", 17, (2, 128, 160)), ("fasterrcnn", 18, (2, 128, 160)),
                                                       ("fasterrcnn", 19, (2, 128, 160)), ("fasterrcnn", 23, (3, 192, 256)),
-                                                      ("fasterrcnn", 29, (8, 512, 640))])      # the last: BASELINE configs[1] at its full size
+                                                      ("fasterrcnn", 29, (8, 512, 640)), ("retinanet", 31, (8, 512, 640))])      # the last two: BASELINE configs[1] (and its RetinaNet variant) at full size
 def test_training_step_matches_oracle(dev, detector_name, seed, shape):
     from hallucidet_amd import synthetic
     from _pins import record, grad_agreement
