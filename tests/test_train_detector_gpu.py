@@ -13,12 +13,10 @@ pytestmark = pytest.mark.gpu
 TRAINABLE_PREFIXES = ("backbone.body.layer2", "backbone.body.layer3", "backbone.body.layer4", "backbone.fpn", "rpn", "roi_heads")
 
 
-@pytest.fixture(scope="module")
-def case(dev):
+def _make_case(dev, N, H, W):
     from hallucidet_amd.models.detector import Detector
     torch.manual_seed(31)
     det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector.to(dev)
-    N, H, W = 2, 96, 128
     images = torch.rand(N, 3, H, W)
     targets = []
     for i in range(N):
@@ -36,6 +34,11 @@ def case(dev):
     return det, oracle, images, targets
 
 
+@pytest.fixture(scope="module")
+def case(dev):
+    return _make_case(dev, 2, 96, 128)
+
+
 def test_trainable_set_matches_torchvision_rule(dev, case):
     det, _, _, _ = case
     det.set_trainable(True)
@@ -51,6 +54,16 @@ def test_trainable_set_matches_torchvision_rule(dev, case):
 def test_parameter_gradients_match_oracle_autograd(dev, case):
     """Linear probe loss on RPN outputs and box-head outputs over FIXED proposals (no sampler): every trainable tensor's
     gradient against torch autograd on the oracle (fp16 activation rounding on both sides)."""
+    _check_parameter_gradients(dev, case)
+
+
+def test_parameter_gradients_match_oracle_autograd_at_full_size(dev):
+    """The same at the size of BASELINE configs[4] (train_detector.py, batch 16 per GPU, 512x640 images -> 16 x 300 x 300): every
+    trainable tensor of the detector (heads, FPN, layer2-4) to rel-L2 <= 3 % / cosine >= 0.999 of the oracle's autograd."""
+    _check_parameter_gradients(dev, _make_case(dev, 16, 512, 640))
+
+
+def _check_parameter_gradients(dev, case):
     from hallucidet_amd.optim import ParamArena
     from _pins import record
     det, oracle, images, targets = case
@@ -61,7 +74,7 @@ def test_parameter_gradients_match_oracle_autograd(dev, case):
     det.invalidate_packs()
     g = torch.Generator().manual_seed(5)
     props = []
-    for i in range(2):
+    for i in range(images.shape[0]):
         xy = torch.rand(40, 2, generator=g) * 200
         wh = torch.rand(40, 2, generator=g) * torch.tensor([90.0, 90.0]) + 8
         props.append(torch.cat([xy, xy + wh], 1))
