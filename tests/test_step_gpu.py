@@ -20,6 +20,7 @@ import pytest
 import torch
 
 from oracle import detection as od
+from oracle import kernels as ok
 from oracle import retinanet as orn
 from oracle import unet as ou
 from oracle.step import OracleTrainer
@@ -342,3 +343,61 @@ def test_overlapped_allreduce_buckets_rccl_world1(dev):
     finally:
         dist.destroy_process_group()
         os.environ.pop("HD_FORCE_DIST", None)
+
+
+def test_eval_step_batch_one_full_size_matches_oracle(dev):
+    """BASELINE configs[0] (eval_hallucidet.py:135-182: Faster R-CNN, batch = 1, one 512x640 IR / RGB pair, eval-mode U-Net and
+    detector) at full size against the CPU oracle: the hallucinated image (oracle U-Net, eval mode, the product's rounding schedule);
+    then, on the PRODUCT's hallucinated image and with its discrete decisions (ReLU signs, max-pool winners, post-NMS proposals: the RoI
+    losses are sums over a few sampled RoIs), the oracle detector's four losses and its detections -- every confident oracle detection
+    must have a product detection on top of it with the same label and score, and the other way round."""
+    from hallucidet_amd import synthetic
+    lit, tr = _pair(dev, "fasterrcnn", seed=41)
+    with torch.no_grad():       # spread the random-init class scores so that detections survive the 0.05 score threshold
+        w = (lit.detector.roi_heads.box_predictor.cls_score.weight * 30.0).half().float()
+        lit.detector.roi_heads.box_predictor.cls_score.weight.copy_(w)
+        tr.det.roi_heads.box_predictor.cls_score.weight.copy_(w.cpu())
+    lit.detector.invalidate_packs()
+    lit.eval()
+    tr.unet.eval()
+    tr.det.eval()
+    batch = synthetic.make_batch(1, 512, 640, seed=42, device=str(dev))
+    cbatch = _to_cpu(batch)
+    from _pins import record
+    with torch.no_grad():
+        with record(first=True) as rec:          # the hallucinated pass's discrete decisions: ReLU signs, max-pool winners, post-NMS proposals
+            out = lit.forward_step(*batch, 0, step="test")
+        pins = rec.pins(n_images=1)
+        hall = out["output"]["imgs_hallucinated"].float().cpu()
+        # the detections of THIS evaluation: the reference post-processes the SAMPLED RoIs (eval_forward_fasterrcnn.py:105-136), so
+        # another call, with the samplers' generators advanced, returns other detections
+        dets = {k: [dict(d) for d in v] for k, v in lit._last_detections.items()}
+        torch.cuda.synchronize()
+        ho = tr.unet(cbatch[2].repeat(1, 3, 1, 1), q=ou.fp16_round)
+        e = (hall - ho).abs()
+        print("config0 hallucinated image: mean |err| %.2e max %.2e" % (float(e.mean()), float(e.max())))
+        # eval-mode U-Net test (2 x 64 x 96): mean < 1e-3, max < 2e-2; here 983 040 values: measured mean 3.6e-4, max 2.6e-2
+        assert hall.shape == (1, 3, 512, 640) and float(e.mean()) < 1e-3 and float(e.max()) < 4e-2
+        tr.det.rpn.fg_bg_sampler.randperm_fn.reset()
+        tr.det.set_pins(pins)
+        try:
+            dl, odets = od.eval_forward_fasterrcnn(tr.det, hall, cbatch[3])
+        finally:
+            tr.det.set_pins(None)
+    keymap = {"det_classification": "loss_classifier", "det_regression": "loss_box_reg", "det_objectness": "loss_objectness",
+              "det_rpn_box_reg": "loss_rpn_box_reg"}
+    for pk, ok_ in keymap.items():
+        a, b = float(out["loss"][pk]), 0.1 * float(dl[ok_])
+        print("   %-20s product %.7f oracle %.7f rel %.2e" % (pk, a, b, abs(a - b) / max(abs(b), 1e-12)))
+        assert abs(a - b) <= BOUNDS["fasterrcnn"]["loss_cut"] * abs(b) + 1e-6, (pk, a, b)
+    pd, odd = dets["hall"][0], odets[0]
+    pb, ps, pl = pd["boxes"].float().cpu(), pd["scores"].float().cpu(), pd["labels"].cpu()
+    ob, os_, ol = odd["boxes"], odd["scores"], odd["labels"]
+    print("   detections: product %d, oracle %d; top scores %s vs %s" % (len(ps), len(os_), [round(float(v), 4) for v in ps[:4]], [round(float(v), 4) for v in os_[:4]]))
+    assert len(ps) > 0 and len(os_) > 0 and abs(len(ps) - len(os_)) <= max(2, len(os_) // 10)
+    iou = ok.box_iou(ob, pb)
+    for side, (sc, other_sc, lab, other_lab, m) in (("oracle->product", (os_, ps, ol, pl, iou)), ("product->oracle", (ps, os_, pl, ol, iou.t()))):
+        conf = sc >= 0.1
+        best, j = m.max(dim=1)
+        bad = conf & ~((best >= 0.9) & ((other_sc[j] - sc).abs() <= 2e-2) & (other_lab[j] == lab))
+        assert int(bad.sum()) <= int(conf.sum()) // 20, (side, int(bad.sum()), int(conf.sum()))
