@@ -309,6 +309,57 @@ __device__ __forceinline__ void red_split(const RedG& g, int64_t i4, bool live, 
   red_store(g, i4, acc);
 }
 
+// ROW form for the large tensors with FEW splits (layer3 / layer4 / decoder 3x3 layers: 2.4 - 9.4 MB of weights, 4 - 40 slices): the
+// one-thread-per-quad form stores every sum as four dwords 36 B apart (the (tap, ci) -> OIHW transpose), 2.4 M partial-line writes per
+// tensor -- measured 2.7 TB/s on a launch of five such tensors while the split form streams at 4.9.  Here a block owns R whole output
+// rows (co): the sums (same order as red_plain: bit-identical) go to LDS in slab order, and the block writes its rows of the OIHW tensor
+// as one contiguous run; reads stay whole 1 KiB runs of a slice per wave.  (Measured slower than this: 64-channel x 9-tap units -- 1008
+// of 1024 threads busy instead of 576 - 1024, but 256-byte read pieces; and issuing both trips of a 1 152-quad row at once.)  `lds`
+// holds R * Ktot floats (<= 8192);
+// every thread of the block must call it (contains a __syncthreads()).
+__device__ __forceinline__ f32x4 red_quad(const RedG& g, const float* s) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 4 <= g.nsplit; k += 4) {
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 0) * g.sstride);
+    f32x4 a1 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 1) * g.sstride);
+    f32x4 a2 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 2) * g.sstride);
+    f32x4 a3 = *reinterpret_cast<const f32x4*>(s + (size_t)(k + 3) * g.sstride);
+    acc += (a0 + a1) + (a2 + a3);
+  }
+  for (; k < g.nsplit; ++k) acc += *reinterpret_cast<const f32x4*>(s + (size_t)k * g.sstride);
+  return acc;
+}
+
+__device__ __forceinline__ void red_rows(const RedG& g, int row0, int R, float* lds) {
+  const int Q = (int)(g.Ktot / 4);
+  const int K = (int)g.Ktot;
+  const int nq = min(R, g.Cout - row0) * Q;                 // quads of this block (rows are consecutive in the slab)
+  const float* base = g.slab + (size_t)row0 * K;
+  f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+  for (int q = threadIdx.x; q < nq; q += blockDim.x) l4[q] = red_quad(g, base + (size_t)q * 4);
+  __syncthreads();
+  const int taps = g.KH * g.KW;
+  for (int j = threadIdx.x; j < nq * 4; j += blockDim.x) {
+    const int r = j / K;
+    const int jj = j - r * K;
+    const int ci = jj / taps;
+    const int t = jj - ci * taps;
+    const float v = lds[r * K + t * g.Cin + ci] * g.scale;
+    const size_t o = (size_t)(row0 + r) * K + jj;
+    g.dw[o] = g.accumulate ? g.dw[o] + v : v;
+  }
+}
+
+// rows per block of the row form (0: the tensor does not take it)
+inline int red_rows_per_block(int KH, int KW, int Cin, int Cin_real, int nsplit) {
+  const int64_t Q = (int64_t)KH * KW * Cin / 4;
+  if (Cin_real != Cin || KH * KW < 2 || Q < 128 || Q > 2048 || nsplit > 64) return 0;
+  // quads a block takes: 1024 = one trip of its threads, 2048 = what the LDS tile holds (experiment knob; the plan hands R to the kernel)
+  static const int cap = getenv("HD_RED_ROWS_QUADS") ? atoi(getenv("HD_RED_ROWS_QUADS")) : 1024;
+  return Q >= 1024 ? 1 : (int)((cap < 1024 ? 1024 : cap > 2048 ? 2048 : cap) / Q);
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int nsplit, int Cout_slab, int Cout,
                                     int KH, int KW, int Cin, int Cin_real, float scale, int accumulate) {
   const RedG g = make_redg(slab, dw, nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, scale, accumulate);
@@ -350,7 +401,8 @@ struct WredTab {
 };
 
 __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const WredTab tab, int n) {
-  __shared__ f32x4 part[16][64];
+  __shared__ f32x4 lds4[2048];                     // split forms: [16][64] partials; row form: R * Ktot sums
+  f32x4 (*part)[64] = reinterpret_cast<f32x4 (*)[64]>(lds4);
   int e = 0;
   for (int i = 1; i < n; ++i)
     if ((int)blockIdx.x >= tab.d[i].first_block) e = i;
@@ -358,7 +410,10 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(const WredTab 
   const RedG g = make_redg(d.slab, d.dw_oihw, d.nsplit, d.Cout_slab, d.Cout, d.KH, d.KW, d.Cin, d.Cin_real, d.scale, d.accumulate);
   const int64_t b = (int64_t)blockIdx.x - d.first_block;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (d.mode == 0) {
+  if (d.mode == 2) {
+    const int R = d.reserved;                     // rows per block, chosen by hd_wgrad_reduce_plan
+    red_rows(g, (int)b * R, R, reinterpret_cast<float*>(lds4));
+  } else if (d.mode == 0) {
     const int64_t i4 = b * 1024 + threadIdx.x;
     if (i4 < g.total4) red_plain(g, i4);
   } else if (d.mode == 1) {
@@ -593,6 +648,11 @@ static bool red_split_on() {
   return on != 0;
 }
 
+static bool red_rows_on() {
+  static const int on = getenv("HD_WGRAD_REDUCE_ROWS") ? atoi(getenv("HD_WGRAD_REDUCE_ROWS")) : 1;
+  return on != 0;
+}
+
 extern "C" int hd_wgrad_reduce(const float* slab, float* dw_oihw, int nsplit, int Cout_slab, int Cout, int KH, int KW, int Cin,
                                int Cin_real, float scale, int accumulate, void* stream) {
   HD_CHECK_ARG(slab && dw_oihw && nsplit >= 1 && Cout <= Cout_slab && Cin_real <= Cin, "hd_wgrad_reduce: bad args");
@@ -630,9 +690,16 @@ extern "C" int hd_wgrad_reduce_plan(hd_wred_desc* table_host, int n) {
     }
     const int64_t total = (int64_t)d.Cout * d.Cin * d.KH * d.KW / 4;
     d.mode = red_mode(total, d.nsplit, red_split_on());
-    const int64_t per = d.mode == 0 ? 1024 : d.mode == 1 ? 16 : 64 * (16 / d.mode);
+    const int R = d.mode == 0 && red_rows_on() ? red_rows_per_block(d.KH, d.KW, d.Cin, d.Cin_real, d.nsplit) : 0;
     d.first_block = (int32_t)first;
-    first += (total + per - 1) / per;
+    if (R > 0) {                       // row form: R whole output rows per block, contiguous OIHW writes
+      d.mode = 2;
+      d.reserved = R;
+      first += (d.Cout + R - 1) / R;
+    } else {
+      const int64_t per = d.mode == 0 ? 1024 : d.mode == 1 ? 16 : 64 * (16 / d.mode);
+      first += (total + per - 1) / per;
+    }
     if (first > 0x7fffffff) { hd_set_error("hd_wgrad_reduce_plan: grid too large"); return HD_E_ARG; }
   }
   return (int)first;

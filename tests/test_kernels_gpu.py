@@ -893,13 +893,19 @@ def test_consumer_side_batchnorm_is_bit_identical_to_bn_apply_then_conv(dev, cin
 
 
 def test_wgrad_reduce_multi_is_bit_identical_to_separate_reductions():
-    """hd_wgrad_reduce_multi (every weight tensor of a backward segment in one launch) against hd_wgrad_reduce per tensor: all five
-    reduction forms (plain, one wave per quad, split x4 / x8 / x16), channel padding dropped, Cout < Cout_slab, accumulate."""
+    """hd_wgrad_reduce_multi (every weight tensor of a backward segment in one launch) against hd_wgrad_reduce per tensor: all six
+    reduction forms (plain, whole rows per block, one wave per quad, split x4 / x8 / x16), channel padding dropped, Cout < Cout_slab,
+    accumulate."""
     from hallucidet_amd import ops
     torch.manual_seed(0)
     dev = "cuda"
     # (nsplit, Cout_slab, Cout, k, Cin, Cin_real, accumulate)
-    shapes = [(3, 512, 512, 3, 512, 512, False),      # plain: few slices, large tensor
+    shapes = [(3, 512, 512, 3, 512, 512, False),      # few slices, large tensor: row form in the batch (one 1 152-quad row per block, two trips), plain alone
+              (16, 256, 256, 3, 256, 256, False),     # row form, one row of 576 quads per block
+              (8, 208, 200, 3, 64, 64, True),         # row form, seven rows per block, ragged last block, Cout < Cout_slab, accumulate
+              (5, 256, 256, 3, 768, 768, False),      # row form, 1 728 quads per row (decoder concat)
+              (7, 48, 40, 3, 96, 96, False),          # row form, 216 quads per row, four rows per block
+              (6, 96, 96, 1, 256, 256, False),        # 1x1: slab order == OIHW order -- stays on the plain form
               (768, 16, 16, 3, 16, 16, False),         # wave: 576 quads x 768 slices
               (256, 64, 64, 3, 64, 64, False),         # split x16 (9 216 quads)
               (64, 128, 128, 3, 128, 128, False),      # split x8 (36 864 quads)
