@@ -185,6 +185,13 @@ def weight_prep(w_oihw, *, out_scale=None, cin_pad=None, cout_pad=None, want_fwd
     return wf, wd
 
 
+# A batch is launched as soon as it holds this many bytes of slabs (not only at the end of a backward segment): slabs that were written
+# by the last two or three weight-gradient launches are still in the 256 MB MALL when the reduction reads them.  Swept 30 / 40 / 80 /
+# 110 / 150 MB and "segment end only" on two boxes: 80 - 110 MB is best, -0.08 ms per training step against segment end only (eleven more
+# launches per step included); one launch per tensor (30) is slower than segment end only.  0 = segment end only.
+_WRED_FLUSH_BYTES = int(float(os.environ.get("HD_WRED_FLUSH_MB", "100")) * 1e6)
+
+
 class WgradReduceBatch:
     """Deferred hd_wgrad_reduce calls of one backward segment, issued as ONE launch per 16 tensors (hd_wgrad_reduce_multi): `add()`
     has the signature of `wgrad_reduce` and keeps the slab alive until `flush()`, which plans the grid on the host and launches
@@ -202,6 +209,8 @@ class WgradReduceBatch:
         Cin_real = Cin if Cin_real is None else Cin_real
         assert dw.numel() == Cout * Cin_real * KH * KW and dw.dtype == torch.float32 and dw.is_contiguous()
         self.items.append((slab, dw, (nsplit, Cout_slab, Cout, KH, KW, Cin, Cin_real, 1 if accumulate else 0, float(scale))))
+        if _WRED_FLUSH_BYTES and sum(s.numel() for s, _, _ in self.items) * 4 >= _WRED_FLUSH_BYTES:
+            self.flush()
 
     def flush(self):
         from ._abi import WredDesc
@@ -210,10 +219,6 @@ class WgradReduceBatch:
         for lo in range(0, len(items), self.MAX):
             part = items[lo:lo + self.MAX]
             n = len(part)
-            if n == 1:
-                slab, dw, a = part[0]
-                check(lib.hd_wgrad_reduce(ptr(slab), ptr(dw), *a[:7], a[8], a[7], _stream()), "hd_wgrad_reduce")
-                continue
             arr = (WredDesc * n)(*[WredDesc(slab.data_ptr(), dw.data_ptr(), *a[:8], a[8], 0, 0, 0) for slab, dw, a in part])
             blocks = lib.hd_wgrad_reduce_plan(C.cast(arr, C.c_void_p), n)
             if blocks <= 0:
