@@ -64,6 +64,8 @@ CONV_CASES = [
     (8, 10, 10, 512, 0, 512, 3, 1, 1, False, 1, True, True),      # layer4 3x3, bias + residual + ReLU
     (8, 10, 10, 2048, 0, 512, 1, 1, 0, False, 0, True, False),    # layer4 1x1
     (2, 19, 19, 1024, 0, 256, 1, 1, 0, False, 1, False, False),   # layer3 1x1
+    # wide-N GEMM (the box head's fc6 data gradient: K = 1024 -> N = 12 544; 17 x 98 tiles, ragged last M tile)
+    (2100, 1, 1, 1024, 0, 12544, 1, 1, 0, False, 0, False, False),
 ]
 
 
