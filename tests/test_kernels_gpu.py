@@ -1071,3 +1071,35 @@ def test_random_shapes_against_aten_fp32_convolution(dev):
             ran += 1
             assert msg == "", (seed, c, msg)
     assert ran > 150
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_nms_on_a_coarse_grid_ties_at_the_threshold_and_degenerate_boxes(dev, seed):
+    """NMS keep masks against the oracle, bit for bit, where the IoU test is decided by the last bit: boxes on a coarse integer or
+    quarter-integer grid (IoU lands EXACTLY on 1/3, 1/2, 2/3 ... -- `>` vs `>=` and the order of the divide matter), many exact
+    duplicates, zero-area and inverted boxes (IoU 0/0), very large coordinates; thresholds that are (0.5, 0.25) and are not (0.3, 0.7,
+    1/3 as float) exactly representable."""
+    from hallucidet_amd import ops
+    g = torch.Generator().manual_seed(1000 + seed)
+    B, n = 4, 333
+    boxes = torch.zeros(B, n + 3, 4)
+    # image 0: integer grid; 1: quarter grid; 2: integer grid shifted to 1e4 (large coordinates); 3: mixture with degenerate boxes
+    for b in range(B):
+        step = 1.0 if b != 1 else 0.25
+        xy = torch.randint(0, 12, (n, 2), generator=g).float() * step
+        wh = torch.randint(1, 7, (n, 2), generator=g).float() * step
+        bb = torch.cat([xy, xy + wh], dim=1)
+        if b == 2:
+            bb = bb + 1.0e4
+        if b == 3:
+            bb[5::7, 2] = bb[5::7, 0]                    # zero width
+            bb[6::11, 3] = bb[6::11, 1] - 1.0            # inverted in y
+            bb[::13] = 0.0                               # the all-zero padding box
+        boxes[b, :n] = bb
+    counts = torch.tensor([n, n, n, n], dtype=torch.int32)
+    for thr in (0.5, 0.25, 0.3, 0.7, float(torch.tensor(1.0 / 3.0))):
+        keep = ops.nms_sorted_batched(boxes.to(dev), counts.to(dev), thr).cpu()
+        for b in range(B):
+            want = ok.nms_sorted(boxes[b, :n], thr)
+            assert torch.equal(keep[b, :n].bool(), want.bool()), (seed, thr, b, int((keep[b, :n].bool() != want.bool()).sum()))
+            assert not keep[b, n:].any()
