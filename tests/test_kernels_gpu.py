@@ -1103,3 +1103,34 @@ def test_nms_on_a_coarse_grid_ties_at_the_threshold_and_degenerate_boxes(dev, se
             want = ok.nms_sorted(boxes[b, :n], thr)
             assert torch.equal(keep[b, :n].bool(), want.bool()), (seed, thr, b, int((keep[b, :n].bool() != want.bool()).sum()))
             assert not keep[b, n:].any()
+
+
+def test_roi_align_degenerate_and_outside_rois(dev):
+    """RoIAlign(aligned=False, sampling_ratio 2) on the RoIs the reference's own path can produce at the edges: zero width / height
+    (roi size clamps to 1), inverted, entirely outside the map on every side (samples beyond [-1, H] contribute zero), a single-pixel
+    map corner, sub-pixel boxes and one covering 40x the map -- single-level and the multi-level (FPN) kernels, forward against the
+    oracle and the backward as the forward's adjoint."""
+    from hallucidet_amd import ops
+    N, H, W, C = 2, 13, 17, 16
+    feat = rnd(N, H, W, C, seed=91)
+    s = 1.0 / 8
+    rois = torch.tensor([[0, 40.0, 40.0, 40.0, 40.0],          # zero size
+                         [1, 60.0, 30.0, 20.0, 10.0],          # inverted
+                         [0, -400.0, -300.0, -200.0, -100.0],  # left / above
+                         [1, 500.0, 400.0, 900.0, 700.0],      # right / below
+                         [0, -8.0, -8.0, 0.0, 0.0],            # touches the corner pixel from outside: samples in [-1, 0]
+                         [1, 135.9, 103.9, 136.1, 104.1],      # sub-pixel box at the far corner
+                         [0, 33.3, 21.7, 33.9, 22.2],          # sub-pixel box inside
+                         [1, -2000.0, -2000.0, 3000.0, 3000.0],  # 40x the map
+                         [0, 0.0, 0.0, 135.99, 103.99]])       # the whole map
+    out = ops.roi_align(feat.to(dev), rois.to(dev), 7, 7, s, 2)
+    want = ok.roi_align_nchw(ok.nhwc_to_nchw(feat.float()), rois, 7, 7, s, 2)
+    assert torch.isfinite(out).all()
+    close(out, want.permute(0, 2, 3, 1).half(), rtol=2e-3, atol=1e-3)
+    assert float(out[2].abs().max()) == 0.0 and float(out[3].abs().max()) == 0.0      # entirely outside: exactly zero
+    dout = rnd(rois.shape[0], 7, 7, C, seed=92)
+    dfeat = ops.roi_align_bwd(dout.to(dev), rois.to(dev), (N, H, W, C), s, 2).cpu()
+    f2 = rnd(N, H, W, C, seed=93)
+    out2 = ops.roi_align(f2.to(dev), rois.to(dev), 7, 7, s, 2).float().cpu()
+    lhs, rhs = (dout.float() * out2).sum(), (dfeat * f2.float()).sum()
+    assert torch.isfinite(dfeat).all() and abs(lhs - rhs) <= 2e-2 * max(1.0, abs(lhs)), (lhs, rhs)
