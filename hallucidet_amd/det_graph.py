@@ -23,6 +23,7 @@ import torch
 
 from .utils import eval_forward_fasterrcnn as _eff
 from .models.detection import LazyDetections, _PAD_IDX_CACHE
+from .segmentation_models.unet import capture_without_gc
 
 
 def _bucket(n):
@@ -179,7 +180,7 @@ class DetectorStepGraph:
             _eff._GRAPH_FLAGS = flags = []
             g = torch.cuda.CUDAGraph()
             kw = dict(pool=self.pool) if self.pool is not None else {}
-            with torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
+            with capture_without_gc(), torch.cuda.graph(g, capture_error_mode="thread_local", **kw):
                 losses_det, total, dets, dimg = body()
         finally:
             _eff._GRAPH_FLAGS = None

@@ -17,6 +17,7 @@ backward pass; weights are re-packed each step from the fp32 masters into [Cout]
 [Cin][KH][KW][Cout] copy the data-gradient consumes); BatchNorm statistics, parameter gradients and the optimizer run
 in fp32 on one flat arena (one all-reduce buffer for data parallelism).
 """
+import contextlib
 import os
 
 import torch
@@ -29,6 +30,24 @@ from ..ops import ACT_NONE, ACT_SIGMOID
 # ----------------------------------------------------------------------------------------------------------------
 # parameter containers (structure only)
 # ----------------------------------------------------------------------------------------------------------------
+
+@contextlib.contextmanager
+def capture_without_gc():
+    """Python's cyclic collector can run at any allocation -- also inside a stream capture, where collecting an unreachable
+    CUDAGraph or a tensor of a captured pool (a graph dropped by a re-capture, an earlier module) calls hipGraphDestroy / hipFree
+    while the stream is capturing, and the runtime aborts the process (seen once in the test suite: 'Fatal Python error: Aborted',
+    'Garbage-collecting' on top of the stack, inside the forward capture).  Collect first, keep the collector off while capturing."""
+    import gc
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -330,7 +349,7 @@ class UnetRunner:
             g["fwd"] = torch.cuda.CUDAGraph()
             # thread_local: the input pipeline's helper thread (DevicePrefetcher) allocates pinned / device memory while this thread
             # captures; in the default 'global' mode such a call from ANOTHER thread invalidates the capture
-            with torch.cuda.graph(g["fwd"], pool=g["pool"], capture_error_mode="thread_local"):
+            with capture_without_gc(), torch.cuda.graph(g["fwd"], pool=g["pool"], capture_error_mode="thread_local"):
                 g["out"] = self.forward(g["x"], training=True, save=True)
             g["saved"] = self.saved
             # the capture itself did not execute: restore the BatchNorm buffers the warm-up touched, then replay
@@ -386,7 +405,7 @@ class UnetRunner:
             torch.cuda.synchronize()
             if not segmented:
                 graphs = [torch.cuda.CUDAGraph()]
-                with torch.cuda.graph(graphs[0], pool=g["pool"], capture_error_mode="thread_local"):
+                with capture_without_gc(), torch.cuda.graph(graphs[0], pool=g["pool"], capture_error_mode="thread_local"):
                     self.backward(g["dout"], keep_saved=True)
             else:
                 # one graph per bucket: end the running capture at every boundary and begin the next one in the same pool
@@ -394,7 +413,7 @@ class UnetRunner:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 hook, self.bucket_hook = self.bucket_hook, None
-                with torch.cuda.stream(side):
+                with capture_without_gc(), torch.cuda.stream(side):
                     graphs[0].capture_begin(pool=g["pool"], capture_error_mode="thread_local")
 
                     def cut(k):
