@@ -41,14 +41,20 @@ def _profile_json(names):
     return None
 
 
+def _stale(j):
+    """True when the PMC summary was collected on another build of the HIP sources (hallucidet_amd.build.source_digest)."""
+    from hallucidet_amd.build import source_digest
+    return j.get("csrc_digest") != source_digest()
+
+
 def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in two separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py) committed under profiles/ for this round.
     bench.py itself cannot collect PMCs (they need rocprofv3 around the process): null if the file is absent."""
-    for name in ("r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
+    for name in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
         j = _profile_json([name])
         try:
-            return round(j["traffic_bytes_per_launch"]), {"static": True, "source": "profiles/" + name, "commit": j.get("commit"),
+            return round(j["traffic_bytes_per_launch"]), {"static": True, "stale": _stale(j), "source": "profiles/" + name, "commit": j.get("commit"),
                                                           "note": "PMC counters need rocprofv3 around the process: collected by tools/collect_profiles.sh, NOT measured in this run"}
         except Exception:
             continue
@@ -58,10 +64,10 @@ def _pmc_traffic():
 def _pmc_mfma_util():
     """MFMA-pipe utilisation of the conv kernels in a training step (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy
     clocks), tools/pmc_mfma.py on a `rocprofv3 --pmc` run of tools/bench_step.py), committed under profiles/."""
-    for name in ("r03_conv_mfma_util.json", "r02_conv_mfma_util.json"):
+    for name in ("r04_conv_mfma_util.json", "r03_conv_mfma_util.json", "r02_conv_mfma_util.json"):
         j = _profile_json([name])
         try:
-            return {"value": j["mfma_util"], "by_kernel": j.get("by_kernel"), "static": True, "source": "profiles/" + name, "commit": j.get("commit"),
+            return {"value": j["mfma_util"], "by_kernel": j.get("by_kernel"), "static": True, "stale": _stale(j), "source": "profiles/" + name, "commit": j.get("commit"),
                     "note": "NOT measured in this run (PMC pass of tools/collect_profiles.sh)"}
         except Exception:
             continue
@@ -398,9 +404,8 @@ def main():
     # environment), rank 0's JSON line relayed.  Nothing in this process has touched the GPU yet, and nothing will.
     from hallucidet_amd import launch
     if launch.need_self_launch(args.gpus):
-        n_vis = torch.cuda.device_count()            # counting devices does not create a HIP context
-        if n_vis < args.gpus:
-            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, n_vis))
+        # the launcher never asks the runtime about devices (a fallback inside torch.cuda.device_count() can initialise HIP, after
+        # which this process may not fork + exec ranks on this pool): a rank whose LOCAL_RANK has no GPU fails at set_device below
         raise SystemExit(launch.launch_ranks(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -412,6 +417,8 @@ def main():
     Config.set_environment()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
+    if local >= torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: rank %d has no GPU (only %d visible)" % (args.gpus, rank, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     force_dist = os.environ.get("HD_FORCE_DIST") == "1"      # exercise the RCCL path on one GPU (world size 1)
     if world > 1 or force_dist:
@@ -440,24 +447,33 @@ def main():
         r = lit.encoder_decoder.runner
         p0, m0, v0 = r.flat_params.clone(), lit.optimizer.exp_avg.clone(), lit.optimizer.exp_avg_sq.clone()
         bufs0 = [b.clone() for b in lit.encoder_decoder.buffers()]
-        sc0, st0 = lit.optimizer.step_count, lit.scaler.scale_value
-        grads = []
-        for ov in (False, True):
+        sc0, st0, good0 = lit.optimizer.step_count, lit.scaler.scale_value, lit.scaler._good
+
+        def one_step(ov):
+            """One step from the snapshot with the seed reset; -> its averaged gradient.  State (parameters, moments, BN buffers,
+            Adam's step count, the scaler's scale / clean-step count / pending update) is put back afterwards."""
             lit.overlap_allreduce = ov
             torch.manual_seed(1000 + rank)
             lit.fit_step(batch)
             torch.cuda.synchronize()
-            grads.append(r.flat_grads.clone())
+            g = r.flat_grads.clone()
+            lit.scaler.resolve()                       # consume this step's overflow flag through the scaler (not behind its back)
             r.flat_params.copy_(p0); lit.optimizer.exp_avg.copy_(m0); lit.optimizer.exp_avg_sq.copy_(v0)
             for b, b0 in zip(lit.encoder_decoder.buffers(), bufs0):
                 b.copy_(b0)
-            lit.optimizer.resolve_found_inf()
-            lit.optimizer.step_count, lit.scaler.scale_value = sc0, st0
+            lit.optimizer.step_count, lit.scaler.scale_value, lit.scaler._good, lit.scaler._update_due = sc0, st0, good0, False
+            return g
+        # The first step of each kind CAPTURES (U-Net graphs per exchange mode, the detector half once): a capture runs eager
+        # warm-up bodies that advance the sampler's generator, so it does not draw what a replay from the same seed draws.
+        # Both kinds are therefore run once unchecked; the compared pair below is two pure replays from one seed.
+        one_step(False)
+        one_step(True)
+        grads = [one_step(False), one_step(True)]
         err = (grads[0] - grads[1]).norm() / grads[0].norm().clamp(min=1e-30)
         bad = torch.tensor([float(not (err <= 1e-4))], device=dev)
         dist.all_reduce(bad, op=dist.ReduceOp.MAX)
         lit.overlap_allreduce = not bool(bad.item())
-        overlap_note = "self-check: overlapped vs un-overlapped averaged gradient rel-L2 %.2e -> overlap %s" % (float(err), "on" if lit.overlap_allreduce else "OFF (fallback)")
+        overlap_note = "self-check (two graph replays from one seed): overlapped vs un-overlapped averaged gradient rel-L2 %.2e -> overlap %s" % (float(err), "on" if lit.overlap_allreduce else "OFF (fallback)")
         del grads, p0, m0, v0, bufs0
 
     for _ in range(args.warmup):

@@ -27,12 +27,26 @@ def _headers_mtime():
     return max(os.path.getmtime(h) for h in hs)
 
 
+def source_digest():
+    """sha256 (12 hex digits) over the HIP sources and headers the library is built from.  The profiling tools stamp it into the PMC
+    summaries they write (profiles/*_conv_mfma_util.json, *_conv_traffic.json) and bench.py compares it with the tree it runs on:
+    counters collected on another build are reported as stale.  (The GPU boxes have no .git, a commit id cannot be read there.)"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "hallucidet_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def build(verbose=False, force=False, trace=False):
     """trace=True builds lib/libhallucidet_hip_trace.so with -DHD_CONV_TRACE (per-block timeline stamps in the conv kernels,
     tools/conv_trace.py); the product library never carries them."""
     objdir = os.path.join(LIBDIR, "obj_trace" if trace else "obj")
     lib_path = os.path.join(LIBDIR, "libhallucidet_hip_trace.so") if trace else LIB
-    flags = FLAGS + (["-DHD_CONV_TRACE"] if trace else [])
+    flags = FLAGS + (["-DHD_CONV_TRACE"] if trace else []) + os.environ.get("HD_EXTRA_FLAGS", "").split()      # HD_EXTRA_FLAGS: experiment builds
     os.makedirs(objdir, exist_ok=True)
     hm = _headers_mtime()
     jobs = []

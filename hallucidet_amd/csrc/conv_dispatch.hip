@@ -74,6 +74,13 @@ bool use_small(const ConvP& p) {
   return on && g_small_ok && hd_conv_small_eligible(p);
 }
 
+// the 64 -> 64 channel 3x3 layers go to the register-resident-weights kernel (conv3x3_c64.hip); HD_CONV_C64=0 keeps them in the igemm
+// family (A/B)
+bool use_c64(const ConvP& p) {
+  static const int on = env_int("HD_CONV_C64", 1);
+  return on && g_small_ok && hd_conv_c64_eligible(p);
+}
+
 // tuning hook (tools/tune_conv.py): force the tile / K-depth / stage choice of the igemm family; -1 = heuristic
 static int g_ov_bm = -1, g_ov_bn = -1, g_ov_bk = -1, g_ov_deep = -1;
 extern "C" int hd_conv_tune_override(int bm, int bn, int bk, int deep) {
@@ -197,6 +204,7 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   int rc = fill_params(a, p);
   if (rc) return rc;
   if (use_small(p)) return hd_conv_small_tiles(p);
+  if (use_c64(p)) return hd_conv_c64_rows(p);
   const TileChoice c = choose_tile(p);
   if (c.p8cfg >= 0) return hd_conv_p8_tiles(p, c.p8cfg);
   return hd_cdiv(p.M, c.bm);
@@ -214,7 +222,7 @@ extern "C" int hd_conv2d_wgrad(const hd_conv_args* a, const hd_wgrad_args* wa, v
   ConvP p;
   int rc = fill_params(a, p);
   if (rc) return rc;
-  if (fuse_on && !use_small(p) && !p.in_scale && !p.x2 && !p.stats && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
+  if (fuse_on && !use_small(p) && !use_c64(p) && !p.in_scale && !p.x2 && !p.stats && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) {
       static const int w8_prio = env_int("HD_W8_PRIO", 0);
@@ -247,7 +255,7 @@ extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
     ConvP& p = mp.p[i];
     int rc = fill_params(&args[i], p);
     if (rc) return rc;
-    if (use_small(p) || p.in_scale || p.x2 || p.in_dil != 1) { ok = false; break; }
+    if (use_small(p) || use_c64(p) || p.in_scale || p.x2 || p.in_dil != 1) { ok = false; break; }
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) { ok = false; break; }
     if (i == 0) c0 = c;
@@ -284,6 +292,11 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
 #endif
   if (use_small(p)) {
     hd_conv_launch_small(p, s);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
+  if (use_c64(p)) {
+    hd_conv_launch_c64(p, s);
     HD_CHECK_LAUNCH();
     return HD_OK;
   }

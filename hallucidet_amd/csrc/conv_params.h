@@ -114,3 +114,7 @@ bool hd_wgrad_takes_w8(const hd_wgrad_args* a);
 bool hd_conv_small_eligible(const ConvP& p);
 int hd_conv_small_tiles(const ConvP& p);
 void hd_conv_launch_small(ConvP& p, hipStream_t s);
+// conv3x3_c64.hip: 3x3 / stride 1 / pad 1, 64 -> 64 channels, weights resident in registers, persistent blocks; rows = partial-sum rows
+bool hd_conv_c64_eligible(const ConvP& p);
+int hd_conv_c64_rows(const ConvP& p);
+void hd_conv_launch_c64(ConvP& p, hipStream_t s);

@@ -69,6 +69,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._inf_host = torch.zeros(1, dtype=torch.float32).pin_memory() if flat.is_cuda else torch.zeros(1)
         self._inf_event = torch.cuda.Event() if flat.is_cuda else None
         self._inf_pending = False
+        self._stash = False          # result of a flag resolved inside step() that no LossScaler.resolve() has seen yet
 
     def zero_grad(self, set_to_none=False):
         # gradients are overwritten (not accumulated) by every backward pass; nothing to do, and the views must stay
@@ -79,8 +80,8 @@ class FusedAdam(torch.optim.Optimizer):
         r = self.runner
         r.flatten_parameters()
         g = self.param_groups[0]
-        if self._inf_pending:               # the previous step's skip flag must be accounted for before it is overwritten
-            self.resolve_found_inf()
+        if self._inf_pending:               # the previous step's skip flag must be accounted for before it is overwritten;
+            self._stash = self.resolve_found_inf()   # a LossScaler.resolve() that comes later still learns of it
         if check_inf:
             self.found_inf.zero_()
             ops.check_finite(r.flat_grads, self.found_inf)
@@ -99,7 +100,8 @@ class FusedAdam(torch.optim.Optimizer):
         step's own kernels (an event behind the pinned copy), which have long finished by the time the next step asks.  A
         skipped step does not count: `step_count` (Adam's bias correction) is rolled back, as torch.optim.Adam never sees it."""
         if not self._inf_pending:
-            return False
+            bad, self._stash = self._stash, False
+            return bad
         if self._inf_event is not None:
             self._inf_event.synchronize()
         self._inf_pending = False

@@ -780,6 +780,55 @@ def test_sample_pos_neg_equals_keyed_topk_path(dev):
     assert int(counts[3].sum()) == 0 and int(counts[0, 0]) == int(B * frac) and int(counts[1, 0]) < int(B * frac)
 
 
+C64_CASES = [
+    # N, H, W, act, bias, res, mask   (3x3 / s1 / p1, 64 -> 64: conv3x3_c64.hip)
+    (2, 16, 20, 0, False, False, False),      # fewer tiles than blocks
+    (1, 13, 37, 1, True, False, False),       # ragged tiles in both directions, bias + ReLU (detector layer1)
+    (3, 75, 75, 1, True, False, True),        # detector size, ReLU mask (data gradient), 150 tiles
+    (2, 128, 160, 0, False, True, False),     # U-Net layer1 size: 640 tiles on 256 persistent blocks, residual (data gradient)
+    (5, 64, 96, 0, False, False, False),      # 960 tiles: ragged tile runs per block
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", C64_CASES)
+def test_conv_c64_register_resident_kernel(dev, case):
+    """conv3x3_c64.hip (default route of the 64 -> 64 channel 3x3 layers) against the oracle and against the implicit-GEMM family
+    (forced through the tuning override): same K order, same fp32 accumulation -> the outputs agree to an fp16 ulp; the BN partial rows
+    differ in number (one per persistent block vs one per 128-row tile) but not in their totals."""
+    from hallucidet_amd import ops, _abi
+    N, H, W, act, use_bias, use_res, use_mask = case
+    x = rnd(N, H, W, 64, seed=21)
+    w = rnd(64, 576, scale=1.0 / 24.0, seed=22)
+    bias = torch.randn(64, generator=torch.Generator().manual_seed(23)) if use_bias else None
+    res = rnd(N, H, W, 64, seed=24) if use_res else None
+    mask = (torch.rand(N, H, W, 64, generator=torch.Generator().manual_seed(25)) > 0.4).half() if use_mask else None
+    d = lambda t: None if t is None else t.to(dev)
+    lib = _abi.load()
+    got, stats = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), mask=d(mask), pad=1, act=act, want_stats=True)
+    tiles = N * ((H + 7) // 8) * ((W + 15) // 16)
+    assert stats.shape[0] == min(tiles, 256)                       # the persistent kernel really ran
+    lib.hd_conv_tune_override(128, 64, 64, 0)
+    try:
+        ref, rstats = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), mask=d(mask), pad=1, act=act, want_stats=True)
+    finally:
+        lib.hd_conv_tune_override(-1, -1, -1, -1)
+    assert rstats.shape[0] == (N * H * W + 127) // 128
+    torch.cuda.synchronize()
+    assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
+    assert torch.allclose(stats.sum(0), rstats.sum(0), rtol=2e-3, atol=2e-2)
+    if N * H * W <= 20000:
+        want, wstats = ok.conv2d_nhwc(x, w, 3, 3, bias=bias, res=res, pad=1, act=0)
+        if use_mask:
+            want = want * mask.float()
+        if act == 1:
+            want = want.clamp(min=0)
+        close(got, want.half())
+    # a second run is bit-identical (static tile runs, fixed summation order)
+    got2, stats2 = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), mask=d(mask), pad=1, act=act, want_stats=True)
+    assert torch.equal(got, got2) and torch.equal(stats, stats2)
+
+
 SMALL_CASES = [c for c in CONV_CASES if c[6] == 3 and c[7] == 1 and c[8] == 1 and c[4] == 0 and c[3] in (8, 16, 32) and c[5] in (16, 32)
                and c[10] == 0 and not c[11] and not c[12]]
 

@@ -1,0 +1,271 @@
+"""Pins for the torchvision-side INTEGER work of the detector half (NMS keep sets, the `batched_nms` offset trick, `filter_proposals`,
+the balanced sampler) that do not rest on this repository's own restatement (oracle/):
+
+  (a) the installed `transformers` wheel ships a plain-PyTorch greedy NMS loop and `box_iou` written outside this repository
+      (transformers/models/owlvit/image_processing_pil_owlvit.py: `post_process_image_guided_detection`, the same IoU formula and the
+      same strict `>` rule as torchvision's `nms`): it and `oracle.kernels.nms_sorted` are driven with the same boxes -- coarse-grid
+      coordinates (ties, duplicates, threshold-exact IoUs) -- and must keep the same sets;
+  (b) torchvision's `batched_nms` coordinate-offset trick re-stated on top of THAT loop must equal `oracle.detection.batched_nms`
+      (both of its branches);
+  (c) `RegionProposalNetwork.filter_proposals` and `BalancedPositiveNegativeSampler` against brute-force definitions written here
+      (python loops over numpy float32 scalars; nothing imported from oracle/ on the checking side), on `hypothesis`-generated inputs.
+
+torchvision itself cannot be installed in this environment (no network); these are the nearest externally held statements.
+CPU only."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detection as od
+from oracle import kernels as ok
+
+hypothesis = pytest.importorskip("hypothesis")
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@pytest.fixture
+def no_torchvision_stub():
+    """Other tests leave stand-in `torchvision*` modules (no __spec__) in sys.modules; transformers probes for torchvision with
+    importlib.util.find_spec, which raises on those.  Hidden for the duration of a test, restored afterwards."""
+    import sys
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules)
+              if (k == "torchvision" or k.startswith("torchvision.")) and getattr(sys.modules[k], "__spec__", None) is None}
+    try:
+        yield
+    finally:
+        sys.modules.update(hidden)
+
+
+def _owlvit():
+    return pytest.importorskip("transformers.models.owlvit.image_processing_pil_owlvit")
+
+
+def owlvit_nms(boxes, logits, thr):
+    """Keep set (ascending candidate index) of transformers' greedy NMS loop.  boxes [n, 4] corner format on a 1/4 grid below 2^12 (the
+    loop takes centre format and converts back: exact on such coordinates), logits [n] whose sigmoids are distinct and within a factor
+    ten of each other (the method reports survivors through display alphas that vanish below a tenth of the best score)."""
+    m = _owlvit()
+    n = boxes.shape[0]
+    cxcywh = torch.stack([(boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2, boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]], dim=1)
+    back = torch.stack([cxcywh[:, 0] - 0.5 * cxcywh[:, 2], cxcywh[:, 1] - 0.5 * cxcywh[:, 3], cxcywh[:, 0] + 0.5 * cxcywh[:, 2], cxcywh[:, 1] + 0.5 * cxcywh[:, 3]], dim=1)
+    assert torch.equal(back, boxes), "coordinates must survive the centre-format round trip exactly"
+    out = types.SimpleNamespace(logits=logits.reshape(1, n, 1).clone(), target_pred_boxes=cxcywh.reshape(1, n, 4).clone())
+    res = m.OwlViTImageProcessorPil.post_process_image_guided_detection(None, out, threshold=0.0, nms_threshold=thr, target_sizes=None)
+    kept_boxes, alphas = res[0]["boxes"], res[0]["scores"]
+    # the method returns the survivors in candidate order with alpha = clip((s - 0.1 max) / (0.9 max)); recover their indices from the
+    # alphas (strictly increasing in s, all s distinct)
+    s = torch.sigmoid(logits)
+    mx = s.max() + 1e-6
+    alpha_all = torch.clip((s - mx * 0.1) / (mx * 0.9), 0.0, 1.0)
+    assert float(alpha_all.min()) > 0 and alpha_all.unique().numel() == n
+    idx = []
+    for a, b in zip(alphas.tolist(), kept_boxes):
+        j = (alpha_all == a).nonzero().flatten()
+        assert j.numel() == 1 and torch.equal(boxes[j[0]], b)
+        idx.append(int(j[0]))
+    assert idx == sorted(idx)
+    return idx
+
+
+def grid_boxes(n, g, extent=64, dup=0.15):
+    """n boxes on a HALF-integer grid inside [0, extent]: many exact ties of coordinates, exact duplicates, nested boxes and IoUs that
+    land exactly on simple fractions (1/2, 1/3, 2/3 ...)."""
+    xy = torch.randint(0, 2 * extent - 8, (n, 2), generator=g).float() / 2
+    wh = torch.randint(2, 24, (n, 2), generator=g).float() / 2
+    b = torch.cat([xy, xy + wh], dim=1)
+    for i in range(1, n):
+        if float(torch.rand(1, generator=g)) < dup:
+            b[i] = b[int(torch.randint(0, i, (1,), generator=g))]
+    return b
+
+
+def distinct_logits(n, g):
+    s = 0.3 + 0.65 * (torch.randperm(n, generator=g).float() + 0.5) / n          # distinct, within [0.3, 0.95]
+    lg = torch.log(s / (1 - s))
+    assert torch.sigmoid(lg).unique().numel() == n
+    return lg
+
+
+@pytest.mark.parametrize("thr", [0.3, 0.5, 0.7, 1.0 / 3.0])
+def test_nms_keep_sets_equal_the_greedy_loop_of_transformers(thr, no_torchvision_stub):
+    g = torch.Generator().manual_seed(int(thr * 1000))
+    hit_exact = 0
+    for trial in range(6):
+        n = 120
+        boxes = grid_boxes(n, g)
+        for k in range(6):                                    # pairs whose IoU is EXACTLY 1/2 and exactly 1/3 (the rule is a strict >)
+            x, y = float(torch.randint(0, 40, (1,), generator=g)), float(torch.randint(0, 40, (1,), generator=g))
+            boxes[4 * k] = torch.tensor([x, y, x + 4, y + 2]); boxes[4 * k + 1] = torch.tensor([x, y, x + 4, y + 1])
+            boxes[4 * k + 2] = torch.tensor([x + 9, y, x + 11, y + 2]); boxes[4 * k + 3] = torch.tensor([x + 10, y, x + 12, y + 2])
+        logits = distinct_logits(n, g)
+        scores = torch.sigmoid(logits)
+        iou = _owlvit().box_iou(boxes, boxes)[0]
+        assert torch.equal(iou, ok.box_iou(boxes, boxes))                 # same formula, same association: bit for bit
+        hit_exact += int(((iou == thr) & ~torch.eye(n, dtype=torch.bool)).sum())
+        theirs = owlvit_nms(boxes, logits, thr)
+        ours = sorted(od.nms(boxes, scores, thr).tolist())
+        assert ours == theirs, (trial, sorted(set(ours) ^ set(theirs)))
+        # and through the sorted-order kernel statement directly
+        order = torch.sort(scores, descending=True, stable=True)[1]
+        assert sorted(order[ok.nms_sorted(boxes[order], thr)].tolist()) == theirs
+    if thr == 0.5:
+        assert hit_exact > 0, "the generator is meant to produce IoUs exactly on the threshold"
+
+
+def batched_nms_on_their_loop(boxes, logits, idxs, thr):
+    """torchvision.ops.boxes._batched_nms_coordinate_trick restated over the NMS loop of transformers: boxes of category c are moved by
+    c * (max coordinate + 1), one NMS over everything, survivors in descending score order."""
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    keep = owlvit_nms(boxes + offsets[:, None], logits, thr)
+    s = torch.sigmoid(logits)
+    return sorted(keep, key=lambda i: -float(s[i]))
+
+
+@pytest.mark.parametrize("n,levels", [(150, 5), (90, 2), (1100, 5)])
+def test_batched_nms_offset_trick_equals_the_restated_form(n, levels, no_torchvision_stub, monkeypatch):
+    """(1100 boxes = 4 400 coordinates: above torchvision's CPU switch-over to the per-category loop, which oracle.detection follows
+    when NMS_VANILLA_NUMEL is set to the CPU value -- both branches must give the one answer.)"""
+    g = torch.Generator().manual_seed(n + levels)
+    boxes = grid_boxes(n, g, extent=128)
+    logits = distinct_logits(n, g)
+    idxs = torch.randint(0, levels, (n,), generator=g)
+    scores = torch.sigmoid(logits)
+    want = batched_nms_on_their_loop(boxes, logits, idxs, 0.7)
+    for numel in (20000, 4000):
+        monkeypatch.setattr(od, "NMS_VANILLA_NUMEL", numel)
+        got = od.batched_nms(boxes, scores, idxs, 0.7).tolist()
+        assert got == want, (numel, len(got), len(want))
+    # categories never interact: the same as one NMS per category
+    per = []
+    for c in range(levels):
+        cur = (idxs == c).nonzero().flatten()
+        if cur.numel():
+            per += cur[torch.tensor(sorted(od.nms(boxes[cur], scores[cur], 0.7).tolist()), dtype=torch.int64)].tolist()
+    assert sorted(per) == sorted(want)
+
+
+# ----------------------------------------------------------------------------- (c) brute-force definitions
+F32 = np.float32
+
+
+def iou_f32(a, b):
+    """torchvision's IoU on float32 scalars: inter / (area_a + area_b - inter)."""
+    aa = F32(F32(a[2] - a[0]) * F32(a[3] - a[1]))
+    ab = F32(F32(b[2] - b[0]) * F32(b[3] - b[1]))
+    w = max(F32(0), F32(min(a[2], b[2]) - max(a[0], b[0])))
+    h = max(F32(0), F32(min(a[3], b[3]) - max(a[1], b[1])))
+    inter = F32(w * h)
+    return F32(inter / F32(F32(aa + ab) - inter))
+
+
+def brute_filter_proposals(proposals, objectness, image_shape, per_level, pre_n, post_n, nms_thr, score_thr, min_size):
+    """All images.  proposals [n_img, A, 4] float32 numpy, objectness [n_img, A]; per image and level: the pre_n best objectness (equal
+    values: lower index first), clip to the image, drop boxes with a side below min_size, drop scores below score_thr, greedy NMS inside
+    the level; all levels' survivors by descending score (equal scores: position in the level-major candidate list), the first post_n.
+    The scores are ATen's sigmoid of the SELECTED objectness values as one [n_img, K] tensor -- the shape torchvision applies it to (the
+    vectorised sigmoid's last bit depends on an element's position in the tensor)."""
+    h, w = image_shape
+    n_img = proposals.shape[0]
+    cands = []
+    for n in range(n_img):
+        cand, off = [], 0
+        for lvl, cnt in enumerate(per_level):
+            idx = sorted(range(off, off + cnt), key=lambda i: (-float(objectness[n][i]), i))[:min(pre_n, cnt)]
+            cand += [(lvl, i) for i in idx]
+            off += cnt
+        cands.append(cand)
+    sel = torch.tensor([[float(objectness[n][i]) for (_, i) in cands[n]] for n in range(n_img)], dtype=torch.float32)
+    prob = torch.sigmoid(sel).numpy()
+    out = []
+    for n in range(n_img):
+        items = []
+        for pos, (lvl, i) in enumerate(cands[n]):
+            b = proposals[n][i].astype(F32).copy()
+            b[0] = min(max(b[0], F32(0)), F32(w)); b[2] = min(max(b[2], F32(0)), F32(w))
+            b[1] = min(max(b[1], F32(0)), F32(h)); b[3] = min(max(b[3], F32(0)), F32(h))
+            s = prob[n][pos]
+            if F32(b[2] - b[0]) >= F32(min_size) and F32(b[3] - b[1]) >= F32(min_size) and s >= F32(score_thr):
+                items.append((pos, lvl, b, s))
+        survivors = []
+        for lvl in range(len(per_level)):
+            mine = sorted([it for it in items if it[1] == lvl], key=lambda it: (-float(it[3]), it[0]))
+            kept = []
+            for it in mine:
+                if all(not (iou_f32(k[2], it[2]) > F32(nms_thr)) for k in kept):
+                    kept.append(it)
+            survivors += kept
+        survivors.sort(key=lambda it: (-float(it[3]), it[0]))
+        survivors = survivors[:post_n]
+        out.append((np.array([it[2] for it in survivors], dtype=F32).reshape(-1, 4), np.array([it[3] for it in survivors], dtype=F32)))
+    return out
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), pre_n=st.integers(1, 9), post_n=st.integers(1, 12), n_img=st.integers(1, 2),
+       coarse=st.booleans())
+def test_filter_proposals_against_a_brute_force_definition(seed, pre_n, post_n, n_img, coarse):
+    g = torch.Generator().manual_seed(seed)
+    per_level = [12, 7, 3]
+    A = sum(per_level)
+    H, W = 40, 48
+    xy = torch.rand(n_img, A, 2, generator=g) * 56 - 8                     # some boxes start outside the image
+    wh = torch.rand(n_img, A, 2, generator=g) * 30
+    wh[torch.rand(n_img, A, generator=g) < 0.15] = 0.0                     # degenerate boxes: removed by the min-size rule
+    props = torch.cat([xy, xy + wh], dim=2)
+    if coarse:
+        props = torch.round(props * 2) / 2                                 # coordinate ties and exact duplicates
+    obj = torch.randn(n_img, A, generator=g)
+    if coarse:
+        obj = torch.round(obj * 2) / 2                                     # many equal scores: the tie rules are exercised
+    rpn = od.RegionProposalNetwork().eval()
+    rpn._pre_nms_top_n = dict(training=pre_n, testing=pre_n)
+    rpn._post_nms_top_n = dict(training=post_n, testing=post_n)
+    rpn.min_size = 1.0
+    fb, fs = rpn.filter_proposals(props.clone(), obj.clone().reshape(n_img, A, 1), [(H, W)] * n_img, per_level)
+    want = brute_filter_proposals(props.numpy(), obj.numpy(), (H, W), per_level, pre_n, post_n, rpn.nms_thresh, rpn.score_thresh, rpn.min_size)
+    for n in range(n_img):
+        wb, ws = want[n]
+        assert fb[n].shape[0] == wb.shape[0] <= post_n
+        assert np.array_equal(fb[n].numpy(), wb), (fb[n], wb)
+        assert np.array_equal(fs[n].numpy(), ws)
+        # properties that hold whatever the arithmetic: inside the image, descending scores, big enough
+        if wb.shape[0]:
+            b = fb[n]
+            assert float(b[:, 0::2].min()) >= 0 and float(b[:, 0::2].max()) <= W and float(b[:, 1::2].min()) >= 0 and float(b[:, 1::2].max()) <= H
+            assert bool((fs[n][:-1] >= fs[n][1:]).all())
+            assert bool(((b[:, 2] - b[:, 0]) >= 1.0).all() and ((b[:, 3] - b[:, 1]) >= 1.0).all())
+
+
+@settings(max_examples=80, deadline=None)
+@given(labels=st.lists(st.lists(st.sampled_from([-1, 0, 0, 0, 1, 2]), min_size=1, max_size=60), min_size=1, max_size=3),
+       batch=st.integers(1, 32), frac=st.sampled_from([0.25, 0.5]), seed=st.integers(0, 10 ** 6))
+def test_balanced_sampler_against_its_definition(labels, batch, frac, seed):
+    """BalancedPositiveNegativeSampler: at most batch * frac positives (label >= 1), the rest of the batch from the negatives
+    (label == 0), ignored entries (label < 0) never drawn, the two masks disjoint; the drawn members are the leading entries of the
+    injected permutations (positives first, then negatives -- the order torchvision consumes its generator in)."""
+    g = torch.Generator().manual_seed(seed)
+    perms = []
+
+    def perm(n):
+        p = torch.randperm(n, generator=g)
+        perms.append(p)
+        return p
+    sampler = od.BalancedPositiveNegativeSampler(batch, frac, perm)
+    ms = [torch.tensor(l, dtype=torch.int64) for l in labels]
+    pos, neg = sampler(ms)
+    assert len(perms) == 2 * len(ms)
+    for i, m in enumerate(ms):
+        P = [j for j, v in enumerate(m.tolist()) if v >= 1]
+        N = [j for j, v in enumerate(m.tolist()) if v == 0]
+        n_pos = min(len(P), int(batch * frac))
+        n_neg = min(len(N), batch - n_pos)
+        pi, ni = pos[i].nonzero().flatten().tolist(), neg[i].nonzero().flatten().tolist()
+        assert len(pi) == n_pos and len(ni) == n_neg
+        assert set(pi) <= set(P) and set(ni) <= set(N) and not (set(pi) & set(ni))
+        assert sorted(pi) == sorted(P[k] for k in perms[2 * i][:n_pos].tolist())
+        assert sorted(ni) == sorted(N[k] for k in perms[2 * i + 1][:n_neg].tolist())
+        assert pos[i].dtype == torch.uint8 and pos[i].shape == m.shape

@@ -59,6 +59,8 @@ for fam in FAMILIES:
         busy_all += busy
         wall_all += wall
 out["mfma_util"] = round(busy_all / 1024.0 / wall_all, 4) if wall_all else None
-out["commit"] = __import__("os").environ.get("HD_COMMIT")      # the tree this profile was taken on (the GPU box has no .git)
+out["commit"] = __import__("os").environ.get("HD_COMMIT")
+sys_path_ = __import__("sys").path; sys_path_.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+out["csrc_digest"] = __import__("hallucidet_amd.build", fromlist=["source_digest"]).source_digest()   # bench.py flags the summary as stale on any other build      # the tree this profile was taken on (the GPU box has no .git)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -24,5 +24,7 @@ out = {"kernel": sys.argv[3], "launches_sampled": [nf, nw], "fetch_bytes_per_lau
        "command": "STEPS=3 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/bench_step.py (two separate passes)"}
 out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
 out["commit"] = __import__("os").environ.get("HD_COMMIT")
+sys_path_ = __import__("sys").path; sys_path_.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+out["csrc_digest"] = __import__("hallucidet_amd.build", fromlist=["source_digest"]).source_digest()   # bench.py flags the summary as stale on any other build
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out))
