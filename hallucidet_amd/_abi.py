@@ -150,7 +150,29 @@ PROTOTYPES = {
     "hd_check_finite": (C.c_int, [vp, c_i64, vp, vp]),
 }
 
+# fp32-storage twins (include/hallucidet_hip.h, last section): same signatures under the suffix _f32
+F32_TWINS = ["hd_conv2d", "hd_conv2d_stats_rows", "hd_wgrad", "hd_weight_prep", "hd_bn_apply", "hd_bn_bwd_reduce", "hd_bn_bwd_apply",
+             "hd_maxpool3x3s2", "hd_maxpool3x3s2_bwd", "hd_maxpool3x3s2_idx", "hd_maxpool3x3s2_bwd_idx", "hd_subsample2", "hd_subsample2_bwd",
+             "hd_nchw_to_nhwc_resize", "hd_nchw_to_nhwc_resize_strided", "hd_nchw_to_nhwc_resize_bwd", "hd_nhwc_to_nchw", "hd_upsample_add",
+             "hd_upsample_add_bwd", "hd_upsample2_bwd", "hd_add_f16", "hd_slice_channels", "hd_sigmoid_bwd_nchw_to_nhwc", "hd_relu_bwd",
+             "hd_f32_to_f16", "hd_f16_to_f32", "hd_pad_cast_f32_f16", "hd_channel_sum_f16", "hd_roi_align", "hd_roi_align_bwd",
+             "hd_roi_align_ml", "hd_roi_align_ml_bwd", "hd_roi_align_ml_bwd_gather", "hd_groupnorm8_relu", "hd_groupnorm8_relu_bwd",
+             "hd_groupnorm8_param_grad"]
+for _n in F32_TWINS:
+    PROTOTYPES[_n + "_f32"] = PROTOTYPES[_n]
+
 _lib = None
+
+
+def fn(name, t):
+    """The entry point `name` for the storage type of tensor `t`: fp16 -> `name`, fp32 -> `name_f32`."""
+    import torch
+    lib = load()
+    if t.dtype == torch.float32:
+        return getattr(lib, name + "_f32")
+    if t.dtype != torch.float16:
+        raise TypeError("hallucidet_amd: activations are float16 or float32 (got %s)" % t.dtype)
+    return getattr(lib, name)
 
 
 def load():

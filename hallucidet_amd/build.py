@@ -15,6 +15,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libhallucidet_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wno-unused-result"]
+# sources built a second time with -DHD_STORE_F32 (fp32 activation storage, entry points suffixed _f32: csrc/hd_common.h)
+TWICE = ("elementwise.hip", "roi_align.hip", "fcos.hip")
 
 
 def _sources():
@@ -52,14 +54,16 @@ def build(verbose=False, force=False, trace=False):
     jobs = []
     objs = []
     for src in _sources():
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        objs.append(obj)
-        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
-            jobs.append((src, obj))
+        variants = [("", [])] + ([("_f32", ["-DHD_STORE_F32"])] if os.path.basename(src) in TWICE else [])
+        for suffix, extra in variants:
+            obj = os.path.join(objdir, os.path.basename(src)[:-4] + suffix + ".o")
+            objs.append(obj)
+            if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hm):
+                jobs.append((src, obj, extra))
 
     def cc(job):
-        src, obj = job
-        cmd = [HIPCC] + flags + ["-c", src, "-o", obj]
+        src, obj, extra = job
+        cmd = [HIPCC] + flags + extra + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

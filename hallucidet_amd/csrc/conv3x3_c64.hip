@@ -194,13 +194,9 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
         HD_C64_MFMA_V(acc0, wr[0][s], cur);
         HD_C64_MFMA_V(acc1, wr[1][s], cur);
       }
-#ifndef C64_X2
       if (s + RING < KSTEPS) bf[s % RING] = HD_C64_B(s + RING);
-#endif
       // the next tile's patch: one piece every six K steps (issued back to back a piece cost this wave ~150 clocks, spread out ~70)
-#ifndef C64_X1
       if (s % 6 == 1 && more) issue_patch(nn, nty, ntx, stage ^ 1, s / 6);
-#endif
     }
 #undef HD_C64_B
     HD_C64_DRAIN(acc0, acc1);

@@ -1,5 +1,5 @@
 // Detection kernels: batched greedy NMS (64-wide bitmask rows: one wavefront lane per
-// mask bit), RoIAlign forward/backward, pairwise IoU.  fp32 box maths with FMA
+// mask bit), pairwise IoU, the fused glue kernels (RoIAlign: roi_align.hip).  fp32 box maths with FMA
 // contraction disabled so the keep decisions match the scalar CPU oracle bit for bit.
 #include "hd_common.h"
 #pragma clang fp contract(off)
@@ -303,588 +303,6 @@ __global__ __launch_bounds__(256) void nms_seg_merge_kernel(const float* __restr
     const int have = total < top_k ? total : top_k;
     for (int r = have + threadIdx.x; r < top_k; r += 256) pick[(size_t)b * top_k + r] = best;
     if (threadIdx.x == 0) picked[b] = have;
-  }
-}
-
-// ------------------------------------------------------------------ RoIAlign
-struct Bilin {
-  int yl, xl, yh, xh;
-  float w1, w2, w3, w4;
-  bool valid;
-};
-
-__device__ __forceinline__ Bilin bilin_setup(float y, float x, int H, int W) {
-  Bilin b;
-  b.valid = !(y < -1.0f || y > (float)H || x < -1.0f || x > (float)W);
-  if (y <= 0.f) y = 0.f;
-  if (x <= 0.f) x = 0.f;
-  int yl = (int)y, xl = (int)x, yh, xh;
-  if (yl >= H - 1) {
-    yh = yl = H - 1;
-    y = (float)yl;
-  } else
-    yh = yl + 1;
-  if (xl >= W - 1) {
-    xh = xl = W - 1;
-    x = (float)xl;
-  } else
-    xh = xl + 1;
-  float ly = y - (float)yl, lx = x - (float)xl;
-  float hy = 1.f - ly, hx = 1.f - lx;
-  b.yl = yl; b.xl = xl; b.yh = yh; b.xh = xh;
-  b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
-  return b;
-}
-
-__global__ void roi_align_kernel(const f16* __restrict__ feat, const float* __restrict__ rois, f16* __restrict__ out, int R,
-                                 int H, int W, int C, int PH, int PW, float scale, int sr) {
-  const int vecs = C / 8;
-  const int64_t total = (int64_t)R * PH * PW * vecs;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int v = (int)(i % vecs);
-    int64_t q = i / vecs;
-    int pw = (int)(q % PW);
-    int ph = (int)((q / PW) % PH);
-    int r = (int)(q / ((int64_t)PW * PH));
-    const float* roi = rois + (size_t)r * 5;
-    int n = (int)roi[0];
-    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
-    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
-    float bh = rh / (float)PH, bw = rw / (float)PW;
-    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
-    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
-    float count = fmaxf((float)(gh * gw), 1.f);
-    float acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    const f16* fb = feat + (size_t)n * H * W * C + v * 8;
-    for (int iy = 0; iy < gh; ++iy) {
-      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
-        Bilin b = bilin_setup(y, x, H, W);
-        if (!b.valid) continue;
-        f16x8 v1 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xl) * C);
-        f16x8 v2 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xh) * C);
-        f16x8 v3 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xl) * C);
-        f16x8 v4 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xh) * C);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += b.w1 * (float)v1[k] + b.w2 * (float)v2[k] + b.w3 * (float)v3[k] + b.w4 * (float)v4[k];
-      }
-    }
-    f16x8 o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] / count);
-    *reinterpret_cast<f16x8*>(out + (size_t)q * C + v * 8) = o;
-  }
-}
-
-__global__ void roi_align_bwd_kernel(const f16* __restrict__ dout, const float* __restrict__ rois, float* __restrict__ dfeat, int R,
-                                     int H, int W, int C, int PH, int PW, float scale, int sr) {
-  const int64_t total = (int64_t)R * PH * PW * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    int64_t q = i / C;
-    int pw = (int)(q % PW);
-    int ph = (int)((q / PW) % PH);
-    int r = (int)(q / ((int64_t)PW * PH));
-    const float* roi = rois + (size_t)r * 5;
-    int n = (int)roi[0];
-    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
-    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
-    float bh = rh / (float)PH, bw = rw / (float)PW;
-    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
-    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
-    float count = fmaxf((float)(gh * gw), 1.f);
-    float g = (float)dout[i] / count;
-    if (g == 0.f) continue;
-    float* fb = dfeat + (size_t)n * H * W * C + c;
-    for (int iy = 0; iy < gh; ++iy) {
-      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
-        Bilin b = bilin_setup(y, x, H, W);
-        if (!b.valid) continue;
-        atomicAdd(fb + ((size_t)b.yl * W + b.xl) * C, g * b.w1);
-        atomicAdd(fb + ((size_t)b.yl * W + b.xh) * C, g * b.w2);
-        atomicAdd(fb + ((size_t)b.yh * W + b.xl) * C, g * b.w3);
-        atomicAdd(fb + ((size_t)b.yh * W + b.xh) * C, g * b.w4);
-      }
-    }
-  }
-}
-
-struct MLFeat {
-  const f16* f[4];
-  float* df[4];
-  int H[4], W[4];
-  float scale[4];
-};
-
-__global__ void roi_align_ml_kernel(MLFeat ml, const float* __restrict__ rois, const int* __restrict__ level, f16* __restrict__ out,
-                                    int R, int C, int PH, int PW, int sr) {
-  const int vecs = C / 8;
-  const int64_t total = (int64_t)R * PH * PW * vecs;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int v = (int)(i % vecs);
-    int64_t q = i / vecs;
-    int pw = (int)(q % PW);
-    int ph = (int)((q / PW) % PH);
-    int r = (int)(q / ((int64_t)PW * PH));
-    int l = level[r];
-    const int H = ml.H[l], W = ml.W[l];
-    const float scale = ml.scale[l];
-    const float* roi = rois + (size_t)r * 5;
-    int n = (int)roi[0];
-    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
-    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
-    float bh = rh / (float)PH, bw = rw / (float)PW;
-    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
-    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
-    float count = fmaxf((float)(gh * gw), 1.f);
-    float acc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-    const f16* fb = ml.f[l] + (size_t)n * H * W * C + v * 8;
-    if (sr == 2) {
-      // the detector's setting (MultiScaleRoIAlign(sampling_ratio=2)): all 16 taps of the 2x2 sample grid are requested
-      // before any is used -- the generic loop below waits for each sample's 4 loads in turn (4 dependent L2 round trips
-      // per output vector: the launch was latency-bound at 9x its output-write time).  Same accumulation order.
-      Bilin bs[4];
-      f16x8 t1[4], t2[4], t3[4], t4[4];
-#pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        const int iy = sidx >> 1, ix = sidx & 1;
-        const float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / 2.f;
-        const float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / 2.f;
-        bs[sidx] = bilin_setup(y, x, H, W);
-        if (bs[sidx].valid) {
-          t1[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yl * W + bs[sidx].xl) * C);
-          t2[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yl * W + bs[sidx].xh) * C);
-          t3[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yh * W + bs[sidx].xl) * C);
-          t4[sidx] = *reinterpret_cast<const f16x8*>(fb + ((size_t)bs[sidx].yh * W + bs[sidx].xh) * C);
-        }
-      }
-#pragma unroll
-      for (int sidx = 0; sidx < 4; ++sidx) {
-        if (!bs[sidx].valid) continue;
-        const Bilin b = bs[sidx];
-#pragma unroll
-        for (int k = 0; k < 8; ++k)
-          acc[k] += b.w1 * (float)t1[sidx][k] + b.w2 * (float)t2[sidx][k] + b.w3 * (float)t3[sidx][k] + b.w4 * (float)t4[sidx][k];
-      }
-      f16x8 o2;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) o2[k] = (f16)(acc[k] / count);
-      *reinterpret_cast<f16x8*>(out + (size_t)q * C + v * 8) = o2;
-      continue;
-    }
-    for (int iy = 0; iy < gh; ++iy) {
-      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
-        Bilin b = bilin_setup(y, x, H, W);
-        if (!b.valid) continue;
-        f16x8 v1 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xl) * C);
-        f16x8 v2 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yl * W + b.xh) * C);
-        f16x8 v3 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xl) * C);
-        f16x8 v4 = *reinterpret_cast<const f16x8*>(fb + ((size_t)b.yh * W + b.xh) * C);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) acc[k] += b.w1 * (float)v1[k] + b.w2 * (float)v2[k] + b.w3 * (float)v3[k] + b.w4 * (float)v4[k];
-      }
-    }
-    f16x8 o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] / count);
-    *reinterpret_cast<f16x8*>(out + (size_t)q * C + v * 8) = o;
-  }
-}
-
-struct RoiGeom {
-  int n, l, H, W, y0, x0, ph_, pw_, gh, gw;
-  float rsw, rsh, bh, bw, count;
-  bool any;
-};
-
-__device__ __forceinline__ RoiGeom roi_geom(const MLFeat& ml, const float* rois, const int* level, int r, int PH, int PW, int sr) {
-  RoiGeom g;
-  g.l = level[r];
-  g.H = ml.H[g.l];
-  g.W = ml.W[g.l];
-  const float scale = ml.scale[g.l];
-  const float* roi = rois + (size_t)r * 5;
-  g.n = (int)roi[0];
-  g.rsw = roi[1] * scale;
-  g.rsh = roi[2] * scale;
-  float rew = roi[3] * scale, reh = roi[4] * scale;
-  float rw = fmaxf(rew - g.rsw, 1.f), rh = fmaxf(reh - g.rsh, 1.f);
-  g.bh = rh / (float)PH;
-  g.bw = rw / (float)PW;
-  g.gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
-  g.gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
-  g.count = fmaxf((float)(g.gh * g.gw), 1.f);
-  // extent of the bilinear footprints (same clamping as bilin_setup)
-  float ymin = g.rsh + .5f * g.bh / (float)g.gh, ymax = g.rsh + (float)(PH - 1) * g.bh + ((float)g.gh - .5f) * g.bh / (float)g.gh;
-  float xmin = g.rsw + .5f * g.bw / (float)g.gw, xmax = g.rsw + (float)(PW - 1) * g.bw + ((float)g.gw - .5f) * g.bw / (float)g.gw;
-  g.any = !(ymax < -1.f || ymin > (float)g.H || xmax < -1.f || xmin > (float)g.W);
-  int y0 = (int)floorf(fmaxf(ymin, 0.f)), y1 = (int)floorf(fmaxf(ymax, 0.f)) + 1;
-  int x0 = (int)floorf(fmaxf(xmin, 0.f)), x1 = (int)floorf(fmaxf(xmax, 0.f)) + 1;
-  y0 = min(max(y0, 0), g.H - 1); y1 = min(max(y1, 0), g.H - 1);
-  x0 = min(max(x0, 0), g.W - 1); x1 = min(max(x1, 0), g.W - 1);
-  g.y0 = y0; g.x0 = x0; g.ph_ = y1 - y0 + 1; g.pw_ = x1 - x0 + 1;
-  return g;
-}
-
-__global__ void roi_align_ml_bwd_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
-                                        const int* __restrict__ level, int R, int C, int PH, int PW, int sr, int px_lo) {
-  const int64_t total = (int64_t)R * PH * PW * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int c = (int)(i % C);
-    int64_t q = i / C;
-    int pw = (int)(q % PW);
-    int ph = (int)((q / PW) % PH);
-    int r = (int)(q / ((int64_t)PW * PH));
-    if (px_lo > 0) {   // RoIs whose patch fits on chip were handled by the patch kernels
-      const RoiGeom gg = roi_geom(ml, rois, level, r, PH, PW, sr);
-      if (gg.any && gg.ph_ * gg.pw_ <= px_lo) continue;
-    }
-    int l = level[r];
-    const int H = ml.H[l], W = ml.W[l];
-    const float scale = ml.scale[l];
-    const float* roi = rois + (size_t)r * 5;
-    int n = (int)roi[0];
-    float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
-    float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
-    float bh = rh / (float)PH, bw = rw / (float)PW;
-    int gh = sr > 0 ? sr : (int)ceilf(rh / (float)PH);
-    int gw = sr > 0 ? sr : (int)ceilf(rw / (float)PW);
-    float count = fmaxf((float)(gh * gw), 1.f);
-    float g = (float)dout[i] / count;
-    if (g == 0.f) continue;
-    float* fb = ml.df[l] + (size_t)n * H * W * C + c;
-    for (int iy = 0; iy < gh; ++iy) {
-      float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / (float)gh;
-      for (int ix = 0; ix < gw; ++ix) {
-        float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / (float)gw;
-        Bilin b = bilin_setup(y, x, H, W);
-        if (!b.valid) continue;
-        atomicAdd(fb + ((size_t)b.yl * W + b.xl) * C, g * b.w1);
-        atomicAdd(fb + ((size_t)b.yl * W + b.xh) * C, g * b.w2);
-        atomicAdd(fb + ((size_t)b.yh * W + b.xl) * C, g * b.w3);
-        atomicAdd(fb + ((size_t)b.yh * W + b.xh) * C, g * b.w4);
-      }
-    }
-  }
-}
-
-// ---- RoIAlign backward with on-chip pre-accumulation ---------------------------------------------------------------
-// Global float atomics run at one chip-wide rate (~1.3 TB/s of added bytes), and the direct kernel issues
-// 7*7*4*4 = 784 of them per RoI and channel.  A RoI only touches the (h+2)x(w+2) feature pixels under it, so a block
-// first accumulates one RoI x 64 channels into an LDS patch (ds_add_f32) and then flushes each touched pixel ONCE:
-// npx atomics instead of 784 (3-10x fewer for the RoIs this path takes).  RoIs whose patch does not fit the class
-// budget are left to the direct kernel (same arithmetic).
-// grid (R, C/64), block = ONE wave: lane = channel.  The wave walks the RoI's sample points in order and accumulates into
-// its private LDS patch with plain read-modify-write (LDS operations of one wave execute in order, so no atomics and
-// no barriers are needed).  Handles RoIs with px_lo < patch pixels <= MAXPX.
-template <int MAXPX>
-__global__ __launch_bounds__(64) void roi_align_ml_bwd_patch_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
-                                                                    const int* __restrict__ level, int R, int C, int PH, int PW,
-                                                                    int sr, int px_lo) {
-  __shared__ float patch[MAXPX * 64];
-  const int r = blockIdx.x;
-  const RoiGeom g = roi_geom(ml, rois, level, r, PH, PW, sr);
-  const int npx = g.ph_ * g.pw_;
-  if (!g.any || npx <= px_lo || npx > MAXPX) return;          // uniform
-  const int lane = threadIdx.x;
-  const int c = blockIdx.y * 64 + lane;
-  for (int i = 0; i < npx; ++i) patch[i * 64 + lane] = 0.f;
-  const f16* dr = dout + (size_t)r * PH * PW * C + c;
-  for (int ph = 0; ph < PH; ++ph) {
-    for (int pw = 0; pw < PW; ++pw) {
-      const float gv = (float)dr[(size_t)(ph * PW + pw) * C] / g.count;
-      for (int iy = 0; iy < g.gh; ++iy) {
-        const float y = g.rsh + (float)ph * g.bh + ((float)iy + .5f) * g.bh / (float)g.gh;
-        for (int ix = 0; ix < g.gw; ++ix) {
-          const float x = g.rsw + (float)pw * g.bw + ((float)ix + .5f) * g.bw / (float)g.gw;
-          const Bilin b = bilin_setup(y, x, g.H, g.W);
-          if (!b.valid) continue;                                 // uniform
-          float* p0 = patch + ((b.yl - g.y0) * g.pw_ + (b.xl - g.x0)) * 64 + lane;
-          const int dy = (b.yh - b.yl) * g.pw_ * 64, dx = (b.xh - b.xl) * 64;
-          p0[0] += gv * b.w1;
-          p0[dx] += gv * b.w2;
-          p0[dy] += gv * b.w3;
-          p0[dy + dx] += gv * b.w4;
-        }
-      }
-    }
-  }
-  float* fb = ml.df[g.l] + (size_t)g.n * g.H * g.W * C + c;
-  for (int py = 0; py < g.ph_; ++py)
-    for (int px = 0; px < g.pw_; ++px) {
-      const float v = patch[(py * g.pw_ + px) * 64 + lane];
-      if (v != 0.f) atomicAdd(fb + ((size_t)(g.y0 + py) * g.W + (g.x0 + px)) * C, v);
-    }
-}
-
-// ---- RoIAlign backward, gather form -------------------------------------------------------------------------------
-// One thread owns ONE feature pixel (and CCH channels) and pulls the gradient from every RoI bin that touches it: no
-// atomics, no zero-initialised fp32 maps, every output element is written exactly once (fp32 accumulate, fp16 store)
-// and the result is bit-reproducible run to run.  The bilinear weight of a sample point is separable, and so is the sum
-// over the SRxSR sample points of a bin:  w(pixel <- bin (ph,pw)) = WY[ph] * WX[pw] / count  with
-// WY[ph] = sum over the bin's sample rows of the row weight of pixel row py (same clamping rules as the forward).
-// Block = 16x16 pixel tile of one (level, image) x CCH channels.  The block first scans the RoI list (any order) for
-// RoIs of its image / level whose touched-pixel box meets the tile (ordered compaction -> deterministic summation
-// order), then every thread walks that list.
-struct GatherRoi {
-  float rsw, rsh, bw, bh;
-  int r;
-  short y0, y1, x0, x1;
-};
-
-template <int SR>
-__device__ __forceinline__ float axis_weight(float start, float bin, int p, int pix, int size) {
-  // sum over the SR sample coordinates of bin `p` of the weight with which they hit pixel `pix` along one axis
-  float acc = 0.f;
-#pragma unroll
-  for (int i = 0; i < SR; ++i) {
-    float y = start + (float)p * bin + ((float)i + .5f) * bin / (float)SR;
-    if (y < -1.0f || y > (float)size) continue;
-    if (y <= 0.f) y = 0.f;
-    int yl = (int)y, yh;
-    if (yl >= size - 1) {
-      yh = yl = size - 1;
-      y = (float)yl;
-    } else
-      yh = yl + 1;
-    const float ly = y - (float)yl, hy = 1.f - ly;
-    acc += (yl == pix ? hy : 0.f) + (yh == pix ? ly : 0.f);
-  }
-  return acc;
-}
-
-template <int PH, int PW, int SR, int CCH>
-__global__ __launch_bounds__(256) void roi_align_ml_bwd_gather_kernel(MLFeat ml, f16* const* __restrict__ dst_unused, const f16* __restrict__ dout,
-                                                                      const float* __restrict__ rois, const int* __restrict__ level,
-                                                                      int R, int C, int L, int4 tile_base, int n_images) {
-  constexpr int CAP = 1024;
-  __shared__ GatherRoi list[CAP];
-  __shared__ int wcnt[4];
-  // ---- which tile
-  int b = blockIdx.x, l = 0;
-  const int bases[4] = {tile_base.x, tile_base.y, tile_base.z, tile_base.w};
-  while (l + 1 < L && b >= bases[l + 1]) ++l;
-  b -= bases[l];
-  const int H = ml.H[l], W = ml.W[l];
-  const int tw = (W + 15) / 16, th = (H + 15) / 16;
-  const int n = b / (tw * th);
-  const int ty = (b / tw) % th, tx = b % tw;
-  const int c0 = blockIdx.y * CCH;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int py = ty * 16 + (tid >> 4), px = tx * 16 + (tid & 15);
-  const bool live = py < H && px < W;
-  const int ty0 = ty * 16, ty1 = min(ty * 16 + 15, H - 1), tx0 = tx * 16, tx1 = min(tx * 16 + 15, W - 1);
-  float acc[CCH];
-#pragma unroll
-  for (int k = 0; k < CCH; ++k) acc[k] = 0.f;
-
-  for (int base = 0; base < R; base += CAP) {
-    // ---- ordered compaction of the RoIs [base, base+CAP) that touch this tile
-    int total = 0;
-    for (int it = 0; it < CAP / 256; ++it) {
-      const int r = base + it * 256 + tid;
-      bool hit = false;
-      GatherRoi e;
-      if (r < R && level[r] == l && (int)rois[(size_t)r * 5] == n) {
-        const RoiGeom g = roi_geom(ml, rois, level, r, PH, PW, SR);
-        if (g.any) {
-          const int y1 = g.y0 + g.ph_ - 1, x1 = g.x0 + g.pw_ - 1;
-          hit = !(y1 < ty0 || g.y0 > ty1 || x1 < tx0 || g.x0 > tx1);
-          e.rsw = g.rsw; e.rsh = g.rsh; e.bw = g.bw; e.bh = g.bh; e.r = r;
-          e.y0 = (short)g.y0; e.y1 = (short)y1; e.x0 = (short)g.x0; e.x1 = (short)x1;
-        }
-      }
-      const unsigned long long m = __ballot(hit);
-      if (lane == 0) wcnt[wave] = __popcll(m);
-      __syncthreads();
-      int off = total;
-      for (int w = 0; w < wave; ++w) off += wcnt[w];
-      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
-      total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-      __syncthreads();
-    }
-    // ---- every pixel walks the list
-    if (live) {
-      for (int i = 0; i < total; ++i) {
-        const GatherRoi e = list[i];
-        if (py < e.y0 || py > e.y1 || px < e.x0 || px > e.x1) continue;
-        float wy[PH], wx[PW];
-        bool anyy = false, anyx = false;
-#pragma unroll
-        for (int p = 0; p < PH; ++p) {
-          // bin p's sample rows lie in [rsh + p*bh, rsh + (p+1)*bh]; they reach pixel row py only within one pixel of it
-          const float lo = e.rsh + (float)p * e.bh, hi = lo + e.bh;
-          const bool near_ = !(hi < (float)py - 1.f || lo > (float)py + 1.f) || py == 0 || py == H - 1;
-          wy[p] = near_ ? axis_weight<SR>(e.rsh, e.bh, p, py, H) : 0.f;
-          anyy |= wy[p] != 0.f;
-        }
-        if (!anyy) continue;
-#pragma unroll
-        for (int p = 0; p < PW; ++p) {
-          const float lo = e.rsw + (float)p * e.bw, hi = lo + e.bw;
-          const bool near_ = !(hi < (float)px - 1.f || lo > (float)px + 1.f) || px == 0 || px == W - 1;
-          wx[p] = near_ ? axis_weight<SR>(e.rsw, e.bw, p, px, W) : 0.f;
-          anyx |= wx[p] != 0.f;
-        }
-        if (!anyx) continue;
-        const f16* dr = dout + (size_t)e.r * PH * PW * C + c0;
-#pragma unroll
-        for (int ph = 0; ph < PH; ++ph) {
-          if (wy[ph] == 0.f) continue;
-#pragma unroll
-          for (int pw = 0; pw < PW; ++pw) {
-            const float w = wy[ph] * wx[pw] * (1.f / (float)(SR * SR));
-            if (w == 0.f) continue;
-            const f16* q = dr + (size_t)(ph * PW + pw) * C;
-#pragma unroll
-            for (int v = 0; v < CCH / 8; ++v) {
-              const f16x8 d = *reinterpret_cast<const f16x8*>(q + v * 8);
-#pragma unroll
-              for (int k = 0; k < 8; ++k) acc[v * 8 + k] += w * (float)d[k];
-            }
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  if (live) {
-    f16* o = const_cast<f16*>(ml.f[l]) + (((size_t)n * H + py) * W + px) * C + c0;
-#pragma unroll
-    for (int v = 0; v < CCH / 8; ++v) {
-      f16x8 t;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = (f16)acc[v * 8 + k];
-      *reinterpret_cast<f16x8*>(o + v * 8) = t;
-    }
-  }
-}
-
-// C % 256 == 0 form of the gather backward (the detector's 256-channel pyramid): 8x8 pixel tile, thread = (pixel, 64-channel
-// quarter).  The per-axis bin weights depend on (RoI, pixel ROW) and (RoI, pixel COLUMN) only, so a tile needs
-// 16 x 7 of them per RoI instead of 64 x 14: they are computed cooperatively into LDS for 32 RoIs at a time and every
-// pixel thread then reads its 14 numbers -- the weight arithmetic, which dominated the generic kernel above, drops ~8x
-// and is no longer repeated per channel chunk.
-template <int PH, int PW, int SR>
-__global__ __launch_bounds__(256) void roi_align_ml_bwd_gather256_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
-                                                                         const int* __restrict__ level, int R, int C, int L, int4 tile_base) {
-  constexpr int CAP = 1024, SB = 32, TS = 8, CQ = 64;
-  static_assert(PH == PW, "square pooler");
-  __shared__ GatherRoi list[CAP];
-  __shared__ float wtab[SB][2][TS][PH];
-  __shared__ int wcnt[4];
-  int b = blockIdx.x, l = 0;
-  const int bases[4] = {tile_base.x, tile_base.y, tile_base.z, tile_base.w};
-  while (l + 1 < L && b >= bases[l + 1]) ++l;
-  b -= bases[l];
-  const int H = ml.H[l], W = ml.W[l];
-  const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS;
-  const int n = b / (tw * th);
-  const int ty = (b / tw) % th, tx = b % tw;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ly = lane >> 3, lx = lane & 7;
-  const int py = ty * TS + ly, px = tx * TS + lx;
-  const bool live = py < H && px < W;
-  const int c0 = blockIdx.y * 256 + wave * CQ;
-  const int ty0 = ty * TS, ty1 = min(ty * TS + TS - 1, H - 1), tx0 = tx * TS, tx1 = min(tx * TS + TS - 1, W - 1);
-  float acc[CQ];
-#pragma unroll
-  for (int k = 0; k < CQ; ++k) acc[k] = 0.f;
-
-  for (int base = 0; base < R; base += CAP) {
-    int total = 0;
-    for (int it = 0; it < CAP / 256; ++it) {
-      const int r = base + it * 256 + tid;
-      bool hit = false;
-      GatherRoi e;
-      if (r < R && level[r] == l && (int)rois[(size_t)r * 5] == n) {
-        const RoiGeom g = roi_geom(ml, rois, level, r, PH, PW, SR);
-        if (g.any) {
-          const int y1 = g.y0 + g.ph_ - 1, x1 = g.x0 + g.pw_ - 1;
-          hit = !(y1 < ty0 || g.y0 > ty1 || x1 < tx0 || g.x0 > tx1);
-          e.rsw = g.rsw; e.rsh = g.rsh; e.bw = g.bw; e.bh = g.bh; e.r = r;
-          e.y0 = (short)g.y0; e.y1 = (short)y1; e.x0 = (short)g.x0; e.x1 = (short)x1;
-        }
-      }
-      const unsigned long long m = __ballot(hit);
-      if (lane == 0) wcnt[wave] = __popcll(m);
-      __syncthreads();
-      int off = total;
-      for (int w = 0; w < wave; ++w) off += wcnt[w];
-      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
-      total += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-      __syncthreads();
-    }
-    for (int sb = 0; sb < total; sb += SB) {
-      const int nsb = min(SB, total - sb);
-      // ---- phase A: bin weights of nsb RoIs for the tile's 8 rows and 8 columns
-      for (int idx = tid; idx < nsb * 2 * TS * PH; idx += 256) {
-        const int p = idx % PH;
-        const int pos = (idx / PH) % TS;
-        const int axis = (idx / (PH * TS)) & 1;
-        const int j = idx / (2 * TS * PH);
-        const GatherRoi e = list[sb + j];
-        const float start = axis ? e.rsw : e.rsh, bin = axis ? e.bw : e.bh;
-        const int pix = axis ? tx * TS + pos : ty * TS + pos, size = axis ? W : H;
-        const float lo = start + (float)p * bin, hi = lo + bin;
-        const bool near_ = pix < size && (!(hi < (float)pix - 1.f || lo > (float)pix + 1.f) || pix == 0 || pix == size - 1);
-        wtab[j][axis][pos][p] = near_ ? axis_weight<SR>(start, bin, p, pix, size) : 0.f;
-      }
-      __syncthreads();
-      // ---- phase B
-      if (live) {
-        for (int j = 0; j < nsb; ++j) {
-          const GatherRoi e = list[sb + j];
-          if (py < e.y0 || py > e.y1 || px < e.x0 || px > e.x1) continue;
-          // the bins that reach a pixel are contiguous along each axis: find the two ranges, then a small 2-D loop
-          // (kept rolled: 49 unrolled bin bodies of 64 FMAs each overflow the instruction cache)
-          const float* WY = &wtab[j][0][ly][0];
-          const float* WX = &wtab[j][1][lx][0];
-          int ya = -1, yb = -1, xa = -1, xb = -1;
-#pragma unroll
-          for (int p = 0; p < PH; ++p) {
-            if (WY[p] != 0.f) { if (ya < 0) ya = p; yb = p; }
-            if (WX[p] != 0.f) { if (xa < 0) xa = p; xb = p; }
-          }
-          if (ya < 0 || xa < 0) continue;
-          const f16* dr = dout + (size_t)e.r * PH * PW * C + c0;
-          for (int ph = ya; ph <= yb; ++ph) {
-            const float wyv = WY[ph] * (1.f / (float)(SR * SR));
-            for (int pw = xa; pw <= xb; ++pw) {
-              const float w = wyv * WX[pw];
-              if (w == 0.f) continue;
-              const f16* q = dr + (size_t)(ph * PW + pw) * C;
-#pragma unroll
-              for (int v = 0; v < CQ / 8; ++v) {
-                const f16x8 d = *reinterpret_cast<const f16x8*>(q + v * 8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[v * 8 + k] += w * (float)d[k];
-              }
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  if (live) {
-    f16* o = const_cast<f16*>(ml.f[l]) + (((size_t)n * H + py) * W + px) * C + c0;
-#pragma unroll
-    for (int v = 0; v < CQ / 8; ++v) {
-      f16x8 t;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = (f16)acc[v * 8 + k];
-      *reinterpret_cast<f16x8*>(o + v * 8) = t;
-    }
   }
 }
 
@@ -1655,32 +1073,6 @@ extern "C" int hd_batched_nms_pick_segments(const float* boxes, const float* sco
   return HD_OK;
 }
 
-extern "C" int hd_roi_align(const void* feat, const float* rois, void* out, int R, int N, int H, int W, int C, int PH, int PW,
-                            float spatial_scale, int sampling_ratio, void* stream) {
-  HD_CHECK_ARG(feat && rois && out && R >= 0 && C % 8 == 0 && N > 0, "hd_roi_align: bad args");
-  if (R == 0) return HD_OK;
-  int64_t total = (int64_t)R * PH * PW * C / 8;
-  int g = (int)((total + 255) / 256);
-  if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(roi_align_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const f16*)feat, rois, (f16*)out, R, H, W, C, PH, PW,
-                     spatial_scale, sampling_ratio);
-  HD_CHECK_LAUNCH();
-  return HD_OK;
-}
-
-extern "C" int hd_roi_align_bwd(const void* dout, const float* rois, float* dfeat_f32, int R, int N, int H, int W, int C, int PH,
-                                int PW, float spatial_scale, int sampling_ratio, void* stream) {
-  HD_CHECK_ARG(dout && rois && dfeat_f32 && R >= 0 && N > 0, "hd_roi_align_bwd: bad args");
-  if (R == 0) return HD_OK;
-  int64_t total = (int64_t)R * PH * PW * C;
-  int g = (int)((total + 255) / 256);
-  if (g > 16384) g = 16384;
-  hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, (const f16*)dout, rois, dfeat_f32, R, H, W, C, PH,
-                     PW, spatial_scale, sampling_ratio);
-  HD_CHECK_LAUNCH();
-  return HD_OK;
-}
-
 extern "C" int hd_box_iou(const float* gt, int G, const float* boxes, int A, float* iou, void* stream) {
   HD_CHECK_ARG(gt && boxes && iou && G >= 0 && A >= 0, "hd_box_iou: bad args");
   if (G == 0 || A == 0) return HD_OK;
@@ -1688,83 +1080,6 @@ extern "C" int hd_box_iou(const float* gt, int G, const float* boxes, int A, flo
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(box_iou_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, gt, G, boxes, A, iou);
-  HD_CHECK_LAUNCH();
-  return HD_OK;
-}
-
-extern "C" int hd_roi_align_ml(const void* const* feats, const int* H, const int* W, const float* scale, int L, const float* rois,
-                               const int* level, void* out, int R, int C, int PH, int PW, int sampling_ratio, void* stream) {
-  HD_CHECK_ARG(feats && H && W && scale && rois && level && out && L >= 1 && L <= 4 && C % 8 == 0 && R >= 0, "hd_roi_align_ml: bad args");
-  if (R == 0) return HD_OK;
-  MLFeat ml = {};
-  for (int l = 0; l < L; ++l) {
-    ml.f[l] = (const f16*)feats[l];
-    ml.H[l] = H[l];
-    ml.W[l] = W[l];
-    ml.scale[l] = scale[l];
-  }
-  int64_t total = (int64_t)R * PH * PW * C / 8;
-  int g = (int)((total + 255) / 256);
-  if (g > 8192) g = 8192;
-  hipLaunchKernelGGL(roi_align_ml_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ml, rois, level, (f16*)out, R, C, PH, PW, sampling_ratio);
-  HD_CHECK_LAUNCH();
-  return HD_OK;
-}
-
-extern "C" int hd_roi_align_ml_bwd_gather(const void* dout, const float* rois, const int* level, void* const* dfeat_f16, const int* H,
-                                          const int* W, const float* scale, int L, int R, int n_images, int C, int PH, int PW,
-                                          int sampling_ratio, void* stream) {
-  HD_CHECK_ARG(dout && rois && level && dfeat_f16 && H && W && scale && L >= 1 && L <= 4 && R >= 0 && n_images >= 0, "hd_roi_align_ml_bwd_gather: bad args");
-  HD_CHECK_ARG(PH == 7 && PW == 7 && sampling_ratio == 2 && C % 32 == 0,
-               "hd_roi_align_ml_bwd_gather: built for the 7x7 / sampling_ratio 2 pooler of the hot path (got %dx%d sr %d C %d)", PH, PW, sampling_ratio, C);
-  if (n_images == 0) return HD_OK;
-  MLFeat ml = {};
-  int base[5] = {0, 0, 0, 0, 0};
-  for (int l = 0; l < L; ++l) {
-    ml.f[l] = (const f16*)dfeat_f16[l];       // destination maps ride in the `f` slots (fp16), written once per element
-    ml.H[l] = H[l];
-    ml.W[l] = W[l];
-    ml.scale[l] = scale[l];
-    const int ts = (C % 256 == 0) ? 8 : 16;
-    base[l + 1] = base[l] + n_images * ((H[l] + ts - 1) / ts) * ((W[l] + ts - 1) / ts);
-  }
-  for (int l = L; l < 4; ++l) base[l + 1] = base[L];
-  if (C % 256 == 0) {
-    hipLaunchKernelGGL((roi_align_ml_bwd_gather256_kernel<7, 7, 2>), dim3(base[L], C / 256), dim3(256), 0, (hipStream_t)stream, ml,
-                       (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]));
-    HD_CHECK_LAUNCH();
-    return HD_OK;
-  }
-  hipLaunchKernelGGL((roi_align_ml_bwd_gather_kernel<7, 7, 2, 32>), dim3(base[L], C / 32), dim3(256), 0, (hipStream_t)stream, ml,
-                     (f16* const*)nullptr, (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]), n_images);
-  HD_CHECK_LAUNCH();
-  return HD_OK;
-}
-
-extern "C" int hd_roi_align_ml_bwd(const void* dout, const float* rois, const int* level, float* const* dfeat_f32, const int* H,
-                                   const int* W, const float* scale, int L, int R, int C, int PH, int PW, int sampling_ratio,
-                                   void* stream) {
-  HD_CHECK_ARG(dout && rois && level && dfeat_f32 && H && W && scale && L >= 1 && L <= 4 && R >= 0, "hd_roi_align_ml_bwd: bad args");
-  if (R == 0) return HD_OK;
-  MLFeat ml = {};
-  for (int l = 0; l < L; ++l) {
-    ml.df[l] = dfeat_f32[l];
-    ml.H[l] = H[l];
-    ml.W[l] = W[l];
-    ml.scale[l] = scale[l];
-  }
-  int64_t total = (int64_t)R * PH * PW * C;
-  int g = (int)((total + 255) / 256);
-  if (g > 16384) g = 16384;
-  int px_lo = 0;
-  if (C % 64 == 0) {
-    // RoIs that touch <= 64 feature pixels: one-wave LDS patch accumulation (16 KB, 10 waves per CU), one global atomic
-    // per touched pixel instead of 784 per RoI.  (A 224-pixel class was measured too: at 56 KB of LDS per wave its
-    // occupancy makes it slower than the direct atomics it replaces.)
-    hipLaunchKernelGGL((roi_align_ml_bwd_patch_kernel<64>), dim3(R, C / 64), dim3(64), 0, (hipStream_t)stream, ml, (const f16*)dout, rois, level, R, C, PH, PW, sampling_ratio, 0);
-    px_lo = 64;
-  }
-  hipLaunchKernelGGL(roi_align_ml_bwd_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, ml, (const f16*)dout, rois, level, R, C, PH, PW, sampling_ratio, px_lo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

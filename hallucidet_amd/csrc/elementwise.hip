@@ -817,6 +817,7 @@ bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 #define S_ ((hipStream_t)stream)
 
+#ifndef HD_STORE_F32
 extern "C" int hd_colsum(const float* in, int rows, int W, float* out, float* ws, void* stream) {
   HD_CHECK_ARG(in && out && rows > 0 && W > 0, "hd_colsum: bad args");
   int R2 = rows > 512 ? 128 : (rows > 32 ? 16 : 1);
@@ -831,14 +832,18 @@ extern "C" int hd_colsum(const float* in, int rows, int W, float* out, float* ws
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif
 
+#ifndef HD_STORE_F32
 extern "C" int hd_rowsum(const float* in, int rows, int W, float* out, int out_rows, void* stream) {
   HD_CHECK_ARG(in && out && rows > 0 && W > 0 && out_rows > 0 && out_rows <= rows, "hd_rowsum: bad args");
   hipLaunchKernelGGL(colsum_stage, dim3(hd_cdiv(W, 64), out_rows), dim3(256), 0, S_, in, rows, W, out, out_rows);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif
 
+#ifndef HD_STORE_F32
 extern "C" int hd_bn_finalize(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                               float* scale, float* shift, void* stream) {
@@ -848,7 +853,9 @@ extern "C" int hd_bn_finalize(const float* part, int rows, int C, double count, 
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif
 
+#ifndef HD_STORE_F32
 extern "C" int hd_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                       float eps, int C, float* scale, float* shift, void* stream) {
   HD_CHECK_ARG(running_mean && running_var && scale && shift && C > 0, "hd_bn_eval_scale_shift: bad args");
@@ -856,8 +863,9 @@ extern "C" int hd_bn_eval_scale_shift(const float* gamma, const float* beta, con
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif
 
-extern "C" int hd_bn_apply(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C,
+extern "C" int HD_API(hd_bn_apply)(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C,
                            int relu, void* stream) {
   HD_CHECK_ARG(y && z && scale && shift && n > 0 && C % 8 == 0 && n % 8 == 0, "hd_bn_apply: bad args");
   HD_CHECK_ARG(pow2(C / 8) && C <= 2048, "hd_bn_apply: C/8 must be a power of two (C=%d)", C);
@@ -869,7 +877,7 @@ extern "C" int hd_bn_apply(const void* y, const void* res, const float* scale, c
   return HD_OK;
 }
 
-extern "C" int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+extern "C" int HD_API(hd_bn_bwd_reduce)(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, float* part, int rows, int64_t npix, int C, int relu,
                                 void* stream) {
   HD_CHECK_ARG(dz && y && mean && invstd && part && rows > 0 && npix > 0, "hd_bn_bwd_reduce: bad args");
@@ -885,7 +893,7 @@ extern "C" int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, co
   return HD_OK;
 }
 
-extern "C" int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
+extern "C" int HD_API(hd_bn_bwd_apply)(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                                const float* gamma, const float* beta, const float* part, int rows, float* coef_ws, void* dy, void* dres,
                                float* dgamma, float* dbeta, float gscale, int accumulate, int64_t npix, int C, int relu,
                                void* stream) {
@@ -905,49 +913,49 @@ extern "C" int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, con
   return HD_OK;
 }
 
-extern "C" int hd_maxpool3x3s2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+extern "C" int HD_API(hd_maxpool3x3s2)(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
   HD_CHECK_ARG(x && y && C % 8 == 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "hd_maxpool3x3s2: bad args");
   hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, N, H, W, C, Ho, Wo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+extern "C" int HD_API(hd_maxpool3x3s2_bwd)(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
   HD_CHECK_ARG(x && dy && dx && C % 8 == 0, "hd_maxpool3x3s2_bwd: bad args");
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const f16*)x, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_maxpool3x3s2_idx(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+extern "C" int HD_API(hd_maxpool3x3s2_idx)(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
   HD_CHECK_ARG(x && y && idx_u8 && C % 8 == 0 && Ho == (H + 2 - 3) / 2 + 1 && Wo == (W + 2 - 3) / 2 + 1, "hd_maxpool3x3s2_idx: bad args");
   hipLaunchKernelGGL(maxpool_idx_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, (unsigned char*)idx_u8, N, H, W, C, Ho, Wo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+extern "C" int HD_API(hd_maxpool3x3s2_bwd_idx)(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
   HD_CHECK_ARG(idx_u8 && dy && dx && C % 8 == 0, "hd_maxpool3x3s2_bwd_idx: bad args");
   hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const unsigned char*)idx_u8, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_subsample2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
+extern "C" int HD_API(hd_subsample2)(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
   HD_CHECK_ARG(x && y && C % 8 == 0 && Ho == (H - 1) / 2 + 1 && Wo == (W - 1) / 2 + 1, "hd_subsample2: bad args");
   hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for((int64_t)N * Ho * Wo * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, N, H, W, C, Ho, Wo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_subsample2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream) {
+extern "C" int HD_API(hd_subsample2_bwd)(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream) {
   HD_CHECK_ARG(dy && dx && C % 8 == 0, "hd_subsample2_bwd: bad args");
   hipLaunchKernelGGL(subsample2_bwd_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo, accumulate);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_nchw_to_nhwc_resize(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream) {
+extern "C" int HD_API(hd_nchw_to_nhwc_resize)(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream) {
   HD_CHECK_ARG(x && y && Cp % 8 == 0 && Cr <= Cp && Cr > 0, "hd_nchw_to_nhwc_resize: bad args");
   float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
   hipLaunchKernelGGL(nchw_to_nhwc_resize_kernel, dim3(grid_for((int64_t)N * Ho * Wo)), dim3(TB), 0, S_, x, (f16*)y, N, Cr, H, W, Ho, Wo, Cp, sh, sw,
@@ -956,7 +964,7 @@ extern "C" int hd_nchw_to_nhwc_resize(const float* x, void* y, int N, int Cr, in
   return HD_OK;
 }
 
-extern "C" int hd_nchw_to_nhwc_resize_strided(const float* x, int64_t nstride, int64_t cstride, void* y, int N, int Cr, int H, int W, int Ho,
+extern "C" int HD_API(hd_nchw_to_nhwc_resize_strided)(const float* x, int64_t nstride, int64_t cstride, void* y, int N, int Cr, int H, int W, int Ho,
                                               int Wo, int Cp, void* stream) {
   HD_CHECK_ARG(x && y && Cp % 8 == 0 && Cr <= Cp && Cr > 0 && nstride >= 0 && cstride >= 0, "hd_nchw_to_nhwc_resize_strided: bad args");
   float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
@@ -966,7 +974,7 @@ extern "C" int hd_nchw_to_nhwc_resize_strided(const float* x, int64_t nstride, i
   return HD_OK;
 }
 
-extern "C" int hd_nchw_to_nhwc_resize_bwd(const void* dy, float* dx, int N, int Cr, int H, int W, int Ho, int Wo, int Cp,
+extern "C" int HD_API(hd_nchw_to_nhwc_resize_bwd)(const void* dy, float* dx, int N, int Cr, int H, int W, int Ho, int Wo, int Cp,
                                           float gscale, void* stream) {
   HD_CHECK_ARG(dy && dx && Cp % 8 == 0 && Cr <= 8 && Cr > 0, "hd_nchw_to_nhwc_resize_bwd: bad args (Cr<=8)");
   float sh = (float)H / (float)Ho, sw = (float)W / (float)Wo;
@@ -975,14 +983,14 @@ extern "C" int hd_nchw_to_nhwc_resize_bwd(const void* dy, float* dx, int N, int 
   return HD_OK;
 }
 
-extern "C" int hd_nhwc_to_nchw(const void* x, float* y, int N, int Cr, int H, int W, int Cp, void* stream) {
+extern "C" int HD_API(hd_nhwc_to_nchw)(const void* x, float* y, int N, int Cr, int H, int W, int Cp, void* stream) {
   HD_CHECK_ARG(x && y && Cr <= Cp, "hd_nhwc_to_nchw: bad args");
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TB), 0, S_, (const f16*)x, y, N, Cr, H, W, Cp);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_upsample_add(const void* a, const void* b, void* y, int N, int H, int W, int C, int Hb, int Wb, void* stream) {
+extern "C" int HD_API(hd_upsample_add)(const void* a, const void* b, void* y, int N, int H, int W, int C, int Hb, int Wb, void* stream) {
   HD_CHECK_ARG(a && b && y && C % 8 == 0, "hd_upsample_add: bad args");
   float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
   hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const f16*)a, (const f16*)b, (f16*)y, N, H, W, C, Hb, Wb, sh, sw);
@@ -990,7 +998,7 @@ extern "C" int hd_upsample_add(const void* a, const void* b, void* y, int N, int
   return HD_OK;
 }
 
-extern "C" int hd_upsample_add_bwd(const void* dy, void* db, int N, int H, int W, int C, int Hb, int Wb, int accumulate, void* stream) {
+extern "C" int HD_API(hd_upsample_add_bwd)(const void* dy, void* db, int N, int H, int W, int C, int Hb, int Wb, int accumulate, void* stream) {
   HD_CHECK_ARG(dy && db && C % 8 == 0, "hd_upsample_add_bwd: bad args");
   float sh = (float)Hb / (float)H, sw = (float)Wb / (float)W;
   hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3(grid_for((int64_t)N * Hb * Wb * C / 8)), dim3(TB), 0, S_, (const f16*)dy, (f16*)db, N, H, W, C, Hb, Wb, sh, sw, accumulate);
@@ -998,28 +1006,28 @@ extern "C" int hd_upsample_add_bwd(const void* dy, void* db, int N, int H, int W
   return HD_OK;
 }
 
-extern "C" int hd_upsample2_bwd(const void* dy_up, void* dx_low, int N, int Hl, int Wl, int C, int Ctot, int c_off, int accumulate, void* stream) {
+extern "C" int HD_API(hd_upsample2_bwd)(const void* dy_up, void* dx_low, int N, int Hl, int Wl, int C, int Ctot, int c_off, int accumulate, void* stream) {
   HD_CHECK_ARG(dy_up && dx_low && C % 8 == 0 && Ctot % 8 == 0 && c_off % 8 == 0 && c_off + C <= Ctot, "hd_upsample2_bwd: bad args");
   hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for((int64_t)N * Hl * Wl * C / 8)), dim3(TB), 0, S_, (const f16*)dy_up, (f16*)dx_low, N, Hl, Wl, C, Ctot, c_off, accumulate);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+extern "C" int HD_API(hd_add_f16)(const void* a, const void* b, void* out, int64_t n, void* stream) {
   HD_CHECK_ARG(a && b && out && n % 8 == 0, "hd_add_f16: bad args");
   hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 8)), dim3(TB), 0, S_, (const f16*)a, (const f16*)b, (f16*)out, n / 8);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_slice_channels(const void* x, void* y, int64_t npix, int Ctot, int c_off, int C, int accumulate, void* stream) {
+extern "C" int HD_API(hd_slice_channels)(const void* x, void* y, int64_t npix, int Ctot, int c_off, int C, int accumulate, void* stream) {
   HD_CHECK_ARG(x && y && C % 8 == 0 && Ctot % 8 == 0 && c_off % 8 == 0 && c_off + C <= Ctot, "hd_slice_channels: bad args");
   hipLaunchKernelGGL(slice_channels_kernel, dim3(grid_for(npix * C / 8)), dim3(TB), 0, S_, (const f16*)x, (f16*)y, npix, Ctot, c_off, C, accumulate);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_sigmoid_bwd_nchw_to_nhwc(const float* dy, const float* s, void* dlogit, int N, int Cr, int H, int W, int Cp,
+extern "C" int HD_API(hd_sigmoid_bwd_nchw_to_nhwc)(const float* dy, const float* s, void* dlogit, int N, int Cr, int H, int W, int Cp,
                                            float gscale, void* stream) {
   HD_CHECK_ARG(dy && s && dlogit && Cp % 8 == 0 && Cr <= Cp, "hd_sigmoid_bwd_nchw_to_nhwc: bad args");
   hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(grid_for((int64_t)N * H * W)), dim3(TB), 0, S_, dy, s, (f16*)dlogit, N, Cr, H, W, Cp, gscale);
@@ -1027,28 +1035,28 @@ extern "C" int hd_sigmoid_bwd_nchw_to_nhwc(const float* dy, const float* s, void
   return HD_OK;
 }
 
-extern "C" int hd_relu_bwd(const void* dy, const void* z, void* dx, int64_t n, void* stream) {
+extern "C" int HD_API(hd_relu_bwd)(const void* dy, const void* z, void* dx, int64_t n, void* stream) {
   HD_CHECK_ARG(dy && z && dx && n % 8 == 0, "hd_relu_bwd: bad args");
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8)), dim3(TB), 0, S_, (const f16*)dy, (const f16*)z, (f16*)dx, n / 8);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_f32_to_f16(const float* x, void* y, int64_t n, float scale, void* stream) {
+extern "C" int HD_API(hd_f32_to_f16)(const float* x, void* y, int64_t n, float scale, void* stream) {
   HD_CHECK_ARG(x && y && n > 0, "hd_f32_to_f16: bad args");
   hipLaunchKernelGGL(f32_to_f16_kernel, dim3(grid_for(n)), dim3(TB), 0, S_, x, (f16*)y, n, scale);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream) {
+extern "C" int HD_API(hd_f16_to_f32)(const void* x, float* y, int64_t n, float scale, void* stream) {
   HD_CHECK_ARG(x && y && n > 0, "hd_f16_to_f32: bad args");
   hipLaunchKernelGGL(f16_to_f32_kernel, dim3(grid_for(n)), dim3(TB), 0, S_, (const f16*)x, y, n, scale);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
-extern "C" int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, int Cp, int64_t rows_per_image, int64_t image_stride, void* stream) {
+extern "C" int HD_API(hd_pad_cast_f32_f16)(const float* x, void* y, int64_t P, int C, int Cp, int64_t rows_per_image, int64_t image_stride, void* stream) {
   HD_CHECK_ARG(x && y && P >= 0 && C > 0 && Cp >= C && rows_per_image > 0 && image_stride >= rows_per_image * C, "hd_pad_cast_f32_f16: bad args");
   if (P == 0) return HD_OK;
   hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for(P * Cp)), dim3(TB), 0, S_, x, (f16*)y, P, C, Cp, rows_per_image, image_stride);
@@ -1056,16 +1064,18 @@ extern "C" int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, in
   return HD_OK;
 }
 
-extern "C" int hd_channel_sum_f16(const void* x, int64_t npix, int C, float* part, int rows, void* stream) {
+extern "C" int HD_API(hd_channel_sum_f16)(const void* x, int64_t npix, int C, float* part, int rows, void* stream) {
   HD_CHECK_ARG(x && part && rows > 0 && C % 8 == 0 && pow2(C / 8) && C / 8 <= TB, "hd_channel_sum_f16: bad args");
   hipLaunchKernelGGL(channel_sum_kernel, dim3(rows), dim3(TB), TB * 8 * sizeof(float), S_, (const f16*)x, npix, C, part);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
 
+#ifndef HD_STORE_F32
 extern "C" int hd_scale_store(const float* in, float* out, int n, float scale, int accumulate, void* stream) {
   HD_CHECK_ARG(in && out && n > 0, "hd_scale_store: bad args");
   hipLaunchKernelGGL(scale_store_kernel, dim3(hd_cdiv(n, 256)), dim3(256), 0, S_, in, out, n, scale, accumulate);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif

@@ -396,7 +396,7 @@ __global__ __launch_bounds__(LB) void fcos_loss_bwd_kernel(const float* __restri
 
 static bool pow2i(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-extern "C" int hd_groupnorm8_relu(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int N, int HW, int C,
+extern "C" int HD_API(hd_groupnorm8_relu)(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int N, int HW, int C,
                                   float eps, int relu, void* stream) {
   HD_CHECK_ARG(x && gamma && beta && y && mean_rstd && N > 0 && HW > 0, "hd_groupnorm8_relu: bad args");
   HD_CHECK_ARG(C % 8 == 0 && pow2i(C / 8) && C / 8 <= 128, "hd_groupnorm8_relu: C/8 (= number of 8-channel groups) must be a power of two <= 128 (C=%d)", C);
@@ -405,7 +405,7 @@ extern "C" int hd_groupnorm8_relu(const void* x, const float* gamma, const float
   return HD_OK;
 }
 
-extern "C" int hd_groupnorm8_relu_bwd(const void* dy, const void* x, const void* y, const float* gamma, const float* mean_rstd, void* dx, int N,
+extern "C" int HD_API(hd_groupnorm8_relu_bwd)(const void* dy, const void* x, const void* y, const float* gamma, const float* mean_rstd, void* dx, int N,
                                       int HW, int C, int relu, void* stream) {
   HD_CHECK_ARG(dy && x && gamma && mean_rstd && dx && (y || !relu) && N > 0 && HW > 0, "hd_groupnorm8_relu_bwd: bad args");
   HD_CHECK_ARG(C % 8 == 0 && pow2i(C / 8) && C / 8 <= 128, "hd_groupnorm8_relu_bwd: C/8 must be a power of two <= 128 (C=%d)", C);
@@ -415,7 +415,7 @@ extern "C" int hd_groupnorm8_relu_bwd(const void* dy, const void* x, const void*
   return HD_OK;
 }
 
-extern "C" int hd_groupnorm8_param_grad(const void* dy, const void* x, const void* y, const float* mean_rstd, float* dgamma, float* dbeta, int N,
+extern "C" int HD_API(hd_groupnorm8_param_grad)(const void* dy, const void* x, const void* y, const float* mean_rstd, float* dgamma, float* dbeta, int N,
                                         int HW, int C, int relu, float scale, int accumulate, void* stream) {
   HD_CHECK_ARG(dy && x && mean_rstd && dgamma && dbeta && (y || !relu) && N > 0 && HW > 0, "hd_groupnorm8_param_grad: bad args");
   HD_CHECK_ARG(C % 8 == 0 && C / 8 <= 128, "hd_groupnorm8_param_grad: C must be a multiple of 8, at most 1024 (C=%d)", C);
@@ -425,6 +425,7 @@ extern "C" int hd_groupnorm8_param_grad(const void* dy, const void* x, const voi
   return HD_OK;
 }
 
+#ifndef HD_STORE_F32
 extern "C" int hd_fcos_match(const float* anchors, const float* gt, const uint8_t* gvalid, int B, int A, int G, int first_level_count,
                              int last_level_start, float center_sampling_radius, int64_t* matched, void* stream) {
   HD_CHECK_ARG(anchors && gt && gvalid && matched && B > 0 && A > 0 && G > 0, "hd_fcos_match: bad args");
@@ -433,7 +434,9 @@ extern "C" int hd_fcos_match(const float* anchors, const float* gt, const uint8_
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif
 
+#ifndef HD_STORE_F32
 extern "C" int hd_fcos_loss(const float* cls_logits, const float* bbox_regression, const float* bbox_ctrness, const int64_t* matched, const float* gt,
                             const int64_t* glab, const float* anchors, int B, int A, int K, int G, float alpha, float gamma, float* part_ws,
                             float* num_fg, float* out3, void* stream) {
@@ -446,7 +449,9 @@ extern "C" int hd_fcos_loss(const float* cls_logits, const float* bbox_regressio
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif
 
+#ifndef HD_STORE_F32
 extern "C" int hd_fcos_loss_bwd(const float* cls_logits, const float* bbox_regression, const float* bbox_ctrness, const int64_t* matched,
                                 const float* gt, const int64_t* glab, const float* anchors, int B, int A, int K, int G, float alpha, float gamma,
                                 const float* num_fg, const float* g3, float* d_cls_logits, float* d_bbox_regression, float* d_bbox_ctrness,
@@ -460,3 +465,4 @@ extern "C" int hd_fcos_loss_bwd(const float* cls_logits, const float* bbox_regre
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
+#endif

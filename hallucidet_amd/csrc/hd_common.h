@@ -5,10 +5,24 @@
 #include <stdio.h>
 #include "../../include/hallucidet_hip.h"
 
+// Storage type of activations.  The bandwidth-bound sources that touch activations without matrix cores (elementwise.hip,
+// roi_align.hip, the GroupNorm kernels of fcos.hip) are built TWICE: as they stand (`f16` = IEEE half: the product's storage type),
+// and with -DHD_STORE_F32, where the same code stores activations as fp32 and every entry point carries the suffix _f32 -- the
+// element-wise half of `--precision 32` (the reference's default, src/config/config.py:149; convolutions: conv_f32.hip).  In that build
+// the names f16 / f16x8 mean "the storage type" (a vector of eight is then two 16-byte accesses), nothing else changes.
+#ifdef HD_STORE_F32
+typedef float f16;
+typedef float f16x2 __attribute__((ext_vector_type(2)));
+typedef float f16x4 __attribute__((ext_vector_type(4)));
+typedef float f16x8 __attribute__((ext_vector_type(8)));
+#define HD_API(name) name##_f32
+#else
 typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define HD_API(name) name
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

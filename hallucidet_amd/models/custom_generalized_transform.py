@@ -18,7 +18,7 @@ from .. import ops
 
 class ImageList:
     def __init__(self, tensors: Tensor, image_sizes: List[Tuple[int, int]]) -> None:
-        self.tensors = tensors            # [N, H, W, 8] float16 NHWC (3 real channels)
+        self.tensors = tensors            # [N, H, W, 8] NHWC in the storage type (float16; float32 with precision=32), 3 real channels
         self.image_sizes = image_sizes
         self.layout = "nhwc8_f16"
 
@@ -47,7 +47,7 @@ class _ResizeManyFn(torch.autograd.Function):
     def forward(ctx, Ho, Wo, *xs):
         ctx.shapes = [tuple(x.shape) for x in xs]
         n = sum(s[0] for s in ctx.shapes)
-        y = torch.empty((n, Ho, Wo, 8), dtype=torch.float16, device=xs[0].device)
+        y = torch.empty((n, Ho, Wo, 8), dtype=ops.act_dtype(), device=xs[0].device)
         lo = 0
         for x in xs:
             ops.nchw_to_nhwc_resize(x, Ho, Wo, 8, out=y[lo:lo + x.shape[0]])

@@ -176,13 +176,13 @@ def _dgrad_many(es, dys, hws, *, ress=None, masks=None):
     return ops.conv2d_multi(calls)
 
 
-def _head_grad_nhwc16(g, H, W, cout_p):
+def _head_grad_nhwc16(g, H, W, cout_p, dtype=None):
     """Gradient of a head output [n, C, H, W] fp32 -> NHWC fp16 with cout_p channels.  When the gradient is the NCHW view of NHWC
     memory (what autograd hands back for `_fwd(..., f32="nhwc")` outputs) this is one pad-and-cast launch."""
     v = g.permute(0, 2, 3, 1)
     if g.dtype == torch.float32 and v.stride()[1:] == (v.shape[2] * v.shape[3], v.shape[3], 1):     # dense images (slices of the flat [N, HWA, C] gradient)
-        return ops.pad_cast_f32_f16(v, cout_p)
-    return ops.nchw_to_nhwc_resize(g.contiguous().float(), H, W, cout_p)
+        return ops.pad_cast_f32_f16(v, cout_p, dtype=dtype)
+    return ops.nchw_to_nhwc_resize(g.contiguous().float(), H, W, cout_p, dtype=dtype)
 
 
 def _dgrad(e, dy, in_hw, *, res=None, mask=None):
@@ -360,7 +360,7 @@ class BackboneWithFPN(nn.Module):
         dP = []
         for i in range(L):
             g = grads[i]
-            dP.append(torch.zeros(shapes[i], dtype=torch.float16, device=dev) if g is None else g.contiguous())
+            dP.append(torch.zeros(shapes[i], dtype=rec["x"].dtype, device=dev) if g is None else g.contiguous())
         top_hw = (shapes[L - 1][1], shapes[L - 1][2])
         if self.p6p7:
             g6, g7, p6 = grads[L], grads[L + 1], rec["p6"]
@@ -432,9 +432,9 @@ class BackboneWithFPN(nn.Module):
         return _dgrad(P["stem"], ds_, (x.shape[1], x.shape[2]))
 
     def forward(self, x, n_active=None):
-        if not (isinstance(x, torch.Tensor) and x.dim() == 4 and x.dtype == torch.float16 and x.shape[-1] == 8):
+        if not (isinstance(x, torch.Tensor) and x.dim() == 4 and x.dtype in (torch.float16, torch.float32) and x.shape[-1] == 8):
             raise TypeError("hallucidet_amd backbone expects ImageList.tensors from CustomGeneralizedRCNNTransform "
-                            "(NHWC float16, 8 channels)")
+                            "(NHWC float16 -- float32 with precision=32 --, 8 channels)")
         if not x.is_cuda:
             raise RuntimeError("hallucidet_amd backbone runs on the GPU only; there is no CPU path")
         if torch.is_grad_enabled() and (x.requires_grad or self.train_params):
@@ -667,7 +667,9 @@ class AnchorGenerator(nn.Module):
         return (torch.stack([-ws, -hs, ws, hs], dim=1) / 2).round()
 
     def forward(self, image_list, feature_maps):
-        grid_sizes = [tuple(fm.shape[-2:]) if fm.dim() == 4 and fm.dtype != torch.float16 else (fm.shape[1], fm.shape[2]) for fm in feature_maps]
+        # the product's feature maps are NHWC (image lists of CustomGeneralizedRCNNTransform carry `layout`); torchvision-style callers pass NCHW
+        nhwc = getattr(image_list, "layout", None) is not None or feature_maps[0].dtype == torch.float16
+        grid_sizes = [(fm.shape[1], fm.shape[2]) if nhwc else tuple(fm.shape[-2:]) for fm in feature_maps]
         ih, iw = image_list.image_sizes[0] if getattr(image_list, "layout", None) else image_list.tensors.shape[-2:]
         device = feature_maps[0].device
         key = (tuple(grid_sizes), ih, iw, str(device))
@@ -715,8 +717,8 @@ class _RPNHeadFn(torch.autograd.Function):
             # frozen head, every level has both gradients (the training step): the three data-gradient convs of ALL levels as three
             # grids -- cls, then box (+ cls result as residual, ReLU mask), then the shared 3x3 conv -- instead of 3 x levels launches
             hws = [(t.shape[1], t.shape[2]) for t in ctx.ts]
-            gls = [_head_grad_nhwc16(grads[2 * i][:na], hws[i][0], hws[i][1], P["cls"]["cout_p"]) for i in range(nl)]
-            grs = [_head_grad_nhwc16(grads[2 * i + 1][:na], hws[i][0], hws[i][1], P["box"]["cout_p"]) for i in range(nl)]
+            gls = [_head_grad_nhwc16(grads[2 * i][:na], hws[i][0], hws[i][1], P["cls"]["cout_p"], P["cls"]["wf"].dtype) for i in range(nl)]
+            grs = [_head_grad_nhwc16(grads[2 * i + 1][:na], hws[i][0], hws[i][1], P["box"]["cout_p"], P["box"]["wf"].dtype) for i in range(nl)]
             dts = _dgrad_many([P["cls"]] * nl, gls, hws)
             dts = _dgrad_many([P["box"]] * nl, grs, hws, ress=dts, masks=list(ctx.ts))
             dfeats = _dgrad_many([P["conv"]] * nl, dts, hws)
@@ -733,13 +735,13 @@ class _RPNHeadFn(torch.autograd.Function):
             dt = None
             tp, inv = ctx.head.train_params, 1.0 / ctx.head.grad_scale
             if dl is not None:
-                gl = _head_grad_nhwc16(dl, H, W, P["cls"]["cout_p"])
+                gl = _head_grad_nhwc16(dl, H, W, P["cls"]["cout_p"], P["cls"]["wf"].dtype)
                 dt = _dgrad(P["cls"], gl, hw)
                 if tp:
                     _wgrad_into(ctx.head.cls_logits.weight, P["cls"], t, gl, inv)
                     _bgrad_into(ctx.head.cls_logits.bias, gl, inv)
             if dr is not None:
-                gr = _head_grad_nhwc16(dr, H, W, P["box"]["cout_p"])
+                gr = _head_grad_nhwc16(dr, H, W, P["box"]["cout_p"], P["box"]["wf"].dtype)
                 dt = _dgrad(P["box"], gr, hw, res=dt, mask=t)
                 if tp:
                     _wgrad_into(ctx.head.bbox_pred.weight, P["box"], t, gr, inv)
@@ -916,7 +918,7 @@ class _RoIAlignFn(torch.autograd.Function):
             n_images = ctx.cfg[3] if len(ctx.cfg) > 3 else None
             dfs = ops.roi_align_ml_bwd_gather(dout, rois, levels, ctx.shapes, scales, sr, n_images)
         else:
-            dfs = [ops.f32_to_f16(d) for d in ops.roi_align_ml_bwd(dout, rois, levels, ctx.shapes, scales, sr)]
+            dfs = [ops.f32_to_f16(d, dtype=dout.dtype) for d in ops.roi_align_ml_bwd(dout, rois, levels, ctx.shapes, scales, sr)]
         if ctx.has_acts:               # ctx.shapes are the [n_active] views' shapes: the maps cover exactly the images that own RoIs
             return (None, None, None, None) + (None,) * len(dfs) + tuple(dfs)
         return (None, None, None, None) + tuple(dfs)
@@ -1007,7 +1009,7 @@ class TwoMLPHead(nn.Module):
             e6 = dict(k=7, stride=1, pad=0, cin=c, cout=rep, cin_p=c, cout_p=rep, bias=self.fc6.bias.detach().float().contiguous())
             e6["wf"], _ = ops.weight_prep(w6, cin_pad=c, cout_pad=rep, want_fwd=True, want_dgrad=False)
             e6["wd"] = None
-            fc6_t = w6.permute(2, 3, 1, 0).reshape(49 * c, rep).half().contiguous()
+            fc6_t = w6.permute(2, 3, 1, 0).reshape(49 * c, rep).to(e6["wf"].dtype).contiguous()
             w7 = self.fc7.weight.detach().float().view(rep, rep, 1, 1)
             e7 = dict(k=1, stride=1, pad=0, cin=rep, cout=rep, cin_p=rep, cout_p=rep, bias=self.fc7.bias.detach().float().contiguous())
             e7["wf"], e7["wd"] = ops.weight_prep(w7, want_fwd=True, want_dgrad=True)
@@ -1042,13 +1044,13 @@ class _PredictorFn(torch.autograd.Function):
         tp, inv = pred.train_params, 1.0 / pred.grad_scale
         dx = None
         if dc is not None:
-            g = ops.nchw_to_nhwc_resize(dc.contiguous().float().view(R, -1, 1, 1), 1, 1, P["cls"]["cout_p"])
+            g = ops.nchw_to_nhwc_resize(dc.contiguous().float().view(R, -1, 1, 1), 1, 1, P["cls"]["cout_p"], dtype=P["cls"]["wf"].dtype)
             dx = _dgrad(P["cls"], g, (1, 1))
             if tp:
                 _wgrad_into(pred.cls_score.weight, P["cls"], ctx.x, g, inv)
                 _bgrad_into(pred.cls_score.bias, g, inv)
         if db is not None:
-            g = ops.nchw_to_nhwc_resize(db.contiguous().float().view(R, -1, 1, 1), 1, 1, P["box"]["cout_p"])
+            g = ops.nchw_to_nhwc_resize(db.contiguous().float().view(R, -1, 1, 1), 1, 1, P["box"]["cout_p"], dtype=P["box"]["wf"].dtype)
             dx = _dgrad(P["box"], g, (1, 1), res=dx)
             if tp:
                 _wgrad_into(pred.bbox_pred.weight, P["box"], ctx.x, g, inv)

@@ -102,7 +102,7 @@ class _HeadFn(torch.autograd.Function):
                 for last, g, conv in lasts:
                     if g is None:
                         continue
-                    gl = D._head_grad_nhwc16(g[:na], H, W, last["cout_p"])
+                    gl = D._head_grad_nhwc16(g[:na], H, W, last["cout_p"], last["wf"].dtype)
                     if tp:                               # the towers and their output convs are shared by the 5 levels: accumulate
                         D._wgrad_into(conv.weight, last, acts[3][2], gl, inv)
                         D._bgrad_into(conv.bias, gl, inv)

@@ -72,8 +72,8 @@ class _HeadFn(torch.autograd.Function):
             # frozen head, every output has a gradient (the training step): the data-gradient conv of layer k of both towers on all
             # levels as one grid, walking the towers backwards; the two towers' first layers meet in the residual of the second
             hws = [(lv[0][0].shape[1], lv[0][0].shape[2]) for lv in ctx.saved]
-            d = [D._head_grad_nhwc16(grads[2 * i][:na], hws[i][0], hws[i][1], P["cls_out"]["cout_p"]) for i in range(nl)] + \
-                [D._head_grad_nhwc16(grads[2 * i + 1][:na], hws[i][0], hws[i][1], P["reg_out"]["cout_p"]) for i in range(nl)]
+            d = [D._head_grad_nhwc16(grads[2 * i][:na], hws[i][0], hws[i][1], P["cls_out"]["cout_p"], P["cls_out"]["wf"].dtype) for i in range(nl)] + \
+                [D._head_grad_nhwc16(grads[2 * i + 1][:na], hws[i][0], hws[i][1], P["reg_out"]["cout_p"], P["reg_out"]["wf"].dtype) for i in range(nl)]
             acts = lambda k: [ctx.saved[i][0][k] for i in range(nl)] + [ctx.saved[i][1][k] for i in range(nl)]
             d = D._dgrad_many([P["cls_out"]] * nl + [P["reg_out"]] * nl, d, hws + hws, masks=acts(3))
             for k in (3, 2, 1):
@@ -93,7 +93,7 @@ class _HeadFn(torch.autograd.Function):
                 acts = lv[j]
                 H, W = acts[0].shape[1], acts[0].shape[2]
                 convs = [l for l in mods[j][0].conv if isinstance(l, nn.Conv2d)]
-                d = D._head_grad_nhwc16(g[:na], H, W, last["cout_p"])
+                d = D._head_grad_nhwc16(g[:na], H, W, last["cout_p"], last["wf"].dtype)
                 if tp:                                   # the towers share their weights over the 5 levels: accumulate
                     D._wgrad_into(mods[j][1].weight, last, acts[3], d, inv)
                     D._bgrad_into(mods[j][1].bias, d, inv)

@@ -1,11 +1,14 @@
 """Thin tensor-level wrappers over the C ABI (one function per entry point family).
 
-Inputs/outputs are torch tensors living on the GPU; activations are NHWC float16.
+Inputs/outputs are torch tensors living on the GPU; activations are NHWC float16 -- or NHWC float32 (`--precision 32`, the reference's
+default): every wrapper takes the storage type from its input tensor and calls the `_f32` twin of the entry point (hallucidet_amd._abi.fn;
+include/hallucidet_hip.h, last section).  A parity mode, not a fast path.
 Nothing here computes on the host and nothing falls back to ATen: a missing library
 or a failing launch raises (``_abi.HipLibraryMissing`` / ``_abi.HipCallError``).
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -13,6 +16,30 @@ from . import _abi
 from ._abi import ConvArgs, WgradArgs, check, ptr
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+
+# Storage type of NEW activation / packed-weight tensors where no input tensor decides it (layout conversions from fp32 images, weight
+# re-packs, head-gradient casts): float16, or float32 inside `with ops.storage(torch.float32):` -- entered by the modules that were
+# built with precision=32 (EncoderDecoderLit / DetectorLit / Detector.calculate_loss) around their forward and backward passes.
+_tls = threading.local()
+
+
+def act_dtype():
+    return getattr(_tls, "dtype", torch.float16)
+
+
+class storage:
+    def __init__(self, dtype):
+        assert dtype in (torch.float16, torch.float32)
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = getattr(_tls, "dtype", torch.float16)
+        _tls.dtype = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        _tls.dtype = self.prev
+        return False
 
 
 def _stream():
@@ -44,7 +71,7 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
     N, Hs, Ws, C1 = x.shape
     C2 = 0 if x2 is None else x2.shape[3]
     Cout = w.shape[0] if cout is None else cout
-    assert w.dtype == torch.float16 and x.dtype == torch.float16 and x.is_contiguous() and w.is_contiguous()
+    assert x.dtype in (torch.float16, torch.float32) and w.dtype == x.dtype and x.is_contiguous() and w.is_contiguous()
     assert w.numel() >= Cout * KH * KW * (C1 + C2), "weight tensor too small"
     if in_dil > 1:
         Hin, Win = 0, 0
@@ -65,21 +92,21 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
     elif out_nhwc_f32:
         y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     else:
-        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float16, device=x.device)
+        y = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
     a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(mask), ptr(y), None,
                  N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
                  1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0),
                  ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
     stats = None
     if want_stats:
-        rows = lib.hd_conv2d_stats_rows(C.byref(a))
+        rows = _abi.fn("hd_conv2d_stats_rows", x)(C.byref(a))
         check(0 if rows > 0 else rows, "hd_conv2d_stats_rows")
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         a.stats = ptr(stats)
     if _defer is not None:          # wgrad_dgrad: the caller launches (the argument block and its tensors are kept by the list)
         _defer.append((a, (x, x2, w, bias, res, mask, y, stats, in_scale, in_shift)))
     else:
-        check(lib.hd_conv2d(C.byref(a), _stream()), "hd_conv2d")
+        check(_abi.fn("hd_conv2d", x)(C.byref(a), _stream()), "hd_conv2d")
     return (y, stats) if want_stats else y
 
 
@@ -94,6 +121,8 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in
     Hin, Win = (Hs * 2, Ws * 2) if up1 else (Hs, Ws)
     K = KH * KW * (C1 + C2)
     M = N * Ho * Wo
+    if nsplit is None and x.dtype == torch.float32:
+        nsplit = pick_nsplit(M, Cout, K)
     if nsplit is None:
         probe = WgradArgs(ptr(x), ptr(x2), ptr(dy), None, N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad, 1 if up1 else 0, 1)
         blocks8 = lib.hd_wgrad_w8_blocks(C.byref(probe))
@@ -113,7 +142,7 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in
     if _defer is not None:
         _defer.append((a, (x, x2, dy, slab, in_scale, in_shift)))
     else:
-        check(lib.hd_wgrad(C.byref(a), _stream()), "hd_wgrad")
+        check(_abi.fn("hd_wgrad", x)(C.byref(a), _stream()), "hd_wgrad")
     return slab
 
 
@@ -121,9 +150,8 @@ def conv2d_multi(calls):
     """calls: [(x, w, KH, KW, kwargs)] -- the arguments of independent `conv2d` calls -> their outputs, issued as ONE grid when all
     of them run in the same 4-wave implicit-GEMM variant (hd_conv2d_multi: the per-level convolutions of an FPN / a detection head),
     else one after the other.  Put the largest problem first (its tile serves all).  Bit-identical to the separate calls."""
-    if len(calls) == 1:
-        x, w, KH, KW, kw = calls[0]
-        return [conv2d(x, w, KH, KW, **kw)]
+    if len(calls) == 1 or calls[0][0].dtype == torch.float32:          # fp32 storage: the parity mode has no multi-problem grid
+        return [conv2d(x, w, KH, KW, **kw) for x, w, KH, KW, kw in calls]
     hold, outs = [], []
     for x, w, KH, KW, kw in calls:
         outs.append(conv2d(x, w, KH, KW, _defer=hold, **kw))
@@ -135,6 +163,9 @@ def conv2d_multi(calls):
 def wgrad_dgrad(x, dy, KH, KW, wd, *, x2=None, stride=1, pad=0, up1=False, in_scale=None, in_shift=None, in_relu=True, dgrad=None):
     """The two consumers of a layer's dY in one call (hd_conv2d_wgrad): -> (slab as `wgrad(x, dy, ...)`, dx as `conv2d(dy, wd, KH, KW,
     **dgrad)`).  One grid when both run in the 8-wave kernels, two launches otherwise; bit-identical to the separate calls."""
+    if x.dtype == torch.float32:
+        slab = wgrad(x, dy, KH, KW, x2=x2, stride=stride, pad=pad, up1=up1, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu)
+        return slab, conv2d(dy, wd, KH, KW, **(dgrad or {}))
     hold = []
     slab = wgrad(x, dy, KH, KW, x2=x2, stride=stride, pad=pad, up1=up1, in_scale=in_scale, in_shift=in_shift, in_relu=in_relu, _defer=hold)
     dx = conv2d(dy, wd, KH, KW, _defer=hold, **(dgrad or {}))
@@ -172,15 +203,16 @@ def wgrad_reduce(slab, dw, KH, KW, Cin, Cin_real=None, Cout=None, scale=1.0, acc
     return dw
 
 
-def weight_prep(w_oihw, *, out_scale=None, cin_pad=None, cout_pad=None, want_fwd=True, want_dgrad=False):
-    """fp32 OIHW -> (f16 [Cout, KH*KW*Cin_pad], f16 [Cin_pad, KH*KW*Cout_pad] flipped)."""
+def weight_prep(w_oihw, *, out_scale=None, cin_pad=None, cout_pad=None, want_fwd=True, want_dgrad=False, dtype=None):
+    """fp32 OIHW -> ([Cout, KH*KW*Cin_pad], [Cin_pad, KH*KW*Cout_pad] flipped) in the storage type `dtype` (float16 / float32)."""
     _need_cuda(w_oihw)
     Cout, Cin, KH, KW = w_oihw.shape
     cin_pad = cin_pad or ((Cin + 7) // 8 * 8)
     cout_pad = cout_pad or ((Cout + 7) // 8 * 8)
-    wf = torch.empty((Cout, KH * KW * cin_pad), dtype=torch.float16, device=w_oihw.device) if want_fwd else None
-    wd = torch.empty((cin_pad, KH * KW * cout_pad), dtype=torch.float16, device=w_oihw.device) if want_dgrad else None
-    check(_abi.load().hd_weight_prep(ptr(w_oihw.contiguous()), ptr(out_scale), ptr(wf), ptr(wd), Cout, Cin, KH, KW,
+    dtype = dtype or act_dtype()
+    wf = torch.empty((Cout, KH * KW * cin_pad), dtype=dtype, device=w_oihw.device) if want_fwd else None
+    wd = torch.empty((cin_pad, KH * KW * cout_pad), dtype=dtype, device=w_oihw.device) if want_dgrad else None
+    check(_abi.fn("hd_weight_prep", wf if wf is not None else wd)(ptr(w_oihw.contiguous()), ptr(out_scale), ptr(wf), ptr(wd), Cout, Cin, KH, KW,
                                      cin_pad, cout_pad, _stream()), "hd_weight_prep")
     return wf, wd
 
@@ -230,15 +262,18 @@ class WeightPrepPlan:
     """All (fp32 master -> fp16 GEMM layouts) conversions of a network as ONE launch: persistent output buffers and a
     device-resident descriptor table built once; `run()` re-packs every layer (hd_weight_prep_multi)."""
 
-    def __init__(self, items):
-        """items: list of (w_oihw fp32 parameter, cin_pad, cout_pad, want_dgrad)."""
+    def __init__(self, items, dtype=None):
+        """items: list of (w_oihw fp32 parameter, cin_pad, cout_pad, want_dgrad).  dtype float32: the same persistent buffers, re-packed
+        by one hd_weight_prep_f32 launch per layer (the parity mode has no multi-layer kernel)."""
         from ._abi import WprepDesc
         dev = items[0][0].device
+        dtype = dtype or act_dtype()
+        self.dtype, self.items = dtype, list(items)
         self.outputs, descs, biggest = [], [], 1
         for w, cin_pad, cout_pad, want_d in items:
             Cout, Cin, KH, KW = w.shape
-            wf = torch.empty((Cout, KH * KW * cin_pad), dtype=torch.float16, device=dev)
-            wd = torch.empty((cin_pad, KH * KW * cout_pad), dtype=torch.float16, device=dev) if want_d else None
+            wf = torch.empty((Cout, KH * KW * cin_pad), dtype=dtype, device=dev)
+            wd = torch.empty((cin_pad, KH * KW * cout_pad), dtype=dtype, device=dev) if want_d else None
             self.outputs.append((wf, wd))
             descs.append(WprepDesc(w.data_ptr(), wf.data_ptr(), wd.data_ptr() if want_d else None, Cout, Cin, KH, KW, cin_pad, cout_pad))
             # blocks a layer can use: one per 32(co) x 32(ci) tile (element-wise form for > 9 taps: 1024 elements per block)
@@ -256,6 +291,12 @@ class WeightPrepPlan:
         return len(params) == self.n and all(p.data_ptr() == q for p, q in zip(params, self._ptrs))
 
     def run(self):
+        if self.dtype == torch.float32:
+            lib = _abi.load()
+            for (w, cin_pad, cout_pad, want_d), (wf, wd) in zip(self.items, self.outputs):
+                Cout, Cin, KH, KW = w.shape
+                check(lib.hd_weight_prep_f32(ptr(w), None, ptr(wf), ptr(wd), Cout, Cin, KH, KW, cin_pad, cout_pad, _stream()), "hd_weight_prep_f32")
+            return self.outputs
         check(_abi.load().hd_weight_prep_multi(ptr(self.table), self.n, self.blocks, _stream()), "hd_weight_prep_multi")
         return self.outputs
 
@@ -311,7 +352,7 @@ def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
 def bn_apply(y, scale, shift, *, res=None, relu=True, out=None):
     _need_cuda(y, scale, shift, res)
     z = torch.empty_like(y) if out is None else out
-    check(_abi.load().hd_bn_apply(ptr(y), ptr(res), ptr(scale), ptr(shift), ptr(z), y.numel(), y.shape[-1],
+    check(_abi.fn("hd_bn_apply", y)(ptr(y), ptr(res), ptr(scale), ptr(shift), ptr(z), y.numel(), y.shape[-1],
                                   1 if relu else 0, _stream()), "hd_bn_apply")
     return z
 
@@ -327,7 +368,7 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
         rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
     lib = _abi.load()
     part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
-    check(lib.hd_bn_bwd_reduce(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
+    check(_abi.fn("hd_bn_bwd_reduce", y)(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
                                1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
     coef = torch.empty((5, C_), dtype=torch.float32, device=y.device)      # A, B, D, scale, shift: written by the coefficient launch
     dy = torch.empty_like(y)
@@ -336,7 +377,7 @@ def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dre
         dgamma = torch.empty(C_, dtype=torch.float32, device=y.device)
     if dbeta is None:
         dbeta = torch.empty(C_, dtype=torch.float32, device=y.device)
-    check(lib.hd_bn_bwd_apply(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), part.shape[0],
+    check(_abi.fn("hd_bn_bwd_apply", y)(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), part.shape[0],
                               ptr(coef), ptr(dy), ptr(dres), ptr(dgamma), ptr(dbeta), gscale, 1 if accumulate else 0, npix, C_,
                               1 if relu else 0, _stream()), "hd_bn_bwd_apply")
     return dy, dres, dgamma, dbeta
@@ -348,7 +389,7 @@ def groupnorm8_relu(x, gamma, beta, eps=1e-5, *, relu=True):
     N, H, W, C_ = x.shape
     y = torch.empty_like(x)
     stat = torch.empty((N, C_ // 8, 2), dtype=torch.float32, device=x.device)
-    check(_abi.load().hd_groupnorm8_relu(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stat), N, H * W, C_, float(eps), 1 if relu else 0, _stream()),
+    check(_abi.fn("hd_groupnorm8_relu", x)(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(stat), N, H * W, C_, float(eps), 1 if relu else 0, _stream()),
           "hd_groupnorm8_relu")
     return y, stat
 
@@ -358,7 +399,7 @@ def groupnorm8_relu_bwd(dy, x, y, gamma, stat, *, relu=True):
     _need_cuda(dy, x, gamma, stat)
     N, H, W, C_ = x.shape
     dx = torch.empty_like(x)
-    check(_abi.load().hd_groupnorm8_relu_bwd(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(stat), ptr(dx), N, H * W, C_, 1 if relu else 0, _stream()),
+    check(_abi.fn("hd_groupnorm8_relu_bwd", x)(ptr(dy), ptr(x), ptr(y), ptr(gamma), ptr(stat), ptr(dx), N, H * W, C_, 1 if relu else 0, _stream()),
           "hd_groupnorm8_relu_bwd")
     return dx
 
@@ -367,27 +408,27 @@ def groupnorm8_param_grad(dy, x, y, stat, dgamma, dbeta, scale=1.0, *, relu=True
     """dgamma / dbeta (fp32 [C], accumulated in place) of groupnorm8_relu over the whole batch."""
     _need_cuda(dy, x, stat, dgamma, dbeta)
     N, H, W, C_ = x.shape
-    check(_abi.load().hd_groupnorm8_param_grad(ptr(dy), ptr(x), ptr(y), ptr(stat), ptr(dgamma), ptr(dbeta), N, H * W, C_, 1 if relu else 0,
+    check(_abi.fn("hd_groupnorm8_param_grad", x)(ptr(dy), ptr(x), ptr(y), ptr(stat), ptr(dgamma), ptr(dbeta), N, H * W, C_, 1 if relu else 0,
                                                float(scale), 1 if accumulate else 0, _stream()), "hd_groupnorm8_param_grad")
 
 
-def pad_cast_f32_f16(x, cp):
+def pad_cast_f32_f16(x, cp, dtype=None):
     """x [n, H, W, C] fp32 whose images are dense (strides (*, W*C, C, 1); the image stride may be larger: a slice of a bigger
     buffer) -> [n, H, W, cp] fp16, extra channels zero (one launch)."""
     _need_cuda(x)
     n, H, W, C_ = x.shape
     assert x.stride()[1:] == (W * C_, C_, 1) or n * H * W == 0
-    y = torch.empty((n, H, W, cp), dtype=torch.float16, device=x.device)
+    y = torch.empty((n, H, W, cp), dtype=dtype or act_dtype(), device=x.device)
     img_stride = x.stride(0) if n > 1 else H * W * C_
-    check(_abi.load().hd_pad_cast_f32_f16(ptr(x), ptr(y), n * H * W, C_, cp, H * W, max(img_stride, H * W * C_), _stream()), "hd_pad_cast_f32_f16")
+    check(_abi.fn("hd_pad_cast_f32_f16", y)(ptr(x), ptr(y), n * H * W, C_, cp, H * W, max(img_stride, H * W * C_), _stream()), "hd_pad_cast_f32_f16")
     return y
 
 
 def maxpool3x3s2(x):
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    y = torch.empty((N, Ho, Wo, C_), dtype=torch.float16, device=x.device)
-    check(_abi.load().hd_maxpool3x3s2(ptr(x), ptr(y), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2")
+    y = torch.empty((N, Ho, Wo, C_), dtype=x.dtype, device=x.device)
+    check(_abi.fn("hd_maxpool3x3s2", x)(ptr(x), ptr(y), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2")
     return y
 
 
@@ -395,17 +436,17 @@ def maxpool3x3s2_idx(x):
     """-> (y, idx uint8 [N,Ho,Wo,C]) ; idx feeds maxpool3x3s2_bwd_idx."""
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    y = torch.empty((N, Ho, Wo, C_), dtype=torch.float16, device=x.device)
+    y = torch.empty((N, Ho, Wo, C_), dtype=x.dtype, device=x.device)
     idx = torch.empty((N, Ho, Wo, C_), dtype=torch.uint8, device=x.device)
-    check(_abi.load().hd_maxpool3x3s2_idx(ptr(x), ptr(y), ptr(idx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_idx")
+    check(_abi.fn("hd_maxpool3x3s2_idx", x)(ptr(x), ptr(y), ptr(idx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_idx")
     return y, idx
 
 
 def maxpool3x3s2_bwd_idx(idx, dy, in_hw):
     N, Ho, Wo, C_ = dy.shape
     H, W = in_hw
-    dx = torch.empty((N, H, W, C_), dtype=torch.float16, device=dy.device)
-    check(_abi.load().hd_maxpool3x3s2_bwd_idx(ptr(idx), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd_idx")
+    dx = torch.empty((N, H, W, C_), dtype=dy.dtype, device=dy.device)
+    check(_abi.fn("hd_maxpool3x3s2_bwd_idx", dy)(ptr(idx), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd_idx")
     return dx
 
 
@@ -413,42 +454,43 @@ def maxpool3x3s2_bwd(x, dy):
     N, H, W, C_ = x.shape
     _, Ho, Wo, _ = dy.shape
     dx = torch.empty_like(x)
-    check(_abi.load().hd_maxpool3x3s2_bwd(ptr(x), ptr(dy), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd")
+    check(_abi.fn("hd_maxpool3x3s2_bwd", x)(ptr(x), ptr(dy), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd")
     return dx
 
 
 def subsample2(x):
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    y = torch.empty((N, Ho, Wo, C_), dtype=torch.float16, device=x.device)
-    check(_abi.load().hd_subsample2(ptr(x), ptr(y), N, H, W, C_, Ho, Wo, _stream()), "hd_subsample2")
+    y = torch.empty((N, Ho, Wo, C_), dtype=x.dtype, device=x.device)
+    check(_abi.fn("hd_subsample2", x)(ptr(x), ptr(y), N, H, W, C_, Ho, Wo, _stream()), "hd_subsample2")
     return y
 
 
 def subsample2_bwd(dy, dx, accumulate=True):
     N, H, W, C_ = dx.shape
     _, Ho, Wo, _ = dy.shape
-    check(_abi.load().hd_subsample2_bwd(ptr(dy), ptr(dx), N, H, W, C_, Ho, Wo, 1 if accumulate else 0, _stream()),
+    check(_abi.fn("hd_subsample2_bwd", dy)(ptr(dy), ptr(dx), N, H, W, C_, Ho, Wo, 1 if accumulate else 0, _stream()),
           "hd_subsample2_bwd")
     return dx
 
 
-def nchw_to_nhwc_resize(x, Ho, Wo, Cp=8, out=None):
-    """`out`: write into this [N, Ho, Wo, Cp] fp16 tensor (e.g. a slice along dim 0 of a larger batch buffer) instead of a new one."""
+def nchw_to_nhwc_resize(x, Ho, Wo, Cp=8, out=None, dtype=None):
+    """`out`: write into this [N, Ho, Wo, Cp] tensor (e.g. a slice along dim 0 of a larger batch buffer) instead of a new one; `dtype`:
+    storage type of a new one (float16 / float32)."""
     _need_cuda(x)
     N, Cr, H, W = x.shape
     assert x.dtype == torch.float32
     if out is None:
-        y = torch.empty((N, Ho, Wo, Cp), dtype=torch.float16, device=x.device)
+        y = torch.empty((N, Ho, Wo, Cp), dtype=dtype or act_dtype(), device=x.device)
     else:
         y = out
-        assert y.shape == (N, Ho, Wo, Cp) and y.dtype == torch.float16 and y.is_contiguous()
+        assert y.shape == (N, Ho, Wo, Cp) and y.dtype in (torch.float16, torch.float32) and y.is_contiguous()
     if x.is_contiguous():
-        check(_abi.load().hd_nchw_to_nhwc_resize(ptr(x), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()), "hd_nchw_to_nhwc_resize")
+        check(_abi.fn("hd_nchw_to_nhwc_resize", y)(ptr(x), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()), "hd_nchw_to_nhwc_resize")
     else:
         # dense planes with arbitrary image / channel strides: the stride-0 channel view of a 1 -> 3 channel `expand`
         assert dense_planes(x), "nchw_to_nhwc_resize: rows of x must be dense (stride (.., .., W, 1))"
-        check(_abi.load().hd_nchw_to_nhwc_resize_strided(ptr(x), x.stride(0), x.stride(1), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()),
+        check(_abi.fn("hd_nchw_to_nhwc_resize_strided", y)(ptr(x), x.stride(0), x.stride(1), ptr(y), N, Cr, H, W, Ho, Wo, Cp, _stream()),
               "hd_nchw_to_nhwc_resize_strided")
     return y
 
@@ -468,7 +510,7 @@ def as_dense_planes_f32(x):
 def nchw_to_nhwc_resize_bwd(dy, N, Cr, H, W, gscale=1.0):
     _, Ho, Wo, Cp = dy.shape
     dx = torch.empty((N, Cr, H, W), dtype=torch.float32, device=dy.device)
-    check(_abi.load().hd_nchw_to_nhwc_resize_bwd(ptr(dy), ptr(dx), N, Cr, H, W, Ho, Wo, Cp, gscale, _stream()),
+    check(_abi.fn("hd_nchw_to_nhwc_resize_bwd", dy)(ptr(dy), ptr(dx), N, Cr, H, W, Ho, Wo, Cp, gscale, _stream()),
           "hd_nchw_to_nhwc_resize_bwd")
     return dx
 
@@ -477,7 +519,7 @@ def nhwc_to_nchw(x, Cr=None):
     N, H, W, Cp = x.shape
     Cr = Cp if Cr is None else Cr
     y = torch.empty((N, Cr, H, W), dtype=torch.float32, device=x.device)
-    check(_abi.load().hd_nhwc_to_nchw(ptr(x), ptr(y), N, Cr, H, W, Cp, _stream()), "hd_nhwc_to_nchw")
+    check(_abi.fn("hd_nhwc_to_nchw", x)(ptr(x), ptr(y), N, Cr, H, W, Cp, _stream()), "hd_nhwc_to_nchw")
     return y
 
 
@@ -485,14 +527,14 @@ def upsample_add(a, b):
     N, H, W, C_ = a.shape
     _, Hb, Wb, _ = b.shape
     y = torch.empty_like(a)
-    check(_abi.load().hd_upsample_add(ptr(a), ptr(b), ptr(y), N, H, W, C_, Hb, Wb, _stream()), "hd_upsample_add")
+    check(_abi.fn("hd_upsample_add", a)(ptr(a), ptr(b), ptr(y), N, H, W, C_, Hb, Wb, _stream()), "hd_upsample_add")
     return y
 
 
 def upsample_add_bwd(dy, db, accumulate):
     N, H, W, C_ = dy.shape
     _, Hb, Wb, _ = db.shape
-    check(_abi.load().hd_upsample_add_bwd(ptr(dy), ptr(db), N, H, W, C_, Hb, Wb, 1 if accumulate else 0, _stream()),
+    check(_abi.fn("hd_upsample_add_bwd", dy)(ptr(dy), ptr(db), N, H, W, C_, Hb, Wb, 1 if accumulate else 0, _stream()),
           "hd_upsample_add_bwd")
     return db
 
@@ -500,14 +542,14 @@ def upsample_add_bwd(dy, db, accumulate):
 def upsample2_bwd(dy_up, dx_low, c_off, accumulate):
     N, Hl, Wl, C_ = dx_low.shape
     Ctot = dy_up.shape[3]
-    check(_abi.load().hd_upsample2_bwd(ptr(dy_up), ptr(dx_low), N, Hl, Wl, C_, Ctot, c_off, 1 if accumulate else 0,
+    check(_abi.fn("hd_upsample2_bwd", dy_up)(ptr(dy_up), ptr(dx_low), N, Hl, Wl, C_, Ctot, c_off, 1 if accumulate else 0,
                                        _stream()), "hd_upsample2_bwd")
     return dx_low
 
 
 def add_f16(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
-    check(_abi.load().hd_add_f16(ptr(a), ptr(b), ptr(out), a.numel(), _stream()), "hd_add_f16")
+    check(_abi.fn("hd_add_f16", a)(ptr(a), ptr(b), ptr(out), a.numel(), _stream()), "hd_add_f16")
     return out
 
 
@@ -515,34 +557,35 @@ def slice_channels(x, y, c_off, accumulate):
     Ctot = x.shape[-1]
     C_ = y.shape[-1]
     npix = y.numel() // C_
-    check(_abi.load().hd_slice_channels(ptr(x), ptr(y), npix, Ctot, c_off, C_, 1 if accumulate else 0, _stream()),
+    check(_abi.fn("hd_slice_channels", x)(ptr(x), ptr(y), npix, Ctot, c_off, C_, 1 if accumulate else 0, _stream()),
           "hd_slice_channels")
     return y
 
 
-def sigmoid_bwd_nchw_to_nhwc(dy, s, Cp=8, gscale=1.0):
+def sigmoid_bwd_nchw_to_nhwc(dy, s, Cp=8, gscale=1.0, dtype=None):
     N, Cr, H, W = s.shape
-    dl = torch.empty((N, H, W, Cp), dtype=torch.float16, device=s.device)
-    check(_abi.load().hd_sigmoid_bwd_nchw_to_nhwc(ptr(dy.contiguous()), ptr(s), ptr(dl), N, Cr, H, W, Cp, gscale,
+    dl = torch.empty((N, H, W, Cp), dtype=dtype or act_dtype(), device=s.device)
+    check(_abi.fn("hd_sigmoid_bwd_nchw_to_nhwc", dl)(ptr(dy.contiguous()), ptr(s), ptr(dl), N, Cr, H, W, Cp, gscale,
                                                   _stream()), "hd_sigmoid_bwd_nchw_to_nhwc")
     return dl
 
 
 def relu_bwd(dy, z):
     dx = torch.empty_like(dy)
-    check(_abi.load().hd_relu_bwd(ptr(dy), ptr(z), ptr(dx), dy.numel(), _stream()), "hd_relu_bwd")
+    check(_abi.fn("hd_relu_bwd", dy)(ptr(dy), ptr(z), ptr(dx), dy.numel(), _stream()), "hd_relu_bwd")
     return dx
 
 
-def f32_to_f16(x, scale=1.0):
-    y = torch.empty(x.shape, dtype=torch.float16, device=x.device)
-    check(_abi.load().hd_f32_to_f16(ptr(x.contiguous()), ptr(y), x.numel(), scale, _stream()), "hd_f32_to_f16")
+def f32_to_f16(x, scale=1.0, dtype=None):
+    """fp32 -> the storage type (a scaled copy when that is float32)."""
+    y = torch.empty(x.shape, dtype=dtype or act_dtype(), device=x.device)
+    check(_abi.fn("hd_f32_to_f16", y)(ptr(x.contiguous()), ptr(y), x.numel(), scale, _stream()), "hd_f32_to_f16")
     return y
 
 
 def f16_to_f32(x, scale=1.0):
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    check(_abi.load().hd_f16_to_f32(ptr(x.contiguous()), ptr(y), x.numel(), scale, _stream()), "hd_f16_to_f32")
+    check(_abi.fn("hd_f16_to_f32", x)(ptr(x.contiguous()), ptr(y), x.numel(), scale, _stream()), "hd_f16_to_f32")
     return y
 
 
@@ -552,7 +595,7 @@ def channel_sum(x, rows=None):
     if rows is None:
         rows = int(max(1, min(512, npix // 64)))
     part = torch.empty((rows, C_), dtype=torch.float32, device=x.device)
-    check(_abi.load().hd_channel_sum_f16(ptr(x), npix, C_, ptr(part), rows, _stream()), "hd_channel_sum_f16")
+    check(_abi.fn("hd_channel_sum_f16", x)(ptr(x), npix, C_, ptr(part), rows, _stream()), "hd_channel_sum_f16")
     return colsum(part)
 
 
@@ -709,8 +752,8 @@ def batched_nms_pick_segments(boxes, scores, valid, seg_sizes, iou_thr, top_n):
 def roi_align(feat, rois, PH, PW, spatial_scale, sampling_ratio):
     N, H, W, C_ = feat.shape
     R = rois.shape[0]
-    out = torch.empty((R, PH, PW, C_), dtype=torch.float16, device=feat.device)
-    check(_abi.load().hd_roi_align(ptr(feat), ptr(rois.contiguous()), ptr(out), R, N, H, W, C_, PH, PW, spatial_scale,
+    out = torch.empty((R, PH, PW, C_), dtype=feat.dtype, device=feat.device)
+    check(_abi.fn("hd_roi_align", feat)(ptr(feat), ptr(rois.contiguous()), ptr(out), R, N, H, W, C_, PH, PW, spatial_scale,
                                    sampling_ratio, _stream()), "hd_roi_align")
     return out
 
@@ -719,7 +762,7 @@ def roi_align_bwd(dout, rois, feat_shape, spatial_scale, sampling_ratio):
     N, H, W, C_ = feat_shape
     R, PH, PW, _ = dout.shape
     dfeat = torch.zeros((N, H, W, C_), dtype=torch.float32, device=dout.device)
-    check(_abi.load().hd_roi_align_bwd(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(dfeat), R, N, H, W, C_, PH, PW,
+    check(_abi.fn("hd_roi_align_bwd", dout)(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(dfeat), R, N, H, W, C_, PH, PW,
                                        spatial_scale, sampling_ratio, _stream()), "hd_roi_align_bwd")
     return dfeat
 
@@ -730,12 +773,12 @@ def roi_align_ml(feats, scales, rois, levels, PH, PW, sampling_ratio):
     _need_cuda(rois, levels, *feats)
     R = rois.shape[0]
     C_ = feats[0].shape[3]
-    out = torch.empty((R, PH, PW, C_), dtype=torch.float16, device=rois.device)
+    out = torch.empty((R, PH, PW, C_), dtype=feats[0].dtype, device=rois.device)
     fp = (C.c_void_p * L)(*[f.data_ptr() for f in feats])
     Hs = (C.c_int * L)(*[f.shape[1] for f in feats])
     Ws = (C.c_int * L)(*[f.shape[2] for f in feats])
     sc = (C.c_float * L)(*scales)
-    check(_abi.load().hd_roi_align_ml(fp, Hs, Ws, sc, L, ptr(rois.contiguous()), ptr(levels), ptr(out), R, C_, PH, PW,
+    check(_abi.fn("hd_roi_align_ml", feats[0])(fp, Hs, Ws, sc, L, ptr(rois.contiguous()), ptr(levels), ptr(out), R, C_, PH, PW,
                                       sampling_ratio, _stream()), "hd_roi_align_ml")
     return out
 
@@ -749,7 +792,7 @@ def roi_align_ml_bwd(dout, rois, levels, feat_shapes, scales, sampling_ratio):
     Hs = (C.c_int * L)(*[s[1] for s in feat_shapes])
     Ws = (C.c_int * L)(*[s[2] for s in feat_shapes])
     sc = (C.c_float * L)(*scales)
-    check(_abi.load().hd_roi_align_ml_bwd(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(levels), fp, Hs, Ws, sc, L, R, C_,
+    check(_abi.fn("hd_roi_align_ml_bwd", dout)(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(levels), fp, Hs, Ws, sc, L, R, C_,
                                           PH, PW, sampling_ratio, _stream()), "hd_roi_align_ml_bwd")
     return dfs
 
@@ -762,12 +805,12 @@ def roi_align_ml_bwd_gather(dout, rois, levels, feat_shapes, scales, sampling_ra
     N = feat_shapes[0][0]
     n_images = N if n_images is None else min(int(n_images), N)
     alloc = torch.empty if n_images == N else torch.zeros
-    dfs = [alloc(s, dtype=torch.float16, device=dout.device) for s in feat_shapes]
+    dfs = [alloc(s, dtype=dout.dtype, device=dout.device) for s in feat_shapes]
     fp = (C.c_void_p * L)(*[f.data_ptr() for f in dfs])
     Hs = (C.c_int * L)(*[s[1] for s in feat_shapes])
     Ws = (C.c_int * L)(*[s[2] for s in feat_shapes])
     sc = (C.c_float * L)(*scales)
-    check(_abi.load().hd_roi_align_ml_bwd_gather(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(levels), fp, Hs, Ws, sc, L, R,
+    check(_abi.fn("hd_roi_align_ml_bwd_gather", dout)(ptr(dout.contiguous()), ptr(rois.contiguous()), ptr(levels), fp, Hs, Ws, sc, L, R,
                                                  n_images, C_, PH, PW, sampling_ratio, _stream()), "hd_roi_align_ml_bwd_gather")
     return dfs
 

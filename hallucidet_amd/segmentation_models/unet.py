@@ -259,6 +259,7 @@ class UnetRunner:
     def __init__(self, module):
         self.module = module
         self.grad_scale = 1.0          # loss scale S applied upstream; parameter gradients are emitted as g/S
+        self.act_dtype = torch.float16 # storage type of activations / packed weights / gradient maps: set_precision(32) -> float32
         self.saved = None
         self.use_graphs = False        # replay the (static-shape) schedule as two hipGraphs: see enable_graphs()
         self._g = None
@@ -488,6 +489,16 @@ class UnetRunner:
         self.flatten_parameters()
         return self._gflat
 
+    def set_precision(self, precision):
+        """16: fp16 storage (BASELINE configs[1]); 32: fp32 storage, the arithmetic of the reference's default `--precision 32`
+        (src/config/config.py:149) -- every kernel of the schedule in its _f32 form (parity mode: not a fast path)."""
+        dt = torch.float32 if int(precision) == 32 else torch.float16
+        if dt != self.act_dtype:
+            self.act_dtype = dt
+            self._wplan = {}
+            self._g = None
+            self.saved = None
+
     def _prep_weights(self, need_dgrad):
         """fp32 OIHW masters -> fp16 GEMM layouts (every step in training: the masters move)."""
         hc = self.head_conv
@@ -497,7 +508,7 @@ class UnetRunner:
             # one launch for every layer (the masters are views of the flat arena: stable pointers -> the table is built once)
             items = [(u.conv.weight, u.cin_p, u.cout_p, need_dgrad and u is not self.stem) for u in self.units]
             items.append((hc.weight, hc.in_channels, 8, need_dgrad))
-            plan = self._wplan[need_dgrad] = ops.WeightPrepPlan(items)
+            plan = self._wplan[need_dgrad] = ops.WeightPrepPlan(items, dtype=self.act_dtype)
         outs = plan.run()
         W = {u.name: outs[i] for i, u in enumerate(self.units)}
         W["head"] = outs[-1]
@@ -540,7 +551,7 @@ class UnetRunner:
         rec = {} if save else None
         Wt = self._prep_weights(need_dgrad=save)
         x = ops.as_dense_planes_f32(x)              # a 1 -> 3 channel `expand` view stays a view (read three times by the kernel below)
-        a0 = ops.nchw_to_nhwc_resize(x, H, Wd, 8)
+        a0 = ops.nchw_to_nhwc_resize(x, H, Wd, 8, dtype=self.act_dtype)
         f1 = self._conv_bn(self.stem, a0, Wt, training, rec)
         cur, pool_idx = ops.maxpool3x3s2_idx(f1) if save else (ops.maxpool3x3s2(f1), None)
         feats = [f1]
@@ -623,7 +634,7 @@ class UnetRunner:
         hc = self.head_conv
         self._red = ops.WgradReduceBatch() if _WRED_MULTI else None
         # head: sigmoid' then conv backward
-        dl = ops.sigmoid_bwd_nchw_to_nhwc(dout.float(), sv["out"], 8, 1.0)
+        dl = ops.sigmoid_bwd_nchw_to_nhwc(dout.float(), sv["out"], 8, 1.0, dtype=self.act_dtype)
         db = ops.channel_sum(dl)
         ops.scale_store(db, hc.bias.grad, inv, accumulate=False)
         ht, isc, ish, irelu = _operand(sv["head_in"])

@@ -14,6 +14,7 @@ inside hd_wgrad_reduce; steps with non-finite gradients are skipped (hd_check_fi
 """
 import torch
 
+from . import ops
 from .config import Config
 from .distributed import GradientAverager, broadcast_parameters
 from .models.detector import Detector
@@ -23,7 +24,7 @@ from .utils.utils import Utils
 
 class DetectorLit:
     def __init__(self, batch_size=4, wandb_logger=None, lr=0.0001, detector_name='fasterrcnn', pretrained=True, optimizer_name='adam',
-                 modality=None, directly_coco=False, detector=None, device='cuda', loss_scale=1024.0):
+                 modality=None, directly_coco=False, detector=None, device='cuda', loss_scale=1024.0, precision=16):
         if not any(k in detector_name for k in ('fasterrcnn', 'retinanet', 'fcos')):
             raise ValueError("unknown detector %r (fasterrcnn / retinanet / fcos)" % (detector_name,))
         self.wandb_logger, self.lr, self.batch_size = wandb_logger, lr, batch_size
@@ -33,7 +34,12 @@ class DetectorLit:
                                                                        n_classes=getattr(getattr(Config, 'Dataset', None), 'n_classes', 2), size=Config.Detector.input_size,
                                                                        modality=modality, directly_coco=directly_coco).detector
         self.detector.fused_passes = False
-        self.loss_scale = float(loss_scale)
+        # precision 32 (the reference's default, src/config/config.py:149 -> train_detector.py:387): fp32 storage, no loss scaling
+        if int(precision) not in (16, 32):
+            raise ValueError("precision must be 16 or 32 (got %r)" % (precision,))
+        self.precision = int(precision)
+        self.act_dtype = torch.float32 if self.precision == 32 else torch.float16
+        self.loss_scale = float(loss_scale) if self.precision == 16 else 1.0
         self.optimizer = self.scaler = self.arena = self.averager = None
         self._last_detections = None
 
@@ -100,14 +106,15 @@ class DetectorLit:
 
     def training_step(self, train_batch, batch_idx):
         imgs, targets = self._unpack(train_batch)
-        losses_det, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=True, model_name=self.detector_name)
+        with ops.storage(self.act_dtype):
+            losses_det, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=True, model_name=self.detector_name)
         total_loss, self._last_losses = self._weighted(losses_det)
         self._last_detections = detections
         return total_loss
 
     def validation_step(self, val_batch, batch_idx):
         imgs, targets = self._unpack(val_batch)
-        with torch.no_grad():
+        with torch.no_grad(), ops.storage(self.act_dtype):
             losses_det, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=False, model_name=self.detector_name)
         self._last_detections = detections
         self._metric('val').update(detections, targets)          # train_detector.py:220
@@ -118,7 +125,7 @@ class DetectorLit:
 
     def test_step(self, test_batch, batch_idx):
         imgs, targets = self._unpack(test_batch)
-        with torch.no_grad():
+        with torch.no_grad(), ops.storage(self.act_dtype):
             _, detections = Detector.calculate_loss(self.detector, imgs, targets, train_det=False, model_name=self.detector_name)
         self._last_detections = detections
         self._metric('test').update(detections, targets)         # train_detector.py:300
@@ -151,8 +158,9 @@ class DetectorLit:
         self.detector.invalidate_packs()              # the fp32 masters moved: rebuild the fp16 GEMM layouts
         g = self.arena.flat_grads
         g.zero_()                                     # optimizer_zero_grad (train_detector.py:344-345); kernels accumulate
-        loss = self.training_step(batch, batch_idx)
-        (loss * self.loss_scale).backward()
+        with ops.storage(self.act_dtype):
+            loss = self.training_step(batch, batch_idx)
+            (loss * self.loss_scale).backward()
         if hasattr(self._last_detections, "flush"):          # deferred post-processing: queue it behind the backward pass
             self._last_detections.flush()
         self.averager.begin(g)

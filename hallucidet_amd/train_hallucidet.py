@@ -10,6 +10,7 @@ import os
 import torch
 import torch.nn as nn
 
+from . import ops
 from .config import Config
 from .distributed import GradientAverager, broadcast_parameters, exchange_and_step
 from .models.detector import Detector
@@ -67,7 +68,14 @@ class EncoderDecoderLit(nn.Module):
         self.detector.eval()
         for p in self.detector.parameters():
             p.requires_grad = False
-        self.precision = precision
+        # precision 16: fp16 storage + dynamic loss scaling (BASELINE configs[1]); 32: fp32 storage, no scaling -- the arithmetic of
+        # the reference's default `--precision 32` (src/config/config.py:149 -> pl.Trainer, train_hallucidet.py:507): every kernel of
+        # the step in its _f32 form (ops.storage); a parity mode, not a fast path
+        if int(precision) not in (16, 32):
+            raise ValueError("precision must be 16 or 32 (got %r)" % (precision,))
+        self.precision = int(precision)
+        self.act_dtype = torch.float32 if self.precision == 32 else torch.float16
+        self.encoder_decoder.runner.set_precision(self.precision)
         self.use_graphs = use_graphs
         self.batch_detector_passes = True
         # The reference evaluates the RGB and IR detector passes in EVERY training step (train_hallucidet.py:183,186) and uses
@@ -84,6 +92,10 @@ class EncoderDecoderLit(nn.Module):
 
     # ------------------------------------------------------------------------------------------------------------
     def forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train'):
+        with ops.storage(self.act_dtype):
+            return self._forward_step(imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step)
+
+    def _forward_step(self, imgs_rgb, targets_rgb, imgs_ir, targets_ir, batch_idx, step='train'):
         device = self.dev
         imgs_ir = Utils.batch_images_for_encoder_decoder(imgs=imgs_ir, device=device)
         imgs_rgb = Utils.batch_images_for_encoder_decoder(imgs=imgs_rgb, device=device)
@@ -247,15 +259,9 @@ class EncoderDecoderLit(nn.Module):
     def configure_optimizers(self):
         self.encoder_decoder.to(self.dev)
         self.optimizer = Config.config_optimizer(self.encoder_decoder, learning_rate=self.lr, name=self.optimizer_name)
-        # Every conv / GEMM of this build stores fp16 (BASELINE configs[1] "fp16"); there is no fp32 trunk, so the loss is
-        # scaled whatever `--precision` says: with the reference's default `--precision 32` and scale 1.0 the detector-loss
-        # gradients underflow through RoIAlign / FPN / the decoder.  GradScaler policy either way.
-        if self.precision != 16 and not getattr(EncoderDecoderLit, "_warned_precision", False):
-            EncoderDecoderLit._warned_precision = True
-            import warnings
-            warnings.warn("hallucidet_amd computes in fp16 storage / fp32 accumulation regardless of --precision=%s; "
-                          "dynamic loss scaling stays enabled" % self.precision)
-        self.scaler = LossScaler(self.encoder_decoder, enabled=True)
+        # precision 16 = Lightning's native AMP: GradScaler policy (fp16 gradient maps underflow without it); precision 32: fp32
+        # storage end to end, no scaler (scale 1.0, no overflow check), as pl.Trainer(precision=32) steps the optimizer
+        self.scaler = LossScaler(self.encoder_decoder, enabled=self.precision == 16)
         # train_hallucidet.py:436-444: ReduceLROnPlateau(optimizer, mode='min') monitored on val_loss (torch defaults:
         # factor 0.1, patience 10); the fused optimizer reads param_groups[0]['lr'] at every step
         self.lr_scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, mode='min')
@@ -284,6 +290,10 @@ class EncoderDecoderLit(nn.Module):
 
     def fit_step(self, batch, batch_idx=0):
         """What Lightning does around training_step: scale -> backward -> all-reduce -> (unscale+clip+Adam fused)."""
+        with ops.storage(self.act_dtype):
+            return self._fit_step(batch, batch_idx)
+
+    def _fit_step(self, batch, batch_idx=0):
         self.encoder_decoder.train()
         loss = self.training_step(batch, batch_idx)
         r = self.encoder_decoder.runner

@@ -467,6 +467,67 @@ int hd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* found_inf[0] = 1 if any element of g is inf/nan */
 int hd_check_finite(const float* g, int64_t n, float* found_inf, void* stream);
 
+/* ------------------------------------------------------------------------
+ * fp32 STORAGE (`--precision 32`, the reference's default: src/config/config.py:149, handed to pl.Trainer at
+ * train_hallucidet.py:507, train_detector.py:387, eval_hallucidet.py:230).  Every entry point above that reads or writes an
+ * ACTIVATION tensor (documented there as "f16") exists a second time with the suffix _f32: same arguments, same semantics,
+ * the activation / weight / gradient tensors stored as fp32 (statistics, losses, box maths and the optimizer are fp32 in
+ * both).  A parity mode, not a fast path: one untuned vector-ALU instance of the convolution / data gradient / FC
+ * (hd_conv2d_f32), of the weight gradient (hd_wgrad_f32; slabs reduced by hd_wgrad_reduce as before) and of the weight
+ * re-pack; the bandwidth-bound kernels are the fp16 sources compiled for fp32 storage.  out_mode 0 and 2 coincide (NHWC
+ * fp32).  What it buys: the whole training step agrees with the reference's fp32 evaluation without shared decisions and
+ * without a rounding schedule (tests/test_fp32_mode_gpu.py).
+ * -------------------------------------------------------------------- */
+int hd_conv2d_f32(const hd_conv_args* a, void* stream);
+int hd_conv2d_stats_rows_f32(const hd_conv_args* a);
+int hd_wgrad_f32(const hd_wgrad_args* a, void* stream);
+int hd_weight_prep_f32(const float* w_oihw, const float* out_scale, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
+                       int Cin_pad, int Cout_pad, void* stream);
+int hd_bn_apply_f32(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C, int relu, void* stream);
+int hd_bn_bwd_reduce_f32(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, float* part, int rows, int64_t npix, int C, int relu, void* stream);
+int hd_bn_bwd_apply_f32(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, const float* gamma,
+                        const float* beta, const float* part, int rows, float* coef_ws, void* dy, void* dres, float* dgamma, float* dbeta,
+                        float gscale, int accumulate, int64_t npix, int C, int relu, void* stream);
+int hd_maxpool3x3s2_f32(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_maxpool3x3s2_bwd_f32(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_maxpool3x3s2_idx_f32(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_maxpool3x3s2_bwd_idx_f32(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_subsample2_f32(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_subsample2_bwd_f32(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream);
+int hd_nchw_to_nhwc_resize_f32(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream);
+int hd_nchw_to_nhwc_resize_strided_f32(const float* x, int64_t nstride, int64_t cstride, void* y, int N, int Cr, int H, int W, int Ho,
+                                       int Wo, int Cp, void* stream);
+int hd_nchw_to_nhwc_resize_bwd_f32(const void* dy, float* dx, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, float gscale, void* stream);
+int hd_nhwc_to_nchw_f32(const void* x, float* y, int N, int Cr, int H, int W, int Cp, void* stream);
+int hd_upsample_add_f32(const void* a, const void* b, void* y, int N, int H, int W, int C, int Hb, int Wb, void* stream);
+int hd_upsample_add_bwd_f32(const void* dy, void* db, int N, int H, int W, int C, int Hb, int Wb, int accumulate, void* stream);
+int hd_upsample2_bwd_f32(const void* dy_up, void* dx_low, int N, int Hl, int Wl, int C, int Ctot, int c_off, int accumulate, void* stream);
+int hd_add_f16_f32(const void* a, const void* b, void* out, int64_t n, void* stream);
+int hd_slice_channels_f32(const void* x, void* y, int64_t npix, int Ctot, int c_off, int C, int accumulate, void* stream);
+int hd_sigmoid_bwd_nchw_to_nhwc_f32(const float* dy, const float* s, void* dlogit, int N, int Cr, int H, int W, int Cp, float gscale, void* stream);
+int hd_relu_bwd_f32(const void* dy, const void* z, void* dx, int64_t n, void* stream);
+int hd_f32_to_f16_f32(const float* x, void* y, int64_t n, float scale, void* stream);
+int hd_f16_to_f32_f32(const void* x, float* y, int64_t n, float scale, void* stream);
+int hd_pad_cast_f32_f16_f32(const float* x, void* y, int64_t P, int C, int Cp, int64_t rows_per_image, int64_t image_stride, void* stream);
+int hd_channel_sum_f16_f32(const void* x, int64_t npix, int C, float* part, int rows, void* stream);
+int hd_roi_align_f32(const void* feat, const float* rois, void* out, int R, int N, int H, int W, int C, int PH, int PW, float spatial_scale,
+                     int sampling_ratio, void* stream);
+int hd_roi_align_bwd_f32(const void* dout, const float* rois, float* dfeat_f32, int R, int N, int H, int W, int C, int PH, int PW,
+                         float spatial_scale, int sampling_ratio, void* stream);
+int hd_roi_align_ml_f32(const void* const* feats, const int* H, const int* W, const float* scale, int L, const float* rois, const int* level,
+                        void* out, int R, int C, int PH, int PW, int sampling_ratio, void* stream);
+int hd_roi_align_ml_bwd_f32(const void* dout, const float* rois, const int* level, float* const* dfeat_f32, const int* H, const int* W,
+                            const float* scale, int L, int R, int C, int PH, int PW, int sampling_ratio, void* stream);
+int hd_roi_align_ml_bwd_gather_f32(const void* dout, const float* rois, const int* level, void* const* dfeat_f16, const int* H, const int* W,
+                                   const float* scale, int L, int R, int n_images, int C, int PH, int PW, int sampling_ratio, void* stream);
+int hd_groupnorm8_relu_f32(const void* x, const float* gamma, const float* beta, void* y, float* mean_rstd, int N, int HW, int C, float eps,
+                           int relu, void* stream);
+int hd_groupnorm8_relu_bwd_f32(const void* dy, const void* x, const void* y, const float* gamma, const float* mean_rstd, void* dx, int N,
+                               int HW, int C, int relu, void* stream);
+int hd_groupnorm8_param_grad_f32(const void* dy, const void* x, const void* y, const float* mean_rstd, float* dgamma, float* dbeta, int N,
+                                 int HW, int C, int relu, float scale, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,18 +41,43 @@ class Pins:
     ReLU whose input is within that noise of zero flips; each flip re-routes the gradient of everything behind it.  With the
     decisions pinned both sides evaluate the SAME piecewise-linear function and differ by rounding / summation order only, which
     is what a tight gradient comparison needs.  `masks`: {tag: float tensor (1 = pass) shaped like the oracle's activation};
-    `pool`: int64 [N, C, Ho, Wo] in 0..8 (row-major position inside the 3x3 window); missing tags fall back to the plain op."""
+    `pool`: int64 [N, C, Ho, Wo] in 0..8 (row-major position inside the 3x3 window); missing tags fall back to the plain op.
 
-    def __init__(self, masks=None, pool=None, proposals=None):
+    A borrowed decision is only legitimate where this restatement's OWN value sits inside the fp16 noise band of the decision
+    boundary, so every use is AUDITED against the oracle's own pre-activation: `audit[tag] = (elements, decisions that differ from the
+    oracle's own, largest |own pre-activation| (ReLU) or value gap between the two winners (max-pool) among those, RMS of the layer's
+    pre-activation, sigma / dmax = RMS / largest difference between the recorded activation and the oracle's own over the elements both
+    sides pass -- the measured noise of that layer, None without `values`)`; for pinned proposals `audit[("proposals", image)] = (pinned
+    boxes, boxes of the oracle's own post-NMS set, pinned boxes that coincide (IoU >= 0.9) with one of the oracle's own CANDIDATES -- every
+    anchor decoded with the oracle's own deltas and clipped, before any score-driven selection)`.
+    tests/_pins.py::assert_borrowed_decisions_are_noise turns the audit into assertions -- a systematically wrong mask in the
+    product would otherwise be copied into the oracle and pass."""
+
+    def __init__(self, masks=None, pool=None, proposals=None, values=None):
         self.masks, self.pool, self.proposals = masks or {}, pool, proposals
+        self.values = values or {}       # {tag: the recorded post-ReLU activation}: gives the audit the layer's measured noise level
         self.used = set()
+        self.audit = {}
 
     def relu(self, tag, x):
         m = self.masks.get(tag)
         if m is None:
             return F.relu(x)
         self.used.add(tag)
-        return x * m.reshape(x.shape)
+        m = m.reshape(x.shape)
+        with torch.no_grad():
+            xd = x.detach()
+            flip = (m > 0) != (xd > 0)
+            nf = int(flip.sum())
+            sigma = dmax = None
+            v = self.values.get(tag)
+            if v is not None:                # difference between the two evaluations where both say "on": the layer's measured noise
+                both = (m > 0) & (xd > 0)
+                d = (v.reshape(x.shape) - xd)[both].abs()
+                sigma = float(d.float().pow(2).mean().sqrt()) if d.numel() else 0.0
+                dmax = float(d.max()) if d.numel() else 0.0
+            self.audit[tag] = (xd.numel(), nf, float(xd[flip].abs().max()) if nf else 0.0, float(xd.float().pow(2).mean().sqrt()), sigma, dmax)
+        return x * m
 
     def maxpool3x3s2(self, x):
         if self.pool is None:
@@ -60,7 +85,14 @@ class Pins:
         xp = F.pad(x, (1, 1, 1, 1), value=float("-inf"))
         win = xp.unfold(2, 3, 2).unfold(3, 3, 2)                       # [N, C, Ho, Wo, 3, 3]
         win = win.reshape(win.shape[:4] + (9,))
-        return win.gather(4, self.pool.reshape(win.shape[:4] + (1,))).squeeze(4)
+        out = win.gather(4, self.pool.reshape(win.shape[:4] + (1,))).squeeze(4)
+        with torch.no_grad():
+            own = win.detach().max(dim=4).values
+            gap = own - out.detach()                                    # >= 0; > 0 where the borrowed winner is not a maximum of the oracle's window
+            diff = gap > 0
+            nf = int(diff.sum())
+            self.audit[("pool",)] = (out.numel(), nf, float(gap.max()) if nf else 0.0, float(x.detach().float().pow(2).mean().sqrt()), None, None)
+        return out
 
 
 NO_PINS = Pins()
@@ -431,6 +463,7 @@ class RegionProposalNetwork(nn.Module):
         self._post_nms_top_n = dict(training=2000, testing=1000)
         self.nms_thresh, self.score_thresh, self.min_size = 0.7, 0.0, 1e-3
         self.pinned_proposals = None
+        self.pins_audit = None
 
     def pre_nms_top_n(self):
         return self._pre_nms_top_n["training" if self.training else "testing"]
@@ -467,6 +500,18 @@ class RegionProposalNetwork(nn.Module):
     def filter_proposals(self, proposals, objectness, image_shapes, num_anchors_per_level):
         if self.pinned_proposals is not None:        # tests: the product's post-NMS proposal sets (Pins docstring)
             fb = [b.clone() for b in self.pinned_proposals]
+            if self.pins_audit is not None:          # ... audited against this restatement's own sets
+                pinned, self.pinned_proposals = self.pinned_proposals, None
+                try:
+                    own, _ = self.filter_proposals(proposals, objectness, image_shapes, num_anchors_per_level)
+                finally:
+                    self.pinned_proposals = pinned
+                for i, (pb, ob) in enumerate(zip(fb, own)):
+                    cand = clip_boxes_to_image(proposals[i].detach().reshape(-1, 4), image_shapes[i])
+                    hit = 0
+                    for lo in range(0, pb.shape[0], 256):               # [256, A] IoU blocks
+                        hit += int((ok.box_iou(pb[lo:lo + 256], cand).max(dim=1).values >= 0.9).sum())
+                    self.pins_audit[("proposals", i)] = (pb.shape[0], ob.shape[0], hit)
             return fb, [torch.zeros(b.shape[0]) for b in fb]
         n_img = proposals.shape[0]
         objectness = objectness.detach().reshape(n_img, -1)
@@ -706,6 +751,7 @@ class FasterRCNN(nn.Module):
         pins = pins or NO_PINS
         self.backbone.pins = self.rpn.head.pins = self.roi_heads.box_head.pins = pins
         self.rpn.pinned_proposals = pins.proposals
+        self.rpn.pins_audit = pins.audit if pins.proposals is not None else None
 
 
 def eval_forward_fasterrcnn(model, images, targets, train_det=False):

@@ -40,7 +40,7 @@ class record:
         """`n_images`: keep the first n images of every recorded map (a fused three-pass evaluation runs hall + RGB + IR as one
         batch; only the leading, hallucinated, images carry a gradient)."""
         cut = (lambda t: t) if n_images is None else (lambda t: t[:n_images])
-        masks, pool = {}, None
+        masks, pool, values = {}, None, {}
         for tag, t in self.tap.items():
             if t is None:
                 continue
@@ -53,12 +53,91 @@ class record:
             elif tag == ("pool",):
                 pool = cut(t).permute(0, 3, 1, 2).long().cpu().contiguous()
             elif tag[0] == "reg_out":                       # NCHW view of an fp32 head output
-                masks[tag] = (cut(t).detach() > 0).float().cpu().contiguous()
+                values[tag] = cut(t).detach().float().cpu().contiguous()
             elif tag[0] in ("fc6", "fc7"):                  # [R, 1, 1, C]: one row per RoI, not per image
-                masks[tag] = (t.detach().permute(0, 3, 1, 2) > 0).float().cpu().contiguous()
+                values[tag] = t.detach().permute(0, 3, 1, 2).float().cpu().contiguous()
             else:                                            # NHWC fp16 activation
-                masks[tag] = (cut(t).detach().permute(0, 3, 1, 2) > 0).float().cpu().contiguous()
-        return od.Pins(masks, pool, proposals)
+                values[tag] = cut(t).detach().permute(0, 3, 1, 2).float().cpu().contiguous()
+        masks = {tag: (v > 0).float() for tag, v in values.items()}
+        return od.Pins(masks, pool, proposals, values)
+
+
+# Bounds on BORROWED decisions.  A decision taken from the product may differ from the oracle's own only where the
+# oracle's own value sits inside the NOISE BAND of the decision boundary; a systematically wrong mask in the product (which the oracle
+# would otherwise copy and pass) flips elements far outside it.  The noise of a layer is MEASURED, not assumed, on the elements both
+# evaluations pass: sigma = RMS, dmax = largest |product activation - oracle's own| (fp16 storage of everything upstream; in the
+# end-to-end tier also the drift of the hallucinated image the detector starts from; per-element errors scale with the raw conv
+# output in front of a BatchNorm, so the tail is heavy and the bound uses the observed maximum, not a multiple of sigma).
+#   * magnitude: every differing ReLU element has |own pre-activation| <= NOISE_C * dmax of its layer -- no further from the boundary
+#     than the two evaluations are SEEN to differ elsewhere in that layer; differing max-pool winners: the oracle's two candidates are
+#     within 2 * NOISE_C * dmax(stem) of each other (each side moves by at most dmax);
+#   * share: at most SHARE_K * sigma / RMS of a layer's elements differ (the mass of a unit-scale density inside a band of width
+#     sigma; measured 0.3 - 0.75 in fp16 storage; in fp32 storage a layer has a handful of flips and the ratio is a small-count
+#     statistic: SHARE_FLOOR of the elements is always allowed), never more than MAX_FLIP_SHARE;
+#   * proposals: at least MIN_PROPOSAL_MATCH of the borrowed post-NMS boxes coincide (IoU >= 0.9) with a box of the oracle's own
+#     candidate set (every anchor decoded with the oracle's deltas, clipped) -- WHICH candidates survive top-k / NMS is decided by
+#     near-ties of a randomly initialised RPN and is what the pin is for; that the boxes ARE the oracle's boxes is checked here.
+# One set of constants for every pinned test, set from the worst cases over the whole -m gpu suite (HD_PINS_AUDIT=1 prints every
+# layer; HD_PINS_MEASURE=1 reports without asserting) with a margin of about two.
+NOISE_C = 2.0
+SHARE_K = 2.0
+SHARE_FLOOR = 2e-4
+MAX_FLIP_SHARE = 0.10
+MIN_PROPOSAL_MATCH = 0.98
+
+
+def assert_borrowed_decisions_are_noise(holder, label=""):
+    """`holder`: an oracle.detection.Pins or an oracle.unet.Ctx (built WITH the recorded values) after the oracle's forward pass.
+    Asserts the bounds above for every audited decision and returns a one-line summary."""
+    import os
+    audit = holder.audit
+    assert audit, "no borrowed decision was audited (%s)" % label
+    measure = os.environ.get("HD_PINS_MEASURE")          # collect, do not assert (setting the constants)
+    worst = dict(share=0.0, kmax=0.0, ksig=0.0, sratio=0.0, tag=None)
+    prop, problems = [], []
+    stem_dmax = stem_sigma = None
+    for tag, rec in audit.items():
+        if isinstance(tag, tuple) and tag and tag[0] == "proposals":
+            pinned, own, hit = rec
+            prop.append((pinned, own, hit))
+            if pinned and hit < MIN_PROPOSAL_MATCH * pinned:
+                problems.append(("proposals", tag, rec))
+            continue
+        n, nf, big, rms, sigma, dmax = rec
+        if tag == ("stem",):
+            stem_dmax, stem_sigma = dmax, sigma
+        limit = NOISE_C * dmax if dmax is not None else None
+        if tag == ("pool",):
+            sigma, dmax = stem_sigma, stem_dmax
+            limit = 2 * NOISE_C * dmax if dmax is not None else None
+        assert sigma is not None and dmax is not None, "decision %s was borrowed without the recorded values (%s)" % (tag, label)
+        share = nf / max(n, 1)
+        kmax = big / dmax if dmax else (0.0 if big == 0 else float("inf"))
+        ksig = big / sigma if sigma else 0.0
+        sratio = share / (sigma / max(rms, 1e-30)) if sigma else (0.0 if nf == 0 else float("inf"))
+        worst["share"] = max(worst["share"], share)
+        worst["ksig"] = max(worst["ksig"], ksig)
+        worst["sratio"] = max(worst["sratio"], sratio)
+        if kmax > worst["kmax"]:
+            worst["kmax"], worst["tag"] = kmax, tag
+        if os.environ.get("HD_PINS_AUDIT"):
+            print("   audit %-28s n %9d differ %7d (%.4f %%) worst |x| %.3e = %.2f dmax = %.1f sigma; sigma/RMS %.2e share/(sigma/RMS) %.2f" % (
+                str(tag), n, nf, 100 * share, big, kmax, ksig, sigma / max(rms, 1e-30), sratio))
+        if big > limit or share > max(SHARE_K * sigma / max(rms, 1e-30), SHARE_FLOOR) or share > MAX_FLIP_SHARE:
+            problems.append((tag, "share %.5f (%.2f sigma/RMS)" % (share, sratio), "worst %.2f dmax" % kmax))
+    summary = "borrowed decisions %s: %d audited, worst share %.4f %% = %.2f sigma/RMS, worst |x| %.2f dmax (%s; %.1f sigma)%s" % (
+        label, len(audit), 100 * worst["share"], worst["sratio"], worst["kmax"], worst["tag"], worst["ksig"],
+        "" if not prop else ", proposals among the oracle's candidates %d / %d" % (sum(p[2] for p in prop), sum(p[0] for p in prop)))
+    print(summary)
+    assert measure or not problems, "borrowed decisions outside the noise band: %s" % problems[:8]
+    return summary
+
+
+def unet_decisions(runner, device="cpu"):
+    """-> (masks, values): the ReLU decisions of the hallucination network's last forward pass and the activations they were taken
+    from (NCHW fp32), for oracle.unet.Ctx(q, masks, values)."""
+    values = {k: v.permute(0, 3, 1, 2).float().to(device) for k, v in runner.saved_activations().items() if not k.endswith("downsample")}
+    return {k: (v > 0).float() for k, v in values.items()}, values
 
 
 def grad_agreement(got, want):

@@ -295,7 +295,7 @@ def test_detector_image_gradient_matches_oracle(dev, case):
     functional of the head outputs over fixed proposals, and the oracle takes every ReLU / max-pool decision from the product's
     own activations (tests/_pins.py), so both sides differentiate the SAME piecewise-linear function: what is left is fp16 storage
     of the gradient maps and summation order.  A missing FPN level, a mis-scaled residual branch or a wrong mask would fail this."""
-    from _pins import record, grad_agreement
+    from _pins import record, grad_agreement, assert_borrowed_decisions_are_noise
     det, oracle, images, targets = case
     g = torch.Generator().manual_seed(5)
     x = images.to(dev).requires_grad_(True)
@@ -331,6 +331,7 @@ def test_detector_image_gradient_matches_oracle(dev, case):
     finally:
         oracle.set_pins(None)
     assert pins.used == set(pins.masks), "every recorded decision must have been consumed by the oracle (same network structure)"
+    assert_borrowed_decisions_are_noise(pins, "detector image gradient")
     oloss = sum((o * w).sum() for o, w in zip(oobj, w_obj)) + sum((o * w).sum() for o, w in zip(oreg, w_reg))
     oloss = oloss + (ologits * w_l).sum() + (oregs * w_r).sum()
     oloss.backward()
@@ -347,7 +348,7 @@ def test_detector_image_gradient_matches_oracle(dev, case):
 def test_detector_image_gradient_per_branch(dev, case, branch):
     """The same comparison with the probe loss restricted to ONE source of gradient (one FPN level of the RPN head, or the box
     head through RoIAlign): in the summed probe above a level whose contribution is small could be dropped unnoticed."""
-    from _pins import record, grad_agreement
+    from _pins import record, grad_agreement, assert_borrowed_decisions_are_noise
     det, oracle, images, targets = case
     g = torch.Generator().manual_seed(7)
     x = images.to(dev).requires_grad_(True)
@@ -370,7 +371,8 @@ def test_detector_image_gradient_per_branch(dev, case, branch):
     S = 64.0
     (sum((o * w.to(dev)).sum() for o, w in zip(outs, ws)) * S).backward()
     gx = x.grad.cpu() / S
-    oracle.set_pins(rec.pins())
+    bpins = rec.pins()
+    oracle.set_pins(bpins)
     try:
         xo = images.clone().requires_grad_(True)
         ol, _ = oracle.transform(xo, None)
@@ -383,6 +385,7 @@ def test_detector_image_gradient_per_branch(dev, case, branch):
             oouts = [oobj[li], oreg[li]]
     finally:
         oracle.set_pins(None)
+    assert_borrowed_decisions_are_noise(bpins, "branch " + branch)
     sum((o * w).sum() for o, w in zip(oouts, ws)).backward()
     cos, rel = grad_agreement(gx, xo.grad)
     print("%s: image-gradient rel-L2 %.6f cosine %.7f |g| %.4e" % (branch, rel, cos, float(xo.grad.norm())))

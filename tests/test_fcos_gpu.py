@@ -256,6 +256,8 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
     finally:
         oracle.set_pins(None)
     assert pins.used == set(pins.masks)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(pins, "fcos")
     (olosses["classification"] + olosses["bbox_regression"] + olosses["bbox_ctrness"]).backward()
     for k in losses:
         print("fcos %s: product %.6f oracle %.6f" % (k, float(losses[k]), float(olosses[k])))
@@ -394,6 +396,8 @@ def test_fcos_parameter_gradients_and_fit_step(dev):
     finally:
         oracle.set_pins(None)
     assert pins.used == set(pins.masks)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(pins, "fcos")
     sum((oho[k] * ws[k]).sum() for k in oho).backward()
     worst = {}
     for n, p in oracle.named_parameters():

@@ -240,11 +240,15 @@ def test_full_size_unet_forward_backward_against_the_oracle_run_on_the_gpu(dev):
     gout = (torch.randn(N, 3, H, W, generator=g) * 1e-2).to(dev)
     net.runner.grad_scale = S
     out = net(x)
-    masks = {k: (v.permute(0, 3, 1, 2) > 0).float() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
+    from _pins import unet_decisions
+    masks, uvalues = unet_decisions(net.runner, device=x.device)
     (out * (gout * S)).sum().backward()
     torch.cuda.synchronize()
     torch.backends.cudnn.allow_tf32 = False
-    wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
+    uctx = ou.Ctx(ou.fp16_round, masks, uvalues)
+    wq = ref(x, q=uctx)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(uctx, "U-Net")
     (wq * gout).sum().backward()
     torch.cuda.synchronize()
     e = (out.detach() - wq.detach()).abs()

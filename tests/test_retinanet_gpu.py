@@ -169,6 +169,8 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
     finally:
         oracle.set_pins(None)
     assert pins.used == set(pins.masks)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(pins, "retinanet")
     (olosses["classification"] + olosses["bbox_regression"]).backward()
     for k in losses:
         print("retinanet %s: product %.6f oracle %.6f" % (k, float(losses[k]), float(olosses[k])))

@@ -89,8 +89,8 @@ def _to_cpu(batch):
 
 
 def _unet_masks(lit):
-    acts = lit.encoder_decoder.runner.saved_activations()
-    return {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in acts.items() if not k.endswith("downsample")}
+    from _pins import unet_decisions
+    return unet_decisions(lit.encoder_decoder.runner)
 
 
 # Bounds (rel-L2 / cosine for gradients, relative for losses).  END TO END the oracle starts from the IR batch and nothing but
@@ -142,7 +142,7 @@ def test_training_step_matches_oracle(dev, detector_name, seed, shape):
     if detector_name == "retinanet":
         assert out["loss"]["det_objectness"] == 0.0 and out["loss"]["det_rpn_box_reg"] == 0.0 and out["loss"]["det_bbox_ctrness"] == 0.0
     pins = rec.pins(n_images=N)
-    umasks = _unet_masks(lit)
+    umasks, uvalues = _unet_masks(lit)
     if detector_name == "fasterrcnn":
         lit.detector.rpn.fg_bg_sampler.randperm_fn.reset()
     grabbed = []
@@ -164,9 +164,15 @@ def test_training_step_matches_oracle(dev, detector_name, seed, shape):
     after = {k: v.detach().cpu() for k, v in lit.encoder_decoder.state_dict().items()}
 
     # ---- (A) END TO END: oracle from the IR batch, sharing only the discrete decisions
-    tr.unet_q = ou.Ctx(ou.fp16_round, umasks)
+    tr.unet_q = ou.Ctx(ou.fp16_round, umasks, uvalues)
     total, olosses, _ = tr.forward_step(*cbatch, det_pins=pins)
     assert pins.used == set(pins.masks), "every recorded detector decision was consumed by the oracle"
+    from _pins import assert_borrowed_decisions_are_noise
+    try:
+        assert_borrowed_decisions_are_noise(pins, "detector (end to end)")
+        assert_borrowed_decisions_are_noise(tr.unet_q, "U-Net (end to end)")
+    except AssertionError as exc:
+        problems.append(("borrowed decisions", str(exc)))
     e = (hall - tr.last_hall).abs()
     print("%s seed %d: hallucinated image mean |err| %.2e max %.2e" % (detector_name, seed, float(e.mean()), float(e.max())))
     # train-mode BatchNorm over 2 x 4 x 5 = 40 positions at the bottleneck amplifies rounding differences at this size (the U-Net
@@ -384,6 +390,8 @@ def test_eval_step_batch_one_full_size_matches_oracle(dev):
             dl, odets = od.eval_forward_fasterrcnn(tr.det, hall, cbatch[3])
         finally:
             tr.det.set_pins(None)
+        from _pins import assert_borrowed_decisions_are_noise
+        assert_borrowed_decisions_are_noise(pins, "config0 eval")
     keymap = {"det_classification": "loss_classifier", "det_regression": "loss_box_reg", "det_objectness": "loss_objectness",
               "det_rpn_box_reg": "loss_rpn_box_reg"}
     for pk, ok_ in keymap.items():

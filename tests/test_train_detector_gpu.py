@@ -109,6 +109,8 @@ def _check_parameter_gradients(dev, case):
     finally:
         oracle.set_pins(None)
     assert pins.used == set(pins.masks)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(pins, "train_detector")
     oloss = sum((o * w).sum() for o, w in zip(oobj, w_obj)) + sum((o * w).sum() for o, w in zip(oreg, w_reg))
     oloss = oloss + (ologits * w_l).sum() + (oregs * w_r).sum()
     oloss.backward()
@@ -252,6 +254,8 @@ def test_retinanet_parameter_gradients_and_fit_step(dev):
     finally:
         oracle.set_pins(None)
     assert pins.used == set(pins.masks)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(pins, "train_detector")
     ((oho["cls_logits"] * w_c).sum() + (oho["bbox_regression"] * w_r).sum()).backward()
     worst = {}
     for n, p in oracle.named_parameters():

@@ -69,10 +69,14 @@ def _train_pair_run(dev, seed, N, H, W, S):
     gout = torch.randn(N, 3, H, W) * 1e-2
     net.runner.grad_scale = S
     out = net(x.to(dev))
-    masks = {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
+    from _pins import unet_decisions
+    masks, uvalues = unet_decisions(net.runner, device="cpu")
     (out * (gout.to(dev) * S)).sum().backward()
     torch.cuda.synchronize()
-    wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
+    uctx = ou.Ctx(ou.fp16_round, masks, uvalues)
+    wq = ref(x, q=uctx)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(uctx, "U-Net")
     (wq * gout).sum().backward()
     return net, ref, out.detach().cpu(), wq.detach()
 
@@ -165,9 +169,13 @@ def test_resnet18_backbone_forward_and_gradients(dev):
     gout = torch.randn(2, 3, 64, 96) * 1e-2
     net.runner.grad_scale = 256.0
     out = net(x.to(dev))
-    masks = {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
+    from _pins import unet_decisions
+    masks, uvalues = unet_decisions(net.runner, device="cpu")
     (out * (gout.to(dev) * 256.0)).sum().backward()
-    wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
+    uctx = ou.Ctx(ou.fp16_round, masks, uvalues)
+    wq = ref(x, q=uctx)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(uctx, "U-Net")
     (wq * gout).sum().backward()
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         a, b = p.grad.detach().cpu().flatten().double(), q.grad.flatten().double()
@@ -190,9 +198,13 @@ def test_resnet50_backbone_forward_and_gradients(dev):
     gout = torch.randn(2, 3, 64, 96) * 1e-2
     net.runner.grad_scale = 256.0
     out = net(x.to(dev))
-    masks = {k: (v.permute(0, 3, 1, 2) > 0).float().cpu() for k, v in net.runner.saved_activations().items() if not k.endswith("downsample")}
+    from _pins import unet_decisions
+    masks, uvalues = unet_decisions(net.runner, device="cpu")
     (out * (gout.to(dev) * 256.0)).sum().backward()
-    wq = ref(x, q=ou.Ctx(ou.fp16_round, masks))
+    uctx = ou.Ctx(ou.fp16_round, masks, uvalues)
+    wq = ref(x, q=uctx)
+    from _pins import assert_borrowed_decisions_are_noise
+    assert_borrowed_decisions_are_noise(uctx, "U-Net")
     (wq * gout).sum().backward()
     worst = 1.0
     for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):

@@ -27,7 +27,7 @@ def main(argv=None):
     dm = SingleModalDataModule(dataset, args.train, args.test, batch_size=args.batch, num_workers=args.num_workers, ext=args.ext or ".jpg",
                                seed=args.seed, rank=rank, world_size=world, modality=args.modality)
     kw = dict(batch_size=args.batch, lr=1e-4 if args.lr is None else args.lr, detector_name=Config.Detector.name, pretrained=args.pretrained,
-              modality=args.modality, directly_coco=args.directly_coco, device=dev)
+              modality=args.modality, directly_coco=args.directly_coco, device=dev, precision=args.precision)
     model = DetectorLit.load_from_checkpoint(args.pre_train_path, **kw) if args.pre_train_path else DetectorLit(**kw)
     model.prepare()
     out_dir = os.path.join("lightning_logs", args.wandb_project, args.wandb_name, "_".join([dataset, args.modality, Config.Detector.name]))
