@@ -27,7 +27,13 @@ from .segmentation_models.unet import capture_without_gc
 
 
 def _bucket(n):
-    return max(8, (int(n) + 7) // 8 * 8)
+    """Rows per image of the staged targets: the next power of two >= 8.  Coarse on purpose -- every new bucket costs two eager warm-up
+    bodies plus a capture in the middle of an epoch (and, under data parallelism, makes the other ranks wait in the all-reduce); capture
+    steps also advance the samplers' generator further than a replay does, so they are not RNG-reproducible."""
+    g = 8
+    while g < int(n):
+        g *= 2
+    return g
 
 
 class _GraphedDetector(torch.autograd.Function):
@@ -59,7 +65,8 @@ class _Entry:
 class DetectorStepGraph:
     def __init__(self, lit):
         self.lit = lit
-        self.entries = {}
+        self.entries = {}                  # insertion order = recency (LRU: see step())
+        self.max_entries = int(os.environ.get("HD_DET_GRAPH_MAX", "6"))
         self.pool = None
         self.usable = True
         self.replays = 0
@@ -241,6 +248,12 @@ class DetectorStepGraph:
                               % (type(err).__name__, err))
                 return lit._detector_section(imgs_hallucinated, imgs_rgb, imgs_ir, targets_rgb, targets_ir, 'train', False)
             self.entries[key] = e
+            # one captured ~700-kernel graph per (shapes, G bucket, weights, ...), each pinning its static buffers in the shared pool:
+            # keep the most recently used few (a dataset with a wide box-count spread visits many G buckets)
+            while len(self.entries) > self.max_entries:
+                self.entries.pop(next(iter(self.entries)))
+        else:
+            self.entries[key] = self.entries.pop(key)          # most recently used last
         # the flag the PREVIOUS batch left behind is read now (a bad box raises the reference's assertion one call later)
         pend = lit.detector.__dict__.pop("_pending_degenerate", None)
         if pend is not None:

@@ -128,29 +128,17 @@ def _conv_entry(conv, bn=None, cin_pad=None):
                 cin_p=cin_p, cout_p=cout_p)
 
 
-# Parity instrumentation (tests only): when `_TAP` is a dict, every activation whose sign pattern is a DISCRETE decision of the
-# forward pass (post-ReLU tensors, the max-pool winner bytes) is recorded under a tag, so that a test can hand the same decisions
-# to the CPU oracle (oracle.detection.Pins) and compare gradients of the same piecewise-linear function.  None in production.
-_TAP = None
-
-
-def _tap(tag, t):
-    if _TAP is not None and tag is not None:
-        _TAP[tag] = t
-    return t
-
-
-def _fwd(e, x, *, act=ACT_NONE, res=None, f32=False, tag=None):
+def _fwd(e, x, *, act=ACT_NONE, res=None, f32=False):
     """f32: False -> NHWC fp16; True -> NCHW fp32; "nhwc" -> NHWC fp32 (returned as its NCHW VIEW: torchvision's
     `permute_and_flatten` of such a tensor is a free view instead of a copy)."""
     if f32 == "nhwc":
         return ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
                           out_nhwc_f32=True, cout=e["cout"]).permute(0, 3, 1, 2)
-    return _tap(tag, ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
-                                out_nchw_f32=f32, cout=e["cout"]))
+    return ops.conv2d(x, e["wf"], e["k"], e["k"], bias=e["bias"], res=res, stride=e["stride"], pad=e["pad"], act=act,
+                      out_nchw_f32=f32, cout=e["cout"])
 
 
-def _fwd_many(es, xs, *, act=ACT_NONE, f32=False, tags=None):
+def _fwd_many(es, xs, *, act=ACT_NONE, f32=False):
     """`_fwd(e, x, ...)` for several independent (entry, input) pairs -- the same layer type on every feature level -- as ONE grid
     where the kernels allow it (ops.conv2d_multi; put the largest level first).  Same outputs as the per-level calls, bit for bit."""
     calls = []
@@ -164,7 +152,7 @@ def _fwd_many(es, xs, *, act=ACT_NONE, f32=False, tags=None):
     outs = ops.conv2d_multi(calls)
     if f32 == "nhwc":
         return [o.permute(0, 3, 1, 2) for o in outs]
-    return [_tap(None if tags is None else tags[i], o) for i, o in enumerate(outs)]
+    return outs
 
 
 def _dgrad_many(es, dys, hws, *, ress=None, masks=None):
@@ -312,18 +300,17 @@ class BackboneWithFPN(nn.Module):
         P = self.pack()
         na = x.shape[0] if n_active is None else n_active
         rec = {"x": x[:na], "blocks": []} if save else None
-        s = _fwd(P["stem"], x, act=ACT_RELU, tag=("stem",))
+        s = _fwd(P["stem"], x, act=ACT_RELU)
         p, pidx = ops.maxpool3x3s2_idx(s) if save else (ops.maxpool3x3s2(s), None)
-        _tap(("pool",), pidx)
         cur = p
         C = []
         for si, stage in enumerate(P["blocks"]):
             srec = []
             for bi, e in enumerate(stage):
-                o1 = _fwd(e["c1"], cur, act=ACT_RELU, tag=("b", si, bi, 1))
-                o2 = _fwd(e["c2"], o1, act=ACT_RELU, tag=("b", si, bi, 2))
+                o1 = _fwd(e["c1"], cur, act=ACT_RELU)
+                o2 = _fwd(e["c2"], o1, act=ACT_RELU)
                 idt = cur if e["ds"] is None else _fwd(e["ds"], cur)
-                out = _fwd(e["c3"], o2, act=ACT_RELU, res=idt, tag=("b", si, bi, 3))
+                out = _fwd(e["c3"], o2, act=ACT_RELU, res=idt)
                 if save:
                     srec.append((cur[:na], o1[:na], o2[:na], out[:na]))
                 cur = out
@@ -340,7 +327,7 @@ class BackboneWithFPN(nn.Module):
         outs = _fwd_many(P["layer"], inner)
         if self.p6p7:
             p6 = _fwd(P["p6"], outs[L - 1])
-            extra = [p6, _fwd(P["p7"], _tap(("p7in",), torch.relu(p6)))]
+            extra = [p6, _fwd(P["p7"], torch.relu(p6))]
         else:
             extra = [ops.subsample2(outs[L - 1])]
         if save:
@@ -696,7 +683,7 @@ class _RPNHeadFn(torch.autograd.Function):
         feats = feats[:nlev]
         P = head.pack()
         nl = len(feats)
-        tfull = _fwd_many([P["conv"]] * nl, feats, act=ACT_RELU, tags=[("rpn", li) for li in range(nl)])
+        tfull = _fwd_many([P["conv"]] * nl, feats, act=ACT_RELU)
         ts = [t[:n_active] for t in tfull]
         heads = _fwd_many([P["cls"]] * nl + [P["box"]] * nl, list(tfull) + list(tfull), f32="nhwc")      # 2 x levels 1x1 convs, one grid
         outs = []
@@ -963,8 +950,8 @@ class _MLPFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, head):
         P = head.pack()
-        h6 = _fwd(P["fc6"], x, act=ACT_RELU, tag=("fc6",))
-        h7 = _fwd(P["fc7"], h6, act=ACT_RELU, tag=("fc7",))
+        h6 = _fwd(P["fc6"], x, act=ACT_RELU)
+        h7 = _fwd(P["fc7"], h6, act=ACT_RELU)
         ctx.head, ctx.h6, ctx.h7, ctx.xshape = head, h6, h7, tuple(x.shape)
         ctx.x = x if head.train_params else None
         ctx.need_dx = x.requires_grad

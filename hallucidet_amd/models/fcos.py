@@ -72,7 +72,6 @@ class _HeadFn(torch.autograd.Function):
                 j, li = (0, idx) if idx < nl else (1, idx - nl)
                 ga, be, eps = (P["cls_tower"] if j == 0 else P["reg_tower"])[k][1]
                 z, stat = ops.groupnorm8_relu(c, ga, be, eps)
-                D._tap(("cls" if j == 0 else "reg", li, k), z)
                 saved[li][j].append((cur[idx][:n_active], c[:n_active], z[:n_active], stat[:n_active]))
                 nxt.append(z)
             cur = nxt
@@ -201,8 +200,6 @@ class FCOSHead(nn.Module):
         acts = D._active_views(feats, na) if na < feats[0].shape[0] else None
         outs = _HeadFn.apply(self._hook, self, na, len(feats), *feats, *(acts or ()))
         K = self.classification_head.cls_logits.out_channels // self.classification_head.num_anchors
-        for li, r in enumerate(outs[1::3]):
-            D._tap(("reg_out", li), r)
 
         def flat(t, k):
             N, _, H, W = t.shape

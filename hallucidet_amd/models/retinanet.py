@@ -45,8 +45,7 @@ class _HeadFn(torch.autograd.Function):
         cur = list(feats) + list(feats)
         saved = [[[], []] for _ in range(nl)]
         for k in range(4):
-            cur = D._fwd_many([P["cls_tower"][k]] * nl + [P["reg_tower"][k]] * nl, cur, act=ACT_RELU,
-                              tags=[("cls", li, k) for li in range(nl)] + [("reg", li, k) for li in range(nl)])
+            cur = D._fwd_many([P["cls_tower"][k]] * nl + [P["reg_tower"][k]] * nl, cur, act=ACT_RELU)
             for li in range(nl):
                 saved[li][0].append(cur[li][:n_active])
                 saved[li][1].append(cur[nl + li][:n_active])

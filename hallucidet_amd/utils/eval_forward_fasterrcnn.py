@@ -12,13 +12,12 @@ from ..models.detection import concat_box_prediction_layers, fastrcnn_loss
 
 
 def _check_targets(targets):
-    for target in targets:
-        boxes = target["boxes"]
-        if isinstance(boxes, torch.Tensor):
-            torch._assert(len(boxes.shape) == 2 and boxes.shape[-1] == 4,
-                          f"Expected target boxes to be a tensor of shape [N, 4], got {boxes.shape}.")
-        else:
-            torch._assert(False, f"Expected target boxes to be of type Tensor, got {type(boxes)}.")
+    """Shape / type test of the target boxes with the reference's messages (:24-31)."""
+    for t in targets:
+        b = t["boxes"]
+        if not isinstance(b, torch.Tensor):
+            torch._assert(False, f"Expected target boxes to be of type Tensor, got {type(b)}.")
+        torch._assert(b.dim() == 2 and b.shape[-1] == 4, f"Expected target boxes to be a tensor of shape [N, 4], got {b.shape}.")
 
 
 def _degenerate_flag(targets):
@@ -105,17 +104,18 @@ def _raise_if_degenerate(flag, targets):
 
 
 def _check_degenerate(targets):
-    # one fused check (single host sync) instead of one `.any()` per image (reference :41-53)
+    """One fused test (a single host sync) instead of one `.any()` per image; on a hit, the reference's message (:41-53) for the first
+    offending box."""
     allb = torch.cat([t["boxes"] for t in targets], dim=0)
-    if allb.numel() and bool((allb[:, 2:] <= allb[:, :2]).any()):
-        for target_idx, target in enumerate(targets):
-            boxes = target["boxes"]
-            degenerate_boxes = boxes[:, 2:] <= boxes[:, :2]
-            if degenerate_boxes.any():
-                bb_idx = torch.where(degenerate_boxes.any(dim=1))[0][0]
-                degen_bb: List[float] = boxes[bb_idx].tolist()
-                torch._assert(False, "All bounding boxes should have positive height and width."
-                              f" Found invalid box {degen_bb} for target at index {target_idx}.")
+    if not (allb.numel() and bool((allb[:, 2:] <= allb[:, :2]).any())):
+        return
+    for ti, t in enumerate(targets):
+        bad = (t["boxes"][:, 2:] <= t["boxes"][:, :2]).any(dim=1)
+        if bad.any():
+            box = t["boxes"][torch.where(bad)[0][0]].tolist()
+            torch._assert(False, "All bounding boxes should have positive height and width."
+                          f" Found invalid box {box} for target at index {ti}.")
+
 
 
 class _ImageSlice:
@@ -170,10 +170,7 @@ def eval_forward_fasterrcnn_multi(model, image_batches, target_lists, model_name
                 proposals, proposal_losses = rpn_eval(model, il_k, f_k, t_k, head_out=(o_k, d_k))
                 detections, detector_losses = roi_heads_eval(model, f_k, proposals, il_k.image_sizes, t_k)
             detections = model.transform.postprocess(detections, il_k.image_sizes, sizes[k])
-        losses = {}
-        losses.update(detector_losses)
-        losses.update(proposal_losses)
-        out.append((losses, detections))
+        out.append(({**detector_losses, **proposal_losses}, detections))
         lo = hi
     return out
 
@@ -186,11 +183,7 @@ def _multi_fused(model, il, targets, nb, sizes, need_grad):
     from ..models import detection as D
     n0 = nb[0]
     flag = _degenerate_flag(targets)
-    for t in targets:
-        if not t["boxes"].dtype in (torch.float, torch.double, torch.half):
-            raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
-        if not t["labels"].dtype == torch.int64:
-            raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
+    _target_dtypes(targets)
     dev = il.tensors.device
     gt, glab, gvalid = D.pad_targets(targets, dev)
     shape = il.image_sizes[0]
@@ -285,7 +278,17 @@ def _scale_tensor(rw, rh, like):
     return t
 
 
+def _target_dtypes(targets):
+    for t in targets:
+        if not t["boxes"].dtype in (torch.float, torch.double, torch.half):
+            raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
+        if not t["labels"].dtype == torch.int64:
+            raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
+
+
 def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name='fasterrcnn'):
+    """One detector pass that returns the training losses AND the detections (reference :13-68; the error texts are the reference's).
+    `model.batched_heads` (default) runs the two stages in padded, batched form (`_heads_batched`); otherwise the list forms below."""
     if train_det:
         # train_detector.py:159 -- the module's mode is left as the caller set it (Lightning: train()); parameter
         # gradients need FasterRCNN.set_trainable(True) (DetectorLit does it), otherwise nothing would be learned
@@ -294,52 +297,25 @@ def eval_forward_fasterrcnn(model, images, targets, train_det=False, model_name=
                                "hallucidet_amd.train_detector.DetectorLit); the frozen-detector kernels emit data gradients only")
     else:
         model.eval()
-
-    for target in targets:
-        boxes = target["boxes"]
-        if isinstance(boxes, torch.Tensor):
-            torch._assert(len(boxes.shape) == 2 and boxes.shape[-1] == 4,
-                          f"Expected target boxes to be a tensor of shape [N, 4], got {boxes.shape}.")
-        else:
-            torch._assert(False, f"Expected target boxes to be of type Tensor, got {type(boxes)}.")
-
-    original_image_sizes: List[Tuple[int, int]] = []
+    _check_targets(targets)
+    sizes_in = []
     for img in images:
-        val = img.shape[-2:]
-        torch._assert(len(val) == 2, f"expecting the last two dimensions of the Tensor to be H and W instead got {img.shape[-2:]}")
-        original_image_sizes.append((val[0], val[1]))
-
+        hw = img.shape[-2:]
+        torch._assert(len(hw) == 2, f"expecting the last two dimensions of the Tensor to be H and W instead got {img.shape[-2:]}")
+        sizes_in.append((hw[0], hw[1]))
     images, targets = model.transform(images, targets)
-
     if targets is not None:
-        # one fused check (single host sync) instead of one `.any()` per image (:41-53)
-        allb = torch.cat([t["boxes"] for t in targets], dim=0)
-        if allb.numel() and bool((allb[:, 2:] <= allb[:, :2]).any()):
-            for target_idx, target in enumerate(targets):
-                boxes = target["boxes"]
-                degenerate_boxes = boxes[:, 2:] <= boxes[:, :2]
-                if degenerate_boxes.any():
-                    bb_idx = torch.where(degenerate_boxes.any(dim=1))[0][0]
-                    degen_bb: List[float] = boxes[bb_idx].tolist()
-                    torch._assert(False, "All bounding boxes should have positive height and width."
-                                  f" Found invalid box {degen_bb} for target at index {target_idx}.")
-
+        _check_degenerate(targets)               # (:41-53) one fused test, the reference's message
     features = model.backbone(images.tensors)
     if isinstance(features, torch.Tensor):
         features = OrderedDict([("0", features)])
-
     if getattr(model, "batched_heads", False):
-        objectness, deltas = model.rpn.head(list(features.values()))
-        proposal_losses, detector_losses, detections = _heads_batched(model, images, features, objectness, deltas, targets)
+        rpn_losses, roi_losses, detections = _heads_batched(model, images, features, *model.rpn.head(list(features.values())), targets)
     else:
-        proposals, proposal_losses = rpn_eval(model, images, features, targets)
-        detections, detector_losses = roi_heads_eval(model, features, proposals, images.image_sizes, targets)
-    detections = model.transform.postprocess(detections, images.image_sizes, original_image_sizes)
-
-    losses = {}
-    losses.update(detector_losses)
-    losses.update(proposal_losses)
-    return losses, detections
+        proposals, rpn_losses = rpn_eval(model, images, features, targets)
+        detections, roi_losses = roi_heads_eval(model, features, proposals, images.image_sizes, targets)
+    detections = model.transform.postprocess(detections, images.image_sizes, sizes_in)
+    return {**roi_losses, **rpn_losses}, detections
 
 
 def _heads_batched(model, images, features, objectness, deltas, targets):
@@ -348,83 +324,56 @@ def _heads_batched(model, images, features, objectness, deltas, targets):
     from ..models import detection as D
     feats = list(features.values())
     anchors = model.rpn.anchor_generator(images, feats)
-    n_img = len(anchors)
-    napl = [o[0].shape[0] * o[0].shape[1] * o[0].shape[2] for o in objectness]
+    napl = [o[0].numel() for o in objectness]
     obj, dl = concat_box_prediction_layers(objectness, deltas)
     shape = images.image_sizes[0]
     pb, _, pc = D.filter_proposals_padded(model.rpn, None, obj, shape, napl, deltas=dl, anchors0=anchors[0])
-    D._tap(("proposals",), (pb, pc))
     if targets is None:
         raise ValueError("targets should not be None")
-    for t in targets:
-        if not t["boxes"].dtype in (torch.float, torch.double, torch.half):
-            raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
-        if not t["labels"].dtype == torch.int64:
-            raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
+    _target_dtypes(targets)
     gt, glab, gvalid = D.pad_targets(targets, obj.device)
     loss_objectness, loss_rpn_box_reg = D.rpn_targets_loss_batched(model.rpn, anchors[0], gt, gvalid, obj, dl)
-    rois, labels, reg_t, per = D.select_training_samples_batched(model.roi_heads, pb, pc, gt, glab, gvalid)
-    box_features = D.roi_pool_rois(model.roi_heads.box_roi_pool, features, rois, shape)
-    box_features = model.roi_heads.box_head(box_features)
-    class_logits, box_regression = model.roi_heads.box_predictor(box_features)
+    rh = model.roi_heads
+    rois, labels, reg_t, per = D.select_training_samples_batched(rh, pb, pc, gt, glab, gvalid)
+    class_logits, box_regression = rh.box_predictor(rh.box_head(D.roi_pool_rois(rh.box_roi_pool, features, rois, shape)))
     loss_classifier, loss_box_reg = D.fastrcnn_loss_flat(class_logits, box_regression, labels, reg_t)
-    sb, ss, sl, counts = D.postprocess_detections_flat(model.roi_heads, class_logits, box_regression, rois, per, shape)
+    sb, ss, sl, counts = D.postprocess_detections_flat(rh, class_logits, box_regression, rois, per, shape)
     dets = [{"boxes": sb[i, :c], "labels": sl[i, :c], "scores": ss[i, :c]} for i, c in enumerate(counts.tolist())]
     return ({"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg},
             {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg}, dets)
 
 
 def rpn_eval(model, images, features, targets, head_out=None):
-    features = list(features.values())
-    objectness, pred_bbox_deltas = model.rpn.head(features) if head_out is None else head_out
-    anchors = model.rpn.anchor_generator(images, features)
-
-    num_images = len(anchors)
-    num_anchors_per_level_shape_tensors = [o[0].shape for o in objectness]
-    num_anchors_per_level = [s[0] * s[1] * s[2] for s in num_anchors_per_level_shape_tensors]
-    objectness, pred_bbox_deltas = concat_box_prediction_layers(objectness, pred_bbox_deltas)
-    proposals = model.rpn.box_coder.decode(pred_bbox_deltas.detach(), anchors)
-    proposals = proposals.view(num_images, -1, 4)
-    boxes, scores = model.rpn.filter_proposals(proposals, objectness, images.image_sizes, num_anchors_per_level)
-    from ..models.detection import _tap
-    _tap(("proposals",), boxes)
-
+    """List form of the RPN stage (reference :72-102) over the module's torchvision-named methods: proposals and the two RPN losses."""
+    rpn = model.rpn
+    feats = list(features.values())
+    obj_l, dl_l = rpn.head(feats) if head_out is None else head_out
+    anchors = rpn.anchor_generator(images, feats)
+    per_level = [o[0].numel() for o in obj_l]
+    obj, dl = concat_box_prediction_layers(obj_l, dl_l)
+    decoded = rpn.box_coder.decode(dl.detach(), anchors).view(len(anchors), -1, 4)
+    boxes, _ = rpn.filter_proposals(decoded, obj, images.image_sizes, per_level)
     if targets is None:
         raise ValueError("targets should not be None")
-    labels, matched_gt_boxes = model.rpn.assign_targets_to_anchors(anchors, targets)
-    regression_targets = model.rpn.box_coder.encode(matched_gt_boxes, anchors)
-    loss_objectness, loss_rpn_box_reg = model.rpn.compute_loss(objectness, pred_bbox_deltas, labels, regression_targets)
-    losses = {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
-    return boxes, losses
+    labels, matched = rpn.assign_targets_to_anchors(anchors, targets)
+    l_obj, l_reg = rpn.compute_loss(obj, dl, labels, rpn.box_coder.encode(matched, anchors))
+    return boxes, {"loss_objectness": l_obj, "loss_rpn_box_reg": l_reg}
 
 
 def roi_heads_eval(model, features, proposals, image_shapes, targets=None, train_det=False):
+    """List form of the RoI stage (reference :105-185): the training sampler also runs at evaluation time, the box head
+    sees the SAMPLED proposals, and those are what is post-processed into detections."""
+    rh = model.roi_heads
     if targets is not None:
-        for t in targets:
-            floating_point_types = (torch.float, torch.double, torch.half)
-            if not t["boxes"].dtype in floating_point_types:
-                raise TypeError(f"target boxes must of float type, instead got {t['boxes'].dtype}")
-            if not t["labels"].dtype == torch.int64:
-                raise TypeError(f"target labels must of int64 type, instead got {t['labels'].dtype}")
-
-    proposals, matched_idxs, labels, regression_targets = model.roi_heads.select_training_samples(proposals, targets)
-
-    box_features = model.roi_heads.box_roi_pool(features, proposals, image_shapes)
-    box_features = model.roi_heads.box_head(box_features)
-    class_logits, box_regression = model.roi_heads.box_predictor(box_features)
-
-    result: List[Dict[str, torch.Tensor]] = []
+        _target_dtypes(targets)
+    proposals, _, labels, reg_targets = rh.select_training_samples(proposals, targets)
+    logits, regression = rh.box_predictor(rh.box_head(rh.box_roi_pool(features, proposals, image_shapes)))
     if labels is None:
         raise ValueError("labels cannot be None")
-    if regression_targets is None:
+    if reg_targets is None:
         raise ValueError("regression_targets cannot be None")
-    loss_classifier, loss_box_reg = fastrcnn_loss(class_logits, box_regression, labels, regression_targets)
-    losses = {"loss_classifier": loss_classifier, "loss_box_reg": loss_box_reg}
-
-    boxes, scores, labels = model.roi_heads.postprocess_detections(class_logits, box_regression, proposals, image_shapes)
-    for i in range(len(boxes)):
-        result.append({"boxes": boxes[i], "labels": labels[i], "scores": scores[i]})
-
-    if model.roi_heads.has_keypoint():
+    l_cls, l_box = fastrcnn_loss(logits, regression, labels, reg_targets)
+    b, sc, lb = rh.postprocess_detections(logits, regression, proposals, image_shapes)
+    if rh.has_keypoint():
         raise NotImplementedError("keypoint branch is dead code for fasterrcnn_resnet50_fpn (SURVEY #7)")
-    return result, losses
+    return [{"boxes": x, "labels": y, "scores": z} for x, y, z in zip(b, lb, sc)], {"loss_classifier": l_cls, "loss_box_reg": l_box}

@@ -48,8 +48,8 @@ class Pins:
     oracle's own, largest |own pre-activation| (ReLU) or value gap between the two winners (max-pool) among those, RMS of the layer's
     pre-activation, sigma / dmax = RMS / largest difference between the recorded activation and the oracle's own over the elements both
     sides pass -- the measured noise of that layer, None without `values`)`; for pinned proposals `audit[("proposals", image)] = (pinned
-    boxes, boxes of the oracle's own post-NMS set, pinned boxes that coincide (IoU >= 0.9) with one of the oracle's own CANDIDATES -- every
-    anchor decoded with the oracle's own deltas and clipped, before any score-driven selection)`.
+    boxes, boxes of the oracle's own post-NMS set, pinned boxes that coincide at IoU >= 0.9 / 0.7 / 0.5 with one of the oracle's own
+    CANDIDATES -- every anchor decoded with the oracle's own deltas and clipped, before any score-driven selection)`.
     tests/_pins.py::assert_borrowed_decisions_are_noise turns the audit into assertions -- a systematically wrong mask in the
     product would otherwise be copied into the oracle and pass."""
 
@@ -508,10 +508,12 @@ class RegionProposalNetwork(nn.Module):
                     self.pinned_proposals = pinned
                 for i, (pb, ob) in enumerate(zip(fb, own)):
                     cand = clip_boxes_to_image(proposals[i].detach().reshape(-1, 4), image_shapes[i])
-                    hit = 0
+                    hit = [0, 0, 0]
                     for lo in range(0, pb.shape[0], 256):               # [256, A] IoU blocks
-                        hit += int((ok.box_iou(pb[lo:lo + 256], cand).max(dim=1).values >= 0.9).sum())
-                    self.pins_audit[("proposals", i)] = (pb.shape[0], ob.shape[0], hit)
+                        best = ok.box_iou(pb[lo:lo + 256], cand).max(dim=1).values
+                        for j, thr in enumerate((0.9, 0.7, 0.5)):
+                            hit[j] += int((best >= thr).sum())
+                    self.pins_audit[("proposals", i)] = (pb.shape[0], ob.shape[0], hit[0], hit[1], hit[2])
             return fb, [torch.zeros(b.shape[0]) for b in fb]
         n_img = proposals.shape[0]
         objectness = objectness.detach().reshape(n_img, -1)

@@ -17,23 +17,151 @@ class _FirstWins(dict):
             super().__setitem__(k, v)
 
 
-class record:
-    """`with record() as r: <product forward>`; afterwards `r.pins()` builds the oracle-side object.  `first=True` keeps the
-    FIRST tensor recorded under a tag (a training step runs the detector three times; only the first, hallucinated, pass
-    carries a gradient)."""
+class _OpsProxy:
+    """Stands in for the `ops` module inside ONE product module for the duration of a recording: chosen functions report their
+    results, everything else passes through."""
 
-    def __init__(self, first=False):
+    def __init__(self, real, **wrapped):
+        self._real, self._wrapped = real, wrapped
+
+    def __getattr__(self, name):
+        return self._wrapped.get(name) or getattr(self._real, name)
+
+
+class record:
+    """`with record(detector) as r: <product forward>`; afterwards `r.pins()` builds the oracle-side object.  `first=True` keeps the
+    FIRST tensor recorded under a tag (a training step runs the detector three times; only the first, hallucinated, pass carries a
+    gradient).
+
+    The product carries NO test hook.  The recording is done from here: for the duration of the `with` block the module-level helpers
+    every detector convolution goes through (`models.detection._fwd` / `_fwd_many`), the batched proposal filter, and the `ops` name
+    of the detection / FCOS modules are wrapped; a call is recognised by the IDENTITY of the packed-weight entry it is given (the
+    detector's `pack()` dictionaries are walked to label them: stem, bottleneck (stage, block, conv), RPN head per level, fc6 / fc7,
+    the RetinaNet / FCOS tower layers), and the post-ReLU output (or the pool's winner bytes, the post-NMS proposals) is stored under
+    the tag the oracle's `Pins.relu(tag, .)` asks for."""
+
+    def __init__(self, model=None, first=False):
+        self.model = model
         self.tap = _FirstWins() if first else {}
+        self._tags = {}
+        self._fcos_tower_ids, self._fcos_nl = set(), 5
+
+    # ---- labels of the packed entries ------------------------------------------------------------------------------------------
+    def _label(self):
+        m, tags = self.model, {}
+        if m is None:
+            return tags
+        bb = getattr(m, "backbone", None)
+        if bb is not None and getattr(bb, "_pack", None) is not None:
+            P = bb._pack
+            tags[id(P["stem"])] = ("stem",)
+            for si, stage in enumerate(P["blocks"]):
+                for bi, e in enumerate(stage):
+                    for k, name in ((1, "c1"), (2, "c2"), (3, "c3")):
+                        tags[id(e[name])] = ("b", si, bi, k)
+            if "p7" in P:
+                tags[id(P["p7"])] = ("p7in", "input")              # the ReLU in front of P7: its input is what is recorded
+        rpn = getattr(m, "rpn", None)
+        if rpn is not None and getattr(rpn.head, "_pack", None) is not None:
+            tags[id(rpn.head._pack["conv"])] = ("rpn", "level")
+        rh = getattr(m, "roi_heads", None)
+        if rh is not None and getattr(rh.box_head, "_pack", None) is not None:
+            tags[id(rh.box_head._pack["fc6"])] = ("fc6",)
+            tags[id(rh.box_head._pack["fc7"])] = ("fc7",)
+        head = getattr(m, "head", None)
+        if head is not None and getattr(head, "_pack", None) is not None:
+            P = head._pack
+            for key, name in (("cls_tower", "cls"), ("reg_tower", "reg")):
+                for k, e in enumerate(P.get(key, [])):
+                    if isinstance(e, dict):                          # RetinaNet: conv + ReLU per tower layer (FCOS: GroupNorm, see below)
+                        tags[id(e)] = (name, "level", k)
+            if isinstance(P.get("cls_tower", [None])[0], tuple):     # FCOS: bbox_reg output (its ReLU comes after)
+                tags[id(P["reg_out"])] = ("reg_out", "level")
+                self._fcos_tower_ids = {id(t[0]) for t in P["cls_tower"]}
+        return tags
+
+    def _tag(self, e):
+        t = self._tags.get(id(e))
+        if t is None:
+            self._tags = self._label()
+            t = self._tags.get(id(e))
+        return t
+
+    def _put(self, tag, t, li=None):
+        if tag is None:
+            return
+        tag = tuple(li if x == "level" else x for x in tag)
+        self.tap[tag] = t
 
     def __enter__(self):
         from hallucidet_amd.models import detection as D
-        assert D._TAP is None
-        D._TAP = self.tap
+        from hallucidet_amd.models import fcos as F
+        from hallucidet_amd.utils import eval_forward_fasterrcnn as G
+        self._saved = (D._fwd, D._fwd_many, D.filter_proposals_padded, D.ops, F.ops, D.RegionProposalNetwork.filter_proposals)
+        o_fwd, o_many, o_filter, o_ops, f_ops, o_list_filter = self._saved
+        rec = self
+
+        def fwd(e, x, **kw):
+            out = o_fwd(e, x, **kw)
+            tag = rec._tag(e)
+            if tag is not None:
+                if tag[-1] == "input":
+                    rec._put(tag[:-1], x)
+                else:
+                    rec._put(tag, out)
+            return out
+
+        def many(es, xs, **kw):
+            outs = o_many(es, xs, **kw)
+            tagged = [rec._tag(e) for e in es]
+            if id(es[0]) in rec._fcos_tower_ids:
+                rec._fcos_nl = len(es) // 2
+            # the same layer on every feature level: the level index is the position among the calls with that entry
+            seen = {}
+            for e, tag, o in zip(es, tagged, outs):
+                if tag is not None:
+                    li = seen.get(id(e), 0)
+                    seen[id(e)] = li + 1
+                    rec._put(tag, o, li)
+            return outs
+
+        def filt(*a, **k):
+            out = o_filter(*a, **k)
+            rec.tap[("proposals",)] = (out[0], out[2])
+            return out
+
+        def list_filt(self_, *a, **k):
+            boxes, scores = o_list_filter(self_, *a, **k)
+            rec.tap[("proposals",)] = boxes
+            return boxes, scores
+
+        def pool(x):
+            y, idx = o_ops.maxpool3x3s2_idx(x)
+            rec.tap[("pool",)] = idx
+            return y, idx
+
+        gn_calls = [0]
+
+        def gn(x, ga, be, eps=1e-5, **kw):
+            # FCOS tower: layer k, then cls levels 0..L-1, then reg levels 0..L-1 (models/fcos.py: _HeadFn.forward)
+            z, stat = f_ops.groupnorm8_relu(x, ga, be, eps, **kw)
+            nl = rec._fcos_nl
+            c = gn_calls[0] % (8 * nl)
+            gn_calls[0] += 1
+            k, idx = divmod(c, 2 * nl)
+            rec.tap[("cls" if idx < nl else "reg", idx % nl, k)] = z
+            return z, stat
+
+        D._fwd, D._fwd_many, D.filter_proposals_padded = fwd, many, filt
+        D.RegionProposalNetwork.filter_proposals = list_filt
+        D.ops = _OpsProxy(o_ops, maxpool3x3s2_idx=pool)
+        F.ops = _OpsProxy(f_ops, groupnorm8_relu=gn)
         return self
 
     def __exit__(self, *exc):
         from hallucidet_amd.models import detection as D
-        D._TAP = None
+        from hallucidet_amd.models import fcos as F
+        D._fwd, D._fwd_many, D.filter_proposals_padded, D.ops, F.ops, D.RegionProposalNetwork.filter_proposals = self._saved
         return False
 
     def pins(self, proposals=None, n_images=None):
@@ -74,12 +202,14 @@ class record:
 #   * share: at most SHARE_K * sigma / RMS of a layer's elements differ (the mass of a unit-scale density inside a band of width
 #     sigma; measured 0.3 - 0.75 in fp16 storage; in fp32 storage a layer has a handful of flips and the ratio is a small-count
 #     statistic: SHARE_FLOOR of the elements is always allowed), never more than MAX_FLIP_SHARE;
-#   * proposals: at least MIN_PROPOSAL_MATCH of the borrowed post-NMS boxes coincide (IoU >= 0.9) with a box of the oracle's own
-#     candidate set (every anchor decoded with the oracle's deltas, clipped) -- WHICH candidates survive top-k / NMS is decided by
-#     near-ties of a randomly initialised RPN and is what the pin is for; that the boxes ARE the oracle's boxes is checked here.
+#   * proposals: at least MIN_PROPOSAL_MATCH of the borrowed post-NMS boxes coincide (IoU >= 0.5; reported at 0.9 / 0.7 / 0.5) with a box
+#     of the oracle's own candidate set (every anchor decoded with the oracle's deltas, clipped) -- WHICH candidates survive top-k / NMS
+#     is decided by near-ties of a randomly initialised RPN and is what the pin is for; that the boxes ARE the oracle's boxes is
+#     checked here.  (fp32 storage: 100 % at IoU 0.9.  fp16 storage end to end: 70 - 88 % at 0.9, 99.5 - 100 % at 0.5 -- the regression
+#     deltas carry the fp16 noise of the trunk and a pixel's shift of a five-pixel box is already IoU 0.7.)
 # One set of constants for every pinned test, set from the worst cases over the whole -m gpu suite (HD_PINS_AUDIT=1 prints every
-# layer; HD_PINS_MEASURE=1 reports without asserting) with a margin of about two.
-NOISE_C = 2.0
+# layer; HD_PINS_MEASURE=1 reports without asserting) with a margin of about two (largest seen: 2.24 dmax on a 6 000-element layer, 0.75 sigma / RMS).
+NOISE_C = 4.0
 SHARE_K = 2.0
 SHARE_FLOOR = 2e-4
 MAX_FLIP_SHARE = 0.10
@@ -98,9 +228,9 @@ def assert_borrowed_decisions_are_noise(holder, label=""):
     stem_dmax = stem_sigma = None
     for tag, rec in audit.items():
         if isinstance(tag, tuple) and tag and tag[0] == "proposals":
-            pinned, own, hit = rec
-            prop.append((pinned, own, hit))
-            if pinned and hit < MIN_PROPOSAL_MATCH * pinned:
+            pinned, own, hit = rec[0], rec[1], rec[2:]
+            prop.append((pinned, own) + tuple(hit))
+            if pinned and hit[-1] < MIN_PROPOSAL_MATCH * pinned:
                 problems.append(("proposals", tag, rec))
             continue
         n, nf, big, rms, sigma, dmax = rec
@@ -127,7 +257,8 @@ def assert_borrowed_decisions_are_noise(holder, label=""):
             problems.append((tag, "share %.5f (%.2f sigma/RMS)" % (share, sratio), "worst %.2f dmax" % kmax))
     summary = "borrowed decisions %s: %d audited, worst share %.4f %% = %.2f sigma/RMS, worst |x| %.2f dmax (%s; %.1f sigma)%s" % (
         label, len(audit), 100 * worst["share"], worst["sratio"], worst["kmax"], worst["tag"], worst["ksig"],
-        "" if not prop else ", proposals among the oracle's candidates %d / %d" % (sum(p[2] for p in prop), sum(p[0] for p in prop)))
+        "" if not prop else ", proposals among the oracle's candidates at IoU 0.9 / 0.7 / 0.5: %d / %d / %d of %d" % (
+            sum(p[2] for p in prop), sum(p[3] for p in prop), sum(p[4] for p in prop), sum(p[0] for p in prop)))
     print(summary)
     assert measure or not problems, "borrowed decisions outside the noise band: %s" % problems[:8]
     return summary

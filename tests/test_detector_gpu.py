@@ -304,7 +304,7 @@ def test_detector_image_gradient_matches_oracle(dev, case):
         xy = torch.rand(30, 2, generator=g) * 200
         wh = torch.rand(30, 2, generator=g) * torch.tensor([90.0, 90.0]) + 8
         props.append(torch.cat([xy, xy + wh], 1))
-    with record() as rec:
+    with record(det) as rec:
         il, _ = det.transform(x, None)
         f = det.backbone(il.tensors)
         obj, reg = det.rpn.head(list(f.values()))
@@ -357,7 +357,7 @@ def test_detector_image_gradient_per_branch(dev, case, branch):
         xy = torch.rand(40, 2, generator=g) * 150
         wh = torch.rand(40, 2, generator=g) * torch.tensor([140.0, 140.0]) + 6
         props.append(torch.cat([xy, (xy + wh).clamp(max=299.0)], 1))
-    with record() as rec:
+    with record(det) as rec:
         il, _ = det.transform(x, None)
         f = det.backbone(il.tensors)
         if branch == "box":

@@ -242,7 +242,7 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
     from _pins import record, grad_agreement
     det, oracle, images, targets = case
     x = images.to(dev).requires_grad_(True)
-    with record() as rec:
+    with record(det) as rec:
         losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="fcos")
     assert set(losses) == {"classification", "bbox_regression", "bbox_ctrness"}
     (losses["classification"] + losses["bbox_regression"] + losses["bbox_ctrness"]).backward()
@@ -365,7 +365,7 @@ def test_fcos_parameter_gradients_and_fit_step(dev):
     arena = ParamArena(det.trainable_parameters())
     det.invalidate_packs()
     from _pins import record
-    with record() as rec:
+    with record(det) as rec:
         feats = list(det.backbone(il.tensors).values())
         ho = det.head(feats)
     g = torch.Generator().manual_seed(6)

@@ -240,7 +240,7 @@ def test_training_step_fp32_matches_plain_oracle(dev, detector_name, seed, shape
     problems = []
 
     # ---- product: the forward pass (recording its decisions for tier 2), then one whole training step from the same weights
-    with record(first=True) as rec:
+    with record(lit.detector, first=True) as rec:
         out = lit.forward_step(*batch, 0, step="train")
     pins = rec.pins(n_images=N)
     umasks, uvalues = unet_decisions(lit.encoder_decoder.runner)

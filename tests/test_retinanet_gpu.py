@@ -154,7 +154,7 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
     from _pins import record, grad_agreement
     det, oracle, images, targets = case
     x = images.to(dev).requires_grad_(True)
-    with record() as rec:
+    with record(det) as rec:
         losses, dets = Detector.calculate_loss(det, x, _t2d(targets, dev), train_det=False, model_name="retinanet")
     assert set(losses) == {"classification", "bbox_regression"}
     (losses["classification"] + losses["bbox_regression"]).backward()

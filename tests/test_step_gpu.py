@@ -133,7 +133,7 @@ def test_training_step_matches_oracle(dev, detector_name, seed, shape):
     # ---- product: forward (recording its decisions), then the whole optimisation step from the same weights
     lit.encoder_decoder.train()
     tr.unet.train()
-    with record(first=True) as rec:
+    with record(lit.detector, first=True) as rec:
         out = lit.forward_step(*batch, 0, step="train")
     assert set(out["loss"]) == {"total", "pixel_rgb", "perceptual_rgb", "pixel_ir", "perceptual_ir", "det_regression",
                                 "det_classification", "det_objectness", "det_rpn_box_reg", "det_bbox_ctrness", "det_total"}
@@ -371,7 +371,7 @@ def test_eval_step_batch_one_full_size_matches_oracle(dev):
     cbatch = _to_cpu(batch)
     from _pins import record
     with torch.no_grad():
-        with record(first=True) as rec:          # the hallucinated pass's discrete decisions: ReLU signs, max-pool winners, post-NMS proposals
+        with record(lit.detector, first=True) as rec:          # the hallucinated pass's discrete decisions: ReLU signs, max-pool winners, post-NMS proposals
             out = lit.forward_step(*batch, 0, step="test")
         pins = rec.pins(n_images=1)
         hall = out["output"]["imgs_hallucinated"].float().cpu()

@@ -78,7 +78,7 @@ def _check_parameter_gradients(dev, case):
         xy = torch.rand(40, 2, generator=g) * 200
         wh = torch.rand(40, 2, generator=g) * torch.tensor([90.0, 90.0]) + 8
         props.append(torch.cat([xy, xy + wh], 1))
-    with record() as rec:
+    with record(det) as rec:
         il, _ = det.transform(images.to(dev), None)
         f = det.backbone(il.tensors)
         obj, reg = det.rpn.head(list(f.values()))
@@ -221,7 +221,7 @@ def test_retinanet_parameter_gradients_and_fit_step(dev):
     arena = ParamArena(det.trainable_parameters())
     det.invalidate_packs()
     from _pins import record
-    with record() as rec:
+    with record(det) as rec:
         feats = list(det.backbone(il.tensors).values())
         ho = det.head(feats)
     g = torch.Generator().manual_seed(6)
