@@ -407,7 +407,12 @@ def main():
                     help="retinanet16 = BASELINE configs[3] (train_hallucidet, RetinaNet, batch 16/GPU); detector16 = configs[4] "
                          "(train_detector.py, Faster R-CNN, RGB, batch 16/GPU).  Not the headline metric: their own JSON lines")
     ap.add_argument("--cpu-protocol", default="bounded", choices=["bounded", "full"])
+    ap.add_argument("--precision", type=int, default=16, choices=[16, 32],
+                    help="16 = BASELINE configs[1] (the headline); 32 = the reference's default --precision 32: fp32 storage and VALU "
+                         "arithmetic end to end (the parity mode, untuned).  Its own JSON line, without the fp16 roofline")
     args = ap.parse_args()
+    if args.precision == 32:
+        args.no_roofline = True
     global BATCH_PER_GPU
     if args.config == "retinanet16":
         args.detector, args.batch = "retinanet", args.batch or 16
@@ -450,7 +455,7 @@ def main():
     dev = "cuda:%d" % local
     if args.config == "detector16":
         return bench_detector_training(args, dev, rank, world)
-    lit = synthetic.make_module(seed=123, device=dev, precision=16, detector_name=args.detector)
+    lit = synthetic.make_module(seed=123, device=dev, precision=args.precision, detector_name=args.detector)
     batch = synthetic.make_batch(BATCH_PER_GPU, H, W, seed=123 + rank, device=dev)   # per-rank shard, resident in HBM
 
     overlap_note = None
@@ -536,8 +541,9 @@ def main():
             "metric": "images/sec train_hallucidet (640x512, batch 8/GPU)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": ("train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
+            "vs_baseline": None, "dtype": "f16" if args.precision == 16 else "f32", "data": "synthetic",
+            "config": {"workload": ("" if args.precision == 16 else "--precision 32 (fp32 storage, NOT the headline configuration) of: ") +
+                                   ("train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "
                                     "U-Net resnet34 fwd+bwd, 3 frozen Faster R-CNN R50-FPN passes @300x300 (one batched evaluation of 24 images: trunk, "
                                     "RPN, RoI heads, NMS for all three; the RGB / IR passes' LOSS VALUES, which the reference computes and "
                                     "discards, are not evaluated), loss scaling, value clip 0.5, Adam") if args.detector == "fasterrcnn" else
