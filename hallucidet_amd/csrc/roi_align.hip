@@ -2,6 +2,7 @@
 // src/utils/eval_forward_fasterrcnn.py:120-123 `box_roi_pool`).  The only detection kernels that touch ACTIVATIONS: this file is built
 // twice (fp16 storage, and -DHD_STORE_F32 for precision=32: entry points with the suffix _f32); box maths in fp32 either way.
 #include "hd_common.h"
+#include <cstdlib>
 #pragma clang fp contract(off)
 
 namespace {
@@ -34,6 +35,35 @@ __device__ __forceinline__ Bilin bilin_setup(float y, float x, int H, int W) {
   b.yl = yl; b.xl = xl; b.yh = yh; b.xh = xh;
   b.w1 = hy * hx; b.w2 = hy * lx; b.w3 = ly * hx; b.w4 = ly * lx;
   return b;
+}
+
+// acc + w * t[K] as ONE fused multiply-add that reads the fp16 element directly (v_fma_mix_f32: no conversion instruction)
+template <int K>
+__device__ __forceinline__ float mac_tap(float w, const f16x8& t, float acc) {
+#ifdef HD_STORE_F32
+  return fmaf(w, t[K], acc);
+#else
+  typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+  const uint32_t pair = __builtin_bit_cast(u32x4_, t)[K >> 1];
+  float d;
+  if (K & 1)
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(w), "v"(acc));
+  else
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(d) : "v"(pair), "v"(w), "v"(acc));
+  return d;
+#endif
+}
+
+// acc[0..7] += w * t[0..7]; FUSED: one v_fma_mix_f32 per element, otherwise convert, multiply, add (the round-3 arithmetic, kept for A/B)
+template <bool FUSED = true>
+__device__ __forceinline__ void mac_vec(float w, const f16x8& t, float* acc) {
+  if (!FUSED) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] += w * (float)t[k];
+    return;
+  }
+  acc[0] = mac_tap<0>(w, t, acc[0]); acc[1] = mac_tap<1>(w, t, acc[1]); acc[2] = mac_tap<2>(w, t, acc[2]); acc[3] = mac_tap<3>(w, t, acc[3]);
+  acc[4] = mac_tap<4>(w, t, acc[4]); acc[5] = mac_tap<5>(w, t, acc[5]); acc[6] = mac_tap<6>(w, t, acc[6]); acc[7] = mac_tap<7>(w, t, acc[7]);
 }
 
 __global__ void roi_align_kernel(const f16* __restrict__ feat, const float* __restrict__ rois, f16* __restrict__ out, int R,
@@ -197,6 +227,99 @@ __global__ void roi_align_ml_kernel(MLFeat ml, const float* __restrict__ rois, c
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] / count);
     *reinterpret_cast<f16x8*>(out + (size_t)q * C + v * 8) = o;
+  }
+}
+
+// The detector's pooler (7x7 bins, sampling_ratio 2) with ONE BLOCK PER RoI: a thread owns one bin column pw and one 8-channel
+// vector and walks the seven bin rows.  roi_align_ml_kernel above spends its time in the VALU, not in memory: every thread
+// re-derives the RoI geometry, four 2-D sample set-ups and sixteen 64-bit tap addresses per output vector (the index split alone
+// is a dozen quarter-rate integer multiplies).  Here the RoI geometry is block-uniform (scalar loads), the two x samples of a
+// thread are set up once, a bin row costs two 1-D y set-ups, and a tap address is one 32-bit add of a row and a column offset
+// onto a uniform base.  The sixteen taps of a bin are accumulated in the same order, each as one fused multiply-add that reads the
+// fp16 element directly (v_fma_mix_f32: 128 VALU instructions per output vector where convert + multiply + add took 256): a result
+// differs from roi_align_ml_kernel's by the roundings the fusion removes -- at most one fp16 ulp of the output (tests/test_kernels_gpu.py).
+struct Samp1 {
+  unsigned lo, hi;      // element offsets of the two taps along this axis
+  float l, h;           // weights of hi / lo tap
+  bool valid;
+};
+
+__device__ __forceinline__ Samp1 samp1_setup(float y, int H, unsigned pitch) {
+  Samp1 s;
+  s.valid = !(y < -1.0f || y > (float)H);
+  if (y <= 0.f) y = 0.f;
+  int yl = (int)y, yh;
+  if (yl >= H - 1) {
+    yh = yl = H - 1;
+    y = (float)yl;
+  } else
+    yh = yl + 1;
+  s.l = y - (float)yl;
+  s.h = 1.f - s.l;
+  s.lo = (unsigned)yl * pitch;
+  s.hi = (unsigned)yh * pitch;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void roi_align_ml_roi7_kernel(MLFeat ml, const float* __restrict__ rois, const int* __restrict__ level,
+                                                                f16* __restrict__ out, int C, int lvecs) {
+  const int r = blockIdx.x;
+  const int l = level[r];
+  const int H = ml.H[l], W = ml.W[l];
+  const float scale = ml.scale[l];
+  const float* roi = rois + (size_t)r * 5;
+  const int n = (int)roi[0];
+  const float rsw = roi[1] * scale, rsh = roi[2] * scale, rew = roi[3] * scale, reh = roi[4] * scale;
+  const float rw = fmaxf(rew - rsw, 1.f), rh = fmaxf(reh - rsh, 1.f);
+  const float bh = rh / 7.f, bw = rw / 7.f;
+  const int t = threadIdx.x;
+  const int v = t & ((1 << lvecs) - 1);
+  const int pw = t >> lvecs;
+  if (pw >= 7) return;
+  const f16* fb = ml.f[l] + (size_t)n * H * W * C;
+  f16* ob = out + (size_t)r * 49 * C;
+  Samp1 xs[2];
+#pragma unroll
+  for (int ix = 0; ix < 2; ++ix) {
+    const float x = rsw + (float)pw * bw + ((float)ix + .5f) * bw / 2.f;
+    xs[ix] = samp1_setup(x, W, (unsigned)C);
+    xs[ix].lo += (unsigned)v * 8u;
+    xs[ix].hi += (unsigned)v * 8u;
+  }
+  const unsigned rowpitch = (unsigned)W * (unsigned)C;
+#pragma unroll 1
+  for (int ph = 0; ph < 7; ++ph) {
+    Samp1 ys[2];
+#pragma unroll
+    for (int iy = 0; iy < 2; ++iy) {
+      const float y = rsh + (float)ph * bh + ((float)iy + .5f) * bh / 2.f;
+      ys[iy] = samp1_setup(y, H, rowpitch);
+    }
+    f16x8 t1[4], t2[4], t3[4], t4[4];
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      const Samp1 a = ys[sidx >> 1], b = xs[sidx & 1];      // (clamped taps are always inside the map: loaded whether valid or not)
+      t1[sidx] = *reinterpret_cast<const f16x8*>(fb + (a.lo + b.lo));
+      t2[sidx] = *reinterpret_cast<const f16x8*>(fb + (a.lo + b.hi));
+      t3[sidx] = *reinterpret_cast<const f16x8*>(fb + (a.hi + b.lo));
+      t4[sidx] = *reinterpret_cast<const f16x8*>(fb + (a.hi + b.hi));
+    }
+    float acc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+      const Samp1 a = ys[sidx >> 1], b = xs[sidx & 1];
+      if (!(a.valid && b.valid)) continue;
+      const float w1 = a.h * b.h, w2 = a.h * b.l, w3 = a.l * b.h, w4 = a.l * b.l;
+#define HD_ROI_MAC(k) acc[k] = mac_tap<k>(w4, t4[sidx], mac_tap<k>(w3, t3[sidx], mac_tap<k>(w2, t2[sidx], mac_tap<k>(w1, t1[sidx], acc[k]))));
+      HD_ROI_MAC(0) HD_ROI_MAC(1) HD_ROI_MAC(2) HD_ROI_MAC(3) HD_ROI_MAC(4) HD_ROI_MAC(5) HD_ROI_MAC(6) HD_ROI_MAC(7)
+#undef HD_ROI_MAC
+    }
+    f16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = (f16)(acc[k] * 0.25f);        // == acc / 4 bit for bit
+    *reinterpret_cast<f16x8*>(ob + ((unsigned)(ph * 7 + pw) * (unsigned)C + (unsigned)v * 8u)) = o;
   }
 }
 
@@ -448,8 +571,7 @@ __global__ __launch_bounds__(256) void roi_align_ml_bwd_gather_kernel(MLFeat ml,
 #pragma unroll
             for (int v = 0; v < CCH / 8; ++v) {
               const f16x8 d = *reinterpret_cast<const f16x8*>(q + v * 8);
-#pragma unroll
-              for (int k = 0; k < 8; ++k) acc[v * 8 + k] += w * (float)d[k];
+              mac_vec(w, d, &acc[v * 8]);
             }
           }
         }
@@ -474,7 +596,7 @@ __global__ __launch_bounds__(256) void roi_align_ml_bwd_gather_kernel(MLFeat ml,
 // 16 x 7 of them per RoI instead of 64 x 14: they are computed cooperatively into LDS for 32 RoIs at a time and every
 // pixel thread then reads its 14 numbers -- the weight arithmetic, which dominated the generic kernel above, drops ~8x
 // and is no longer repeated per channel chunk.
-template <int PH, int PW, int SR>
+template <int PH, int PW, int SR, bool FUSED>
 __global__ __launch_bounds__(256) void roi_align_ml_bwd_gather256_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
                                                                          const int* __restrict__ level, int R, int C, int L, int4 tile_base) {
   constexpr int CAP = 1024, SB = 32, TS = 8, CQ = 64;
@@ -566,8 +688,7 @@ __global__ __launch_bounds__(256) void roi_align_ml_bwd_gather256_kernel(MLFeat 
 #pragma unroll
               for (int v = 0; v < CQ / 8; ++v) {
                 const f16x8 d = *reinterpret_cast<const f16x8*>(q + v * 8);
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc[v * 8 + k] += w * (float)d[k];
+                mac_vec<FUSED>(w, d, &acc[v * 8]);
               }
             }
           }
@@ -616,6 +737,128 @@ extern "C" int HD_API(hd_roi_align_bwd)(const void* dout, const float* rois, flo
   return HD_OK;
 }
 
+// Round 4: the same gather with the lanes of a wave laid along the CHANNELS.  Above, the 64 lanes of a wave are 64 different pixels,
+// so one 16-byte load instruction touches up to 64 cache lines (a lane walks its own 128-byte run over eight instructions) and the
+// wave runs the union of 64 pixels' bin ranges.  Here a wave is one tile ROW: lane = (pixel column, 16-byte channel slot), a thread
+// owns the four slots cv, cv + 8, cv + 16, cv + 24 of a 256-channel chunk, so every load instruction reads eight full 128-byte lines,
+// the eight pixels of a wave share their row's bin range, and a thread carries 32 accumulators instead of 64.  512 threads per 8x8
+// tile; list building, weight table and summation order per element are those of the kernel above (equal results).
+template <int PH, int PW, int SR>
+__global__ __launch_bounds__(512) void roi_align_ml_bwd_gather256_rows_kernel(MLFeat ml, const f16* __restrict__ dout, const float* __restrict__ rois,
+                                                                              const int* __restrict__ level, int R, int C, int L, int4 tile_base) {
+  constexpr int CAP = 1024, SB = 32, TS = 8, NT = 512;
+  static_assert(PH == PW, "square pooler");
+  __shared__ GatherRoi list[CAP];
+  __shared__ float wtab[SB][2][TS][PH];
+  __shared__ int wcnt[NT / 64];
+  int b = blockIdx.x, l = 0;
+  const int bases[4] = {tile_base.x, tile_base.y, tile_base.z, tile_base.w};
+  while (l + 1 < L && b >= bases[l + 1]) ++l;
+  b -= bases[l];
+  const int H = ml.H[l], W = ml.W[l];
+  const int tw = (W + TS - 1) / TS, th = (H + TS - 1) / TS;
+  const int n = b / (tw * th);
+  const int ty = (b / tw) % th, tx = b % tw;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ly = wave, lx = lane >> 3, cv = lane & 7;
+  const int py = ty * TS + ly, px = tx * TS + lx;
+  const bool live = py < H && px < W;
+  const int c0 = blockIdx.y * 256 + cv * 8;
+  const int ty0 = ty * TS, ty1 = min(ty * TS + TS - 1, H - 1), tx0 = tx * TS, tx1 = min(tx * TS + TS - 1, W - 1);
+  float acc[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) acc[k] = 0.f;
+
+  for (int base = 0; base < R; base += CAP) {
+    int total = 0;
+    for (int it = 0; it < CAP / NT; ++it) {
+      const int r = base + it * NT + tid;
+      bool hit = false;
+      GatherRoi e;
+      if (r < R && level[r] == l && (int)rois[(size_t)r * 5] == n) {
+        const RoiGeom g = roi_geom(ml, rois, level, r, PH, PW, SR);
+        if (g.any) {
+          const int y1 = g.y0 + g.ph_ - 1, x1 = g.x0 + g.pw_ - 1;
+          hit = !(y1 < ty0 || g.y0 > ty1 || x1 < tx0 || g.x0 > tx1);
+          e.rsw = g.rsw; e.rsh = g.rsh; e.bw = g.bw; e.bh = g.bh; e.r = r;
+          e.y0 = (short)g.y0; e.y1 = (short)y1; e.x0 = (short)g.x0; e.x1 = (short)x1;
+        }
+      }
+      const unsigned long long m = __ballot(hit);
+      if (lane == 0) wcnt[wave] = __popcll(m);
+      __syncthreads();
+      int off = total, all = 0;
+#pragma unroll
+      for (int w = 0; w < NT / 64; ++w) {
+        if (w < wave) off += wcnt[w];
+        all += wcnt[w];
+      }
+      if (hit) list[off + __popcll(m & ((1ull << lane) - 1ull))] = e;
+      total += all;
+      __syncthreads();
+    }
+    for (int sb = 0; sb < total; sb += SB) {
+      const int nsb = min(SB, total - sb);
+      for (int idx = tid; idx < nsb * 2 * TS * PH; idx += NT) {
+        const int p = idx % PH;
+        const int pos = (idx / PH) % TS;
+        const int axis = (idx / (PH * TS)) & 1;
+        const int j = idx / (2 * TS * PH);
+        const GatherRoi e = list[sb + j];
+        const float start = axis ? e.rsw : e.rsh, bin = axis ? e.bw : e.bh;
+        const int pix = axis ? tx * TS + pos : ty * TS + pos, size = axis ? W : H;
+        const float lo = start + (float)p * bin, hi = lo + bin;
+        const bool near_ = pix < size && (!(hi < (float)pix - 1.f || lo > (float)pix + 1.f) || pix == 0 || pix == size - 1);
+        wtab[j][axis][pos][p] = near_ ? axis_weight<SR>(start, bin, p, pix, size) : 0.f;
+      }
+      __syncthreads();
+      if (live) {
+        for (int j = 0; j < nsb; ++j) {
+          const GatherRoi e = list[sb + j];
+          if (py < e.y0 || py > e.y1 || px < e.x0 || px > e.x1) continue;
+          const float* WY = &wtab[j][0][ly][0];
+          const float* WX = &wtab[j][1][lx][0];
+          int ya = -1, yb = -1, xa = -1, xb = -1;
+#pragma unroll
+          for (int p = 0; p < PH; ++p) {
+            if (WY[p] != 0.f) { if (ya < 0) ya = p; yb = p; }
+            if (WX[p] != 0.f) { if (xa < 0) xa = p; xb = p; }
+          }
+          if (ya < 0 || xa < 0) continue;
+          const f16* dr = dout + (size_t)e.r * PH * PW * C + c0;
+          for (int ph = ya; ph <= yb; ++ph) {
+            const float wyv = WY[ph] * (1.f / (float)(SR * SR));
+            for (int pw = xa; pw <= xb; ++pw) {
+              const float w = wyv * WX[pw];
+              if (w == 0.f) continue;
+              const f16* q = dr + (size_t)(ph * PW + pw) * C;
+              const f16x8 d0 = *reinterpret_cast<const f16x8*>(q);
+              const f16x8 d1 = *reinterpret_cast<const f16x8*>(q + 64);
+              const f16x8 d2 = *reinterpret_cast<const f16x8*>(q + 128);
+              const f16x8 d3 = *reinterpret_cast<const f16x8*>(q + 192);
+              mac_vec(w, d0, &acc[0]);
+              mac_vec(w, d1, &acc[8]);
+              mac_vec(w, d2, &acc[16]);
+              mac_vec(w, d3, &acc[24]);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (live) {
+    f16* o = const_cast<f16*>(ml.f[l]) + (((size_t)n * H + py) * W + px) * C + c0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      f16x8 t;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = (f16)acc[v * 8 + k];
+      *reinterpret_cast<f16x8*>(o + v * 64) = t;
+    }
+  }
+}
+
 extern "C" int HD_API(hd_roi_align_ml)(const void* const* feats, const int* H, const int* W, const float* scale, int L, const float* rois,
                                const int* level, void* out, int R, int C, int PH, int PW, int sampling_ratio, void* stream) {
   HD_CHECK_ARG(feats && H && W && scale && rois && level && out && L >= 1 && L <= 4 && C % 8 == 0 && R >= 0, "hd_roi_align_ml: bad args");
@@ -626,6 +869,18 @@ extern "C" int HD_API(hd_roi_align_ml)(const void* const* feats, const int* H, c
     ml.H[l] = H[l];
     ml.W[l] = W[l];
     ml.scale[l] = scale[l];
+  }
+  // the hot path's pooler: one block per RoI (HD_ROI_ROWS=0 keeps the one-thread-per-output form: A/B, and the fallback for other poolers)
+  static const int rows_on = getenv("HD_ROI_ROWS") ? atoi(getenv("HD_ROI_ROWS")) : 1;
+  const int vecs = C / 8;
+  bool small_maps = true;
+  for (int l = 0; l < L; ++l) small_maps = small_maps && (int64_t)H[l] * W[l] * C < (int64_t)1 << 31;
+  if (rows_on && PH == 7 && PW == 7 && sampling_ratio == 2 && (vecs & (vecs - 1)) == 0 && vecs <= 32 && small_maps) {
+    int lv = 0;
+    while ((1 << lv) < vecs) ++lv;
+    hipLaunchKernelGGL(roi_align_ml_roi7_kernel, dim3(R), dim3((7 * vecs + 63) / 64 * 64), 0, (hipStream_t)stream, ml, rois, level, (f16*)out, C, lv);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
   }
   int64_t total = (int64_t)R * PH * PW * C / 8;
   int g = (int)((total + 255) / 256);
@@ -654,8 +909,16 @@ extern "C" int HD_API(hd_roi_align_ml_bwd_gather)(const void* dout, const float*
   }
   for (int l = L; l < 4; ++l) base[l + 1] = base[L];
   if (C % 256 == 0) {
-    hipLaunchKernelGGL((roi_align_ml_bwd_gather256_kernel<7, 7, 2>), dim3(base[L], C / 256), dim3(256), 0, (hipStream_t)stream, ml,
-                       (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]));
+    static const int fused_on = getenv("HD_ROI_ROWS") ? atoi(getenv("HD_ROI_ROWS")) : 1;
+    if (fused_on == 1)
+      hipLaunchKernelGGL((roi_align_ml_bwd_gather256_rows_kernel<7, 7, 2>), dim3(base[L], C / 256), dim3(512), 0, (hipStream_t)stream, ml,
+                         (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]));
+    else if (fused_on)
+      hipLaunchKernelGGL((roi_align_ml_bwd_gather256_kernel<7, 7, 2, true>), dim3(base[L], C / 256), dim3(256), 0, (hipStream_t)stream, ml,
+                         (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]));
+    else
+      hipLaunchKernelGGL((roi_align_ml_bwd_gather256_kernel<7, 7, 2, false>), dim3(base[L], C / 256), dim3(256), 0, (hipStream_t)stream, ml,
+                         (const f16*)dout, rois, level, R, C, L, make_int4(base[0], base[1], base[2], base[3]));
     HD_CHECK_LAUNCH();
     return HD_OK;
   }

@@ -1183,3 +1183,55 @@ def test_roi_align_degenerate_and_outside_rois(dev):
     out2 = ops.roi_align(f2.to(dev), rois.to(dev), 7, 7, s, 2).float().cpu()
     lhs, rhs = (dout.float() * out2).sum(), (dfeat * f2.float()).sum()
     assert torch.isfinite(dfeat).all() and abs(lhs - rhs) <= 2e-2 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+def test_roi_align_one_block_per_roi_and_channel_lane_gather_at_256_channels(dev):
+    """The detector's pooler at its channel count (round 4: hd_roi_align_ml runs one block per RoI, hd_roi_align_ml_bwd_gather lays the
+    lanes of a wave along the channels; both accumulate with fused multiply-adds): forward against the oracle on regular, sub-pixel,
+    zero-size, inverted, partly and entirely outside RoIs spread over three levels and two images, entirely-outside RoIs exactly zero;
+    the backward is the forward's adjoint and leaves images without RoIs zero."""
+    from hallucidet_amd import ops
+    from oracle import detection as od
+    C, N = 256, 3
+    shapes = [(N, 40, 52, C), (N, 20, 26, C), (N, 10, 13, C)]
+    scales = [0.25, 0.125, 0.0625]
+    feats = [rnd(*s, seed=120 + i) for i, s in enumerate(shapes)]
+    g = torch.Generator().manual_seed(12)
+    rois, levels = [], []
+    for k in range(90):
+        sz = [3.0, 9.0, 27.0, 60.0, 150.0][k % 5]
+        x1, y1 = float(torch.rand(1, generator=g) * 190), float(torch.rand(1, generator=g) * 150)
+        ar = 0.5 + float(torch.rand(1, generator=g))
+        rois.append([k % 2, x1, y1, x1 + sz * ar, y1 + sz / ar])
+        levels.append(k % 3)
+    special = [[0, 40.0, 40.0, 40.0, 40.0], [1, 60.0, 30.0, 20.0, 10.0], [0, -400.0, -300.0, -200.0, -100.0], [1, 500.0, 400.0, 900.0, 700.0],
+               [0, -8.0, -8.0, 0.0, 0.0], [1, 207.9, 159.9, 208.1, 160.1], [0, 33.3, 21.7, 33.9, 22.2], [1, -2000.0, -2000.0, 3000.0, 3000.0],
+               [0, 0.0, 0.0, 207.99, 159.99]]
+    for k, r in enumerate(special):
+        rois.append(r)
+        levels.append(k % 3)
+    rois = torch.tensor(rois)
+    lv = torch.tensor(levels, dtype=torch.int32)
+    R = rois.shape[0]
+    out = ops.roi_align_ml([f.to(dev) for f in feats], scales, rois.to(dev), lv.to(dev), 7, 7, 2)
+    assert out.dtype == torch.float16 and torch.isfinite(out).all()
+    outc = out.float().cpu()
+    for l in range(3):
+        idx = [i for i in range(R) if levels[i] == l]
+        want = od.roi_align_autograd(ok.nhwc_to_nchw(feats[l].float()), rois[idx], 7, scales[l], 2).permute(0, 2, 3, 1)
+        close(outc[idx], want.half(), rtol=2e-3, atol=1e-3)
+    assert float(outc[92].abs().max()) == 0.0 and float(outc[93].abs().max()) == 0.0          # entirely outside: exactly zero
+    dout = rnd(R, 7, 7, C, seed=125)
+    dfs = ops.roi_align_ml_bwd_gather(dout.to(dev), rois.to(dev), lv.to(dev), shapes, scales, 2, n_images=2)
+    lhs = float((dout.float() * outc).sum())
+    rhs = sum(float((d.float().cpu() * f.float()).sum()) for d, f in zip(dfs, feats))
+    assert abs(lhs - rhs) <= 1e-2 * max(1.0, abs(lhs)), (lhs, rhs)
+    assert all(float(d[2].abs().max()) == 0.0 for d in dfs)
+    for l in range(3):
+        f = torch.zeros(N, C, shapes[l][1], shapes[l][2], requires_grad=True)
+        idx = [i for i in range(R) if levels[i] == l]
+        o = od.roi_align_autograd(f, rois[idx], 7, scales[l], 2)
+        o.backward(dout[idx].float().permute(0, 3, 1, 2))
+        want = ok.nchw_to_nhwc(f.grad)
+        err = (dfs[l].float().cpu() - want).abs()
+        assert float((err / (1e-2 + 2e-3 * want.abs())).max()) < 1.0, (l, float(err.max()))

@@ -1,6 +1,6 @@
 # Round profiles: kernel-trace summary of a training-step run and of the bench command, PMC passes (MFMA utilisation, HBM traffic).
 # Run on the GPU box from the repo root:  bash tools/collect_profiles.sh r02
-R=${1:-r03}
+R=${1:-r04}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -12,10 +12,11 @@ STEPS=3 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch --outp
 STEPS=3 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write --output-format csv -- python3 tools/bench_step.py > gpurun_out/pmc_write.log 2>&1
 python3 tools/pmc_mfma.py gpurun_out/pmc_mfma gpurun_out/pmc_gui gpurun_out/${R}_conv_mfma_util.json > /dev/null
 F=$(ls gpurun_out/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls gpurun_out/pmc_write/*/*counter_collection.csv | head -1)
-python3 tools/pmc_traffic.py $F $W conv_igemm_kernel,conv3x3_small_kernel,conv3x3_w8_kernel gpurun_out/${R}_conv_traffic.json > /dev/null
+python3 tools/pmc_traffic.py $F $W conv_igemm_kernel,conv3x3_small_kernel,conv3x3_w8_kernel,conv3x3_c64_kernel gpurun_out/${R}_conv_traffic.json > /dev/null
 STEPS=12 rocprofv3 --kernel-trace -d gpurun_out/trace_ss --output-format csv -- python3 tools/bench_step.py > gpurun_out/trace_ss.log 2>&1
 python3 tools/trace_gaps.py $(ls gpurun_out/trace_ss/*/*kernel_trace.csv | head -1) 0.5 --table --aten > gpurun_out/${R}_steady_state.txt 2>&1
 rm -rf gpurun_out/trace_ss
+python3 tools/conv_table.py all > gpurun_out/${R}_conv_table.txt 2>&1
 python3 bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
 cp $(ls gpurun_out/prof_step/*/*kernel_stats.csv | head -1) gpurun_out/${R}_train_step_kernel_stats.csv
 cp $(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_kernel_stats.csv
