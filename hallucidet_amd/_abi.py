@@ -93,6 +93,8 @@ PROTOTYPES = {
     "hd_maxpool3x3s2_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_maxpool3x3s2_idx": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_maxpool3x3s2_bwd_idx": (C.c_int, [vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_maxpool3x3s2_bwd_idx_add": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 6 + [vp]),
+    "hd_concat_up_bwd": (C.c_int, [vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "hd_subsample2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
     "hd_subsample2_bwd": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
     "hd_nchw_to_nhwc_resize": (C.c_int, [vp, vp] + [C.c_int] * 7 + [vp]),
@@ -152,7 +154,7 @@ PROTOTYPES = {
 
 # fp32-storage twins (include/hallucidet_hip.h, last section): same signatures under the suffix _f32
 F32_TWINS = ["hd_conv2d", "hd_conv2d_stats_rows", "hd_wgrad", "hd_weight_prep", "hd_bn_apply", "hd_bn_bwd_reduce", "hd_bn_bwd_apply",
-             "hd_maxpool3x3s2", "hd_maxpool3x3s2_bwd", "hd_maxpool3x3s2_idx", "hd_maxpool3x3s2_bwd_idx", "hd_subsample2", "hd_subsample2_bwd",
+             "hd_maxpool3x3s2", "hd_maxpool3x3s2_bwd", "hd_maxpool3x3s2_idx", "hd_maxpool3x3s2_bwd_idx", "hd_maxpool3x3s2_bwd_idx_add", "hd_concat_up_bwd", "hd_subsample2", "hd_subsample2_bwd",
              "hd_nchw_to_nhwc_resize", "hd_nchw_to_nhwc_resize_strided", "hd_nchw_to_nhwc_resize_bwd", "hd_nhwc_to_nchw", "hd_upsample_add",
              "hd_upsample_add_bwd", "hd_upsample2_bwd", "hd_add_f16", "hd_slice_channels", "hd_sigmoid_bwd_nchw_to_nhwc", "hd_relu_bwd",
              "hd_f32_to_f16", "hd_f16_to_f32", "hd_pad_cast_f32_f16", "hd_channel_sum_f16", "hd_roi_align", "hd_roi_align_bwd",

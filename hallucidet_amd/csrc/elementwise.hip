@@ -470,8 +470,11 @@ __global__ void maxpool_idx_kernel(const f16* __restrict__ x, f16* __restrict__ 
   }
 }
 
-__global__ void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const f16* __restrict__ dy, f16* __restrict__ dx, int N,
-                                       int H, int W, int C, int Ho, int Wo) {
+// ADD: dx = f16(f16(routed gradient) + add) -- the sum of the routed gradient with a second gradient of the pooled tensor's INPUT
+// (the U-Net's f1 also feeds a decoder skip), rounded exactly as the separate hd_add_f16 pass it replaces
+template <bool ADD>
+__global__ void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, const f16* __restrict__ dy, const f16* __restrict__ add,
+                                       f16* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
   const int vecs = C / 8;
   const int64_t total = (int64_t)N * H * W * vecs;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -500,6 +503,11 @@ __global__ void maxpool_bwd_idx_kernel(const unsigned char* __restrict__ idx, co
     f16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+    if (ADD) {
+      const f16x8 e = ld8(add + (size_t)p * C + v * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (f16)((float)o[k] + (float)e[k]);
+    }
     st8(dx + (size_t)p * C + v * 8, o);
   }
 }
@@ -722,6 +730,43 @@ __global__ void slice_channels_kernel(const f16* __restrict__ x, f16* __restrict
   }
 }
 
+// Gradient of cat([nearest_2x(a), skip], channel) in ONE launch: the first `n_low` vectors are the 2x2 sum-pool of channels [0, Cup)
+// into the low-resolution tensor (hd_upsample2_bwd's arithmetic and order), the rest copy channels [Cup, Cup + Cskip) into the
+// skip gradient (hd_slice_channels).  Reference: the autograd of decoder.py:37-41 (interpolate + torch.cat).
+__global__ void concat_up_bwd_kernel(const f16* __restrict__ dcat, f16* __restrict__ dlow, f16* __restrict__ dskip, int N, int Hl, int Wl,
+                                     int Cup, int Cskip) {
+  const int Ctot = Cup + Cskip, Hu = Hl * 2, Wu = Wl * 2;
+  const int vu = Cup / 8, vs = Cskip / 8;
+  const int64_t n_low = (int64_t)N * Hl * Wl * vu, total = n_low + (int64_t)N * Hu * Wu * vs;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    if (i < n_low) {
+      const int v = (int)(i % vu);
+      const int64_t p = i / vu;
+      const int w = (int)(p % Wl), h = (int)((p / Wl) % Hl), n = (int)(p / ((int64_t)Wl * Hl));
+      float acc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const f16x8 g = ld8(dcat + ((size_t)(n * Hu + 2 * h + a) * Wu + 2 * w + b) * Ctot + v * 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[k] += (float)g[k];
+        }
+      f16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = (f16)acc[k];
+      st8(dlow + (size_t)p * Cup + v * 8, o);
+    } else {
+      const int64_t j = i - n_low;
+      const int v = (int)(j % vs);
+      const int64_t p = j / vs;
+      st8(dskip + (size_t)p * Cskip + v * 8, ld8(dcat + (size_t)p * Ctot + Cup + v * 8));
+    }
+  }
+}
+
 __global__ void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ s, f16* __restrict__ dl, int N,
                                    int Cr, int H, int W, int Cp, float gscale) {
   const int64_t total = (int64_t)N * H * W;
@@ -936,7 +981,15 @@ extern "C" int HD_API(hd_maxpool3x3s2_idx)(const void* x, void* y, void* idx_u8,
 
 extern "C" int HD_API(hd_maxpool3x3s2_bwd_idx)(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream) {
   HD_CHECK_ARG(idx_u8 && dy && dx && C % 8 == 0, "hd_maxpool3x3s2_bwd_idx: bad args");
-  hipLaunchKernelGGL(maxpool_bwd_idx_kernel, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const unsigned char*)idx_u8, (const f16*)dy, (f16*)dx, N, H, W, C, Ho, Wo);
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel<false>, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const unsigned char*)idx_u8, (const f16*)dy, (const f16*)nullptr, (f16*)dx, N, H, W, C, Ho, Wo);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int HD_API(hd_maxpool3x3s2_bwd_idx_add)(const void* idx_u8, const void* dy, const void* add, void* dx, int N, int H, int W, int C, int Ho,
+                                                   int Wo, void* stream) {
+  HD_CHECK_ARG(idx_u8 && dy && add && dx && C % 8 == 0, "hd_maxpool3x3s2_bwd_idx_add: bad args");
+  hipLaunchKernelGGL(maxpool_bwd_idx_kernel<true>, dim3(grid_for((int64_t)N * H * W * C / 8)), dim3(TB), 0, S_, (const unsigned char*)idx_u8, (const f16*)dy, (const f16*)add, (f16*)dx, N, H, W, C, Ho, Wo);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
@@ -1009,6 +1062,14 @@ extern "C" int HD_API(hd_upsample_add_bwd)(const void* dy, void* db, int N, int 
 extern "C" int HD_API(hd_upsample2_bwd)(const void* dy_up, void* dx_low, int N, int Hl, int Wl, int C, int Ctot, int c_off, int accumulate, void* stream) {
   HD_CHECK_ARG(dy_up && dx_low && C % 8 == 0 && Ctot % 8 == 0 && c_off % 8 == 0 && c_off + C <= Ctot, "hd_upsample2_bwd: bad args");
   hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(grid_for((int64_t)N * Hl * Wl * C / 8)), dim3(TB), 0, S_, (const f16*)dy_up, (f16*)dx_low, N, Hl, Wl, C, Ctot, c_off, accumulate);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int HD_API(hd_concat_up_bwd)(const void* dcat, void* dlow, void* dskip, int N, int Hl, int Wl, int Cup, int Cskip, void* stream) {
+  HD_CHECK_ARG(dcat && dlow && (dskip || Cskip == 0) && Cup > 0 && Cup % 8 == 0 && Cskip >= 0 && Cskip % 8 == 0, "hd_concat_up_bwd: bad args");
+  const int64_t vecs = (int64_t)N * Hl * Wl * (Cup / 8) + (int64_t)N * Hl * 2 * Wl * 2 * (Cskip / 8);
+  hipLaunchKernelGGL(concat_up_bwd_kernel, dim3(grid_for(vecs)), dim3(TB), 0, S_, (const f16*)dcat, (f16*)dlow, (f16*)dskip, N, Hl, Wl, Cup, Cskip);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

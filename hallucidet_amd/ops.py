@@ -442,12 +442,31 @@ def maxpool3x3s2_idx(x):
     return y, idx
 
 
-def maxpool3x3s2_bwd_idx(idx, dy, in_hw):
+def maxpool3x3s2_bwd_idx(idx, dy, in_hw, add=None):
+    """Gradient of the 3x3 / stride-2 max-pool routed by the recorded winners; `add` [N,H,W,C]: a second gradient of the pooled
+    tensor's input summed in the same pass (== maxpool3x3s2_bwd_idx followed by add_f16, bit for bit)."""
     N, Ho, Wo, C_ = dy.shape
     H, W = in_hw
     dx = torch.empty((N, H, W, C_), dtype=dy.dtype, device=dy.device)
-    check(_abi.fn("hd_maxpool3x3s2_bwd_idx", dy)(ptr(idx), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd_idx")
+    if add is None:
+        check(_abi.fn("hd_maxpool3x3s2_bwd_idx", dy)(ptr(idx), ptr(dy.contiguous()), ptr(dx), N, H, W, C_, Ho, Wo, _stream()), "hd_maxpool3x3s2_bwd_idx")
+    else:
+        assert add.shape == dx.shape and add.dtype == dy.dtype and add.is_contiguous()
+        check(_abi.fn("hd_maxpool3x3s2_bwd_idx_add", dy)(ptr(idx), ptr(dy.contiguous()), ptr(add), ptr(dx), N, H, W, C_, Ho, Wo, _stream()),
+              "hd_maxpool3x3s2_bwd_idx_add")
     return dx
+
+
+def concat_up_bwd(dcat, c_up):
+    """Gradient of cat([nearest_2x(a), skip], channel): -> (da [N,H/2,W/2,c_up], dskip [N,H,W,C-c_up] or None), one launch
+    (== upsample2_bwd + slice_channels, bit for bit)."""
+    N, H, W, Ct = dcat.shape
+    assert dcat.is_contiguous() and H % 2 == 0 and W % 2 == 0
+    da = torch.empty((N, H // 2, W // 2, c_up), dtype=dcat.dtype, device=dcat.device)
+    ds = torch.empty((N, H, W, Ct - c_up), dtype=dcat.dtype, device=dcat.device) if Ct > c_up else None
+    check(_abi.fn("hd_concat_up_bwd", dcat)(ptr(dcat), ptr(da), ptr(ds) if ds is not None else None, N, H // 2, W // 2, c_up, Ct - c_up, _stream()),
+          "hd_concat_up_bwd")
+    return da, ds
 
 
 def maxpool3x3s2_bwd(x, dy):

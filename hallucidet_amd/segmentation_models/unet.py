@@ -649,12 +649,7 @@ class UnetRunner:
             u1, u2, cin, cskip = self.dec[i]
             dz1, _ = self._unit_bwd(u2, dz, S)
             dcat, _ = self._unit_bwd(u1, dz1, S)
-            xin = _operand(sv["rec"][u1.name]["x"])[0]
-            dz = torch.empty_like(xin)
-            ops.upsample2_bwd(dcat, dz, 0, accumulate=False)
-            if cskip:
-                dskip[i] = torch.empty_like(skips[i])
-                ops.slice_channels(dcat, dskip[i], cin, accumulate=False)
+            dz, dskip[i] = ops.concat_up_bwd(dcat, cin)        # 2x2 sum-pool of the upsampled half + the skip's slice, one launch
         self._segment_done(0)                  # head + decoder parameter gradients are final
         # dz is now the gradient of f5; dskip[0..3] belong to f4, f3, f2, f1
         dfeat = {4: dz, 3: dskip[0], 2: dskip[1], 1: dskip[2], 0: dskip[3]}
@@ -678,8 +673,7 @@ class UnetRunner:
             if si > 0:
                 self._segment_done(4 - si)     # layer4 -> 1, layer3 -> 2, layer2 -> 3
         # d_out = gradient of the max-pooled stem output
-        df1 = ops.maxpool3x3s2_bwd_idx(sv["pool_idx"], d_out, (sv["f1"].shape[1], sv["f1"].shape[2]))
-        df1 = ops.add_f16(df1, dfeat[0], out=df1)
+        df1 = ops.maxpool3x3s2_bwd_idx(sv["pool_idx"], d_out, (sv["f1"].shape[1], sv["f1"].shape[2]), add=dfeat[0])
         dx = None
         if need_dx:
             raise NotImplementedError("gradient w.r.t. the Unet input is not on the hot path (IR images are data)")

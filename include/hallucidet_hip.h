@@ -224,6 +224,11 @@ int hd_maxpool3x3s2_bwd(const void* x, const void* dy, void* dx, int N, int H, i
  * window instead of 9 inputs) */
 int hd_maxpool3x3s2_idx(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int hd_maxpool3x3s2_bwd_idx(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+/* the same with a second gradient of the pooled tensor's input added in the same pass: dx = f16(f16(routed) + add), the rounding of
+ * hd_maxpool3x3s2_bwd_idx followed by hd_add_f16 (the U-Net's stem output feeds the max-pool AND the last decoder skip,
+ * src/segmentation_models/encoders/resnet.py:50-51 + decoders/unet/decoder.py:37-41) */
+int hd_maxpool3x3s2_bwd_idx_add(const void* idx_u8, const void* dy, const void* add, void* dx, int N, int H, int W, int C, int Ho, int Wo,
+                                void* stream);
 /* generic strided-subsample (LastLevelMaxPool k=1,s=2 [EXT]) */
 int hd_subsample2(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int hd_subsample2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream);
@@ -248,6 +253,9 @@ int hd_upsample_add_bwd(const void* dy, void* db, int N, int H, int W, int C, in
 /* 2x2 sum-pool of the gradient of a nearest-2x upsample: dx_low[n,h,w,c] (+)= sum dy_up[n,2h+i,2w+j, c_off + c] */
 int hd_upsample2_bwd(const void* dy_up, void* dx_low, int N, int Hl, int Wl, int C, int Ctot, int c_off, int accumulate,
                      void* stream);
+/* gradient of cat([nearest_2x(a), skip], channel) (decoders/unet/decoder.py:37-41) in one launch: dlow [N,Hl,Wl,Cup] = 2x2 sum-pool of
+ * dcat[..., :Cup] (hd_upsample2_bwd's arithmetic), dskip [N,2Hl,2Wl,Cskip] = dcat[..., Cup:] (dskip may be NULL when Cskip == 0) */
+int hd_concat_up_bwd(const void* dcat, void* dlow, void* dskip, int N, int Hl, int Wl, int Cup, int Cskip, void* stream);
 /* out = a + b ; out = copy channel slice ; all f16, vectors of 8 */
 int hd_add_f16(const void* a, const void* b, void* out, int64_t n, void* stream);
 int hd_slice_channels(const void* x, void* y, int64_t npix, int Ctot, int c_off, int C, int accumulate, void* stream);
@@ -493,6 +501,9 @@ int hd_maxpool3x3s2_f32(const void* x, void* y, int N, int H, int W, int C, int 
 int hd_maxpool3x3s2_bwd_f32(const void* x, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int hd_maxpool3x3s2_idx_f32(const void* x, void* y, void* idx_u8, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int hd_maxpool3x3s2_bwd_idx_f32(const void* idx_u8, const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, void* stream);
+int hd_maxpool3x3s2_bwd_idx_add_f32(const void* idx_u8, const void* dy, const void* add, void* dx, int N, int H, int W, int C, int Ho, int Wo,
+                                    void* stream);
+int hd_concat_up_bwd_f32(const void* dcat, void* dlow, void* dskip, int N, int Hl, int Wl, int Cup, int Cskip, void* stream);
 int hd_subsample2_f32(const void* x, void* y, int N, int H, int W, int C, int Ho, int Wo, void* stream);
 int hd_subsample2_bwd_f32(const void* dy, void* dx, int N, int H, int W, int C, int Ho, int Wo, int accumulate, void* stream);
 int hd_nchw_to_nhwc_resize_f32(const float* x, void* y, int N, int Cr, int H, int W, int Ho, int Wo, int Cp, void* stream);

@@ -1235,3 +1235,26 @@ def test_roi_align_one_block_per_roi_and_channel_lane_gather_at_256_channels(dev
         want = ok.nchw_to_nhwc(f.grad)
         err = (dfs[l].float().cpu() - want).abs()
         assert float((err / (1e-2 + 2e-3 * want.abs())).max()) < 1.0, (l, float(err.max()))
+
+
+def test_fused_gradient_plumbing_equals_the_separate_passes(dev):
+    """hd_concat_up_bwd == hd_upsample2_bwd + hd_slice_channels and hd_maxpool3x3s2_bwd_idx_add == hd_maxpool3x3s2_bwd_idx + hd_add_f16,
+    bit for bit (round 4: four launches less per decoder block pair / stem in the U-Net's backward pass)."""
+    from hallucidet_amd import ops
+    for (N, H, W, cup, cskip) in [(2, 12, 20, 64, 32), (1, 6, 10, 32, 0), (3, 8, 8, 16, 8)]:
+        dcat = rnd(N, H, W, cup + cskip, seed=130 + cup).to(dev)
+        da, ds = ops.concat_up_bwd(dcat, cup)
+        want_a = ops.upsample2_bwd(dcat, torch.empty(N, H // 2, W // 2, cup, device=dev, dtype=torch.float16), 0, accumulate=False)
+        assert torch.equal(da, want_a)
+        if cskip:
+            want_s = ops.slice_channels(dcat, torch.empty(N, H, W, cskip, device=dev, dtype=torch.float16), cup, accumulate=False)
+            assert torch.equal(ds, want_s)
+        else:
+            assert ds is None
+    x = rnd(2, 17, 22, 16, seed=140).to(dev)
+    y, idx = ops.maxpool3x3s2_idx(x)
+    dy = rnd(*y.shape, seed=141).to(dev)
+    other = rnd(*x.shape, seed=142).to(dev)
+    got = ops.maxpool3x3s2_bwd_idx(idx, dy, (17, 22), add=other)
+    want = ops.add_f16(ops.maxpool3x3s2_bwd_idx(idx, dy, (17, 22)), other)
+    assert torch.equal(got, want)
