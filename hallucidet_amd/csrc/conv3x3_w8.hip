@@ -369,7 +369,61 @@ __device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, 
         for (int k = 0; k < 8; ++k) v[it][k] = ((float)mv[it][k] > 0.f) ? v[it][k] : 0.f;
       }
   }
-  if (statsp) {
+  if (statsp && p.bs_y) {
+    // hd_conv_args.bs_*: this tile of y IS the gradient dz of a BatchNorm unit -- its backward sums (sum dz*m, sum dz*m*xhat; the
+    // expressions of bn_bwd_reduce_kernel on the fp16-rounded dz) leave through the statistics rows, and the separate reduction
+    // pass (one more read of dz, one launch) is not run.  The unit's y (and z) vectors are pulled row by row: the registers of the
+    // tile pass above are still live.
+    const f16* __restrict__ byp = p.bs_y;
+    const f16* __restrict__ bzp = p.bs_z;
+    const bool relu = p.bs_relu != 0;
+    float mu[8], is[8], sc[8], sh[8];
+    {
+      f32x4 m0 = {0.f, 0.f, 0.f, 0.f}, m1 = m0, i0 = m0, i1 = m0, g0 = {1.f, 1.f, 1.f, 1.f}, g1 = g0, b0 = m0, b1 = m0;
+      if (cvalid) {
+        m0 = *reinterpret_cast<const f32x4*>(p.bs_mean + co); m1 = *reinterpret_cast<const f32x4*>(p.bs_mean + co + 4);
+        i0 = *reinterpret_cast<const f32x4*>(p.bs_invstd + co); i1 = *reinterpret_cast<const f32x4*>(p.bs_invstd + co + 4);
+        if (p.bs_gamma) { g0 = *reinterpret_cast<const f32x4*>(p.bs_gamma + co); g1 = *reinterpret_cast<const f32x4*>(p.bs_gamma + co + 4); }
+        if (p.bs_beta) { b0 = *reinterpret_cast<const f32x4*>(p.bs_beta + co); b1 = *reinterpret_cast<const f32x4*>(p.bs_beta + co + 4); }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        mu[k] = k < 4 ? m0[k] : m1[k - 4];
+        is[k] = k < 4 ? i0[k] : i1[k - 4];
+        const float g = k < 4 ? g0[k] : g1[k - 4], b = k < 4 ? b0[k] : b1[k - 4];
+        sc[k] = g * is[k];
+        sh[k] = b - mu[k] * g * is[k];
+      }
+    }
+    // rows in groups of HB: all of a group's y (and z) vectors are requested before the first is used (one exposed round trip per
+    // group instead of one per row; the group size is what the register budget of the 2-blocks-per-CU kernels leaves)
+    constexpr int HB = ITER < 4 ? ITER : 4;
+#pragma unroll
+    for (int h0 = 0; h0 < ITER; h0 += HB) {
+      f16x8 yy[HB], zz[HB];
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const unsigned o = ok[h0 + j] ? off[h0 + j] : off[0];      // (a clamped, valid address: the value is discarded below)
+        yy[j] = *reinterpret_cast<const f16x8*>(byp + (ok[0] ? o : 0u));
+        if (bzp) zz[j] = *reinterpret_cast<const f16x8*>(bzp + (ok[0] ? o : 0u));
+      }
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const float keep = ok[h0 + j] ? 1.f : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float gk = (float)(f16)v[h0 + j][k] * keep;
+          if (relu) {
+            const bool on = bzp ? ((float)zz[j][k] > 0.f) : ((float)(f16)hd_bn_affine((float)yy[j][k], sc[k], sh[k]) > 0.f);
+            gk = on ? gk : 0.f;
+          }
+          const float xh = ((float)yy[j][k] - mu[k]) * is[k];
+          ssum8[k] += gk;
+          ssq8[k] += gk * xh;
+        }
+      }
+    }
+  } else if (statsp) {
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
       const float keep = ok[it] ? 1.f : 0.f;        // rows outside the image / channels outside Cout do not count

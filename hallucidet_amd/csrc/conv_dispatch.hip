@@ -40,6 +40,10 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.act = a->act; p.out_mode = a->out_mode;
   HD_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "hd_conv2d: in_scale / in_shift must be given together");
   p.in_scale = a->in_scale; p.in_shift = a->in_shift; p.in_relu = a->in_relu;
+  p.bs_y = (const f16*)a->bs_y; p.bs_z = (const f16*)a->bs_z;
+  p.bs_mean = a->bs_mean; p.bs_invstd = a->bs_invstd; p.bs_gamma = a->bs_gamma; p.bs_beta = a->bs_beta; p.bs_relu = a->bs_relu;
+  HD_CHECK_ARG(!p.bs_y || (p.stats && p.bs_mean && p.bs_invstd && !a->mask && a->act == HD_ACT_NONE && a->out_mode == HD_OUT_NHWC_F16 && !a->bias),
+               "hd_conv2d: bs_* (BatchNorm backward sums) need stats, bs_mean, bs_invstd and exclude mask / act / bias / non-f16 output");
   HD_CHECK_ARG(p.out_mode >= HD_OUT_NHWC_F16 && p.out_mode <= HD_OUT_NHWC_F32, "hd_conv2d: out_mode %d", p.out_mode);
   p.M = a->N * a->Ho * a->Wo;
   p.cin8 = p.Cin / 8;
@@ -213,6 +217,19 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
 extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream);
 extern "C" int hd_conv2d(const hd_conv_args* a, void* stream);
 
+// does this problem run in a kernel whose epilogue implements hd_conv_args.bs_* ?  (the 8-wave patch-staged 3x3 family)
+static bool bstat_kernel(const ConvP& p) {
+  static const int on = env_int("HD_CONV_BSTAT", 1);
+  if (!on || use_small(p) || use_c64(p) || p.in_scale || p.in_dil != 1 || p.out_mode != HD_OUT_NHWC_F16) return false;
+  return choose_tile(p).p8cfg >= 0;
+}
+
+extern "C" int hd_conv2d_bstat_ok(const hd_conv_args* a) {
+  ConvP p;
+  if (fill_params(a, p)) return 0;
+  return bstat_kernel(p) ? 1 : 0;
+}
+
 // Data gradient + weight gradient of one layer (both read the same dY): ONE grid when the convolution runs in the 8-wave
 // patch-staged family and the weight gradient in its 8-wave kernel (conv3x3_w8_wgrad_kernel), otherwise hd_conv2d then hd_wgrad.
 // Bit-identical to the two calls either way.  HD_FUSE_DGRAD_WGRAD=0: always two launches (A/B).
@@ -222,7 +239,7 @@ extern "C" int hd_conv2d_wgrad(const hd_conv_args* a, const hd_wgrad_args* wa, v
   ConvP p;
   int rc = fill_params(a, p);
   if (rc) return rc;
-  if (fuse_on && !use_small(p) && !use_c64(p) && !p.in_scale && !p.x2 && !p.stats && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
+  if (fuse_on && !use_small(p) && !use_c64(p) && !p.in_scale && !p.x2 && (!p.stats || p.bs_y) && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) {
       static const int w8_prio = env_int("HD_W8_PRIO", 0);
@@ -255,7 +272,7 @@ extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
     ConvP& p = mp.p[i];
     int rc = fill_params(&args[i], p);
     if (rc) return rc;
-    if (use_small(p) || use_c64(p) || p.in_scale || p.x2 || p.in_dil != 1) { ok = false; break; }
+    if (use_small(p) || use_c64(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y) { ok = false; break; }
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) { ok = false; break; }
     if (i == 0) c0 = c;
@@ -290,6 +307,8 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   p.trace = g_trace;
   p.trace_tid = env_int("HD_TRACE_TID", 0);
 #endif
+  HD_CHECK_ARG(!p.bs_y || bstat_kernel(p), "hd_conv2d: bs_* (BatchNorm backward sums) are implemented by the 8-wave 3x3 kernels only; "
+                                           "ask hd_conv2d_bstat_ok first");
   if (use_small(p)) {
     hd_conv_launch_small(p, s);
     HD_CHECK_LAUNCH();

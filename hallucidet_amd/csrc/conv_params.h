@@ -24,6 +24,11 @@ struct ConvP {
   const float* in_scale;   // consumer-side BatchNorm of the x operand (hd_conv_args.in_scale / in_shift / in_relu): small-channel kernel only
   const float* in_shift;
   int in_relu;
+  // producer-side sums of the next BatchNorm backward (hd_conv_args.bs_*): 8-wave 3x3 kernels; rows go to `stats`
+  const f16* bs_y;
+  const f16* bs_z;
+  const float *bs_mean, *bs_invstd, *bs_gamma, *bs_beta;
+  int bs_relu;
 #ifdef HD_CONV_TRACE
   unsigned long long* trace;   // profiling builds only (tools/conv_trace.py): 16 stamps per block
   int trace_tid;               // which thread of the block stamps (HD_TRACE_TID, default 0)

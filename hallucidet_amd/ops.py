@@ -58,8 +58,12 @@ def conv_out_size(h, k, stride, pad):
 
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
            out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None,
-           in_scale=None, in_shift=None, in_relu=True, _defer=None):
+           in_scale=None, in_shift=None, in_relu=True, bstat=None, _defer=None):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
+
+    ``bstat`` (dict y, z|None, mean, invstd, gamma, beta, relu): the output of this call is the incoming gradient of a BatchNorm unit
+    with raw conv output ``y``; where the kernel supports it (hd_conv2d_bstat_ok) the unit's backward sums leave with the call and
+    ``bstat["part"]`` receives the [rows, 2*Cout] tensor `bn_backward(part=...)` takes; otherwise ``bstat["part"]`` is None.
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
     ``in_scale`` / ``in_shift`` ([C1] fp32): consumer-side BatchNorm -- x holds the RAW output of the producing conv and the kernel
@@ -98,13 +102,25 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
                  1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0),
                  ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
     stats = None
+    if bstat is not None:
+        bstat["part"] = None
+        if x.dtype == torch.float16 and not want_stats and lib.hd_conv2d_bstat_ok(C.byref(a)) == 1:
+            rows = lib.hd_conv2d_stats_rows(C.byref(a))
+            check(0 if rows > 0 else rows, "hd_conv2d_stats_rows")
+            part = torch.empty((rows, 2 * Cout), dtype=torch.float32, device=x.device)
+            by, bz = bstat["y"], bstat.get("z")
+            assert by.shape == y.shape and by.dtype == y.dtype and by.is_contiguous() and (bz is None or (bz.shape == y.shape and bz.is_contiguous()))
+            a.stats, a.bs_y, a.bs_z = ptr(part), ptr(by), ptr(bz)
+            a.bs_mean, a.bs_invstd, a.bs_gamma, a.bs_beta = ptr(bstat["mean"]), ptr(bstat["invstd"]), ptr(bstat.get("gamma")), ptr(bstat.get("beta"))
+            a.bs_relu = 1 if bstat.get("relu", True) else 0
+            bstat["part"] = part
     if want_stats:
         rows = _abi.fn("hd_conv2d_stats_rows", x)(C.byref(a))
         check(0 if rows > 0 else rows, "hd_conv2d_stats_rows")
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         a.stats = ptr(stats)
     if _defer is not None:          # wgrad_dgrad: the caller launches (the argument block and its tensors are kept by the list)
-        _defer.append((a, (x, x2, w, bias, res, mask, y, stats, in_scale, in_shift)))
+        _defer.append((a, (x, x2, w, bias, res, mask, y, stats, in_scale, in_shift, bstat)))
     else:
         check(_abi.fn("hd_conv2d", x)(C.byref(a), _stream()), "hd_conv2d")
     return (y, stats) if want_stats else y
@@ -358,18 +374,22 @@ def bn_apply(y, scale, shift, *, res=None, relu=True, out=None):
 
 
 def bn_backward(dz, z, y, mean, invstd, gamma, beta=None, *, relu=True, want_dres=False, gscale=1.0, dgamma=None, dbeta=None,
-                accumulate=False, rows=None):
-    """Backward of z = relu(bn_train(y) (+res)).  `z=None` (no residual): the ReLU mask is recomputed from y.
+                accumulate=False, rows=None, part=None):
+    """Backward of z = relu(bn_train(y) (+res)).  `z=None` (no residual): the ReLU mask is recomputed from y.  `part` [rows, 2C]: the
+    reduction's partial rows when the kernel that produced dz already emitted them (conv2d(bstat=...)): the reduction pass is skipped.
     Returns (dy, dres|None, dgamma, dbeta)."""
     _need_cuda(dz, y)
     C_ = y.shape[-1]
     npix = y.numel() // C_
-    if rows is None:
-        rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
     lib = _abi.load()
-    part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
-    check(_abi.fn("hd_bn_bwd_reduce", y)(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
-                               1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
+    if part is None:
+        if rows is None:
+            rows = int(max(1, min(512, npix // 64)))      # swept 128..4096 (tools/tune_bn.py): 512 is at or within 1 % of the best everywhere; npix // 16 and // 8 for the small tensors: no change (those launches are latency chains, not bandwidth)
+        part = torch.empty((rows, 2 * C_), dtype=torch.float32, device=y.device)
+        check(_abi.fn("hd_bn_bwd_reduce", y)(ptr(dz), ptr(z), ptr(y), ptr(mean), ptr(invstd), ptr(gamma), ptr(beta), ptr(part), rows, npix, C_,
+                                   1 if relu else 0, _stream()), "hd_bn_bwd_reduce")
+    else:
+        assert part.dtype == torch.float32 and part.dim() == 2 and part.shape[1] == 2 * C_ and part.is_contiguous()
     coef = torch.empty((5, C_), dtype=torch.float32, device=y.device)      # A, B, D, scale, shift: written by the coefficient launch
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_dres else None

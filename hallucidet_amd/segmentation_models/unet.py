@@ -295,6 +295,9 @@ class UnetRunner:
         # four largest activations of the network (32 ch @ 256x320 x2, 16 ch @ 512x640 x2) are never written / re-read in normalised
         # form.  HD_BN_FUSE=0: every unit materialises its activation (A/B knob; the two forms are bit-identical, tested).
         self.fuse_bn = os.environ.get("HD_BN_FUSE", "1") != "0"
+        # BatchNorm backward sums from the epilogue of the data-gradient kernel that produces the unit's incoming gradient
+        # (hd_conv_args.bs_*: 8-wave 3x3 kernels); HD_BN_BWD_SUMS=0: always the separate reduction pass (A/B)
+        self.fuse_bwd_sums = os.environ.get("HD_BN_BWD_SUMS", "1") != "0"
         self._raw_units = set()
         nd = len(self.dec)
         for i, (u1, u2, cin, cskip) in enumerate(self.dec):
@@ -597,18 +600,32 @@ class UnetRunner:
         flat += 1
 
     # ------------------------------------------------------------------ backward pieces
-    def _unit_bwd(self, u, dz, S, *, want_dres=False, need_dx=True, dx_res=None):
+    def _bstat_of(self, v):
+        """conv2d(bstat=...) request for unit `v`: the data gradient about to be computed is v's incoming gradient, so the kernel that
+        writes it can emit v's BatchNorm backward sums (hd_conv_args.bs_*); None when v's output did not reach the consumer as a plain
+        materialised activation (consumer-side BatchNorm units keep their own reduction)."""
+        if v is None or not self.fuse_bwd_sums:
+            return None
+        r = self.saved["rec"][v.name]
+        if isinstance(r["z"], _RawAct):
+            return None
+        return dict(y=r["y"], z=r["z"] if r["has_res"] else None, mean=r["mean"], invstd=r["invstd"], gamma=v.bn.weight, beta=v.bn.bias, relu=v.relu)
+
+    def _unit_bwd(self, u, dz, S, *, want_dres=False, need_dx=True, dx_res=None, part=None, dx_is_dz_of=None):
         """Backward through z = relu(bn(conv(x)) (+res)).  Writes dW/dgamma/dbeta into the flat gradient arena.
-        Returns (dx over the logical conv input or None, dres or None)."""
+        `part`: the BatchNorm reduction rows of THIS unit when the kernel that produced dz emitted them; `dx_is_dz_of`: the unit whose
+        output is this convolution's input and receives no other gradient -- its reduction rows are requested from the data-gradient
+        kernel.  Returns (dx over the logical conv input or None, dres or None, rows for dx_is_dz_of or None)."""
         r = self.saved["rec"][u.name]
         inv = 1.0 / S
         # the saved activation is only needed as a ReLU mask when a residual was added; otherwise it is recomputed from y
         dy, dres, _, _ = ops.bn_backward(dz, r["z"] if r["has_res"] else None, r["y"], r["mean"], r["invstd"], u.bn.weight, u.bn.bias,
                                          relu=u.relu, want_dres=want_dres,
-                                         gscale=inv, dgamma=u.bn.weight.grad, dbeta=u.bn.bias.grad)
+                                         gscale=inv, dgamma=u.bn.weight.grad, dbeta=u.bn.bias.grad, part=part)
         xt, isc, ish, irelu = _operand(r["x"])
         wkw = dict(x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"], **(dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}))
         dx = None
+        bstat = None
         if need_dx:
             # weight gradient and data gradient read the same dY and are independent: one call, ONE grid where both run in the 8-wave
             # kernels (ops.wgrad_dgrad / hd_conv2d_wgrad: the deep layers' 160-tile data gradients leave 96 CUs idle on their own)
@@ -618,11 +635,13 @@ class UnetRunner:
                 hw = (x.shape[1] * 2, x.shape[2] * 2)
             else:
                 hw = (x.shape[1], x.shape[2])
-            slab, dx = ops.wgrad_dgrad(xt, dy, u.k, u.k, wd, dgrad=dict(stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res), **wkw)
+            bstat = self._bstat_of(dx_is_dz_of) if (u.stride == 1 and not r["up1"] and r["x2"] is None) else None
+            slab, dx = ops.wgrad_dgrad(xt, dy, u.k, u.k, wd, dgrad=dict(stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res,
+                                                                        **(dict(bstat=bstat) if bstat is not None else {})), **wkw)
         else:
             slab = ops.wgrad(xt, dy, u.k, u.k, **wkw)
         self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
-        return dx, dres
+        return dx, dres, (bstat["part"] if bstat is not None else None)
 
     def backward(self, dout, need_dx=False, keep_saved=False):
         sv = self.saved
@@ -647,28 +666,32 @@ class UnetRunner:
         dskip = [None] * 5
         for i in range(len(self.dec) - 1, -1, -1):
             u1, u2, cin, cskip = self.dec[i]
-            dz1, _ = self._unit_bwd(u2, dz, S)
-            dcat, _ = self._unit_bwd(u1, dz1, S)
+            dz1, _, rows1 = self._unit_bwd(u2, dz, S, dx_is_dz_of=u1)
+            dcat, _, _ = self._unit_bwd(u1, dz1, S, part=rows1)
             dz, dskip[i] = ops.concat_up_bwd(dcat, cin)        # 2x2 sum-pool of the upsampled half + the skip's slice, one launch
         self._segment_done(0)                  # head + decoder parameter gradients are final
         # dz is now the gradient of f5; dskip[0..3] belong to f4, f3, f2, f1
         dfeat = {4: dz, 3: dskip[0], 2: dskip[1], 1: dskip[2], 0: dskip[3]}
-        d_out = dfeat[4]
+        d_out, rows_out = dfeat[4], None          # rows_out: BatchNorm reduction rows of the unit whose output gradient d_out is
         for si in range(3, -1, -1):
             blocks = self.stages[si]
             for bi in range(len(blocks) - 1, -1, -1):
                 us, ud = blocks[bi]
                 # gradient that the block INPUT also receives from elsewhere (decoder skip) when it is a stage output
                 extra = dfeat[si] if bi == 0 and si > 0 else None
-                dz1, dres = self._unit_bwd(us[-1], d_out, S, want_dres=True)
-                for u in reversed(us[1:-1]):          # Bottleneck's middle 3x3
-                    dz1, _ = self._unit_bwd(u, dz1, S)
+                # the unit below in the chain receives its whole gradient from this unit's data gradient
+                dz1, dres, rows = self._unit_bwd(us[-1], d_out, S, want_dres=True, part=rows_out, dx_is_dz_of=us[-2] if len(us) > 1 else None)
+                for j in range(len(us) - 2, 0, -1):          # Bottleneck's middle 3x3
+                    dz1, _, rows = self._unit_bwd(us[j], dz1, S, part=rows, dx_is_dz_of=us[j - 1])
+                # the block input is the previous block's output (same stage, bi > 0): with the identity path and the skip folded in
+                # through dx_res, this data gradient is that unit's complete incoming gradient
+                prev_out = blocks[bi - 1][0][-1] if bi > 0 else None
                 if ud is None:
                     acc = dres if extra is None else ops.add_f16(dres, extra)
-                    d_in, _ = self._unit_bwd(us[0], dz1, S, dx_res=acc)
+                    d_in, _, rows_out = self._unit_bwd(us[0], dz1, S, dx_res=acc, part=rows, dx_is_dz_of=prev_out)
                 else:
-                    d_in, _ = self._unit_bwd(us[0], dz1, S, dx_res=extra)
-                    d_in, _ = self._unit_bwd(ud, dres, S, dx_res=d_in)
+                    d_in, _, _ = self._unit_bwd(us[0], dz1, S, dx_res=extra, part=rows)
+                    d_in, _, rows_out = self._unit_bwd(ud, dres, S, dx_res=d_in, dx_is_dz_of=prev_out)
                 d_out = d_in
             if si > 0:
                 self._segment_done(4 - si)     # layer4 -> 1, layer3 -> 2, layer2 -> 3
@@ -677,7 +700,7 @@ class UnetRunner:
         dx = None
         if need_dx:
             raise NotImplementedError("gradient w.r.t. the Unet input is not on the hot path (IR images are data)")
-        self._unit_bwd(self.stem, df1, S, need_dx=False)
+        self._unit_bwd(self.stem, df1, S, need_dx=False)          # (rows_out is None here: layer1.0's input is the max-pooled stem)
         self._segment_done(4)                  # layer1 + stem
         if not keep_saved:
             self.saved = None

@@ -86,9 +86,27 @@ typedef struct hd_conv_args {
   const float* in_scale; /* [C1] or NULL */
   const float* in_shift; /* [C1] or NULL */
   int32_t in_relu, reserved0;
+  /* Producer-side sums of a BatchNorm's backward pass (bs_y NULL: off).  The tensor this call writes (y, f16 NHWC) is then the incoming
+   * gradient dz of a Conv2dReLU unit (src/segmentation_models/base/modules.py:10-47) whose raw convolution output is bs_y, and `stats`
+   * receives, per M tile, the rows hd_bn_bwd_reduce would produce from the stored dz: [gridM][2][Cout] = (sum dz*m, sum dz*m*xhat) with
+   * xhat = (bs_y - mean) * invstd and the ReLU mask m = (bs_z > 0) when bs_z is given (residual units), else
+   * fp16(fma(bs_y, gamma*invstd, beta - mean*gamma*invstd)) > 0 -- the same expressions on the same fp16-rounded dz; only the fp32
+   * summation order differs.  One full read of dz and one launch per unit disappear (the rows go to hd_bn_bwd_apply unchanged).
+   * Implemented in the 8-wave 3x3 kernels (hd_conv2d_bstat_ok says whether this problem is routed there); excludes act / mask / the
+   * forward statistics. */
+  const void* bs_y;       /* f16 NHWC [N,Ho,Wo,Cout] or NULL */
+  const void* bs_z;       /* f16 NHWC [N,Ho,Wo,Cout] or NULL */
+  const float* bs_mean;   /* [Cout] */
+  const float* bs_invstd; /* [Cout] */
+  const float* bs_gamma;  /* [Cout] or NULL (1) */
+  const float* bs_beta;   /* [Cout] or NULL (0) */
+  int32_t bs_relu, reserved1;
 } hd_conv_args;
 
 int hd_conv2d(const hd_conv_args* a, void* stream);
+/* 1 if hd_conv2d / hd_conv2d_wgrad route this problem to a kernel that implements the bs_* sums (the answer does not depend on the
+ * bs_* fields themselves), else 0: the caller then runs hd_bn_bwd_reduce as before */
+int hd_conv2d_bstat_ok(const hd_conv_args* a);
 /* number of M tiles (rows of `stats`) hd_conv2d will use for this problem */
 int hd_conv2d_stats_rows(const hd_conv_args* a);
 /* tuning hook for hd_conv2d's tile choice (tools/tune_conv.py): bm in {64,128}, bn in {32,64,128}, bk in {32,64}, deep in {0,1};

@@ -1258,3 +1258,39 @@ def test_fused_gradient_plumbing_equals_the_separate_passes(dev):
     got = ops.maxpool3x3s2_bwd_idx(idx, dy, (17, 22), add=other)
     want = ops.add_f16(ops.maxpool3x3s2_bwd_idx(idx, dy, (17, 22)), other)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("use_z,res", [(False, False), (True, True)])
+def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dev, use_z, res):
+    """hd_conv_args.bs_*: the 8-wave 3x3 kernel that writes a unit's incoming gradient dz also emits the unit's BatchNorm backward sums.
+    The summed rows equal hd_bn_bwd_reduce's on the stored dz (same expressions on the same fp16 values, different fp32 order), and the
+    convolution output itself is bit-identical to the plain call."""
+    from hallucidet_amd import ops
+    N, H, W, Cc = 4, 32, 40, 256
+    g = torch.Generator().manual_seed(77)
+    dyv = (torch.randn(N, H, W, Cc, generator=g) * 0.3).half().to(dev)
+    wd = (torch.randn(Cc, 9 * Cc, generator=g) / 48.0).half().to(dev)
+    y_u = torch.randn(N, H, W, Cc, generator=g).half().to(dev)
+    z_u = torch.relu(torch.randn(N, H, W, Cc, generator=g)).half().to(dev) if use_z else None
+    r = (torch.randn(N, H, W, Cc, generator=g) * 0.2).half().to(dev) if res else None
+    mean, invstd = torch.randn(Cc, generator=g).mul(0.1).to(dev), (torch.rand(Cc, generator=g) + 0.5).to(dev)
+    gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(dev), torch.randn(Cc, generator=g).mul(0.2).to(dev)
+    bs = dict(y=y_u, z=z_u, mean=mean, invstd=invstd, gamma=gamma, beta=beta, relu=True)
+    dz = ops.conv2d(dyv, wd, 3, 3, pad=1, res=r, bstat=bs)
+    assert bs["part"] is not None, "the 256-channel 3x3 data gradient runs in the 8-wave kernel"
+    plain = ops.conv2d(dyv, wd, 3, 3, pad=1, res=r)
+    assert torch.equal(dz, plain)
+    got = bs["part"].double().sum(0)
+    rows = 64
+    part = torch.empty(rows, 2 * Cc, device=dev)
+    from hallucidet_amd import _abi
+    ops.check(_abi.load().hd_bn_bwd_reduce(ops.ptr(dz), ops.ptr(z_u), ops.ptr(y_u), ops.ptr(mean), ops.ptr(invstd), ops.ptr(gamma), ops.ptr(beta),
+                                           ops.ptr(part), rows, N * H * W, Cc, 1, ops._stream()), "hd_bn_bwd_reduce")
+    want = part.double().sum(0)
+    scale = want.abs().max()
+    assert float((got - want).abs().max()) <= 2e-5 * float(scale), (float((got - want).abs().max()), float(scale))
+    # and through bn_backward: same dy either way
+    a = ops.bn_backward(dz, z_u, y_u, mean, invstd, gamma, beta, relu=True, part=bs["part"])
+    b = ops.bn_backward(dz, z_u, y_u, mean, invstd, gamma, beta, relu=True)
+    assert float((a[0].float() - b[0].float()).abs().max()) <= 2e-3 * float(b[0].float().abs().max())
+    assert torch.allclose(a[2], b[2], rtol=1e-4, atol=1e-4 * float(b[2].abs().max())) and torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-4 * float(b[3].abs().max()))

@@ -326,3 +326,40 @@ def test_one_to_three_channel_repeat_is_a_view_and_bit_identical(dev):
     det = Detector(name="fasterrcnn", pretrained=False, n_classes=2, size=300).detector.to(dev).eval()
     a, _ = det.transform.forward_batches([full, view], None)
     assert torch.equal(a.tensors[:2], a.tensors[2:]) and a.tensors.shape == (4, 300, 300, 8)
+
+
+def test_backward_sums_from_epilogues_equal_the_separate_reductions(dev):
+    """Round 4: the BatchNorm backward sums of 25 units leave with the data-gradient kernels (runner.fuse_bwd_sums).  Same parameter
+    gradients as with the separate hd_bn_bwd_reduce passes up to fp32 summation order."""
+    net, _ = _pair(dev, seed=5)
+    net.train()
+    x = torch.rand(4, 3, 256, 320, device=dev)
+    g = torch.randn(4, 3, 256, 320, generator=torch.Generator().manual_seed(6)).to(dev) * 1e-3
+    r = net.runner
+    r.enable_graphs(False)
+    grads, bufs = [], {k: v.clone() for k, v in net.state_dict().items()}
+    for on in (False, True):
+        net.load_state_dict(bufs)                    # same BatchNorm running statistics for both runs
+        r.fuse_bwd_sums = on
+        r.grad_scale = 256.0
+        for p_ in net.parameters():
+            p_.grad = None
+        out = net(x)
+        out.backward(g * 256.0)
+        grads.append(r.flat_grads.clone())
+    a, b = grads[0].double(), grads[1].double()
+    assert float(a.abs().max()) > 0 and torch.isfinite(b).all()
+    rel = float((a - b).norm() / a.norm())
+    print("whole gradient arena, fused vs separate BatchNorm backward sums: rel-L2 %.2e" % rel)
+    # Not 1e-6: with fp16 storage ANY re-ordering of an fp32 sum grows to the fp16 ulp within a few layers of the backward chain -- a
+    # 1e-7 change of a BatchNorm sum flips the fp16 rounding of ~1e-4 of the next gradient tensor's elements (1e-5 in L2), the next
+    # layer flips ~1e-2 of its elements ... the fixed point is ~1e-3.  Measured along the chain: 1.4e-7 at the first fused unit
+    # (decoder block 1), 1e-5, 7e-5, 4e-4 one, two, three units later, 1.0 - 2.5e-3 from layer3 down to the stem.
+    assert rel <= 5e-3
+    first = dict(net.named_parameters())["decoder.blocks.1.conv1.1.bias"]
+    lo = sum(p_.numel() for n_, p_ in list(net.named_parameters())[:list(dict(net.named_parameters())).index("decoder.blocks.1.conv1.1.bias")])
+    sl = slice(lo, lo + first.numel())
+    if torch.equal(r.flat_params[sl], first.detach().flatten()):          # (the arena is in parameter order)
+        d1 = float((a[sl] - b[sl]).norm() / a[sl].norm())
+        print("first fused unit (decoder block 1, conv1): dbeta rel-L2 %.2e" % d1)
+        assert d1 <= 1e-5
