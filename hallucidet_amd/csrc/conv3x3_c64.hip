@@ -34,6 +34,8 @@ constexpr int KTOT = 576, KSTEPS = 36;
 constexpr int W_OFF = 2 * STAGE_BYTES;           // weight staging (72 KiB), later the statistics transpose
 constexpr int W_BYTES = 64 * KTOT * 2;
 constexpr int LDS_BYTES = W_OFF + W_BYTES;       // 120 KiB: one block per CU
+constexpr int CF_OFF = W_OFF + 4 * 64 * 65 * 4;  // per-channel coefficients of the bs_* modes: behind the statistics transpose, inside the weight staging
+static_assert(CF_OFF + 4 * 64 * 4 <= LDS_BYTES, "coefficient table fits");
 constexpr unsigned OOBB = 0x80000000u;
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -57,7 +59,10 @@ constexpr int NA = 32;         // K steps whose two weight fragments live in AGP
 
 // EPI: 1 residual, 2 bias, 4 ReLU mask, 8 ReLU (template: as run-time flags the epilogue was 1 200 instructions with ~60 branches and
 // took 3 100 clocks per tile without a single store)
-template <bool STATS, int EPI>
+// STATS: 0 none | 1 BatchNorm forward sums (sum y, sum y^2) | 2, 3 hd_conv_args.bs_*: the output is the gradient dz of a BatchNorm unit and
+// its BACKWARD sums (sum dz*m, sum dz*m*xhat) leave through the same rows -- ReLU mask m recomputed from the unit's y (2) or read from
+// its saved activation z (3); per-channel coefficients sit in the dead weight-staging area of LDS
+template <int STATS, int EPI>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_total) {
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -141,6 +146,20 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
       wr[b][s] = *reinterpret_cast<const f16x8*>(lds + W_OFF + row * (KTOT * 2) + slot * 16);
     }
 
+  if (STATS >= 2) {
+    __syncthreads();                                    // every wave has its weight fragments: the staging area is free
+    float* cf = reinterpret_cast<float*>(lds + CF_OFF);  // [mean | invstd | scale | shift][64]
+    if (tid < 64) {
+      const float mu = p.bs_mean[tid], is = p.bs_invstd[tid];
+      const float g = p.bs_gamma ? p.bs_gamma[tid] : 1.f, b = p.bs_beta ? p.bs_beta[tid] : 0.f;
+      cf[tid] = mu;
+      cf[64 + tid] = is;
+      cf[128 + tid] = g * is;
+      cf[192 + tid] = b - mu * g * is;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (ordered against the readers by the tile loop's first barrier)
+  }
+
   // ---- B fragment addresses: this lane's pixel (two tile rows per wave) at tap (kh, kw), 16-channel group c, half h
   const int y0l = 2 * wave + ((lane >> 4) & 1), x0l = lane & 15;
   int ab[3][4];
@@ -152,7 +171,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
   }
 
   float s1[2][16], s2[2][16];
-  if (STATS) {
+  if (STATS != 0) {
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -224,55 +243,88 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
 #pragma unroll
       for (int j = 0; j < 8; ++j) bv[j] = *reinterpret_cast<const f32x4*>(biasp + 8 * j + 4 * h);
     }
-    unsigned pk[8][2];                     // [4b + g]: four channels as two packed f16 pairs
+    // rv / y / z vectors of the whole tile are requested up front; the packed output of a group pair is exchanged and stored as soon
+    // as it exists (a separate store pass would keep all sixteen packed registers alive next to the resident weights)
+    f16x4 byv[8], bzv[8];
+    if (STATS >= 2) {
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+      for (int j = 0; j < 8; ++j) byv[j] = okp ? *reinterpret_cast<const f16x4*>(p.bs_y + eoff + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
+      if (STATS == 3) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int j = 4 * b + g;
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = b ? acc1[4 * g + i] : acc0[4 * g + i];
-        if (EPI & 1) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += (float)rv[j][i];
-        }
-        if (EPI & 2) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] += bv[j][i];
-        }
-        if (EPI & 4) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = ((float)mv[j][i] > 0.f) ? v[i] : 0.f;
-        }
-        if (STATS) {
-          const float keep = okp ? 1.f : 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float vr = (float)(f16)v[i] * keep;
-            s1[b][4 * g + i] += vr;
-            s2[b][4 * g + i] += vr * vr;
-          }
-        }
-        if (EPI & 8) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
-        }
-        const f16x2 o01 = {(f16)v[0], (f16)v[1]}, o23 = {(f16)v[2], (f16)v[3]};
-        pk[j][0] = __builtin_bit_cast(unsigned, o01);
-        pk[j][1] = __builtin_bit_cast(unsigned, o23);
+        for (int j = 0; j < 8; ++j) bzv[j] = okp ? *reinterpret_cast<const f16x4*>(p.bs_z + eoff + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
       }
-    // 16-byte stores: lanes l and l + 32 hold the two 4-channel halves of the same pixel's 8-channel groups; one half exchange
-    // (v_permlane32_swap) per register leaves lane l with all of group g, lane l + 32 with all of group g + 1
+    }
+    // STATS 2: (scale, shift) of this lane's channels for the ReLU mask, re-read per tile through an offset the compiler cannot see
+    // through (hoisted out of the tile loop the 64 floats push weight fragments into scratch)
+    int tile_zero = 0;
+    if (STATS == 2) asm volatile("v_mov_b32 %0, 0" : "=v"(tile_zero));
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int g = 0; g < 4; g += 2) {
-        const int j = 4 * b + g;
-        const auto q0 = __builtin_amdgcn_permlane32_swap(pk[j][0], pk[j + 1][0], false, false);
-        const auto q1 = __builtin_amdgcn_permlane32_swap(pk[j][1], pk[j + 1][1], false, false);
+      for (int gp = 0; gp < 4; gp += 2) {
+        unsigned pk[2][2];                 // groups gp, gp + 1: four channels each as two packed f16 pairs
+#pragma unroll
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = gp + gg, j = 4 * b + g;
+          float v[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = b ? acc1[4 * g + i] : acc0[4 * g + i];
+          if (EPI & 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += (float)rv[j][i];
+          }
+          if (EPI & 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += bv[j][i];
+          }
+          if (EPI & 4) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ((float)mv[j][i] > 0.f) ? v[i] : 0.f;
+          }
+          if (STATS == 1) {
+            const float keep = okp ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float vr = (float)(f16)v[i] * keep;
+              s1[b][4 * g + i] += vr;
+              s2[b][4 * g + i] += vr * vr;
+            }
+          }
+          if (STATS >= 2) {
+            // sum dz*m and sum dz*m*y of this lane's channels 8j + 4h .. + 3 on the fp16-rounded dz; sum dz*m*xhat =
+            // invstd * (sum dz*m*y - mean * sum dz*m) is formed once per block below (no per-channel mean / invstd in this loop)
+            f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = sc;
+            if (STATS == 2) {
+              const float* cf = reinterpret_cast<const float*>(lds + CF_OFF + tile_zero) + 8 * j + 4 * h;
+              sc = *reinterpret_cast<const f32x4*>(cf + 128);
+              sh = *reinterpret_cast<const f32x4*>(cf + 192);
+            }
+            const float keep = okp ? 1.f : 0.f;
+            const bool relu = p.bs_relu != 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float gk = (float)(f16)v[i] * keep;
+              const float yk = (float)byv[j][i];
+              const bool on = STATS == 3 ? ((float)bzv[j][i] > 0.f) : ((float)(f16)hd_bn_affine(yk, sc[i], sh[i]) > 0.f);
+              gk = (on || !relu) ? gk : 0.f;
+              s1[b][4 * g + i] += gk;
+              s2[b][4 * g + i] += gk * yk;
+            }
+          }
+          if (EPI & 8) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.f);
+          }
+          const f16x2 o01 = {(f16)v[0], (f16)v[1]}, o23 = {(f16)v[2], (f16)v[3]};
+          pk[gg][0] = __builtin_bit_cast(unsigned, o01);
+          pk[gg][1] = __builtin_bit_cast(unsigned, o23);
+        }
+        // 16-byte stores: lanes l and l + 32 hold the two 4-channel halves of the same pixel's 8-channel groups; one half exchange
+        // (v_permlane32_swap) per register leaves lane l with all of group g, lane l + 32 with all of group g + 1
+        const auto q0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
+        const auto q1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
         const u32x4 o = {q0[0], q1[0], q0[1], q1[1]};
-        if (okp) *reinterpret_cast<u32x4*>(yp + eoff + 32 * b + 8 * (g + h)) = o;
+        if (okp) *reinterpret_cast<u32x4*>(yp + eoff + 32 * b + 8 * (gp + h)) = o;
       }
     cn = nn; cty = nty; ctx = ntx;
     __builtin_amdgcn_sched_barrier(0);
@@ -287,7 +339,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
   HD_TRACE(12, (unsigned long long)(t_end - t_begin));
 #endif
 
-  if (STATS) {
+  if (STATS != 0) {
     // ---- one partial row per block: transpose the 64 per-lane sums of a wave through LDS (pitch 65 floats: conflict-free both ways),
     //      lane j adds value j over the 32 pixel lanes of each half, then 128 threads add the four waves -- fixed order throughout
     __syncthreads();                                   // patch stages and weight staging are dead
@@ -317,6 +369,14 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
       for (int w4 = 0; w4 < 4; ++w4) s += red2[(w4 * 64 + v) * 2 + hh];
       const int which = v >> 5, b = (v >> 4) & 1, r = v & 15;
       const int c = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (STATS >= 2 && which == 1) {
+        // s = sum dz*m*y of channel c; its partner sum dz*m sits 32 values below in red2
+        float s0 = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) s0 += red2[(w4 * 64 + v - 32) * 2 + hh];
+        const float* cf = reinterpret_cast<const float*>(lds + CF_OFF);
+        s = cf[64 + c] * (s - cf[c] * s0);
+      }
       p.stats[((size_t)blockIdx.x * 2 + which) * 64 + c] = s;
     }
   }
@@ -350,8 +410,18 @@ void hd_conv_launch_c64(ConvP& p, hipStream_t s) {
   const int tiles = c64_tiles(p);
   dim3 grid(hd_conv_c64_rows(p));
   const int epi = (p.res ? 1 : 0) | (p.bias ? 2 : 0) | (p.mask ? 4 : 0) | (p.act == HD_ACT_RELU ? 8 : 0);
-#define LAUNCH(E) case E: if (p.stats) hipLaunchKernelGGL((conv3x3_c64_kernel<true, E>), grid, dim3(256), 0, s, p, tiles); \
-                          else hipLaunchKernelGGL((conv3x3_c64_kernel<false, E>), grid, dim3(256), 0, s, p, tiles); break
+  if (p.bs_y) {          // BatchNorm backward sums (data gradients: plain or + residual; fill_params excludes bias / mask / act)
+    if (p.bs_z) {
+      if (epi & 1) hipLaunchKernelGGL((conv3x3_c64_kernel<3, 1>), grid, dim3(256), 0, s, p, tiles);
+      else hipLaunchKernelGGL((conv3x3_c64_kernel<3, 0>), grid, dim3(256), 0, s, p, tiles);
+    } else {
+      if (epi & 1) hipLaunchKernelGGL((conv3x3_c64_kernel<2, 1>), grid, dim3(256), 0, s, p, tiles);
+      else hipLaunchKernelGGL((conv3x3_c64_kernel<2, 0>), grid, dim3(256), 0, s, p, tiles);
+    }
+    return;
+  }
+#define LAUNCH(E) case E: if (p.stats) hipLaunchKernelGGL((conv3x3_c64_kernel<1, E>), grid, dim3(256), 0, s, p, tiles); \
+                          else hipLaunchKernelGGL((conv3x3_c64_kernel<0, E>), grid, dim3(256), 0, s, p, tiles); break
   switch (epi) {
     LAUNCH(0); LAUNCH(1); LAUNCH(2); LAUNCH(3); LAUNCH(4); LAUNCH(5); LAUNCH(6); LAUNCH(7);
     LAUNCH(8); LAUNCH(9); LAUNCH(10); LAUNCH(11); LAUNCH(12); LAUNCH(13); LAUNCH(14); LAUNCH(15);

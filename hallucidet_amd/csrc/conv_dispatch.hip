@@ -220,7 +220,8 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream);
 // does this problem run in a kernel whose epilogue implements hd_conv_args.bs_* ?  (the 8-wave patch-staged 3x3 family)
 static bool bstat_kernel(const ConvP& p) {
   static const int on = env_int("HD_CONV_BSTAT", 1);
-  if (!on || use_small(p) || use_c64(p) || p.in_scale || p.in_dil != 1 || p.out_mode != HD_OUT_NHWC_F16) return false;
+  if (!on || use_small(p) || p.in_scale || p.in_dil != 1 || p.out_mode != HD_OUT_NHWC_F16) return false;
+  if (use_c64(p)) return true;                         // the register-resident 64 -> 64 kernel implements them too
   return choose_tile(p).p8cfg >= 0;
 }
 
@@ -307,7 +308,7 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   p.trace = g_trace;
   p.trace_tid = env_int("HD_TRACE_TID", 0);
 #endif
-  HD_CHECK_ARG(!p.bs_y || bstat_kernel(p), "hd_conv2d: bs_* (BatchNorm backward sums) are implemented by the 8-wave 3x3 kernels only; "
+  HD_CHECK_ARG(!p.bs_y || bstat_kernel(p), "hd_conv2d: bs_* (BatchNorm backward sums) are implemented by the 8-wave and the 64-channel 3x3 kernels only; "
                                            "ask hd_conv2d_bstat_ok first");
   if (use_small(p)) {
     hd_conv_launch_small(p, s);

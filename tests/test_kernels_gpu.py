@@ -1260,13 +1260,14 @@ def test_fused_gradient_plumbing_equals_the_separate_passes(dev):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("use_z,res", [(False, False), (True, True)])
-def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dev, use_z, res):
+@pytest.mark.parametrize("Cc", [256, 64])                 # 256: the 8-wave kernel; 64: the register-resident 64 -> 64 kernel
+@pytest.mark.parametrize("use_z,res", [(False, False), (True, True), (False, True)])
+def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dev, use_z, res, Cc):
     """hd_conv_args.bs_*: the 8-wave 3x3 kernel that writes a unit's incoming gradient dz also emits the unit's BatchNorm backward sums.
     The summed rows equal hd_bn_bwd_reduce's on the stored dz (same expressions on the same fp16 values, different fp32 order), and the
     convolution output itself is bit-identical to the plain call."""
     from hallucidet_amd import ops
-    N, H, W, Cc = 4, 32, 40, 256
+    N, H, W = (4, 32, 40) if Cc == 256 else (3, 50, 70)          # (50 x 70: ragged 8 x 16 tiles)
     g = torch.Generator().manual_seed(77)
     dyv = (torch.randn(N, H, W, Cc, generator=g) * 0.3).half().to(dev)
     wd = (torch.randn(Cc, 9 * Cc, generator=g) / 48.0).half().to(dev)
@@ -1277,7 +1278,7 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dev, use_z, res
     gamma, beta = (torch.rand(Cc, generator=g) + 0.5).to(dev), torch.randn(Cc, generator=g).mul(0.2).to(dev)
     bs = dict(y=y_u, z=z_u, mean=mean, invstd=invstd, gamma=gamma, beta=beta, relu=True)
     dz = ops.conv2d(dyv, wd, 3, 3, pad=1, res=r, bstat=bs)
-    assert bs["part"] is not None, "the 256-channel 3x3 data gradient runs in the 8-wave kernel"
+    assert bs["part"] is not None, "these 3x3 data gradients run in kernels that implement the sums"
     plain = ops.conv2d(dyv, wd, 3, 3, pad=1, res=r)
     assert torch.equal(dz, plain)
     got = bs["part"].double().sum(0)

@@ -337,7 +337,7 @@ def test_backward_sums_from_epilogues_equal_the_separate_reductions(dev):
     g = torch.randn(4, 3, 256, 320, generator=torch.Generator().manual_seed(6)).to(dev) * 1e-3
     r = net.runner
     r.enable_graphs(False)
-    grads, bufs = [], {k: v.clone() for k, v in net.state_dict().items()}
+    grads, named, bufs = [], [], {k: v.clone() for k, v in net.state_dict().items()}
     for on in (False, True):
         net.load_state_dict(bufs)                    # same BatchNorm running statistics for both runs
         r.fuse_bwd_sums = on
@@ -347,6 +347,7 @@ def test_backward_sums_from_epilogues_equal_the_separate_reductions(dev):
         out = net(x)
         out.backward(g * 256.0)
         grads.append(r.flat_grads.clone())
+        named.append({n_: p_.grad.detach().clone().double() for n_, p_ in net.named_parameters()})
     a, b = grads[0].double(), grads[1].double()
     assert float(a.abs().max()) > 0 and torch.isfinite(b).all()
     rel = float((a - b).norm() / a.norm())
@@ -356,10 +357,11 @@ def test_backward_sums_from_epilogues_equal_the_separate_reductions(dev):
     # layer flips ~1e-2 of its elements ... the fixed point is ~1e-3.  Measured along the chain: 1.4e-7 at the first fused unit
     # (decoder block 1), 1e-5, 7e-5, 4e-4 one, two, three units later, 1.0 - 2.5e-3 from layer3 down to the stem.
     assert rel <= 5e-3
-    first = dict(net.named_parameters())["decoder.blocks.1.conv1.1.bias"]
-    lo = sum(p_.numel() for n_, p_ in list(net.named_parameters())[:list(dict(net.named_parameters())).index("decoder.blocks.1.conv1.1.bias")])
-    sl = slice(lo, lo + first.numel())
-    if torch.equal(r.flat_params[sl], first.detach().flatten()):          # (the arena is in parameter order)
-        d1 = float((a[sl] - b[sl]).norm() / a[sl].norm())
-        print("first fused unit (decoder block 1, conv1): dbeta rel-L2 %.2e" % d1)
-        assert d1 <= 1e-5
+    # the first unit of the backward chain whose sums come from an epilogue: decoder block 2's conv1 (its gradient is written by the
+    # 64 -> 64 kernel); everything before it in the chain is bit-identical, the unit itself differs by fp32 summation order only
+    for n_ in ("decoder.blocks.4.conv1.1.bias", "decoder.blocks.3.conv2.1.bias", "decoder.blocks.2.conv2.1.bias"):
+        assert torch.equal(named[0][n_], named[1][n_]), n_
+    x0, x1 = named[0]["decoder.blocks.2.conv1.1.bias"], named[1]["decoder.blocks.2.conv1.1.bias"]
+    d1 = float((x0 - x1).norm() / x0.norm())
+    print("first fused unit (decoder block 2, conv1): dbeta rel-L2 %.2e" % d1)
+    assert d1 <= 1e-5
