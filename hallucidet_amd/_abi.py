@@ -72,6 +72,7 @@ PROTOTYPES = {
     "hd_conv2d": (C.c_int, [C.POINTER(ConvArgs), vp]),
     "hd_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvArgs)]),
     "hd_conv2d_bstat_ok": (C.c_int, [C.POINTER(ConvArgs)]),
+    "hd_conv7x7s2_dgrad_thin": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "hd_conv_tune_override": (C.c_int, [C.c_int] * 4),
     "hd_conv_tune_w8": (C.c_int, [C.c_int, C.c_int]),
     "hd_wgrad_w8_blocks": (C.c_int, [C.POINTER(WgradArgs)]),

@@ -111,6 +111,9 @@ class FeaturePyramidNetwork(nn.Module):
                 nn.init.constant_(m.bias, 0)
 
 
+_STEM_SUBPIXEL = os.environ.get("HD_STEM_SUBPIXEL", "1") != "0"      # 0: the stem's data gradient through hd_conv2d's in_dil = 2 route (A/B)
+
+
 def _conv_entry(conv, bn=None, cin_pad=None):
     """Fold FrozenBN into the conv and build the fp16 GEMM layouts (+ data-gradient layout)."""
     w = conv.weight.detach().float()
@@ -414,8 +417,14 @@ class BackboneWithFPN(nn.Module):
                     t = gm if extra is None else ops.add_f16(gm, extra)
                 gm = _dgrad(e["c1"], d1, hw_x, res=t, mask=xmask)
         ds_ = ops.maxpool3x3s2_bwd_idx(rec["pool_idx"], gm, (rec["stem"].shape[1], rec["stem"].shape[2]))
-        ds_ = ops.relu_bwd(ds_, rec["stem"])
         x = rec["x"]
+        e = P["stem"]
+        if _STEM_SUBPIXEL and ds_.dtype == torch.float16 and e["k"] == 7 and e["stride"] == 2 and e["pad"] == 3 and e["cout"] == 64 and e["cin"] <= 4 and e["cin_p"] == 8:
+            # the gradient handed to the hallucination network: sub-pixel form of the stem's data gradient, its ReLU backward in the staging
+            if "wsub" not in e:
+                e["wsub"] = ops.stem_dgrad_weights(e["wf"], e["cin_p"])
+            return ops.conv7x7s2_dgrad_thin(ds_, e["wsub"], (x.shape[1], x.shape[2]), mask_z=rec["stem"])
+        ds_ = ops.relu_bwd(ds_, rec["stem"])
         return _dgrad(P["stem"], ds_, (x.shape[1], x.shape[2]))
 
     def forward(self, x, n_active=None):

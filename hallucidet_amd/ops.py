@@ -162,6 +162,34 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in
     return slab
 
 
+def stem_dgrad_weights(wf, cin_p=8):
+    """The 16 x 1024 sub-pixel weight matrix of hd_conv7x7s2_dgrad_thin from the forward GEMM layout wf [64, 7*7*cin_p] (f16) of a
+    7x7 / stride-2 / pad-3 convolution with <= 4 real input channels."""
+    w = wf.view(64, 7, 7, cin_p).float()
+    out = torch.zeros(16, 16, 64, dtype=torch.float32, device=wf.device)             # [row][tap][ch]
+    for a in range(2):
+        for b in range(2):
+            for di in range(-1, 3):
+                for dj in range(-1, 3):
+                    kh, kw = a + 3 - 2 * di, b + 3 - 2 * dj
+                    if 0 <= kh <= 6 and 0 <= kw <= 6:
+                        for c in range(min(3, cin_p)):
+                            out[(2 * a + b) * 4 + c, (di + 1) * 4 + dj + 1] = w[:, kh, kw, c]
+    return out.view(16, 1024).half().contiguous()
+
+
+def conv7x7s2_dgrad_thin(dy, w16, in_hw, mask_z=None):
+    """Data gradient of the ResNet stem convolution in sub-pixel form (hd_conv7x7s2_dgrad_thin): dy [N,Hl,Wl,64] f16 -> [N,H,W,8] f16."""
+    _need_cuda(dy, w16, mask_z)
+    N, Hl, Wl, C_ = dy.shape
+    H, W = in_hw
+    assert C_ == 64 and dy.dtype == torch.float16 and dy.is_contiguous() and w16.shape == (16, 1024) and w16.dtype == torch.float16
+    assert mask_z is None or (mask_z.shape == dy.shape and mask_z.dtype == dy.dtype and mask_z.is_contiguous())
+    dx = torch.empty((N, H, W, 8), dtype=torch.float16, device=dy.device)
+    check(_abi.load().hd_conv7x7s2_dgrad_thin(ptr(dy), ptr(mask_z), ptr(w16), ptr(dx), N, Hl, Wl, H, W, _stream()), "hd_conv7x7s2_dgrad_thin")
+    return dx
+
+
 def conv2d_multi(calls):
     """calls: [(x, w, KH, KW, kwargs)] -- the arguments of independent `conv2d` calls -> their outputs, issued as ONE grid when all
     of them run in the same 4-wave implicit-GEMM variant (hd_conv2d_multi: the per-level convolutions of an FPN / a detection head),

@@ -109,6 +109,14 @@ int hd_conv2d(const hd_conv_args* a, void* stream);
 int hd_conv2d_bstat_ok(const hd_conv_args* a);
 /* number of M tiles (rows of `stats`) hd_conv2d will use for this problem */
 int hd_conv2d_stats_rows(const hd_conv_args* a);
+/* Data gradient of a 7x7 / stride-2 / pad-3 convolution with 64 output and <= 4 input channels (torchvision ResNet.conv1 [EXT] of the
+ * frozen detector: the last step of the gradient that trains the hallucination network, src/models/detector.py:24-141) in sub-pixel
+ * form: the four output pixels (2I + a, 2J + b) of a low-resolution position are one GEMM row block over the 4 x 4 window
+ * dy[I - 1 .. I + 2, J - 1 .. J + 2].  dy: f16 NHWC [N,Hl,Wl,64]; mask_z (or NULL): the stem's output, dy is taken as dy * (mask_z > 0)
+ * (the ReLU backward fused into the operand staging); w16: f16 [16][1024], row (2a + b) * 4 + c, column ((di + 1) * 4 + dj + 1) * 64 + ch
+ * holds w[ch][a + 3 - 2 di][b + 3 - 2 dj][c] (0 outside the 7 x 7 support and for c = 3); dx: f16 NHWC [N,H,W,8] (channels 3..7 zero).
+ * Same products as hd_conv2d's in_dil = 2 route, fp32 sums in another order. */
+int hd_conv7x7s2_dgrad_thin(const void* dy, const void* mask_z, const void* w16, void* dx, int N, int Hl, int Wl, int H, int W, void* stream);
 /* tuning hook for hd_conv2d's tile choice (tools/tune_conv.py): bm in {64,128}, bn in {32,64,128}, bk in {32,64}, deep in {0,1};
  * -1 = the built-in heuristic.  Process-wide; not for production use. */
 int hd_conv_tune_override(int bm, int bn, int bk, int deep);

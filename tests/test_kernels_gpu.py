@@ -1295,3 +1295,29 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dev, use_z, res
     b = ops.bn_backward(dz, z_u, y_u, mean, invstd, gamma, beta, relu=True)
     assert float((a[0].float() - b[0].float()).abs().max()) <= 2e-3 * float(b[0].float().abs().max())
     assert torch.allclose(a[2], b[2], rtol=1e-4, atol=1e-4 * float(b[2].abs().max())) and torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-4 * float(b[3].abs().max()))
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 300), (1, 75, 101), (3, 64, 38)])
+def test_stem_data_gradient_in_sub_pixel_form(dev, shape):
+    """hd_conv7x7s2_dgrad_thin (round 4) against the implicit-GEMM route it replaces (hd_conv2d with in_dil = 2 after hd_relu_bwd) and
+    against ATen's fp32 transposed convolution: even and odd extents, ragged tiles, the ReLU mask of the stem fused into the staging."""
+    from hallucidet_amd import ops
+    N, H, W = shape
+    Hl, Wl = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    g = torch.Generator().manual_seed(91)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05
+    wf, wd = ops.weight_prep(w.to(dev), cin_pad=8, cout_pad=64, want_fwd=True, want_dgrad=True)
+    dy = (torch.randn(N, Hl, Wl, 64, generator=g) * 0.5).half().to(dev)
+    z = torch.relu(torch.randn(N, Hl, Wl, 64, generator=g)).half().to(dev)
+    w16 = ops.stem_dgrad_weights(wf, 8)
+    got = ops.conv7x7s2_dgrad_thin(dy, w16, (H, W), mask_z=z)
+    masked = ops.relu_bwd(dy, z)
+    old = ops.conv2d(masked, wd, 7, 7, stride=1, pad=3, in_dil=2, out_hw=(H, W), cout=8)
+    assert got.shape == old.shape == (N, H, W, 8) and float(got[..., 3:].abs().max()) == 0.0
+    err = float((got.float() - old.float()).abs().max())
+    assert err <= 2e-3 * float(old.float().abs().max()) + 1e-3, err
+    want = torch.nn.functional.conv_transpose2d(masked.float().permute(0, 3, 1, 2), wf.view(64, 7, 7, 8)[..., :3].float().permute(0, 3, 1, 2).contiguous(),
+                                                stride=2, padding=3, output_padding=(H + 6 - 7 - 2 * (Hl - 1), W + 6 - 7 - 2 * (Wl - 1)))
+    assert want.shape[2:] == (H, W)
+    close(got[..., :3], want.permute(0, 2, 3, 1).half(), rtol=3e-3, atol=3e-3)
+    assert torch.equal(ops.conv7x7s2_dgrad_thin(dy, w16, (H, W)), ops.conv7x7s2_dgrad_thin(dy, w16, (H, W), mask_z=torch.ones_like(z)))

@@ -10,18 +10,35 @@ import csv, json, sys
 
 def per_launch(path, counter, match):
     tot, n = 0.0, 0
+    fam = {}
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and any(m in r["Kernel_Name"] for m in match.split(",")):
-            tot += float(r["Counter_Value"])
-            n += 1
-    return tot / max(n, 1), n
+        if r["Counter_Name"] != counter:
+            continue
+        for m in match.split(","):
+            if m in r["Kernel_Name"]:
+                tot += float(r["Counter_Value"])
+                n += 1
+                f = fam.setdefault(m, [0.0, 0])
+                f[0] += float(r["Counter_Value"])
+                f[1] += 1
+                break
+    return tot / max(n, 1), n, fam
 
 
-fetch_kib, nf = per_launch(sys.argv[1], "FETCH_SIZE", sys.argv[3])
-write_kib, nw = per_launch(sys.argv[2], "WRITE_SIZE", sys.argv[3])
+# families that are looked at but NOT part of `traffic_bytes_per_launch` (their launches hold several problems / a weight gradient as
+# well: no per-launch algorithmic figure to hold them against); listed so that a change of the sample's composition is visible
+EXTRA = "conv_igemm_multi_kernel,conv3x3_w8_wgrad_kernel"
+fetch_kib, nf, ffam = per_launch(sys.argv[1], "FETCH_SIZE", sys.argv[3])
+write_kib, nw, wfam = per_launch(sys.argv[2], "WRITE_SIZE", sys.argv[3])
+_, _, fx = per_launch(sys.argv[1], "FETCH_SIZE", EXTRA)
+_, _, wx = per_launch(sys.argv[2], "WRITE_SIZE", EXTRA)
 out = {"kernel": sys.argv[3], "launches_sampled": [nf, nw], "fetch_bytes_per_launch": fetch_kib * 1024 * 2.0, "write_bytes_per_launch": write_kib * 1024,
        "corrections": "FETCH_SIZE [KiB] x 1024 x 2 (gfx950 tallies 16-B/lane streaming reads at half); WRITE_SIZE [KiB] x 1024",
-       "command": "STEPS=3 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/bench_step.py (two separate passes)"}
+       "command": "STEPS=3 rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/bench_step.py (two separate passes)",
+       "by_kernel": {k: {"launches": ffam[k][1], "fetch_MB_per_launch": round(ffam[k][0] * 2048 / max(ffam[k][1], 1) / 1e6, 2),
+                         "write_MB_per_launch": round(wfam.get(k, [0, 0])[0] * 1024 / max(wfam.get(k, [0, 1])[1], 1) / 1e6, 2)} for k in ffam},
+       "not_in_the_per_launch_figure": {k: {"launches": fx[k][1], "fetch_MB_per_launch": round(fx[k][0] * 2048 / max(fx[k][1], 1) / 1e6, 2),
+                                           "write_MB_per_launch": round(wx.get(k, [0, 0])[0] * 1024 / max(wx.get(k, [0, 1])[1], 1) / 1e6, 2)} for k in fx}}
 out["traffic_bytes_per_launch"] = out["fetch_bytes_per_launch"] + out["write_bytes_per_launch"]
 out["commit"] = __import__("os").environ.get("HD_COMMIT")
 sys_path_ = __import__("sys").path; sys_path_.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
