@@ -1319,5 +1319,5 @@ def test_stem_data_gradient_in_sub_pixel_form(dev, shape):
     want = torch.nn.functional.conv_transpose2d(masked.float().permute(0, 3, 1, 2), wf.view(64, 7, 7, 8)[..., :3].float().permute(0, 3, 1, 2).contiguous(),
                                                 stride=2, padding=3, output_padding=(H + 6 - 7 - 2 * (Hl - 1), W + 6 - 7 - 2 * (Wl - 1)))
     assert want.shape[2:] == (H, W)
-    close(got[..., :3], want.permute(0, 2, 3, 1).half(), rtol=3e-3, atol=3e-3)
+    close(got[..., :3].cpu(), want.permute(0, 2, 3, 1).half().cpu(), rtol=3e-3, atol=3e-3)
     assert torch.equal(ops.conv7x7s2_dgrad_thin(dy, w16, (H, W)), ops.conv7x7s2_dgrad_thin(dy, w16, (H, W), mask_z=torch.ones_like(z)))
