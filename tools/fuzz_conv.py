@@ -67,6 +67,8 @@ def draw_case(r):
     Cout = r.choice(CH_OUT)
     while N * H * W * (4 if up1 else 1) * max(C1 + C2, Cout) > 40_000_000:
         H, W = max(K, H // 2), max(K, W // 2)
+    if r.random() < 0.12:                   # the register-resident 64 -> 64 kernel's domain (conv3x3_c64.hip)
+        K, stride, pad, up1, C1, C2, Cout = 3, 1, 1, False, 64, 0, 64
     return dict(N=N, H=H, W=W, C1=C1, C2=C2, Cout=Cout, K=K, stride=stride, pad=pad, up1=up1,
                 act=r.choice([0, 1, 1, 2]), bias=r.random() < 0.5, res=r.random() < 0.3, stats=r.random() < 0.5)
 
@@ -169,6 +171,48 @@ def run_fused(ops, c, gen):
     return ""
 
 
+def run_bstat(ops, r, gen):
+    """hd_conv_args.bs_*: the BatchNorm backward sums emitted by a 3x3 data gradient against hd_bn_bwd_reduce on the stored gradient;
+    the gradient itself bit-identical to the plain call."""
+    from hallucidet_amd import _abi
+    Cc = r.choice([64, 64, 128, 256])
+    N, H, W = r.choice([1, 2, 4, 8]), r.randint(6, 70), r.randint(6, 90)
+    while N * H * W * Cc > 20_000_000:
+        H, W = max(6, H // 2), max(6, W // 2)
+    use_z, res = r.random() < 0.5, r.random() < 0.5
+    dyv, wd = rnd(gen, N, H, W, Cc, scale=0.3), (torch.randn(Cc, 9 * Cc, generator=gen, device="cuda") / math.sqrt(9 * Cc)).half()
+    y_u = rnd(gen, N, H, W, Cc)
+    z_u = torch.relu(rnd(gen, N, H, W, Cc)) if use_z else None
+    rr = rnd(gen, N, H, W, Cc, scale=0.2) if res else None
+    mean, invstd = torch.randn(Cc, generator=gen, device="cuda") * 0.1, torch.rand(Cc, generator=gen, device="cuda") + 0.5
+    gamma, beta = torch.rand(Cc, generator=gen, device="cuda") + 0.5, torch.randn(Cc, generator=gen, device="cuda") * 0.2
+    bs = dict(y=y_u, z=z_u, mean=mean, invstd=invstd, gamma=gamma, beta=beta, relu=r.random() < 0.85)
+    dz = ops.conv2d(dyv, wd, 3, 3, pad=1, res=rr, bstat=bs)
+    if bs["part"] is None:
+        return None                        # this shape is not routed to a kernel with the sums (the caller keeps hd_bn_bwd_reduce)
+    if not torch.equal(dz, ops.conv2d(dyv, wd, 3, 3, pad=1, res=rr)):
+        return "bstat: the data gradient differs from the plain call"
+    part = torch.empty(64, 2 * Cc, device="cuda")
+    ops.check(_abi.load().hd_bn_bwd_reduce(ops.ptr(dz), ops.ptr(z_u), ops.ptr(y_u), ops.ptr(mean), ops.ptr(invstd), ops.ptr(gamma), ops.ptr(beta),
+                                           ops.ptr(part), 64, N * H * W, Cc, 1 if bs["relu"] else 0, ops._stream()), "hd_bn_bwd_reduce")
+    got, want = bs["part"].double().sum(0), part.double().sum(0)
+    e = float((got - want).abs().max()) / max(float(want.abs().max()), 1e-6)
+    return "" if e <= 5e-5 else "bstat: sums differ from hd_bn_bwd_reduce by %.2e of the largest" % e
+
+
+def run_stem_subpixel(ops, r, gen):
+    """hd_conv7x7s2_dgrad_thin against hd_conv2d's in_dil = 2 route for the same 7x7 / stride-2 data gradient."""
+    N, H, W = r.choice([1, 2, 3, 8]), r.randint(8, 320), r.randint(8, 320)
+    Hl, Wl = (H + 6 - 7) // 2 + 1, (W + 6 - 7) // 2 + 1
+    w = torch.randn(64, 3, 7, 7, generator=gen, device="cuda") * 0.05
+    wf, wd = ops.weight_prep(w, cin_pad=8, cout_pad=64, want_fwd=True, want_dgrad=True)
+    dy, z = rnd(gen, N, Hl, Wl, 64, scale=0.5), torch.relu(rnd(gen, N, Hl, Wl, 64))
+    got = ops.conv7x7s2_dgrad_thin(dy, ops.stem_dgrad_weights(wf, 8), (H, W), mask_z=z)
+    old = ops.conv2d(ops.relu_bwd(dy, z), wd, 7, 7, stride=1, pad=3, in_dil=2, out_hw=(H, W), cout=8)
+    e = float((got.float() - old.float()).abs().max())
+    return "" if e <= 2e-3 * float(old.float().abs().max()) + 1e-3 else "stem sub-pixel gradient differs by %.3g" % e
+
+
 def run_consumer_bn(ops, r, gen):
     """in_scale / in_shift (the producer's BatchNorm + ReLU applied while the small-channel kernels stage their operand) against
     hd_bn_apply followed by the plain call: outputs, BatchNorm partial sums and weight-gradient slabs bit for bit."""
@@ -226,7 +270,7 @@ def main():
     from hallucidet_amd import ops
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
-    t0, fails, ran = time.time(), [], {"forward": 0, "dgrad": 0, "wgrad": 0, "fused": 0, "multi": 0, "consumer_bn": 0}
+    t0, fails, ran = time.time(), [], {"forward": 0, "dgrad": 0, "wgrad": 0, "fused": 0, "multi": 0, "consumer_bn": 0, "bstat": 0, "stem_subpixel": 0}
     for i in range(args.cases):
         if time.time() - t0 > args.max_seconds:
             break
@@ -240,6 +284,10 @@ def main():
             legs.append(("multi", lambda: run_multi(ops, r, gen)))
         if i % 4 == 1:
             legs.append(("consumer_bn", lambda: run_consumer_bn(ops, r, gen)))
+        if i % 4 == 2:
+            legs.append(("bstat", lambda: run_bstat(ops, r, gen)))
+        if i % 8 == 3:
+            legs.append(("stem_subpixel", lambda: run_stem_subpixel(ops, r, gen)))
         for name, leg in legs:
             try:
                 msg = leg()
