@@ -85,6 +85,13 @@ bool use_c64(const ConvP& p) {
   return on && g_small_ok && hd_conv_c64_eligible(p);
 }
 
+// the ResNet stem (7x7 / stride 2, 8 -> 64 channels) goes to its own register-resident kernel (conv7x7s2_stem.hip); HD_CONV_STEM=0
+// keeps it in the igemm family (A/B)
+bool use_stem(const ConvP& p) {
+  static const int on = env_int("HD_CONV_STEM", 1);
+  return on && g_small_ok && hd_conv_stem_eligible(p);
+}
+
 // tuning hook (tools/tune_conv.py): force the tile / K-depth / stage choice of the igemm family; -1 = heuristic
 static int g_ov_bm = -1, g_ov_bn = -1, g_ov_bk = -1, g_ov_deep = -1;
 extern "C" int hd_conv_tune_override(int bm, int bn, int bk, int deep) {
@@ -209,6 +216,7 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (rc) return rc;
   if (use_small(p)) return hd_conv_small_tiles(p);
   if (use_c64(p)) return hd_conv_c64_rows(p);
+  if (use_stem(p)) return hd_conv_stem_rows(p);
   const TileChoice c = choose_tile(p);
   if (c.p8cfg >= 0) return hd_conv_p8_tiles(p, c.p8cfg);
   return hd_cdiv(p.M, c.bm);
@@ -240,7 +248,7 @@ extern "C" int hd_conv2d_wgrad(const hd_conv_args* a, const hd_wgrad_args* wa, v
   ConvP p;
   int rc = fill_params(a, p);
   if (rc) return rc;
-  if (fuse_on && !use_small(p) && !use_c64(p) && !p.in_scale && !p.x2 && (!p.stats || p.bs_y) && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
+  if (fuse_on && !use_small(p) && !use_c64(p) && !use_stem(p) && !p.in_scale && !p.x2 && (!p.stats || p.bs_y) && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) {
       static const int w8_prio = env_int("HD_W8_PRIO", 0);
@@ -273,7 +281,7 @@ extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
     ConvP& p = mp.p[i];
     int rc = fill_params(&args[i], p);
     if (rc) return rc;
-    if (use_small(p) || use_c64(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y) { ok = false; break; }
+    if (use_small(p) || use_c64(p) || use_stem(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y) { ok = false; break; }
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) { ok = false; break; }
     if (i == 0) c0 = c;
@@ -317,6 +325,11 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   }
   if (use_c64(p)) {
     hd_conv_launch_c64(p, s);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
+  if (use_stem(p)) {
+    hd_conv_launch_stem(p, s);
     HD_CHECK_LAUNCH();
     return HD_OK;
   }

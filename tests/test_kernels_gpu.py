@@ -1321,3 +1321,54 @@ def test_stem_data_gradient_in_sub_pixel_form(dev, shape):
     assert want.shape[2:] == (H, W)
     close(got[..., :3].cpu(), want.permute(0, 2, 3, 1).half().cpu(), rtol=3e-3, atol=3e-3)
     assert torch.equal(ops.conv7x7s2_dgrad_thin(dy, w16, (H, W)), ops.conv7x7s2_dgrad_thin(dy, w16, (H, W), mask_z=torch.ones_like(z)))
+
+
+STEM_CASES = [
+    # N, H, W, act, bias   (7x7 / s2 / p3, 8 -> 64: conv7x7s2_stem.hip)
+    (2, 64, 80, 0, False),        # fewer tiles than blocks
+    (1, 75, 101, 1, True),        # odd extents, ragged tiles, bias + ReLU (the detector's stem)
+    (3, 300, 300, 1, True),       # detector size
+    (2, 512, 640, 0, False),      # U-Net size: 1 280 tiles on 256 persistent blocks, BatchNorm partial sums
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", STEM_CASES)
+def test_conv_stem_register_resident_kernel(dev, case):
+    """conv7x7s2_stem.hip (default route of the ResNet stem) against ATen's fp32 convolution on the GPU and against the implicit-GEMM
+    family (forced through the tuning override): outputs to an fp16 ulp, BatchNorm partial rows equal in their totals, runs bit-identical."""
+    from hallucidet_amd import ops, _abi
+    N, H, W, act, use_bias = case
+    g = torch.Generator().manual_seed(31)
+    x = torch.zeros(N, H, W, 8)
+    x[..., :3] = torch.rand(N, H, W, 3, generator=g)
+    x = x.half()
+    w4 = torch.zeros(64, 7, 7, 8)
+    w4[..., :3] = torch.randn(64, 7, 7, 3, generator=g) * 0.08
+    w = w4.view(64, 392).half()
+    bias = torch.randn(64, generator=g) * 0.3 if use_bias else None
+    d = lambda t: None if t is None else t.to(dev)
+    lib = _abi.load()
+    got, stats = ops.conv2d(d(x), d(w), 7, 7, bias=d(bias), stride=2, pad=3, act=act, want_stats=True)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    assert got.shape == (N, Ho, Wo, 64)
+    tiles = N * ((Ho + 7) // 8) * ((Wo + 15) // 16)
+    assert stats.shape[0] == min(tiles, 256)                       # the persistent kernel really ran
+    lib.hd_conv_tune_override(128, 64, 32, 0)
+    try:
+        ref, rstats = ops.conv2d(d(x), d(w), 7, 7, bias=d(bias), stride=2, pad=3, act=act, want_stats=True)
+    finally:
+        lib.hd_conv_tune_override(-1, -1, -1, -1)
+    assert rstats.shape[0] != stats.shape[0] or tiles <= 256
+    torch.cuda.synchronize()
+    assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
+    assert torch.allclose(stats.sum(0), rstats.sum(0), rtol=2e-3, atol=2e-2)
+    want = torch.nn.functional.conv2d(d(x).float().permute(0, 3, 1, 2), d(w).float().view(64, 7, 7, 8).permute(0, 3, 1, 2), bias=d(bias), stride=2, padding=3)
+    if act == 1:
+        want = want.clamp(min=0)
+    close(got.cpu(), want.permute(0, 2, 3, 1).half().cpu(), rtol=3e-3, atol=3e-3)
+    got2, stats2 = ops.conv2d(d(x), d(w), 7, 7, bias=d(bias), stride=2, pad=3, act=act, want_stats=True)
+    assert torch.equal(got, got2) and torch.equal(stats, stats2)
+    # image n of the batch == the same image alone (tile choice and K order do not depend on N)
+    one = ops.conv2d(d(x[:1]), d(w), 7, 7, bias=d(bias), stride=2, pad=3, act=act)
+    assert torch.equal(one[0], got[0])
