@@ -4,6 +4,7 @@ R=${1:-r04}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+export HD_COMMIT=${HD_COMMIT:-unknown}
 STEPS=20 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_step --output-format csv -- python3 tools/bench_step.py > gpurun_out/prof_step.log 2>&1
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1
 STEPS=3 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace -d gpurun_out/pmc_mfma --output-format csv -- python3 tools/bench_step.py > gpurun_out/pmc_mfma.log 2>&1
