@@ -207,7 +207,30 @@ __device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in
   const int frow = lane & 31;
   const int fh = lane >> 5;
   const int swz = (frow >> 2) & 3;
+  // both K sub-steps' fragments requested before the first MFMA (two register sets; see conv_igemm_bk64.hip)
+  auto compute_db = [&](int stage) {
+    const f16* sa = lds + stage * STAGE;
+    const f16* sb = sa + BM * LDS_ROW;
+    f16x8 af[2][MT], bf[2][NT];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int slot = ((ks * 2 + fh) ^ swz) * 8;
+#pragma unroll
+      for (int a = 0; a < MT; ++a) af[ks][a] = *reinterpret_cast<const f16x8*>(sa + (wm * MT * 32 + a * 32 + frow) * LDS_ROW + slot);
+#pragma unroll
+      for (int b = 0; b < NT; ++b) bf[ks][b] = *reinterpret_cast<const f16x8*>(sb + (wn * NT * 32 + b * 32 + frow) * LDS_ROW + slot);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
   auto compute = [&](int stage) {
+    if (p.xp) { compute_db(stage); return; }
     const f16* sa = lds + stage * STAGE;
     const f16* sb = sa + BM * LDS_ROW;
 #pragma unroll
