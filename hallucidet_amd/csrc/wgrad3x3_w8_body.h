@@ -156,15 +156,28 @@ __device__ __forceinline__ void wgrad3x3_w8_body(const Wg8P& p, f16* lds, int bx
     if (t + 1 < t_end) issue_tile(t + 1, st ^ 1);
     const unsigned sb = (unsigned)(st * STAGE * 2);
     // K steps of this wave's pixel half: 2 pixel rows (16 pixels) each; row step = 8 dY pixels (1 KiB) / 10 patch pixels (1 280 B)
+    // The 36 MFMAs of a tile (4 K steps x 9 taps) as ONE software-pipelined stream: the patch fragment of MFMA j + RINGW is requested
+    // right after MFMA j is issued, the dY fragment of the next K step while the current one runs.  Written as the plain loop
+    // "read b; mfma" the compiler kept one register set and put s_waitcnt lgkmcnt(0) in front of EVERY MFMA: an LDS round trip
+    // (~120 clocks) per 32 clocks of matrix work -- the 0.25 MFMA utilisation this kernel was measured at in rounds 2 and 3.
+    constexpr int RINGW = 4, NMM = (TH / 4) * 9;
+    f16x8 bq[RINGW], aq[2];
+#define HD_WG8_B(J) tr_pair(lb + sb + xa[(J) % 9][0] + ((J) / 9) * 2560, lb + sb + xa[(J) % 9][1] + ((J) / 9) * 2560)
+#define HD_WG8_A(S) tr_pair(lb + sb + ya[0] + (S) * 2048, lb + sb + ya[1] + (S) * 2048)
+    aq[0] = HD_WG8_A(0);
 #pragma unroll
-    for (int s = 0; s < TH / 4; ++s) {
-      const f16x8 a = tr_pair(lb + sb + ya[0] + s * 2048, lb + sb + ya[1] + s * 2048);
+    for (int j = 0; j < RINGW; ++j) bq[j] = HD_WG8_B(j);
 #pragma unroll
-      for (int tp9 = 0; tp9 < 9; ++tp9) {
-        const f16x8 b = tr_pair(lb + sb + xa[tp9][0] + s * 2560, lb + sb + xa[tp9][1] + s * 2560);
-        acc[tp9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[tp9], 0, 0, 0);
-      }
+    for (int j = 0; j < NMM; ++j) {
+      const int s = j / 9, tp9 = j % 9;
+      if (tp9 == 0 && s + 1 < TH / 4) aq[(s + 1) & 1] = HD_WG8_A(s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[tp9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s & 1], bq[j % RINGW], acc[tp9], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + RINGW < NMM) bq[j % RINGW] = HD_WG8_B(j + RINGW);
     }
+#undef HD_WG8_A
+#undef HD_WG8_B
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
