@@ -165,18 +165,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgP p) {
   auto compute = [&](int buf) {
     const f16* sa = lds + buf * STAGE;
     const f16* sb = sa + BP * RSA;
+    // both K sub-steps' fragments are requested before the first MFMA (two register sets, pinned by the scheduling barriers: the
+    // compiler otherwise re-uses one set and waits for the LDS in the middle of every sub-step; see conv_igemm_bk64.hip)
+    f16x8 af[2][MT], bf[2][NT];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      f16x8 af[MT], bf[NT];
 #pragma unroll
-      for (int a = 0; a < MT; ++a) af[a] = tr_frag(sa + (ks * 16 + krow) * RSA + (wm * MT * 32 + a * 32) + coff, RSA);
+      for (int a = 0; a < MT; ++a) af[ks][a] = tr_frag(sa + (ks * 16 + krow) * RSA + (wm * MT * 32 + a * 32) + coff, RSA);
 #pragma unroll
-      for (int b = 0; b < NT; ++b) bf[b] = tr_frag(sb + (ks * 16 + krow) * RSB + (wn * NT * 32 + b * 32) + coff, RSB);
+      for (int b = 0; b < NT; ++b) bf[ks][b] = tr_frag(sb + (ks * 16 + krow) * RSB + (wn * NT * 32 + b * 32) + coff, RSB);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
+        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
   };
   // tiles beyond nk load zeros (pix >= pend): the loop runs an even number of tiles
   u32x4 ra0[A_LOADS], rb0[B_LOADS], ra1[A_LOADS], rb1[B_LOADS];
