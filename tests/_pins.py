@@ -201,7 +201,8 @@ class record:
 #     within 2 * NOISE_C * dmax(stem) of each other (each side moves by at most dmax);
 #   * share: at most SHARE_K * sigma / RMS of a layer's elements differ (the mass of a unit-scale density inside a band of width
 #     sigma; measured 0.3 - 0.75 in fp16 storage; in fp32 storage a layer has a handful of flips and the ratio is a small-count
-#     statistic: SHARE_FLOOR of the elements is always allowed), never more than MAX_FLIP_SHARE;
+#     statistic: SHARE_FLOOR of the elements and SMALL_COUNT flips per layer are always allowed -- one flip in a 4 608-element pyramid
+#     level is 2.2e-4 --), never more than MAX_FLIP_SHARE;
 #   * proposals: at least MIN_PROPOSAL_MATCH of the borrowed post-NMS boxes coincide (IoU >= 0.5; reported at 0.9 / 0.7 / 0.5) with a box
 #     of the oracle's own candidate set (every anchor decoded with the oracle's deltas, clipped) -- WHICH candidates survive top-k / NMS
 #     is decided by near-ties of a randomly initialised RPN and is what the pin is for; that the boxes ARE the oracle's boxes is
@@ -212,6 +213,7 @@ class record:
 NOISE_C = 4.0
 SHARE_K = 2.0
 SHARE_FLOOR = 2e-4
+SMALL_COUNT = 2
 MAX_FLIP_SHARE = 0.10
 MIN_PROPOSAL_MATCH = 0.98
 
@@ -253,7 +255,9 @@ def assert_borrowed_decisions_are_noise(holder, label=""):
         if os.environ.get("HD_PINS_AUDIT"):
             print("   audit %-28s n %9d differ %7d (%.4f %%) worst |x| %.3e = %.2f dmax = %.1f sigma; sigma/RMS %.2e share/(sigma/RMS) %.2f" % (
                 str(tag), n, nf, 100 * share, big, kmax, ksig, sigma / max(rms, 1e-30), sratio))
-        if big > limit or share > max(SHARE_K * sigma / max(rms, 1e-30), SHARE_FLOOR) or share > MAX_FLIP_SHARE:
+        # (one or two flips in a layer are a COUNT, not a share: a 4 608-element pyramid level with one flipped element reads 2.2e-4;
+        #  the magnitude bound applies to them all the same)
+        if big > limit or (nf > SMALL_COUNT and share > max(SHARE_K * sigma / max(rms, 1e-30), SHARE_FLOOR)) or share > MAX_FLIP_SHARE:
             problems.append((tag, "share %.5f (%.2f sigma/RMS)" % (share, sratio), "worst %.2f dmax" % kmax))
     summary = "borrowed decisions %s: %d audited, worst share %.4f %% = %.2f sigma/RMS, worst |x| %.2f dmax (%s; %.1f sigma)%s" % (
         label, len(audit), 100 * worst["share"], worst["sratio"], worst["kmax"], worst["tag"], worst["ksig"],
