@@ -51,11 +51,6 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.nk = 0;
   p.Ktot = a->KH * a->KW * p.Cin;
   p.prio = 0;
-  {
-    const char* v = getenv("HD_IGEMM_XP");
-    static const int xp = v ? atoi(v) : 2;
-    p.xp = xp;
-  }
   p.par = p.ph = p.pw = p.Hc = p.Wc = p.t0h = p.t0w = 0;
   p.inv_cin8 = 1.0f / (float)p.cin8;
   p.inv_kw = 1.0f / (float)a->KW;

@@ -207,8 +207,9 @@ __device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in
   const int frow = lane & 31;
   const int fh = lane >> 5;
   const int swz = (frow >> 2) & 3;
-  // both K sub-steps' fragments requested before the first MFMA (two register sets; see conv_igemm_bk64.hip)
-  auto compute_db = [&](int stage) {
+  // both K sub-steps' fragments are requested before the first MFMA (two register sets pinned by scheduling barriers; see
+  // conv_igemm_bk64.hip)
+  auto compute = [&](int stage) {
     const f16* sa = lds + stage * STAGE;
     const f16* sb = sa + BM * LDS_ROW;
     f16x8 af[2][MT], bf[2][NT];
@@ -228,26 +229,6 @@ __device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks][a], bf[ks][b], acc[a][b], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-  };
-  auto compute = [&](int stage) {
-    if (p.xp) { compute_db(stage); return; }
-    const f16* sa = lds + stage * STAGE;
-    const f16* sb = sa + BM * LDS_ROW;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int slot = ((ks * 2 + fh) ^ swz) * 8;
-      f16x8 af[MT], bf[NT];
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-        af[a] = *reinterpret_cast<const f16x8*>(sa + (wm * MT * 32 + a * 32 + frow) * LDS_ROW + slot);
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-        bf[b] = *reinterpret_cast<const f16x8*>(sb + (wn * NT * 32 + b * 32 + frow) * LDS_ROW + slot);
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
-    }
   };
 
   // prologue: NSTAGE-1 tiles in flight

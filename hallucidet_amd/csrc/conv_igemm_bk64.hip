@@ -216,6 +216,11 @@ __device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in
   const int swz = (frow >> 1) & 7;
   // fragments of K sub-step ks + 1 are requested before the MFMAs of sub-step ks are issued (two register sets): left to itself the
   // compiler re-used ONE set and waited for lgkmcnt(0) in the middle of every sub-step
+  // Fragments of K sub-step ks + 2 are requested right after the MFMAs of sub-step ks are issued (two register sets), and the first two
+  // sub-steps' fragments BEFORE the next tile's DMA pieces (their LDS round trip runs under the DMA issue).  Left to itself the compiler
+  // re-used ONE set and waited for lgkmcnt(0) in the middle of every sub-step; written as two sets it folded them back -- the
+  // scheduling barriers pin the order.  (One code path: a run-time switch between this and the plain form doubled the register count
+  // and halved the occupancy of every variant -- the A/B that missed it compared two slow halves of one binary.)
   f16x8 afd[2][MT], bfd[2][NT];
   auto frag = [&](int stage, int ks, int buf) {
     const f16* sa = lds + stage * STAGE;
@@ -226,47 +231,16 @@ __device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in
 #pragma unroll
     for (int b = 0; b < NT; ++b) bfd[buf][b] = *reinterpret_cast<const f16x8*>(sb + (wn * NT * 32 + b * 32 + frow) * LDS_ROW + slot);
   };
-  // xp == 2: the first two sub-steps' fragments are requested BEFORE the next tile's DMA pieces are issued (compute_pre), so that their
-  // LDS round trip runs under the DMA issue instead of in front of the first MFMA
-  auto compute_pre = [&](int stage) {
-    frag(stage, 0, 0);
-    frag(stage, 1, 1);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  auto compute_db = [&](int stage, bool pre_done) {
-    if (!pre_done) {
-      frag(stage, 0, 0);
-      frag(stage, 1, 1);
-    }
+  auto compute = [&](int stage) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      __builtin_amdgcn_sched_barrier(0);          // (the scheduler otherwise folds the two register sets back into one)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(afd[ks & 1][a], bfd[ks & 1][b], acc[a][b], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (ks + 2 < BK / 16) frag(stage, ks + 2, ks & 1);
-    }
-  };
-  auto compute = [&](int stage) {
-    if (p.xp) { compute_db(stage, p.xp == 2); return; }
-    const f16* sa = lds + stage * STAGE;
-    const f16* sb = sa + BM * LDS_ROW;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int slot = ((ks * 2 + fh) ^ swz) * 8;
-      f16x8 af[MT], bf[NT];
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-        af[a] = *reinterpret_cast<const f16x8*>(sa + (wm * MT * 32 + a * 32 + frow) * LDS_ROW + slot);
-#pragma unroll
-      for (int b = 0; b < NT; ++b)
-        bf[b] = *reinterpret_cast<const f16x8*>(sb + (wn * NT * 32 + b * 32 + frow) * LDS_ROW + slot);
-#pragma unroll
-      for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[a], bf[b], acc[a][b], 0, 0, 0);
     }
   };
 
@@ -283,7 +257,9 @@ __device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in
 #ifdef HD_CONV_TRACE
     if (kt == 0) HD_TRACE(3, clock64());
 #endif
-    if (p.xp == 2) compute_pre(rd);
+    frag(rd, 0, 0);
+    frag(rd, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
     gload(wr);                      // tile kt+NSTAGE-1 (zeros beyond the last tile: out-of-range offsets)
     compute(rd);
     rd = (rd + 1 == NSTAGE) ? 0 : rd + 1;

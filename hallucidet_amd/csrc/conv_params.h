@@ -20,7 +20,6 @@ struct ConvP {
   // only sees the taps with kh = (pad - ph) mod 2 (+2, +4, ...) -- the others hit the zeros of the dilated input -- so a class
   // walks a quarter of the taps (none at all for three classes of a 1x1).  `par` is set by the dispatcher, the rest by the kernel.
   int par, ph, pw, Hc, Wc, t0h, t0w;
-  int xp;              // experiment knob of the 4-wave 64-deep family (HD_IGEMM_XP): 1 = fragments of the next K sub-step requested before this one's MFMAs
   int prio;            // 8-wave families: s_setprio policy (experiment knob HD_W8_PRIO: 0 none, 1 MFMA phase, 2 MEM phase)
   const float* in_scale;   // consumer-side BatchNorm of the x operand (hd_conv_args.in_scale / in_shift / in_relu): small-channel kernel only
   const float* in_shift;
