@@ -18,6 +18,8 @@ STEPS=12 rocprofv3 --kernel-trace -d gpurun_out/trace_ss --output-format csv -- 
 python3 tools/trace_gaps.py $(ls gpurun_out/trace_ss/*/*kernel_trace.csv | head -1) 0.5 --table --aten > gpurun_out/${R}_steady_state.txt 2>&1
 rm -rf gpurun_out/trace_ss
 python3 tools/conv_table.py all > gpurun_out/${R}_conv_table.txt 2>&1
+# the bench line quotes the PMC summaries from profiles/: put this run's there first (else the line marks them stale)
+cp gpurun_out/${R}_conv_mfma_util.json gpurun_out/${R}_conv_traffic.json profiles/
 python3 bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_line.err
 cp $(ls gpurun_out/prof_step/*/*kernel_stats.csv | head -1) gpurun_out/${R}_train_step_kernel_stats.csv
 cp $(ls gpurun_out/prof_bench/*/*kernel_stats.csv | head -1) gpurun_out/${R}_bench_kernel_stats.csv
