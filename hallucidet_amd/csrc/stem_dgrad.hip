@@ -17,6 +17,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int TH = 8, TW = 32;                 // low-resolution tile
 constexpr int PH = TH + 3, PW = TW + 3;        // window rows / columns -1 .. +2
 constexpr int CH = 64;
+constexpr int PITCH = CH + 8;                  // halves per patch pixel in LDS: 144 bytes -- sixteen lanes that read the same chunk of consecutive
+                                               // pixels start 36 banks apart (distinct 4-bank groups), and every tap is a CONSTANT byte offset
 constexpr int KSTEPS = 32;                     // 16 taps x 2 halves of 32 channels
 constexpr int CHUNKS = PH * PW * 8;            // 16-byte chunks of the patch
 constexpr int XL = (CHUNKS + 255) / 256;
@@ -24,7 +26,7 @@ constexpr int XL = (CHUNKS + 255) / 256;
 __global__ __launch_bounds__(256) void conv7x7s2_dgrad_thin_kernel(const f16* __restrict__ dy, const f16* __restrict__ maskz,
                                                                       const f16* __restrict__ w16, f16* __restrict__ dx, int N, int Hl, int Wl,
                                                                       int H, int W, int tiles_x, int tiles_y) {
-  __shared__ __attribute__((aligned(16))) f16 s_patch[PH * PW * CH];
+  __shared__ __attribute__((aligned(16))) f16 s_patch[PH * PW * PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pl = lane & 15, g = lane >> 4;
   const int tiles_total = N * tiles_x * tiles_y;
@@ -74,29 +76,39 @@ __global__ __launch_bounds__(256) void conv7x7s2_dgrad_thin_kernel(const f16* __
     for (int i = 0; i < XL; ++i) {
       const int e = tid + i * 256;
       const int c8 = e & 7, pp = e >> 3;
-      // chunk c of patch pixel pp sits in slot c ^ (pp & 7): sixteen lanes that read the same chunk of consecutive pixels hit distinct banks
-      if (e < CHUNKS) *reinterpret_cast<f16x8*>(s_patch + pp * CH + ((c8 ^ (pp & 7)) * 8)) = rx[i];
+      if (e < CHUNKS) *reinterpret_cast<f16x8*>(s_patch + pp * PITCH + c8 * 8) = rx[i];
     }
     __syncthreads();
     gload(tile + gridDim.x);
 
-    // ---- wave w owns low-resolution rows 2w, 2w + 1: four pixel groups of 16
+    // ---- wave w owns low-resolution rows 2w, 2w + 1: four pixel groups of 16.  The 128 MFMAs of a tile (32 K steps x 4 pixel groups) run
+    //      as ONE software-pipelined stream: the fragment of MFMA j + RING is requested right after MFMA j is issued (left to the compiler
+    //      every MFMA waited for its own fragment: an LDS round trip per 16 clocks of matrix work, 15 us per tile).  A fragment's address
+    //      is the pixel group's base (one register each) plus a compile-time byte offset (tap and channel half).
     f32x4_t acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const char* pb[4];
 #pragma unroll
-    for (int s = 0; s < KSTEPS; ++s) {
-      const int tap = s >> 1, half = s & 1;
-      const int di = tap >> 2, dj = tap & 3;          // window offset + 1
-      const int c8 = half * 4 + g;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int oy = wave * 2 + (t >> 1), ox = (t & 1) * 16 + pl;
-        const int pp = (oy + di) * PW + ox + dj;
-        const f16x8 bf = *reinterpret_cast<const f16x8*>(s_patch + pp * CH + ((c8 ^ (pp & 7)) * 8));
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[s], bf, acc[t], 0, 0, 0);
-      }
+    for (int t = 0; t < 4; ++t) {
+      const int oy = wave * 2 + (t >> 1), ox = (t & 1) * 16 + pl;
+      pb[t] = reinterpret_cast<const char*>(s_patch) + ((oy * PW + ox) * PITCH + g * 8) * 2;
     }
+    constexpr int RING = 6, NMM = KSTEPS * 4;
+#define HD_SD_OFF(S) (((((S) >> 1) >> 2) * PW + (((S) >> 1) & 3)) * PITCH + ((S) & 1) * 32) * 2
+#define HD_SD_B(J) (*reinterpret_cast<const f16x8*>(pb[(J) & 3] + HD_SD_OFF((J) >> 2)))
+    f16x8 bq[RING];
+#pragma unroll
+    for (int j = 0; j < RING; ++j) bq[j] = HD_SD_B(j);
+#pragma unroll
+    for (int j = 0; j < NMM; ++j) {
+      __builtin_amdgcn_sched_barrier(0);
+      acc[j & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wr[j >> 2], bq[j % RING], acc[j & 3], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j + RING < NMM) bq[j % RING] = HD_SD_B(j + RING);
+    }
+#undef HD_SD_B
+#undef HD_SD_OFF
     // ---- lane (pl, g): the four channels of output pixel (2I + (g >> 1), 2J + (g & 1)) -> one 16-byte store (channels 3..7 zero)
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -119,7 +131,7 @@ extern "C" int hd_conv7x7s2_dgrad_thin(const void* dy, const void* mask_z, const
   const int tiles_x = (Wl + TW - 1) / TW, tiles_y = (Hl + TH - 1) / TH;
   const int tiles = N * tiles_x * tiles_y;
   // an odd H / W leaves the last input row / column without an output pixel pair of its own: rows 2I + a with I < Hl cover 0 .. 2 Hl - 1 >= H - 1
-  hipLaunchKernelGGL(conv7x7s2_dgrad_thin_kernel, dim3(tiles < 512 ? tiles : 512), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)mask_z,
+  hipLaunchKernelGGL(conv7x7s2_dgrad_thin_kernel, dim3(tiles < 256 ? tiles : 256), dim3(256), 0, (hipStream_t)stream, (const f16*)dy, (const f16*)mask_z,
                      (const f16*)w16, (f16*)dx, N, Hl, Wl, H, W, tiles_x, tiles_y);
   HD_CHECK_LAUNCH();
   return HD_OK;
