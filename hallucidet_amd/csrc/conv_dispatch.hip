@@ -92,6 +92,12 @@ bool use_stem(const ConvP& p) {
   return on && g_small_ok && hd_conv_stem_eligible(p);
 }
 
+// the 32 -> 128 channel 3x3 data gradient goes to its register-resident kernel (conv3x3_c32to128.hip); HD_CONV_C32=0: igemm family (A/B)
+bool use_c32(const ConvP& p) {
+  static const int on = env_int("HD_CONV_C32", 1);
+  return on && g_small_ok && !p.stats && hd_conv_c32to128_eligible(p);
+}
+
 // tuning hook (tools/tune_conv.py): force the tile / K-depth / stage choice of the igemm family; -1 = heuristic
 static int g_ov_bm = -1, g_ov_bn = -1, g_ov_bk = -1, g_ov_deep = -1;
 extern "C" int hd_conv_tune_override(int bm, int bn, int bk, int deep) {
@@ -281,7 +287,7 @@ extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
     ConvP& p = mp.p[i];
     int rc = fill_params(&args[i], p);
     if (rc) return rc;
-    if (use_small(p) || use_c64(p) || use_stem(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y) { ok = false; break; }
+    if (use_small(p) || use_c64(p) || use_stem(p) || use_c32(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y) { ok = false; break; }
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) { ok = false; break; }
     if (i == 0) c0 = c;
@@ -330,6 +336,11 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   }
   if (use_stem(p)) {
     hd_conv_launch_stem(p, s);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
+  if (use_c32(p)) {
+    hd_conv_launch_c32to128(p, s);
     HD_CHECK_LAUNCH();
     return HD_OK;
   }

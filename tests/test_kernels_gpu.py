@@ -1372,3 +1372,28 @@ def test_conv_stem_register_resident_kernel(dev, case):
     # image n of the batch == the same image alone (tile choice and K order do not depend on N)
     one = ops.conv2d(d(x[:1]), d(w), 7, 7, bias=d(bias), stride=2, pad=3, act=act)
     assert torch.equal(one[0], got[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 16, 20), (1, 13, 37), (8, 256, 320)])
+def test_conv_32_to_128_register_resident_kernel(dev, shape):
+    """conv3x3_c32to128.hip (decoder block 3's data gradient: 32 -> 128 channels) against the implicit-GEMM family (forced through the
+    tuning override; same K order: outputs to an fp16 ulp) and ATen's fp32 convolution; runs bit-identical, image n == the image alone."""
+    from hallucidet_amd import ops, _abi
+    N, H, W = shape
+    x = rnd(N, H, W, 32, seed=41).to(dev)
+    w = rnd(128, 288, scale=1.0 / 17.0, seed=42).to(dev)
+    lib = _abi.load()
+    got = ops.conv2d(x, w, 3, 3, pad=1)
+    lib.hd_conv_tune_override(128, 32, 32, 0)
+    try:
+        ref = ops.conv2d(x, w, 3, 3, pad=1)
+    finally:
+        lib.hd_conv_tune_override(-1, -1, -1, -1)
+    torch.cuda.synchronize()
+    assert got.shape == (N, H, W, 128)
+    assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
+    want = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(128, 3, 3, 32).permute(0, 3, 1, 2), padding=1)
+    close(got.cpu(), want.permute(0, 2, 3, 1).half().cpu(), rtol=3e-3, atol=3e-3)
+    assert torch.equal(got, ops.conv2d(x, w, 3, 3, pad=1))
+    assert torch.equal(ops.conv2d(x[:1].contiguous(), w, 3, 3, pad=1)[0], got[0])
