@@ -98,6 +98,13 @@ bool use_c32(const ConvP& p) {
   return on && g_small_ok && !p.stats && hd_conv_c32to128_eligible(p);
 }
 
+// decoder block 3's first convolution (upsample + concat, 64 + 64 -> 32 channels) goes to its register-resident kernel
+// (conv3x3_cat128to32.hip); HD_CONV_CAT=0: igemm family (A/B)
+bool use_cat(const ConvP& p) {
+  static const int on = env_int("HD_CONV_CAT", 1);
+  return on && g_small_ok && hd_conv_cat128to32_eligible(p);
+}
+
 // tuning hook (tools/tune_conv.py): force the tile / K-depth / stage choice of the igemm family; -1 = heuristic
 static int g_ov_bm = -1, g_ov_bn = -1, g_ov_bk = -1, g_ov_deep = -1;
 extern "C" int hd_conv_tune_override(int bm, int bn, int bk, int deep) {
@@ -223,6 +230,7 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (use_small(p)) return hd_conv_small_tiles(p);
   if (use_c64(p)) return hd_conv_c64_rows(p);
   if (use_stem(p)) return hd_conv_stem_rows(p);
+  if (use_cat(p)) return hd_conv_cat128to32_rows(p);
   const TileChoice c = choose_tile(p);
   if (c.p8cfg >= 0) return hd_conv_p8_tiles(p, c.p8cfg);
   return hd_cdiv(p.M, c.bm);
@@ -341,6 +349,11 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   }
   if (use_c32(p)) {
     hd_conv_launch_c32to128(p, s);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
+  if (use_cat(p)) {
+    hd_conv_launch_cat128to32(p, s);
     HD_CHECK_LAUNCH();
     return HD_OK;
   }

@@ -125,6 +125,10 @@ int hd_conv_c64_rows(const ConvP& p);
 // conv3x3_c32to128.hip: 3x3 / stride 1 / pad 1, 32 -> 128 channels, plain output (decoder block 3's data gradient), weights in registers
 bool hd_conv_c32to128_eligible(const ConvP& p);
 void hd_conv_launch_c32to128(ConvP& p, hipStream_t s);
+// conv3x3_cat128to32.hip: 3x3 / stride 1 / pad 1 over cat([nearest_2x(x), x2]), 64 + 64 -> 32 channels (decoder block 3's first conv)
+bool hd_conv_cat128to32_eligible(const ConvP& p);
+int hd_conv_cat128to32_rows(const ConvP& p);
+void hd_conv_launch_cat128to32(ConvP& p, hipStream_t s);
 // conv7x7s2_stem.hip: the ResNet stem (7x7 / stride 2 / pad 3, 8 -> 64 channels), weights resident in registers
 bool hd_conv_stem_eligible(const ConvP& p);
 int hd_conv_stem_rows(const ConvP& p);

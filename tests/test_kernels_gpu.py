@@ -1397,3 +1397,35 @@ def test_conv_32_to_128_register_resident_kernel(dev, shape):
     close(got.cpu(), want.permute(0, 2, 3, 1).half().cpu(), rtol=3e-3, atol=3e-3)
     assert torch.equal(got, ops.conv2d(x, w, 3, 3, pad=1))
     assert torch.equal(ops.conv2d(x[:1].contiguous(), w, 3, 3, pad=1)[0], got[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 8, 10), (1, 7, 19), (8, 128, 160)])
+def test_conv_upsample_concat_128_to_32_register_resident_kernel(dev, shape):
+    """conv3x3_cat128to32.hip (decoder block 3's first convolution: cat([nearest_2x(a), skip]) 64 + 64 -> 32 channels, with BatchNorm
+    partial sums) against the implicit-GEMM family (tuning override; outputs to an fp16 ulp, sums equal in their totals) and ATen's fp32
+    convolution of the materialised upsample + concat; runs bit-identical, image n == the image alone."""
+    from hallucidet_amd import ops, _abi
+    N, Hs, Ws = shape                                 # low-resolution extent; the output is 2 Hs x 2 Ws
+    a = rnd(N, Hs, Ws, 64, seed=51).to(dev)
+    skip = rnd(N, 2 * Hs, 2 * Ws, 64, seed=52).to(dev)
+    w = rnd(32, 9 * 128, scale=1.0 / 34.0, seed=53).to(dev)
+    lib = _abi.load()
+    got, stats = ops.conv2d(a, w, 3, 3, x2=skip, up1=True, pad=1, want_stats=True)
+    tiles = N * ((2 * Hs + 7) // 8) * ((2 * Ws + 15) // 16)
+    assert got.shape == (N, 2 * Hs, 2 * Ws, 32) and stats.shape[0] == min(tiles, 256)          # the persistent kernel really ran
+    lib.hd_conv_tune_override(128, 32, 64, 0)
+    try:
+        ref, rstats = ops.conv2d(a, w, 3, 3, x2=skip, up1=True, pad=1, want_stats=True)
+    finally:
+        lib.hd_conv_tune_override(-1, -1, -1, -1)
+    torch.cuda.synchronize()
+    assert float((got.float() - ref.float()).abs().max()) <= 2e-3 * max(1.0, float(ref.float().abs().max()))
+    assert torch.allclose(stats.sum(0), rstats.sum(0), rtol=2e-3, atol=2e-2)
+    up = a.float().permute(0, 3, 1, 2).repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
+    cat = torch.cat([up, skip.float().permute(0, 3, 1, 2)], dim=1)
+    want = torch.nn.functional.conv2d(cat, w.float().view(32, 3, 3, 128).permute(0, 3, 1, 2), padding=1)
+    close(got.cpu(), want.permute(0, 2, 3, 1).half().cpu(), rtol=3e-3, atol=3e-3)
+    got2, stats2 = ops.conv2d(a, w, 3, 3, x2=skip, up1=True, pad=1, want_stats=True)
+    assert torch.equal(got, got2) and torch.equal(stats, stats2)
+    assert torch.equal(ops.conv2d(a[:1].contiguous(), w, 3, 3, x2=skip[:1].contiguous(), up1=True, pad=1)[0], got[0])

@@ -69,6 +69,13 @@ def draw_case(r):
         H, W = max(K, H // 2), max(K, W // 2)
     if r.random() < 0.12:                   # the register-resident 64 -> 64 kernel's domain (conv3x3_c64.hip)
         K, stride, pad, up1, C1, C2, Cout = 3, 1, 1, False, 64, 0, 64
+    elif r.random() < 0.06:                 # conv3x3_c32to128.hip
+        K, stride, pad, up1, C1, C2, Cout = 3, 1, 1, False, 32, 0, 128
+    elif r.random() < 0.06:                 # conv3x3_cat128to32.hip (upsample + concat)
+        K, stride, pad, up1, C1, C2, Cout = 3, 1, 1, True, 64, 64, 32
+        H, W = max(2, min(H, 40)), max(2, min(W, 60))
+    elif r.random() < 0.05:                 # conv7x7s2_stem.hip
+        K, stride, pad, up1, C1, C2, Cout = 7, 2, 3, False, 8, 0, 64
     return dict(N=N, H=H, W=W, C1=C1, C2=C2, Cout=Cout, K=K, stride=stride, pad=pad, up1=up1,
                 act=r.choice([0, 1, 1, 2]), bias=r.random() < 0.5, res=r.random() < 0.3, stats=r.random() < 0.5)
 
