@@ -23,6 +23,15 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 constexpr int TH = 8, TW = 32;               // output tile
 constexpr int PH = TH + 2, PW = TW + 2;      // input patch
 
+// sum over the 16 lanes of a DPP row, left in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  return v;
+}
+
 template <int CIN, int COUT>
 __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
   constexpr int KTOT = 9 * CIN;
@@ -197,15 +206,15 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
     }
     if (p.stats) {
       // the 16 lanes of a K group hold the same couts for 16 different pixels: fold them, then the 4 waves through LDS
+      // (DPP row operations: one VALU instruction per step -- the __shfl_xor form was a ds_bpermute + wait + add, 64 LDS-pipe round trips
+      //  per tile; after quad xor-1, quad xor-2, half-row mirror, row mirror every lane holds the sum over its 16-lane row)
 #pragma unroll
-      for (int d = 1; d < 16; d <<= 1)
+      for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            ssum[m][r] += __shfl_xor(ssum[m][r], d);
-            ssq[m][r] += __shfl_xor(ssq[m][r], d);
-          }
+        for (int r = 0; r < 4; ++r) {
+          ssum[m][r] = row16_sum(ssum[m][r]);
+          ssq[m][r] = row16_sum(ssq[m][r]);
+        }
       if (pl == 0) {
 #pragma unroll
         for (int m = 0; m < MT; ++m)
