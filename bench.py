@@ -244,7 +244,8 @@ def conv_roofline(lit, batch, reps=5):
             "mfma_util": _pmc_mfma_util(), "traffic": _pmc_traffic()[0], "traffic_provenance": _pmc_traffic()[1], "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
             "kernel": "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + "
-                      "conv3x3_c64_kernel / conv7x7s2_stem_kernel (persistent, register-resident weights: the 64 -> 64 channel 3x3 layers, the 7x7 stems) + "
+                      "conv3x3_c64_kernel / conv7x7s2_stem_kernel / conv3x3_cat128to32_kernel / conv3x3_c32to128_kernel (persistent, register-resident weights: "
+                      "the 64 -> 64 channel 3x3 layers, the 7x7 stems, decoder block 3) + "
                       "conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
             "avg_launch_us": round(step_conv_ms * 1e3 / max(n, 1), 2), "avg_launch_us_isolated": round(tot_ms * 1e3 / max(n, 1), 2),
             "avg_launch_gflop": round(tot_fl / max(n, 1) / 1e9, 3),
