@@ -35,7 +35,8 @@ constexpr int W_OFF = 2 * STAGE_BYTES;           // weight staging (72 KiB), lat
 constexpr int W_BYTES = 64 * KTOT * 2;
 constexpr int LDS_BYTES = W_OFF + W_BYTES;       // 120 KiB: one block per CU
 constexpr int CF_OFF = W_OFF + 4 * 64 * 65 * 4;  // per-channel coefficients of the bs_* modes: behind the statistics transpose, inside the weight staging
-static_assert(CF_OFF + 4 * 64 * 4 <= LDS_BYTES, "coefficient table fits");
+constexpr int BIAS_OFF = CF_OFF + 4 * 64 * 4;    // the bias vector (EPI & 2): read per tile from LDS, not from memory
+static_assert(BIAS_OFF + 64 * 4 <= LDS_BYTES, "coefficient table and bias fit");
 constexpr unsigned OOBB = 0x80000000u;
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -146,6 +147,11 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
       wr[b][s] = *reinterpret_cast<const f16x8*>(lds + W_OFF + row * (KTOT * 2) + slot * 16);
     }
 
+  if (EPI & 2) {
+    __syncthreads();                                    // every wave has its weight fragments: the staging area is free
+    if (tid < 64) reinterpret_cast<float*>(lds + BIAS_OFF)[tid] = p.bias[tid];
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // (ordered against the readers by the tile loop's first barrier)
+  }
   if (STATS >= 2) {
     __syncthreads();                                    // every wave has its weight fragments: the staging area is free
     float* cf = reinterpret_cast<float*>(lds + CF_OFF);  // [mean | invstd | scale | shift][64]
@@ -195,6 +201,34 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
     int nn = 0, nty = 0, ntx = 0;
     if (more) tile_pos(t + 1, nn, nty, ntx);
     const char* sb = lds + stage * STAGE_BYTES;
+    // bs_* modes: the unit's y (and z) vectors of this tile are requested BEFORE the K loop -- after it they were an exposed HBM round trip
+    // per tile on a kernel that runs one wave per SIMD (the 64-channel data gradients read 31.7 us with the sums against 17.7 without)
+    f16x4 byv[8], bzv[8], rv[8], mv[8];
+    if (EPI & 4) {          // the ReLU-mask operand likewise
+      const int oy_ = cty * TH + y0l, ox_ = ctx * TW + x0l;
+      const bool okp_ = oy_ < p.Ho && ox_ < p.Wo;
+      const unsigned eoff_ = (unsigned)(((cn * p.Ho + oy_) * p.Wo + ox_) * 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mv[j] = okp_ ? *reinterpret_cast<const f16x4*>(maskp + eoff_ + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
+    }
+    if (EPI & 1) {          // the residual operand too (requested after the K loop it cost the residual variants 7 us per launch)
+      const int oy_ = cty * TH + y0l, ox_ = ctx * TW + x0l;
+      const bool okp_ = oy_ < p.Ho && ox_ < p.Wo;
+      const unsigned eoff_ = (unsigned)(((cn * p.Ho + oy_) * p.Wo + ox_) * 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rv[j] = okp_ ? *reinterpret_cast<const f16x4*>(resp + eoff_ + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
+    }
+    if (STATS >= 2) {
+      const int oy_ = cty * TH + y0l, ox_ = ctx * TW + x0l;
+      const bool okp_ = oy_ < p.Ho && ox_ < p.Wo;
+      const unsigned eoff_ = (unsigned)(((cn * p.Ho + oy_) * p.Wo + ox_) * 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) byv[j] = okp_ ? *reinterpret_cast<const f16x4*>(p.bs_y + eoff_ + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
+      if (STATS == 3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bzv[j] = okp_ ? *reinterpret_cast<const f16x4*>(p.bs_z + eoff_ + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
+      }
+    }
     f32x16 acc0, acc1;
     f16x8 bf[RING];
 #define HD_C64_B(S) (*reinterpret_cast<const f16x8*>(sb + ab[((S) >> 2) % 3][(S) & 3] + ((S) / 12) * (PW * 128)))
@@ -229,31 +263,13 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvP p, int tiles_tot
     const int oy = cty * TH + y0l, ox = ctx * TW + x0l;
     const bool okp = oy < p.Ho && ox < p.Wo;
     const unsigned eoff = (unsigned)(((cn * p.Ho + oy) * p.Wo + ox) * 64);          // < 2^30 elements (eligibility)
-    f16x4 rv[8], mv[8];
     f32x4 bv[8];
-    if (EPI & 1) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rv[j] = okp ? *reinterpret_cast<const f16x4*>(resp + eoff + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
-    }
-    if (EPI & 4) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) mv[j] = okp ? *reinterpret_cast<const f16x4*>(maskp + eoff + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
-    }
     if (EPI & 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = *reinterpret_cast<const f32x4*>(biasp + 8 * j + 4 * h);
+      for (int j = 0; j < 8; ++j) bv[j] = *reinterpret_cast<const f32x4*>(lds + BIAS_OFF + (8 * j + 4 * h) * 4);
     }
     // rv / y / z vectors of the whole tile are requested up front; the packed output of a group pair is exchanged and stored as soon
     // as it exists (a separate store pass would keep all sixteen packed registers alive next to the resident weights)
-    f16x4 byv[8], bzv[8];
-    if (STATS >= 2) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) byv[j] = okp ? *reinterpret_cast<const f16x4*>(p.bs_y + eoff + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
-      if (STATS == 3) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) bzv[j] = okp ? *reinterpret_cast<const f16x4*>(p.bs_z + eoff + 8 * j + 4 * h) : (f16x4){0, 0, 0, 0};
-      }
-    }
     // STATS 2: (scale, shift) of this lane's channels for the ReLU mask, re-read per tile through an offset the compiler cannot see
     // through (hoisted out of the tile loop the 64 floats push weight fragments into scratch)
     int tile_zero = 0;

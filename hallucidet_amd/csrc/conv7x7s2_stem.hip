@@ -26,7 +26,8 @@ constexpr int PPW = (NPIECE + 3) / 4;                // pieces per wave (4; thre
 constexpr int STAGE_BYTES = 4 * PPW * 1024;          // 16 KiB
 constexpr int KSTEPS = 25, NTAP = 49, KROW = NTAP * 8;
 constexpr int RED_OFF = 2 * STAGE_BYTES;             // statistics transpose [4 waves][64][65] floats
-constexpr int LDS_BYTES = RED_OFF + 4 * 64 * 65 * 4;
+constexpr int BIAS_OFF = RED_OFF + 4 * 64 * 65 * 4;  // the bias vector (EPI & 2): read per tile from LDS, not from memory
+constexpr int LDS_BYTES = BIAS_OFF + 64 * 4;
 constexpr unsigned OOBB = 0x80000000u;
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -119,8 +120,11 @@ __global__ __launch_bounds__(256) void conv7x7s2_stem_kernel(ConvP p, int tiles_
   }
   const f16* __restrict__ resp = p.res;
   const f16* __restrict__ maskp = p.mask;
-  const float* __restrict__ biasp = p.bias;
   f16* __restrict__ yp = reinterpret_cast<f16*>(p.y);
+  if (EPI & 2) {
+    if (tid < 64) reinterpret_cast<float*>(lds + BIAS_OFF)[tid] = p.bias[tid];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (ordered against the readers by the tile loop's first barrier)
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   for (int t = t_begin; t < t_end; ++t) {
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(256) void conv7x7s2_stem_kernel(ConvP p, int tiles_
     }
     if (EPI & 2) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = *reinterpret_cast<const f32x4*>(biasp + 8 * j + 4 * h);
+      for (int j = 0; j < 8; ++j) bv[j] = *reinterpret_cast<const f32x4*>(lds + BIAS_OFF + (8 * j + 4 * h) * 4);
     }
 #pragma unroll
     for (int b = 0; b < 2; ++b)
