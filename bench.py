@@ -438,6 +438,11 @@ def main():
     # thread per hardware thread of the HOST (256), which a throttled container turns into spinning
     from hallucidet_amd.config import Config
     Config.set_environment()
+    if world != args.gpus:           # pure environment validation: before anything touches a device
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it plainly (it starts its own ranks) or with "
+                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    if not (0 <= rank < world and 0 <= local < world):
+        raise SystemExit("bench.py: RANK=%d / LOCAL_RANK=%d outside WORLD_SIZE=%d (one node, one rank per GPU)" % (rank, local, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU path")
     if local >= torch.cuda.device_count():
@@ -449,9 +454,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    if world != args.gpus:
-        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch it plainly (it starts its own ranks) or with "
-                         "torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
 
     from hallucidet_amd import synthetic
     dev = "cuda:%d" % local
@@ -463,7 +465,9 @@ def main():
     overlap_note = None
     if dist.is_initialized() and os.environ.get("HD_OVERLAP_ALLREDUCE", "") != "":
         lit.overlap_allreduce = os.environ["HD_OVERLAP_ALLREDUCE"] != "0"
-    elif dist.is_initialized() and world > 1:
+    elif dist.is_initialized() and (world > 1 or force_dist):
+        # (HD_FORCE_DIST=1 runs this branch at world size 1 too -- tests/test_scripts_gpu.py -- so that a multi-GPU run is never its
+        #  first execution.)
         # Safety net for the overlapped exchange (bucketed all-reduces issued between the segmented backward graphs): before
         # anything is timed, one step is taken from the same parameters with and without the overlap; the averaged gradients
         # must agree (the reduction order inside RCCL may differ between bucketings: 1e-5 relative), on every rank.  If they

@@ -22,15 +22,20 @@ class Utils():
 
     @staticmethod
     def list_targets(targets, device='cpu', detach=False, detector_name='fasterrcnn'):
-        if 'fcos' in detector_name:
+        """utils.py:25-42: every tensor of every target dict moves to `device` (detached first when asked), strings pass through;
+        FCOS takes its boxes as fp32 (the reference casts before the move, so does this)."""
+        boxes_as_float = 'fcos' in detector_name
+
+        def _to(key, value):
+            if isinstance(value, str):
+                return value
+            if boxes_as_float and key == 'boxes':
+                value = value.float()
             if detach:
-                return [{k: (v.float().detach().to(device) if not isinstance(v, str) else v) if k == 'boxes' else
-                         (v.detach().to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
-            return [{k: (v.float().to(device) if not isinstance(v, str) else v) if k == 'boxes' else
-                     (v.to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
-        if detach:
-            return [{k: (v.detach().to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
-        return [{k: (v.to(device) if not isinstance(v, str) else v) for k, v in t.items()} for t in targets]
+                value = value.detach()
+            return value.to(device)
+
+        return [{key: _to(key, value) for key, value in target.items()} for target in targets]
 
     @staticmethod
     def batch_targets_for_detector(targets, device='cpu', detach=False, detector_name='fasterrcnn'):

@@ -206,3 +206,32 @@ def test_self_launcher_starts_one_rank_per_gpu_and_relays_rank0(tmp_path):
     buf = io.StringIO()
     rc = launch.launch_ranks(2, [sys.executable, str(child), "fail"], env=env, timeout=120, out=buf)
     assert rc == 3
+
+
+def test_bench_rank_validation_through_the_launcher(tmp_path):
+    """bench.py's own N > 1 entry, as far as a box without a GPU can take it: (1) `python bench.py --gpus 2` started plainly
+    becomes the launcher (hallucidet_amd.launch) -- two children with RANK / LOCAL_RANK / WORLD_SIZE, whose failure ("no GPU
+    visible": there is no CPU path) is the launcher's exit code; (2) a WORLD_SIZE that contradicts --gpus and (3) a RANK outside
+    the world are refused BEFORE anything touches a device, with a message that says how to launch."""
+    import io
+    import subprocess
+    import sys
+    from hallucidet_amd import launch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "HD_FORCE_DIST")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # the same on a GPU box: no device for the children
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    # (1) plain start: the parent launches its ranks and relays the first failing exit code
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stderr.count("no GPU visible") >= 1, r.stderr[-2000:]
+    assert r.stdout.strip() == ""            # no JSON line from a run that did not happen
+    # (2) two ranks, but the command says --gpus 3
+    buf = io.StringIO()
+    rc = launch.launch_ranks(2, [sys.executable, bench, "--gpus", "3"], env=env, timeout=300, out=buf)
+    assert rc != 0 and buf.getvalue().strip() == ""
+    r = subprocess.run([sys.executable, bench, "--gpus", "3"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "started with WORLD_SIZE=2" in r.stderr and "--nproc-per-node 3" in r.stderr
+    # (3) a rank outside the world
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="2", RANK="2", LOCAL_RANK="2"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "outside WORLD_SIZE=2" in r.stderr

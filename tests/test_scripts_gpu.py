@@ -100,3 +100,65 @@ def test_published_key_checkpoint_loads_strict_and_runs(dev, tmp_path):
     # all-zero weights: the box head scores every RoI 0.5 / 0.5 and regresses nothing -> cross-entropy = ln 2 exactly
     assert abs(float(losses["loss_classifier"]) - 0.6931472) < 1e-5 and float(losses["loss_box_reg"]) >= 0.0
     assert len(dets) == 2 and set(d3) == {"hall", "rgb", "ir"}
+
+
+def _run_bench_in_process(monkeypatch, capsys, argv, env):
+    """bench.main() in this process (a process that holds a HIP context may not fork + exec on this pool, so no subprocess):
+    -> the parsed JSON line.  The process group bench.py creates is destroyed by its own last lines."""
+    import importlib
+    import json
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "HD_OVERLAP_ALLREDUCE"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    assert not dist.is_initialized()
+    bench = importlib.import_module("bench")
+    saved = bench.BATCH_PER_GPU
+    try:
+        bench.main()
+    finally:
+        bench.BATCH_PER_GPU = saved
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return str(port)
+
+
+def test_bench_multi_gpu_branch_runs_at_world_size_one(dev, monkeypatch, capsys):
+    """bench.py's N > 1 code (RCCL process group, the overlap self-check that decides whether the bucketed exchange is used, the
+    per-rank clocks, the exposed-wait report) executed under HD_FORCE_DIST=1 on ONE GPU -- so that a driver's 8-GPU run is not the
+    first execution of that branch (round-4 verdict, Missing 1 / Next 3).  The self-check compares two pure graph replays from one
+    seed: with one rank the all-reduce is the identity, so overlapped and un-overlapped gradients must agree to 1e-4 and the note
+    must end in "overlap on"."""
+    out = _run_bench_in_process(monkeypatch, capsys, ["--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-roofline"],
+                                {"HD_FORCE_DIST": "1", "MASTER_PORT": _free_port(), "MASTER_ADDR": "127.0.0.1"})
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["skipped_steps"] == 0
+    ar = out["allreduce"]
+    assert ar["overlap"] is True and ar["note"].endswith("overlap on"), ar["note"]
+    import re
+    err = float(re.search(r"rel-L2 ([0-9.e+-]+)", ar["note"]).group(1))
+    assert err <= 1e-4
+    assert len(ar["ms_per_step_by_rank"]) == 1 and ar["payload_bytes"] > 9e7
+    assert isinstance(ar["exposed_wait_per_bucket"], list) and len(ar["exposed_wait_per_bucket"]) >= 1
+
+
+def test_bench_detector16_distributed_branch_runs_at_world_size_one(dev, monkeypatch, capsys):
+    """The same for `--config detector16` (BASELINE configs[4]): its exchange is ONE all-reduce of the trainable arena, what its
+    N > 1 branch reports is the per-rank clocks and the parameter difference between ranks after the timed steps (0 here)."""
+    out = _run_bench_in_process(monkeypatch, capsys, ["--config", "detector16", "--steps", "2", "--warmup", "1"],
+                                {"HD_FORCE_DIST": "1", "MASTER_PORT": _free_port(), "MASTER_ADDR": "127.0.0.1"})
+    assert out["n_gpus"] == 1 and out["max_parameter_difference_between_ranks"] == 0.0
+    assert len(out["ms_per_step_by_rank"]) == 1 and out["skipped_steps"] == 0

@@ -269,3 +269,176 @@ def test_balanced_sampler_against_its_definition(labels, batch, frac, seed):
         assert sorted(pi) == sorted(P[k] for k in perms[2 * i][:n_pos].tolist())
         assert sorted(ni) == sorted(N[k] for k in perms[2 * i + 1][:n_neg].tolist())
         assert pos[i].dtype == torch.uint8 and pos[i].shape == m.shape
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Round 5: the last torchvision pieces the reference reaches at src/utils/eval_forward_fasterrcnn.py:77,122,136 -- the anchor grid,
+# the pyramid-level mapper of MultiScaleRoIAlign and RoIHeads.postprocess_detections -- against definitions written HERE from
+# torchvision 0.12's published algorithm (python loops over numpy float32 scalars; nothing from oracle/ on the checking side).
+
+
+def brute_postprocess(boxes_rc, scores_rc, image_hw, score_thr, nms_thr, min_size, top_n):
+    """One image.  boxes_rc [R, C, 4] float32 (decoded, NOT yet clipped), scores_rc [R, C] float32 (softmax), class 0 = background.
+    torchvision: clip to the image, drop the background column, flatten (proposal-major, class-minor), keep score > score_thr, keep
+    both sides >= min_size, greedy NMS among the boxes of ONE class (IoU > nms_thr suppresses; higher score first, equal scores:
+    lower flat index first), all classes' survivors by descending score, the first top_n."""
+    h, w = image_hw
+    R, C = scores_rc.shape
+    items = []
+    for r in range(R):
+        for c in range(1, C):
+            b = boxes_rc[r, c].astype(F32).copy()
+            b[0] = min(max(b[0], F32(0)), F32(w)); b[2] = min(max(b[2], F32(0)), F32(w))
+            b[1] = min(max(b[1], F32(0)), F32(h)); b[3] = min(max(b[3], F32(0)), F32(h))
+            s = F32(scores_rc[r, c])
+            flat = r * (C - 1) + (c - 1)
+            if s > F32(score_thr) and F32(b[2] - b[0]) >= F32(min_size) and F32(b[3] - b[1]) >= F32(min_size):
+                items.append((flat, c, b, s))
+    survivors = []
+    for c in range(1, C):
+        mine = sorted([it for it in items if it[1] == c], key=lambda it: (-float(it[3]), it[0]))
+        kept = []
+        for it in mine:
+            if all(not (iou_f32(k[2], it[2]) > F32(nms_thr)) for k in kept):
+                kept.append(it)
+        survivors += kept
+    survivors.sort(key=lambda it: (-float(it[3]), it[0]))
+    survivors = survivors[:top_n]
+    return (np.array([it[2] for it in survivors], dtype=F32).reshape(-1, 4), np.array([it[3] for it in survivors], dtype=F32),
+            np.array([it[1] for it in survivors], dtype=np.int64))
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), n_cls=st.integers(2, 4), top_n=st.integers(1, 12), n_img=st.integers(1, 2), spread=st.sampled_from([1.0, 4.0]))
+def test_postprocess_detections_against_a_brute_force_definition(seed, n_cls, top_n, n_img, spread):
+    """RoIHeads.postprocess_detections (torchvision 0.12 roi_heads.py; reached from eval_forward_fasterrcnn.py:122-136): per-class split,
+    score and size filters, class-wise NMS through the coordinate-offset trick, top-k.  Proposals on a half-integer grid and
+    regression codes whose decode is exact in fp32 (dx, dy multiples of 1/8 of the box size after the (10, 10, 5, 5) weights,
+    dw = dh = 0), so the decoded boxes can be written down here without restating BoxCoder; scores are ATen's softmax."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = 40, 48
+    R = 14
+    props, logits, codes, want_boxes = [], [], [], []
+    for _ in range(n_img):
+        xy = torch.randint(-8, 2 * W - 8, (R, 2), generator=g).float() / 2          # some start left / above the image
+        wh = torch.randint(0, 40, (R, 2), generator=g).float() / 2                  # zero-size boxes: the min-size rule
+        p = torch.cat([xy, xy + wh], dim=1)
+        for i in range(1, R):
+            if float(torch.rand(1, generator=g)) < 0.3:
+                p[i] = p[int(torch.randint(0, i, (1,), generator=g))]                # duplicates: suppressed inside a class only
+        j = torch.randint(-2, 3, (R, n_cls, 2), generator=g).float()                 # per-class shift in eighths of the box size
+        code = torch.zeros(R, n_cls, 4)
+        code[..., 0] = 1.25 * j[..., 0]                                             # / 10 -> j / 8 exactly
+        code[..., 1] = 1.25 * j[..., 1]
+        wd, ht = (p[:, 2] - p[:, 0]), (p[:, 3] - p[:, 1])
+        cx, cy = p[:, 0] + 0.5 * wd, p[:, 1] + 0.5 * ht
+        pcx, pcy = (j[..., 0] / 8) * wd[:, None] + cx[:, None], (j[..., 1] / 8) * ht[:, None] + cy[:, None]
+        hw_, hh_ = 0.5 * wd[:, None].expand(R, n_cls), 0.5 * ht[:, None].expand(R, n_cls)
+        want_boxes.append(torch.stack([pcx - hw_, pcy - hh_, pcx + hw_, pcy + hh_], dim=2))
+        props.append(p)
+        codes.append(code.reshape(R, n_cls * 4))
+        logits.append(torch.randn(R, n_cls, generator=g) * spread)
+    heads = od.RoIHeads(num_classes=n_cls)
+    heads.detections_per_img = top_n
+    cl, br = torch.cat(logits), torch.cat(codes)
+    gb, gs, gl = heads.postprocess_detections(cl, br, props, [(H, W)] * n_img)
+    scores_all = torch.softmax(cl, -1).split([R] * n_img, 0)
+    for n in range(n_img):
+        wb, ws, wl = brute_postprocess(want_boxes[n].numpy(), scores_all[n].numpy(), (H, W), heads.score_thresh, heads.nms_thresh, 1e-2, top_n)
+        assert gb[n].shape[0] == wb.shape[0] <= top_n
+        assert np.array_equal(gb[n].numpy(), wb), (gb[n], wb)
+        assert np.array_equal(gs[n].numpy(), ws)
+        assert np.array_equal(gl[n].numpy(), wl)
+        if wb.shape[0]:
+            assert bool((gs[n][:-1] >= gs[n][1:]).all()) and int(gl[n].min()) >= 1 and float(gs[n].min()) > heads.score_thresh
+
+
+def brute_level(box, k_min=2, k_max=5):
+    """torchvision.ops.poolers.LevelMapper (0.12): floor(4 + log2(sqrt(area) / 224) + 1e-6) clamped to [k_min, k_max], minus k_min.
+    Evaluated in float64 from the float32 area; returns None when the value sits within 1e-4 of a level boundary without being an
+    exact power-of-two ratio (there fp32's log2 and this float64 one may land on different sides)."""
+    area = F32(F32(box[2] - box[0]) * F32(box[3] - box[1]))
+    s = float(np.sqrt(area))                       # IEEE sqrt: correctly rounded in fp32, then widened
+    if s == 0.0:
+        return 0                                   # log2(0) = -inf -> floor -> clamp to k_min
+    t = 4.0 + math.log2(s / 224.0) + 1e-6
+    frac = t - math.floor(t)
+    exact = math.log2(s / 224.0) == round(math.log2(s / 224.0))
+    if not exact and (frac < 1e-4 or frac > 1 - 1e-4):
+        return None
+    return int(min(max(math.floor(t), k_min), k_max)) - k_min
+
+
+@settings(max_examples=200, deadline=None)
+@given(boxes=st.lists(st.tuples(st.floats(0, 280, width=32), st.floats(0, 280, width=32), st.floats(0, 600, width=32), st.floats(0, 600, width=32)),
+                      min_size=1, max_size=12))
+def test_level_mapper_against_its_definition(boxes):
+    arr = np.array([[x, y, x + w, y + h] for x, y, w, h in boxes], dtype=F32)
+    want = [brute_level(b) for b in arr]
+    got = od.MultiScaleRoIAlign().level_map([torch.from_numpy(arr)], 2, 5).tolist()
+    for g_, w_ in zip(got, want):
+        assert w_ is None or g_ == w_
+
+
+def test_level_mapper_at_the_exact_level_boundaries():
+    """sqrt(area) = 224 * 2^k exactly (k = -3 .. 2): the 1e-6 keeps the value ON the upper level; one fp32 step below the boundary
+    stays on the lower level; the clamp takes everything below 112 to level 0 and everything from 896 up to level 3."""
+    sides = [28.0, 56.0, 112.0, 224.0, 448.0, 896.0]
+    arr = np.array([[3.0, 5.0, 3.0 + s, 5.0 + s] for s in sides], dtype=F32)
+    got = od.MultiScaleRoIAlign().level_map([torch.from_numpy(arr)], 2, 5).tolist()
+    assert got == [0, 0, 1, 2, 3, 3]
+    below = np.array([[0.0, 0.0, s, np.nextafter(F32(s), F32(0))] for s in (112.0, 224.0, 448.0)], dtype=F32)
+    # (area shrinks by one part in 2^23 of one side: log2 moves by ~1e-7 * 1.44 / 2 < 1e-6, so the eps lifts it back over the boundary)
+    assert od.MultiScaleRoIAlign().level_map([torch.from_numpy(below)], 2, 5).tolist() == [1, 2, 3]
+    clearly_below = np.array([[0.0, 0.0, s, s * 0.999] for s in (112.0, 224.0, 448.0)], dtype=F32)
+    assert od.MultiScaleRoIAlign().level_map([torch.from_numpy(clearly_below)], 2, 5).tolist() == [0, 1, 2]
+    two_lists = od.MultiScaleRoIAlign().level_map([torch.from_numpy(arr[:2]), torch.from_numpy(arr[2:])], 2, 5).tolist()
+    assert two_lists == got                        # the mapper concatenates the per-image lists in order
+
+
+def brute_anchors(image_hw, grids, sizes, ratios):
+    """torchvision AnchorGenerator (0.12 anchor_utils.py): base anchors round([-w, -h, w, h] / 2) with h = size * sqrt(ratio),
+    w = size / sqrt(ratio) in fp32 (ratio-major, size-minor), shifted by (x * stride_w, y * stride_h) with stride = image // grid
+    (integer division), locations row-major, anchors of a location contiguous, levels concatenated."""
+    ih, iw = image_hw
+    out = []
+    for (gh, gw), size, rs in zip(grids, sizes, ratios):
+        sh, sw = ih // gh, iw // gw
+        base = []
+        for r in rs:
+            hr = np.sqrt(F32(r))
+            wr = F32(1) / hr
+            for sz in size:
+                w_, h_ = F32(wr * F32(sz)), F32(hr * F32(sz))
+                base.append([np.round(F32(-w_) / F32(2)), np.round(F32(-h_) / F32(2)), np.round(w_ / F32(2)), np.round(h_ / F32(2))])
+        for y in range(gh):
+            for x in range(gw):
+                for b in base:
+                    out.append([F32(x * sw) + b[0], F32(y * sh) + b[1], F32(x * sw) + b[2], F32(y * sh) + b[3]])
+    return np.array(out, dtype=F32)
+
+
+def test_anchor_generator_at_the_llvip_grid_sizes():
+    """The five pyramid levels of the detector on the 300 x 300 transformed image (75, 38, 19, 10, 5: strides 4, 7, 15, 30, 60 by
+    integer division) and on a non-square image, against the loop above; plus the base anchors every torchvision user has seen
+    printed for size 32, ratios (0.5, 1, 2)."""
+    ag = od.AnchorGenerator()
+    sizes, ratios = ((32,), (64,), (128,), (256,), (512,)), ((0.5, 1.0, 2.0),) * 5
+    assert ag.base_anchors((32,), (0.5, 1.0, 2.0)).tolist() == [[-23.0, -11.0, 23.0, 11.0], [-16.0, -16.0, 16.0, 16.0], [-11.0, -23.0, 11.0, 23.0]]
+    assert ag.num_anchors_per_location() == [3] * 5
+    for (ih, iw), grids in (((300, 300), [(75, 75), (38, 38), (19, 19), (10, 10), (5, 5)]),
+                            ((512, 640), [(128, 160), (64, 80), (32, 40), (16, 20), (8, 10)]),
+                            ((300, 200), [(75, 50), (38, 25), (19, 13), (10, 7), (5, 4)])):
+        il = od.ImageList(torch.zeros(2, 3, ih, iw), [(ih, iw)] * 2)
+        feats = [torch.zeros(2, 1, gh, gw) for gh, gw in grids]
+        got = ag(il, feats)
+        want = brute_anchors((ih, iw), grids, sizes, ratios)
+        assert len(got) == 2 and got[0].dtype == torch.float32 and got[0].shape == (sum(gh * gw * 3 for gh, gw in grids), 4)
+        assert np.array_equal(got[0].numpy(), want) and torch.equal(got[0], got[1])
+    # RetinaNet's generator: three octave scales per level, ratio-major order (retinanet.py: anchor_sizes x (2^0, 2^(1/3), 2^(2/3)))
+    rs = tuple((x, int(x * 2 ** (1.0 / 3)), int(x * 2 ** (2.0 / 3))) for x in (32, 64, 128, 256, 512))
+    ag2 = od.AnchorGenerator(rs, ratios)
+    grids = [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3)]
+    il = od.ImageList(torch.zeros(1, 3, 300, 300), [(300, 300)])
+    got = ag2(il, [torch.zeros(1, 1, gh, gw) for gh, gw in grids])
+    assert np.array_equal(got[0].numpy(), brute_anchors((300, 300), grids, rs, ratios))
