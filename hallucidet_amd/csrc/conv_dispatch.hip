@@ -52,6 +52,8 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.Ktot = a->KH * a->KW * p.Cin;
   p.prio = 0;
   p.par = p.ph = p.pw = p.Hc = p.Wc = p.t0h = p.t0w = 0;
+  p.gm = p.gn = 0;
+  p.tgroup = 1;
   p.inv_cin8 = 1.0f / (float)p.cin8;
   p.inv_kw = 1.0f / (float)a->KW;
   int64_t xb = (int64_t)a->N * a->Hsrc * a->Wsrc * a->C1 * 2;
@@ -103,6 +105,31 @@ bool use_c32(const ConvP& p) {
 bool use_cat(const ConvP& p) {
   static const int on = env_int("HD_CONV_CAT", 1);
   return on && g_small_ok && hd_conv_cat128to32_eligible(p);
+}
+
+// Large-tile GEMM (gemm_w8.hip) for the plain-GEMM problems that are big enough to fill the chip with 256-row tiles: the box head's
+// fc6 / fc7 and fc6's data gradient.  Bit-identical to the igemm family (same products, same K order), so the choice may look at
+// the batch.  Tiles: 256 x 128 when that grid is one (nearly) full round of the 256 CUs, 256 x 256 from ~1.75 rounds up
+// (tools/probe_gemm8.py: fc6 forward 256 -> 212 us, its data gradient 197 -> 138, fc7 43.5 -> 25.3; 128-tile grids lose to the
+// 4-wave family's 256 smaller tiles, e.g. fc6 on 4 096 rows 148 vs 171).
+// hd_gemm_w8_mode (tests / tools): -1 = this rule, 0 = never, 128 / 256 = that tile wherever eligible.  HD_GEMM8=0: off (A/B).
+static int g_gemm8_mode = -1;
+extern "C" int hd_gemm_w8_mode(int mode) {
+  HD_CHECK_ARG(mode == -1 || mode == 0 || mode == 128 || mode == 256, "hd_gemm_w8_mode: mode in {-1, 0, 128, 256}");
+  g_gemm8_mode = mode;
+  return HD_OK;
+}
+bool hd_gemm_w8_eligible(const ConvP& p);
+void hd_gemm_w8_launch(ConvP& p, int bn, hipStream_t s);
+static int choose_gemm8(const ConvP& p) {
+  static const int on = env_int("HD_GEMM8", 1);
+  if (!on || g_gemm8_mode == 0 || !g_small_ok || !hd_gemm_w8_eligible(p)) return 0;
+  if (g_gemm8_mode > 0) return g_gemm8_mode;
+  if (p.M < 2048 || p.Cout < 512 || p.Ktot < 512) return 0;
+  const int64_t t128 = (int64_t)hd_cdiv(p.M, 256) * hd_cdiv(p.Cout, 128), t256 = (int64_t)hd_cdiv(p.M, 256) * hd_cdiv(p.Cout, 256);
+  if (t128 >= 160 && t128 <= 256) return 128;
+  if (t256 >= 448) return 256;
+  return 0;
 }
 
 // tuning hook (tools/tune_conv.py): force the tile / K-depth / stage choice of the igemm family; -1 = heuristic
@@ -295,7 +322,7 @@ extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
     ConvP& p = mp.p[i];
     int rc = fill_params(&args[i], p);
     if (rc) return rc;
-    if (use_small(p) || use_c64(p) || use_stem(p) || use_c32(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y) { ok = false; break; }
+    if (use_small(p) || use_c64(p) || use_stem(p) || use_c32(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y || choose_gemm8(p)) { ok = false; break; }
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) { ok = false; break; }
     if (i == 0) c0 = c;
@@ -354,6 +381,11 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   }
   if (use_cat(p)) {
     hd_conv_launch_cat128to32(p, s);
+    HD_CHECK_LAUNCH();
+    return HD_OK;
+  }
+  if (const int g8 = choose_gemm8(p)) {
+    hd_gemm_w8_launch(p, g8, s);
     HD_CHECK_LAUNCH();
     return HD_OK;
   }

@@ -62,7 +62,8 @@ __device__ __forceinline__ void conv_igemm_body(ConvP& p, int bid_in, int nwg_in
     const int nwg = nwg_in, xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
     bid = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   }
-  const int tile_m = bid / p.gn, tile_n = bid - tile_m * p.gn;
+  int tile_m, tile_n;
+  hd_conv_tile_of(p, bid, tile_m, tile_n);
   if (p.par && !hd_par_setup<BM, 4>(p, tile_m)) return;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int j = (tid & 3) ^ ((tid >> 4) & 3);   // logical chunk this lane fetches into slot tid&3 of row tid>>2
@@ -274,6 +275,7 @@ template <int BM, int BN, int WM, int WN, int NS>
 static void launch_variant_bk32(ConvP& p, hipStream_t s) {
   p.gm = hd_cdiv(p.M, BM);
   p.gn = hd_cdiv(p.Cout, BN);
+  p.tgroup = hd_conv_tile_order(p);
   dim3 grid(p.gm * p.gn, p.par ? 4 : 1);
   const bool dual = p.x2 != nullptr;
   const bool kgen = (p.cin8 % (32 / 8)) != 0;
@@ -309,6 +311,7 @@ static bool launch_multi_bk32(ConvMulti& mp, hipStream_t s) {
     p.nk = (p.nchunks + 32 / 8 - 1) / (32 / 8);
     p.gm = hd_cdiv(p.M, BM);
     p.gn = hd_cdiv(p.Cout, BN);
+    p.tgroup = hd_conv_tile_order(p);
     mp.first[i] = total;
     total += p.gm * p.gn;
   }

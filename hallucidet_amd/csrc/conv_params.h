@@ -1,5 +1,7 @@
 // Shared parameter block of the implicit-GEMM convolution kernels (conv_igemm_bk32.hip / conv_igemm_bk64.hip).
 #pragma once
+#include <stdlib.h>
+
 #include "hd_common.h"
 
 struct ConvP {
@@ -15,6 +17,7 @@ struct ConvP {
   int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1, in_dil, act, out_mode;
   int M, cin8, nchunks, nk, Ktot;
   int gm, gn;          // grid extent in M / N tiles
+  int tgroup;          // tile list order: super-rows of `tgroup` M tiles, M fastest inside (1 = plain N-fastest list): hd_conv_tile_order
   float inv_cin8, inv_kw;
   // Data gradient of a stride-2 convolution as FOUR output-parity classes (blockIdx.y = 2*ph + pw): output pixel (2i+ph, 2j+pw)
   // only sees the taps with kh = (pad - ph) mod 2 (+2, +4, ...) -- the others hit the zeros of the dilated input -- so a class
@@ -100,6 +103,49 @@ __device__ __forceinline__ int hd_par_pixel(const ConvP& p, int m) {
   const int i = fast ? hd_fdiv(rem, p.Wc, hd_rcp(p.Wc)) : rem / p.Wc;
   const int jj = rem - i * p.Wc;
   return (n * p.Ho + 2 * i + p.ph) * p.Wo + 2 * jj + p.pw;
+}
+
+// Which tiles share an XCD's L2 (round 5).  Blocks are dealt round-robin over the 8 XCDs and each XCD gets a contiguous run of the
+// tile list.  With the N tiles fastest (group 1) a run is a few M tiles x ALL N tiles, walked M tile by M tile: the pixels of an M
+// tile are fetched once and the weight matrix is re-walked for every M tile -- free while it stays in the XCD's 4 MiB L2 (the U-Net,
+// the large detector maps), but the detector's deep stages and the box head have weight matrices of 2 - 26 MB: 10x10x512 3x3 at
+// batch 8 streamed its 4.7 MB of weights from beyond L2 in every XCD for every M tile (1.18 MB per 64x64 block at the 33 - 49 GB/s a
+// CU gets from the Infinity Cache: what bound those launches), fc6's data gradient its 25.7 MB four times per XCD (~820 MB of
+// traffic for a 137 MB problem).  Grouped order (the list is cut into super-rows of `group` M tiles, M tiles fastest inside one):
+// an XCD's run is then `group` M tiles x a range of N tiles, the pixels of the group stay L2-resident and every weight tile is
+// fetched once per XCD that shares the super-row.  Measured (tools/probe_ks.py, same box): fc6's data gradient 212.9 -> 197.7 us, the
+// 10x10x512 3x3 layers 26.0 -> 25.3 / 31.5 -> 30.8 us; applied to the 2 MB matrices too it cost 16.5 -> 21.7 us on 24x10x10x2048 -> 512,
+// hence the L2-size threshold below.  With s XCDs per super-row the traffic beyond L2 is s * A + 8 * W / s (A, W =
+// input / weight bytes): s is chosen to minimise it among {1, 2, 4, 8} with the group's pixels (A * s / 8) within half the L2.
+// The arithmetic does not change (bit-identical).  HD_CONV_TGROUP=0: always N-fastest (A/B).
+static inline int hd_conv_tile_order(const ConvP& p) {
+  static const int on = [] { const char* v = getenv("HD_CONV_TGROUP"); return v ? atoi(v) : 1; }();
+  const double A = (double)p.xbytes + (double)p.x2bytes, W = (double)p.wbytes;
+  if (!on || p.par || p.gm < 2 || p.gn < 2 || W <= 4.0e6) return 1;   // a weight matrix that fits the 4 MiB L2 is re-walked for free
+  int best_s = 1;
+  double best = 1e30;
+  for (int s = 1; s <= 8; s *= 2) {
+    if (s > 1 && A * s / 8.0 > 2.0e6) break;
+    const double t = s * A + 8.0 * W / s;
+    if (t < best) { best = t; best_s = s; }
+  }
+  const int g = (p.gm * best_s + 7) / 8;
+  return g < 1 ? 1 : g;
+}
+// tile of list position `bid` under that order
+__device__ __forceinline__ void hd_conv_tile_of(const ConvP& p, int bid, int& tile_m, int& tile_n) {
+  if (p.tgroup <= 1) {
+    tile_m = bid / p.gn;
+    tile_n = bid - tile_m * p.gn;
+  } else {
+    const int width = p.tgroup * p.gn;
+    const int gid = bid / width;
+    const int first_m = gid * p.tgroup;
+    const int gsz = p.gm - first_m < p.tgroup ? p.gm - first_m : p.tgroup;
+    const int r = bid - gid * width;
+    tile_n = r / gsz;
+    tile_m = first_m + r - tile_n * gsz;
+  }
 }
 
 void hd_conv_launch_bk32(ConvP& p, int bm, int bn, bool deep, hipStream_t s);

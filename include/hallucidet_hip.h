@@ -124,6 +124,10 @@ int hd_conv_tune_override(int bm, int bn, int bk, int deep);
  * tile {256x128, 128x128, 256x64, 128x64} wherever eligible.  `nslices` is ignored (kept for the call's shape: the im2col 8-wave
  * family with split-K that used it was measured no faster than the 4-wave kernels on any shape and removed in round 3). */
 int hd_conv_tune_w8(int cfg, int nslices);
+/* test / tuning hook of the large-tile GEMM path (gemm_w8.hip: the plain-GEMM problems of hd_conv2d -- 1x1 / stride-1 convolutions
+ * and fully connected layers -- on 256 x 256 / 256 x 128 tiles, 8 waves, register-only epilogue; bit-identical to the implicit-GEMM
+ * family): -1 = the built-in rule, 0 = never, 128 / 256 = that tile wherever the problem is eligible.  Process-wide. */
+int hd_gemm_w8_mode(int mode);
 
 /* ------------------------------------------------------------------------
  * Weight-gradient implicit GEMM: dW[co][kh][kw][ci] = sum_pix dY[pix,co] * X[pix@(kh,kw),ci]

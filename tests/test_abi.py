@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
 
 
 def test_identity(lib):
-    assert lib.hd_abi_version() == 4
+    assert lib.hd_abi_version() == 5
     assert lib.hd_arch() == b"gfx950"
 
 

@@ -150,6 +150,64 @@ def test_conv2d_eight_wave_families(dev, cfg):
         lib.hd_conv_tune_w8(-1, 0)
 
 
+GEMM8_CASES = [
+    # N, H, W, Cin, Cout, K (window = map), bias + ReLU, mask
+    (700, 1, 1, 1024, 1000, 1, True, False),        # FC: ragged last row tile (700 = 2 x 256 + 188), ragged channel tile (1000)
+    (300, 7, 7, 256, 1024, 7, True, False),         # fc6: the 7 x 7 window over a 7 x 7 map is the stored row (K = 12 544: 196 K steps)
+    (513, 1, 1, 1024, 12544, 1, False, False),      # fc6's data gradient: 49 / 98 channel tiles, one row past two tiles
+    (2, 19, 21, 512, 256, 1, False, True),          # 1x1 / stride-1 convolution with the ReLU-backward mask
+    (3, 10, 10, 2048, 520, 1, True, True),          # Cout % 8 == 0 only: a channel tile with 8 live channels
+    (1, 1, 1, 64, 8, 1, False, False),              # one row, one 8-channel group, one K step
+]
+
+
+@pytest.mark.parametrize("bn", [128, 256])
+def test_gemm_w8_matches_the_igemm_family_bit_for_bit(dev, bn):
+    """gemm_w8.hip (8 waves, 256 x bn tiles, register-only epilogue) forced through hd_gemm_w8_mode wherever hd_conv2d's problem is a
+    plain GEMM over stored tensors, against (a) the oracle and (b) the 4-wave implicit-GEMM family on the same inputs BIT FOR BIT: the
+    products and the fp32 summation order over K are the same, so which path a problem takes may depend on the batch size without
+    breaking batch invariance (image n of a batch == the image alone: asserted here across the two paths)."""
+    from hallucidet_amd import ops, _abi
+    lib = _abi.load()
+    try:
+        for N, H, W, Cin, Cout, K, bias_relu, use_mask in GEMM8_CASES:
+            x = rnd(N, H, W, Cin, seed=1).to(dev)
+            Kt = K * K * Cin
+            w = rnd(Cout, Kt, scale=1.0 / math.sqrt(Kt), seed=3).to(dev)
+            Ho, Wo = (1, 1) if K > 1 else (H, W)
+            bias = torch.randn(Cout, generator=torch.Generator().manual_seed(4)).to(dev) if bias_relu else None
+            mask = (torch.rand(N, Ho, Wo, Cout, generator=torch.Generator().manual_seed(6)) > 0.4).half().to(dev) if use_mask else None
+            kw = dict(bias=bias, mask=mask, act=1 if bias_relu else 0)
+            lib.hd_gemm_w8_mode(0)
+            ref = ops.conv2d(x, w, K, K, **kw)
+            lib.hd_gemm_w8_mode(bn)
+            got = ops.conv2d(x, w, K, K, **kw)
+            again = ops.conv2d(x, w, K, K, **kw)
+            one = ops.conv2d(x[N // 2:N // 2 + 1].contiguous(), w, K, K, bias=bias, act=kw["act"],
+                             mask=None if mask is None else mask[N // 2:N // 2 + 1].contiguous())
+            torch.cuda.synchronize()
+            assert torch.equal(got, ref), (bn, N, H, W, Cin, Cout)
+            assert torch.equal(got, again) and torch.equal(one, ref[N // 2:N // 2 + 1])
+            want, _ = ok.conv2d_nhwc(x.cpu(), w.cpu(), K, K, bias=None if bias is None else bias.cpu(), act=0)
+            if use_mask:
+                want = want * mask.cpu().float()
+            if bias_relu:
+                want = want.clamp_min(0)
+            close(got, want.half())
+        # what the large-tile path does not implement stays where it was (residual, BatchNorm sums, strides, fp32 outputs) -- same call,
+        # same answer as with the path switched off
+        x = rnd(600, 1, 1, 512, seed=1).to(dev)
+        w = rnd(512, 512, scale=1.0 / math.sqrt(512), seed=3).to(dev)
+        res = rnd(600, 1, 1, 512, seed=5).to(dev)
+        lib.hd_gemm_w8_mode(bn)
+        a, sa = ops.conv2d(x, w, 1, 1, res=res, want_stats=True)
+        lib.hd_gemm_w8_mode(0)
+        b, sb = ops.conv2d(x, w, 1, 1, res=res, want_stats=True)
+        assert torch.equal(a, b) and torch.equal(sa, sb)
+    finally:
+        lib.hd_gemm_w8_mode(-1)
+
+
 def test_conv2d_nchw_f32_output(dev):
     from hallucidet_amd import ops
     x = rnd(2, 12, 16, 16, seed=1)

@@ -114,6 +114,43 @@ def run_forward(ops, c, gen):
     return msg
 
 
+def run_gemm8(ops, c, gen):
+    """The large-tile GEMM path (gemm_w8.hip) forced on every case that is a plain GEMM: both tiles against the implicit-GEMM family
+    bit for bit and against ATen."""
+    if c["K"] != 1 or c["stride"] != 1 or c["pad"] != 0 or c["up1"] or c["C2"] or c["C1"] % 64 or c["Cout"] % 8 or c["act"] == 2:
+        return None
+    from hallucidet_amd import _abi
+    lib = _abi.load()
+    N, H, W, C1, Cout = c["N"], c["H"], c["W"], c["C1"], c["Cout"]
+    x = rnd(gen, N, H, W, C1)
+    w = rnd(gen, Cout, C1, scale=1.0 / math.sqrt(C1))
+    bias = torch.randn(Cout, generator=gen, device="cuda") if c["bias"] else None
+    mask = (torch.rand(N, H, W, Cout, generator=gen, device="cuda") > 0.4).half() if c["res"] else None
+    kw = dict(bias=bias, mask=mask, act=c["act"])
+    try:
+        lib.hd_gemm_w8_mode(0)
+        ref = ops.conv2d(x, w, 1, 1, **kw)
+        outs = []
+        for bn in (128, 256):
+            lib.hd_gemm_w8_mode(bn)
+            outs.append(ops.conv2d(x, w, 1, 1, **kw))
+        torch.cuda.synchronize()
+    finally:
+        lib.hd_gemm_w8_mode(-1)
+    for bn, o in zip((128, 256), outs):
+        if not torch.equal(o, ref):
+            return "gemm_w8 tile 256x%d differs from the igemm family (%d elements)" % (bn, int((o != ref).sum()))
+    want = x.reshape(-1, C1).float() @ w.float().t()
+    if bias is not None:
+        want = want + bias
+    if mask is not None:
+        want = want * (mask.reshape(want.shape).float() > 0)
+    if c["act"] == 1:
+        want = want.clamp_min(0)
+    nbad, emax = err_of(outs[0].reshape(want.shape), want, 4e-3, 3e-3)
+    return "" if nbad == 0 else "gemm_w8: %d elements off, max err %.4g" % (nbad, emax)
+
+
 def run_dgrad(ops, c, gen):
     if c["up1"] or c["C2"]:
         return None
@@ -277,7 +314,7 @@ def main():
     from hallucidet_amd import ops
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
-    t0, fails, ran = time.time(), [], {"forward": 0, "dgrad": 0, "wgrad": 0, "fused": 0, "multi": 0, "consumer_bn": 0, "bstat": 0, "stem_subpixel": 0}
+    t0, fails, ran = time.time(), [], {"forward": 0, "dgrad": 0, "wgrad": 0, "fused": 0, "multi": 0, "consumer_bn": 0, "bstat": 0, "stem_subpixel": 0, "gemm8": 0}
     for i in range(args.cases):
         if time.time() - t0 > args.max_seconds:
             break
@@ -286,7 +323,8 @@ def main():
         gen = torch.Generator(device="cuda").manual_seed(seed)
         c = draw_case(r)
         legs = [("forward", lambda: run_forward(ops, c, gen)), ("dgrad", lambda: run_dgrad(ops, c, gen)),
-                ("wgrad", lambda: run_wgrad(ops, c, gen, r)), ("fused", lambda: run_fused(ops, c, gen))]
+                ("wgrad", lambda: run_wgrad(ops, c, gen, r)), ("fused", lambda: run_fused(ops, c, gen)),
+                ("gemm8", lambda: run_gemm8(ops, c, gen))]
         if i % 4 == 0:
             legs.append(("multi", lambda: run_multi(ops, r, gen)))
         if i % 4 == 1:
