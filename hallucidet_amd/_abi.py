@@ -91,9 +91,6 @@ PROTOTYPES = {
     "hd_bn_finalize": (C.c_int, [vp, C.c_int, C.c_int, c_d, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp]),
     "hd_bn_eval_scale_shift": (C.c_int, [vp, vp, vp, vp, c_f, C.c_int, vp, vp, vp]),
     "hd_bn_apply": (C.c_int, [vp, vp, vp, vp, vp, c_i64, C.c_int, C.c_int, vp]),
-    "hd_bn_fold_ok": (C.c_int, [C.c_int, C.c_int]),
-    "hd_bn_fold_limit": (C.c_int, [C.c_int]),
-    "hd_bn_finalize_apply": (C.c_int, [vp, C.c_int, C.c_int, C.c_double, vp, vp, vp, vp, c_f, c_f, vp, vp, vp, vp, vp, vp, vp, c_i64, C.c_int, vp]),
     "hd_bn_bwd_reduce": (C.c_int, [vp] * 8 + [C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "hd_bn_bwd_apply": (C.c_int, [vp] * 8 + [C.c_int] + [vp] * 5 + [c_f, C.c_int, c_i64, C.c_int, C.c_int, vp]),
     "hd_maxpool3x3s2": (C.c_int, [vp, vp] + [C.c_int] * 6 + [vp]),
@@ -160,7 +157,7 @@ PROTOTYPES = {
 }
 
 # fp32-storage twins (include/hallucidet_hip.h, last section): same signatures under the suffix _f32
-F32_TWINS = ["hd_conv2d", "hd_conv2d_stats_rows", "hd_wgrad", "hd_weight_prep", "hd_bn_apply", "hd_bn_fold_ok", "hd_bn_fold_limit", "hd_bn_finalize_apply", "hd_bn_bwd_reduce", "hd_bn_bwd_apply",
+F32_TWINS = ["hd_conv2d", "hd_conv2d_stats_rows", "hd_wgrad", "hd_weight_prep", "hd_bn_apply", "hd_bn_bwd_reduce", "hd_bn_bwd_apply",
              "hd_maxpool3x3s2", "hd_maxpool3x3s2_bwd", "hd_maxpool3x3s2_idx", "hd_maxpool3x3s2_bwd_idx", "hd_maxpool3x3s2_bwd_idx_add", "hd_concat_up_bwd", "hd_subsample2", "hd_subsample2_bwd",
              "hd_nchw_to_nhwc_resize", "hd_nchw_to_nhwc_resize_strided", "hd_nchw_to_nhwc_resize_bwd", "hd_nhwc_to_nchw", "hd_upsample_add",
              "hd_upsample_add_bwd", "hd_upsample2_bwd", "hd_add_f16", "hd_slice_channels", "hd_sigmoid_bwd_nchw_to_nhwc", "hd_relu_bwd",

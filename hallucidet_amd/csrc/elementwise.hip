@@ -1,7 +1,5 @@
 // Bandwidth-bound kernels of the hot path: BatchNorm pieces, pooling, resampling,
 // layout conversion.  All activations NHWC f16, 8 halves (16 B) per lane.
-#include <stdlib.h>
-
 #include "hd_common.h"
 
 namespace {
@@ -34,106 +32,6 @@ __global__ void colsum_stage(const float* __restrict__ in, int rows, int W, floa
   if (rl == 0 && c < W) out[(size_t)blockIdx.y * W + c] = (float)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
-// ---------------------------------------------------------------- BN partial rows: ONE summation order for every kernel
-// Column `col` of the partial rows [rows][stride], row lane q of 64: rows q, q + 64, q + 128, ... -- four at a time while four are
-// left, then one by one.  bn_finalize_kernel / bn_bwd_coef_kernel compute the 64 lane sums in 64 threads and add them in lane order;
-// the folded kernels (bn_finalize_apply_kernel, bn_bwd_apply_fold_kernel: every block re-derives the coefficients it needs, no
-// finalize / coefficient launch) walk the same lanes in one thread -- the same additions in the same order, bit-identical results.
-__device__ __forceinline__ double bn_lane_sum_f64(const float* __restrict__ part, int rows, int stride, int col, int q) {
-  double s = 0.0;
-  int r = q;
-  for (; r + 192 < rows; r += 256) {           // four loads in flight
-    const float a0 = part[(size_t)r * stride + col], a1 = part[(size_t)(r + 64) * stride + col];
-    const float a2 = part[(size_t)(r + 128) * stride + col], a3 = part[(size_t)(r + 192) * stride + col];
-    s += (double)a0 + (double)a1 + (double)a2 + (double)a3;
-  }
-  for (; r < rows; r += 64) s += (double)part[(size_t)r * stride + col];
-  return s;
-}
-__device__ __forceinline__ float bn_lane_sum_f32(const float* __restrict__ part, int rows, int stride, int col, int q) {
-  float s = 0.f;
-  int r = q;
-  for (; r + 192 < rows; r += 256) {
-    const float a0 = part[(size_t)r * stride + col], a1 = part[(size_t)(r + 64) * stride + col];
-    const float a2 = part[(size_t)(r + 128) * stride + col], a3 = part[(size_t)(r + 192) * stride + col];
-    s += (a0 + a1) + (a2 + a3);
-  }
-  for (; r < rows; r += 64) s += part[(size_t)r * stride + col];
-  return s;
-}
-// The 64 lane sums are added in EIGHT CHUNKS of eight consecutive lanes, the chunk sums in chunk order (all left to right): the
-// legacy kernels do it in one thread per channel from LDS, the folded kernels compute a (column, chunk) per work item and add the
-// eight chunk sums per column afterwards.
-template <typename T>
-__device__ __forceinline__ T bn_sum_lanes_chunked(const T* lane_sums, int lane_stride) {      // 64 lane sums at lane_sums[q * lane_stride]
-  T t = (T)0;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    T cs = (T)0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) cs += lane_sums[(j * 8 + i) * lane_stride];
-    t += cs;
-  }
-  return t;
-}
-// Chunk j (lanes 8j .. 8j + 7) of column `col` for rows <= 256: every lane has at most four rows (q, q + 64, q + 128, q + 192), all
-// requested at once (up to 32 loads in flight), missing rows read as 0 -- which reproduces bn_lane_sum_* exactly: one group of four
-// from s = 0, or up to three single rows, in the same association.
-template <typename T>
-__device__ __forceinline__ T bn_chunk_sum_le256(const float* __restrict__ part, int rows, int stride, int col, int j) {
-  float v[4][8];
-  const int kmax = (rows + 63) >> 6;
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = j * 8 + i + 64 * k;
-      v[k][i] = (k < kmax && r < rows) ? part[(size_t)r * stride + col] : 0.f;
-    }
-  T cs = (T)0;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    T L;
-    if (sizeof(T) == 8) L = (((T)v[0][i] + (T)v[1][i]) + (T)v[2][i]) + (T)v[3][i];
-    else L = ((T)v[0][i] + (T)v[1][i]) + ((T)v[2][i] + (T)v[3][i]);
-    cs += L;
-  }
-  return cs;
-}
-// Block-wide: the totals of `ncol` columns (rows <= 256) into tot[0 .. ncol) (LDS, type T), by all threads of the block; `cs` is LDS
-// scratch for 8 * ncol values of T.  Ends with a barrier.
-template <typename T>
-__device__ __forceinline__ void bn_block_col_totals(const float* __restrict__ part, int rows, int stride, int ncol, T* cs, T* tot) {
-  const int nchunk = rows < 64 ? (rows + 7) >> 3 : 8;
-  const int items = ncol * nchunk;
-  for (int it = threadIdx.x; it < items; it += blockDim.x) {
-    const int j = it / ncol, col = it - j * ncol;
-    cs[j * ncol + col] = bn_chunk_sum_le256<T>(part, rows, stride, col, j);
-  }
-  __syncthreads();
-  for (int col = threadIdx.x; col < ncol; col += blockDim.x) {
-    T t = (T)0;
-    for (int j = 0; j < nchunk; ++j) t += cs[j * ncol + col];
-    tot[col] = t;
-  }
-  __syncthreads();
-}
-// batch statistics of one channel from its two column totals -> mean, invstd, the forward scale / shift
-__device__ __forceinline__ void bn_channel_stats(double s1, double s2, double count, float eps, float g, float b, double& m, double& var,
-                                                 float& is, float& scale, float& shift) {
-  m = s1 / count;
-  var = s2 / count - m * m;
-  if (var < 0.0) var = 0.0;
-  is = (float)(1.0 / sqrt(var + (double)eps));
-  scale = g * is;
-  shift = b - (float)m * g * is;
-}
-__device__ __forceinline__ void bn_running_update(int c, double m, double var, double count, float momentum, float* running_mean, float* running_var) {
-  const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-  running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-  running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-}
-
 // ---------------------------------------------------------------- BN finalize
 // part [rows][2][C] partial (sum, sumsq) rows of the conv epilogue are added here, ANY number of rows: block = 64 row lanes x
 // 4 channels (fixed order: deterministic), so a 1 280-tile layer costs each thread 20 independent loads instead of a separate
@@ -147,23 +45,44 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int c = blockIdx.x * 4 + cl;
   double s1 = 0.0, s2 = 0.0;
   if (c < C) {
-    s1 = bn_lane_sum_f64(part, rows, 2 * C, c, rl);
-    s2 = bn_lane_sum_f64(part, rows, 2 * C, C + c, rl);
+    int r = rl;
+    for (; r + 192 < rows; r += 256) {           // four loads of each kind in flight
+      const float a0 = part[(size_t)r * 2 * C + c], a1 = part[(size_t)(r + 64) * 2 * C + c];
+      const float a2 = part[(size_t)(r + 128) * 2 * C + c], a3 = part[(size_t)(r + 192) * 2 * C + c];
+      const float b0 = part[(size_t)r * 2 * C + C + c], b1 = part[(size_t)(r + 64) * 2 * C + C + c];
+      const float b2 = part[(size_t)(r + 128) * 2 * C + C + c], b3 = part[(size_t)(r + 192) * 2 * C + C + c];
+      s1 += (double)a0 + (double)a1 + (double)a2 + (double)a3;
+      s2 += (double)b0 + (double)b1 + (double)b2 + (double)b3;
+    }
+    for (; r < rows; r += 64) {
+      s1 += (double)part[(size_t)r * 2 * C + c];
+      s2 += (double)part[(size_t)r * 2 * C + C + c];
+    }
   }
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  s1 = bn_sum_lanes_chunked<double>(&red[0][0][cl], 4);
-  s2 = bn_sum_lanes_chunked<double>(&red[1][0][cl], 4);
-  double m, var;
-  float is, sc, sh;
-  bn_channel_stats(s1, s2, count, eps, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, m, var, is, sc, sh);
+  s1 = s2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < 64; ++q) {
+    s1 += red[0][q][cl];
+    s2 += red[1][q][cl];
+  }
+  double m = s1 / count;
+  double var = s2 / count - m * m;
+  if (var < 0.0) var = 0.0;
+  float is = (float)(1.0 / sqrt(var + (double)eps));
+  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   if (mean) mean[c] = (float)m;
   if (invstd) invstd[c] = is;
-  scale[c] = sc;
-  shift[c] = sh;
-  if (running_mean) bn_running_update(c, m, var, count, momentum, running_mean, running_var);
+  scale[c] = g * is;
+  shift[c] = b - (float)m * g * is;
+  if (running_mean) {
+    double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
 }
 
 __global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, int C,
@@ -198,65 +117,6 @@ __global__ void bn_apply_kernel(const f16* __restrict__ y, const f16* __restrict
   float sc[8], sh[8];
   ld8f(scale + c0, sc);
   ld8f(shift + c0, sh);
-  for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    f16x8 v = ld8(y + i * 8);
-    f16x8 r;
-    if (RES) r = ld8(res + i * 8);
-    f16x8 o;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float f = hd_bn_affine((float)v[k], sc[k], sh[k]);
-      if (RES) f += (float)r[k];
-      if (RELU) f = fmaxf(f, 0.f);
-      o[k] = (f16)f;
-    }
-    st8(z + i * 8, o);
-  }
-}
-
-// ---------------------------------------------------------------- BN finalize folded into the apply pass (round 5)
-// The Conv2dReLU unit's training-mode BatchNorm2d (+ residual) (+ ReLU) (reference src/segmentation_models/base/modules.py:28-47) as
-// ONE launch behind the convolution: every block first re-derives the batch statistics of ALL C channels from the partial rows of
-// the conv epilogue (thread c: channels c, c + 256, ...; the canonical order above, so mean / invstd / scale / shift are bit for
-// bit what hd_bn_finalize computes), keeps scale / shift in LDS and then runs hd_bn_apply's loop.  Block 0 also writes mean / invstd /
-// scale / shift (the backward pass reads them) and updates the running statistics.  No release / acquire, no atomics: a block
-// re-reads rows x 2C floats from L2 (<= 192 KB, the caller's rule) instead of waiting for a 5 us dependent launch; at most 256
-// blocks so that a CU does this once.
-template <bool RES, bool RELU>
-__global__ __launch_bounds__(256) void bn_finalize_apply_kernel(const float* __restrict__ part, int rows, int C, double count,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* running_mean, float* running_var, float momentum, float eps,
-                                                                float* mean, float* invstd, float* scale, float* shift,
-                                                                const f16* __restrict__ y, const f16* __restrict__ res, f16* __restrict__ z,
-                                                                int64_t nvec) {
-  extern __shared__ double fold_lds[];  // [chunks][2C] chunk sums, [2C] totals (double); the first 2C floats are reused as scale, shift
-  double* tot = fold_lds + (rows < 64 ? (rows + 7) >> 3 : 8) * 2 * C;
-  bn_block_col_totals<double>(part, rows, 2 * C, 2 * C, fold_lds, tot);
-  float* coef = reinterpret_cast<float*>(fold_lds);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const double s1 = tot[c], s2 = tot[C + c];
-    double m, var;
-    float is, sc, sh;
-    bn_channel_stats(s1, s2, count, eps, gamma ? gamma[c] : 1.f, beta ? beta[c] : 0.f, m, var, is, sc, sh);
-    coef[c] = sc;
-    coef[C + c] = sh;
-    if (blockIdx.x == 0) {
-      if (mean) mean[c] = (float)m;
-      if (invstd) invstd[c] = is;
-      scale[c] = sc;
-      shift[c] = sh;
-      if (running_mean) bn_running_update(c, m, var, count, momentum, running_mean, running_var);
-    }
-  }
-  __syncthreads();
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c0 = (int)((i0 * 8) % C);
-  float sc[8], sh[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    sc[k] = coef[c0 + k];
-    sh[k] = coef[C + c0 + k];
-  }
   for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     f16x8 v = ld8(y + i * 8);
     f16x8 r;
@@ -386,26 +246,6 @@ __device__ __forceinline__ void sum_part_rows(const float* __restrict__ part, in
   }
 }
 
-// the five per-channel coefficients of the BN backward (A, B, D below, forward scale, forward shift) from the two column totals;
-// `write`: this caller also owns dgamma / dbeta (one writer per channel)
-__device__ __forceinline__ void bn_bwd_channel_coef(int c, float sg, float sgx, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float invM, float gscale,
-                                                    int accumulate, float* dgamma, float* dbeta, bool write, float (&cf)[5]) {
-  if (write) {
-    const float dg = sgx * gscale, db = sg * gscale;
-    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
-  }
-  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, is = invstd[c], mu = mean[c];
-  const float a_ = ga * is;
-  const float b_ = -a_ * is * sgx * invM;
-  cf[0] = a_;
-  cf[1] = b_;
-  cf[2] = -a_ * sg * invM - b_ * mu;
-  cf[3] = ga * is;
-  cf[4] = be - mu * ga * is;
-}
-
 // Per-channel coefficients of the BN backward, ONCE per unit: sums any number of partial rows (64 row lanes x 4 channels per
 // block, fixed order), writes coef [5][C] = A, B, D (below), forward scale, forward shift, and dgamma / dbeta.  Before, every
 // block of the apply kernel summed the partial rows itself: up to 64 x 2C floats per block, ten times its payload on the small
@@ -419,18 +259,41 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
   const int c = blockIdx.x * 4 + cl;
   float s1 = 0.f, s2 = 0.f;
   if (c < C) {
-    s1 = bn_lane_sum_f32(part, rows, 2 * C, c, rl);
-    s2 = bn_lane_sum_f32(part, rows, 2 * C, C + c, rl);
+    int r = rl;
+    for (; r + 192 < rows; r += 256) {
+      const float a0 = part[(size_t)r * 2 * C + c], a1 = part[(size_t)(r + 64) * 2 * C + c];
+      const float a2 = part[(size_t)(r + 128) * 2 * C + c], a3 = part[(size_t)(r + 192) * 2 * C + c];
+      const float b0 = part[(size_t)r * 2 * C + C + c], b1 = part[(size_t)(r + 64) * 2 * C + C + c];
+      const float b2 = part[(size_t)(r + 128) * 2 * C + C + c], b3 = part[(size_t)(r + 192) * 2 * C + C + c];
+      s1 += (a0 + a1) + (a2 + a3);
+      s2 += (b0 + b1) + (b2 + b3);
+    }
+    for (; r < rows; r += 64) {
+      s1 += part[(size_t)r * 2 * C + c];
+      s2 += part[(size_t)r * 2 * C + C + c];
+    }
   }
   red[0][rl][cl] = s1;
   red[1][rl][cl] = s2;
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  const float sg = bn_sum_lanes_chunked<float>(&red[0][0][cl], 4), sgx = bn_sum_lanes_chunked<float>(&red[1][0][cl], 4);
-  float cf[5];
-  bn_bwd_channel_coef(c, sg, sgx, mean, invstd, gamma, beta, invM, gscale, accumulate, dgamma, dbeta, true, cf);
+  float sg = 0.f, sgx = 0.f;
 #pragma unroll
-  for (int k = 0; k < 5; ++k) coef[k * C + c] = cf[k];
+  for (int q = 0; q < 64; ++q) {
+    sg += red[0][q][cl];
+    sgx += red[1][q][cl];
+  }
+  const float dg = sgx * gscale, db = sg * gscale;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, is = invstd[c], mu = mean[c];
+  const float a_ = ga * is;
+  const float b_ = -a_ * is * sgx * invM;
+  coef[c] = a_;
+  coef[C + c] = b_;
+  coef[2 * C + c] = -a_ * sg * invM - b_ * mu;
+  coef[3 * C + c] = ga * is;
+  coef[4 * C + c] = be - mu * ga * is;
 }
 
 // dy = A[c]*g + B[c]*y + D[c]  with  A = gamma*invstd, B = -A*invstd*sum_gx/M, D = -A*sum_g/M - B*mean
@@ -450,60 +313,6 @@ __global__ void bn_bwd_apply_kernel(const f16* __restrict__ dz, const f16* __res
   ld8f(cf + 2 * C + c0, D);
   ld8f(cf + 3 * C + c0, sc);
   ld8f(cf + 4 * C + c0, sh);
-  for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
-    f16x8 g = ld8(dz + i * 8), yy = ld8(y + i * 8), zz;
-    if (USEZ) zz = ld8(z + i * 8);
-    f16x8 o, gr;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      float gk = (float)g[k];
-      const float yk = (float)yy[k];
-      if (RELU) {
-        const bool on = USEZ ? ((float)zz[k] > 0.f) : ((float)(f16)hd_bn_affine(yk, sc[k], sh[k]) > 0.f);
-        gk = on ? gk : 0.f;
-      }
-      o[k] = (f16)(A[k] * gk + B[k] * yk + D[k]);
-      gr[k] = (f16)gk;
-    }
-    st8(dy + i * 8, o);
-    if (DRES) st8(dres + i * 8, gr);
-  }
-}
-
-// BN backward with the coefficient launch folded in (round 5): every block re-derives A, B, D, scale, shift of all C channels from the
-// reduction's partial rows (canonical order: bit-identical to bn_bwd_coef_kernel), keeps them in LDS and runs bn_bwd_apply_kernel's
-// loop; block 0 writes dgamma / dbeta.  At most 256 blocks.
-template <bool RELU, bool USEZ, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_apply_fold_kernel(const f16* __restrict__ dz, const f16* __restrict__ z, const f16* __restrict__ y,
-                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                const float* __restrict__ part, int rows, float invM, float gscale, int accumulate,
-                                                                float* dgamma, float* dbeta, f16* __restrict__ dy, f16* __restrict__ dres,
-                                                                int64_t npix, int C) {
-  extern __shared__ float foldb_lds[];  // [5][C] coefficients | [chunks][2C] chunk sums | [2C] totals
-  float* coef = foldb_lds;
-  float* tot = foldb_lds + 5 * C + (rows < 64 ? (rows + 7) >> 3 : 8) * 2 * C;
-  bn_block_col_totals<float>(part, rows, 2 * C, 2 * C, foldb_lds + 5 * C, tot);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float sg = tot[c], sgx = tot[C + c];
-    float cf[5];
-    bn_bwd_channel_coef(c, sg, sgx, mean, invstd, gamma, beta, invM, gscale, accumulate, dgamma, dbeta, blockIdx.x == 0, cf);
-#pragma unroll
-    for (int k = 0; k < 5; ++k) coef[k * C + c] = cf[k];
-  }
-  __syncthreads();
-  const int64_t nvec = npix * C / 8;
-  const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int c0 = (int)((i0 * 8) % C);
-  float A[8], B[8], D[8], sc[8], sh[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    A[k] = coef[c0 + k];
-    B[k] = coef[C + c0 + k];
-    D[k] = coef[2 * C + c0 + k];
-    sc[k] = coef[3 * C + c0 + k];
-    sh[k] = coef[4 * C + c0 + k];
-  }
   for (int64_t i = i0; i < nvec; i += (int64_t)gridDim.x * blockDim.x) {
     f16x8 g = ld8(dz + i * 8), yy = ld8(y + i * 8), zz;
     if (USEZ) zz = ld8(z + i * 8);
@@ -1113,39 +922,6 @@ extern "C" int HD_API(hd_bn_apply)(const void* y, const void* res, const float* 
   return HD_OK;
 }
 
-// Is re-deriving the coefficients in every block of the apply pass cheaper than a dependent 5 us launch?  rows x 2C floats per block
-// (L2 reads, <= 256 blocks): up to 192 KB yes (tools/bench_bn.py), beyond that the separate launch stays.  HD_BN_FOLD=0: never (A/B).
-static int g_bn_fold_limit = -1;     // hd_bn_fold_limit (tests / tools): -1 = the rule, 0 = never fold, n = fold up to n floats
-static bool bn_fold_ok(int rows, int C) {
-  static const int on = [] { const char* v = getenv("HD_BN_FOLD"); return v ? atoi(v) : 1; }();
-  static const int limit = [] { const char* v = getenv("HD_BN_FOLD_FLOATS"); return v ? atoi(v) : 49152; }();
-  const int lim = g_bn_fold_limit >= 0 ? g_bn_fold_limit : (on ? limit : 0);
-  return rows <= 256 && C <= 512 && (int64_t)rows * 2 * C <= lim;      // (the in-block form of the summation order covers <= 4 rows per lane)
-}
-
-extern "C" int HD_API(hd_bn_fold_ok)(int rows, int C) { return bn_fold_ok(rows, C) ? 1 : 0; }
-extern "C" int HD_API(hd_bn_fold_limit)(int floats) {
-  g_bn_fold_limit = floats;
-  return HD_OK;
-}
-
-extern "C" int HD_API(hd_bn_finalize_apply)(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
-                                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                                            float* scale, float* shift, const void* y, const void* res, void* z, int64_t n, int relu,
-                                            void* stream) {
-  HD_CHECK_ARG(part && rows > 0 && scale && shift && C > 0 && count > 0 && y && z && n > 0, "hd_bn_finalize_apply: bad args");
-  HD_CHECK_ARG(C % 8 == 0 && n % 8 == 0 && pow2(C / 8) && C <= 2048, "hd_bn_finalize_apply: C/8 must be a power of two (C=%d)", C);
-  const int grid = grid_for(n / 8, TB, 256);
-  const size_t lds = (size_t)((rows < 64 ? (rows + 7) >> 3 : 8) + 1) * 2 * C * sizeof(double);      // [chunks][2C] chunk sums + [2C] totals
-#define HD_BNF(RS, RL) hipLaunchKernelGGL((bn_finalize_apply_kernel<RS, RL>), dim3(grid), dim3(TB), lds, S_, part, rows, C, count, gamma, beta, \
-                                          running_mean, running_var, momentum, eps, mean, invstd, scale, shift, (const f16*)y, (const f16*)res, (f16*)z, n / 8)
-  if (res) { if (relu) HD_BNF(true, true); else HD_BNF(true, false); }
-  else { if (relu) HD_BNF(false, true); else HD_BNF(false, false); }
-#undef HD_BNF
-  HD_CHECK_LAUNCH();
-  return HD_OK;
-}
-
 extern "C" int HD_API(hd_bn_bwd_reduce)(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                                 const float* gamma, const float* beta, float* part, int rows, int64_t npix, int C, int relu,
                                 void* stream) {
@@ -1168,21 +944,9 @@ extern "C" int HD_API(hd_bn_bwd_apply)(const void* dz, const void* z, const void
                                void* stream) {
   HD_CHECK_ARG(dz && y && mean && invstd && part && rows > 0 && coef_ws && dy && npix > 0, "hd_bn_bwd_apply: bad args");
   HD_CHECK_ARG(C % 8 == 0 && pow2(C / 8) && C <= 2048, "hd_bn_bwd_apply: C/8 must be a power of two (C=%d)", C);
-  const bool usez = relu && z != nullptr;
-  if (bn_fold_ok(rows, C)) {      // coefficients re-derived per block (bit-identical), no coefficient launch; coef_ws stays untouched
-#define HD_APF(R, Z, D)                                                                                                               \
-  hipLaunchKernelGGL((bn_bwd_apply_fold_kernel<R, Z, D>), dim3(grid_for(npix * C / 8, TB, 256)), dim3(TB), (size_t)(5 + 2 * ((rows < 64 ? (rows + 7) >> 3 : 8) + 1)) * C * sizeof(float), S_, \
-                     (const f16*)dz, (const f16*)z, (const f16*)y, mean, invstd, gamma, beta, part, rows, 1.f / (float)npix, gscale, accumulate, \
-                     dgamma, dbeta, (f16*)dy, (f16*)dres, npix, C)
-    if (!relu) { if (dres) HD_APF(false, false, true); else HD_APF(false, false, false); }
-    else if (usez) { if (dres) HD_APF(true, true, true); else HD_APF(true, true, false); }
-    else { if (dres) HD_APF(true, false, true); else HD_APF(true, false, false); }
-#undef HD_APF
-    HD_CHECK_LAUNCH();
-    return HD_OK;
-  }
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(hd_cdiv(C, 4)), dim3(256), 0, S_, part, rows, C, mean, invstd, gamma, beta, 1.f / (float)npix, gscale,
                      accumulate, dgamma, dbeta, coef_ws);
+  const bool usez = relu && z != nullptr;
 #define HD_APP(R, Z, D)                                                                                                              \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<R, Z, D>), dim3(grid_for(npix * C / 8, TB, 2048)), dim3(TB), 0, S_, (const f16*)dz, (const f16*)z, \
                      (const f16*)y, mean, invstd, gamma, beta, (const float*)coef_ws, (f16*)dy, (f16*)dres, npix, C)

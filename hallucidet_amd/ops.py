@@ -384,32 +384,6 @@ def bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, e
     return mean, invstd, scale, shift
 
 
-def bn_finalize_apply(part, count, gamma, beta, running_mean, running_var, momentum, eps, y, *, res=None, relu=True):
-    """bn_finalize + bn_apply of one unit -> (mean, invstd, scale, shift, z).  ONE launch (hd_bn_finalize_apply: every block of the
-    apply pass re-derives the statistics from the partial rows; bit-identical to the two calls) where the rows are few enough for
-    that to beat a dependent launch (hd_bn_fold_ok), the two launches otherwise."""
-    if part.dim() == 3:
-        part = part.reshape(part.shape[0], -1)
-    elif part.dim() == 1:
-        part = part.reshape(1, -1)
-    rows, W = part.shape
-    C_ = W // 2
-    if not _abi.fn("hd_bn_fold_ok", y)(rows, C_):
-        mean, invstd, scale, shift = bn_finalize(part, count, gamma, beta, running_mean, running_var, momentum, eps)
-        return mean, invstd, scale, shift, bn_apply(y, scale, shift, res=res, relu=relu)
-    _need_cuda(y, part, res)
-    dev = part.device
-    mean = torch.empty(C_, dtype=torch.float32, device=dev)
-    invstd = torch.empty_like(mean)
-    scale = torch.empty_like(mean)
-    shift = torch.empty_like(mean)
-    z = torch.empty_like(y)
-    check(_abi.fn("hd_bn_finalize_apply", y)(ptr(part), rows, C_, float(count), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                                             momentum, eps, ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(y), ptr(res), ptr(z),
-                                             y.numel(), 1 if relu else 0, _stream()), "hd_bn_finalize_apply")
-    return mean, invstd, scale, shift, z
-
-
 def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
     C_ = running_mean.numel()
     scale = torch.empty(C_, dtype=torch.float32, device=running_mean.device)

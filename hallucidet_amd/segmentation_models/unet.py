@@ -526,24 +526,18 @@ class UnetRunner:
         xin = x
         x, isc, ish, irelu = _operand(xin)
         bnk = dict(in_scale=isc, in_shift=ish, in_relu=irelu) if isc is not None else {}
-        z = None
-        raw = self.fuse_bn and res is None and u.name in self._raw_units
         if training:
             y, stats = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1, want_stats=True, **bnk)
             npix = y.numel() // u.cout
-            if raw:
-                mean, invstd, scale, shift = ops.bn_finalize(stats, npix, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
-                                                             u.bn.momentum, u.bn.eps)
-            else:       # statistics + normalisation in one launch where the partial rows are few (ops.bn_finalize_apply)
-                mean, invstd, scale, shift, z = ops.bn_finalize_apply(stats, npix, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
-                                                                      u.bn.momentum, u.bn.eps, y, res=res, relu=u.relu)
+            mean, invstd, scale, shift = ops.bn_finalize(stats, npix, u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var,
+                                                         u.bn.momentum, u.bn.eps)
         else:
             y = ops.conv2d(x, wf, u.k, u.k, x2=x2, stride=u.stride, pad=u.pad, up1=up1, **bnk)
             scale, shift = ops.bn_eval_scale_shift(u.bn.weight, u.bn.bias, u.bn.running_mean, u.bn.running_var, u.bn.eps)
             mean = invstd = None
-        if raw:
+        if self.fuse_bn and res is None and u.name in self._raw_units:
             z = _RawAct(y, scale, shift, u.relu)
-        elif z is None:
+        else:
             z = ops.bn_apply(y, scale, shift, res=res, relu=u.relu)
         if rec is not None:
             rec[u.name] = dict(x=xin, x2=x2, up1=up1, y=y, z=z, mean=mean, invstd=invstd, has_res=res is not None)

@@ -231,16 +231,6 @@ int hd_bn_eval_scale_shift(const float* gamma, const float* beta, const float* r
 /* z = act(y*scale[c] + shift[c] (+ res)) , all f16 NHWC, n = number of elements (multiple of 8) */
 int hd_bn_apply(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C,
                 int relu, void* stream);
-/* hd_bn_finalize + hd_bn_apply of one Conv2dReLU unit (src/segmentation_models/base/modules.py:28-47) as ONE launch: every block of the
- * apply pass re-derives the batch statistics from the partial rows itself (the summation order of hd_bn_finalize: mean / invstd /
- * scale / shift, the running statistics and z are bit-identical to the two calls), block 0 writes the per-channel outputs.  Pays
- * while rows * 2C floats stay within what a block re-reads from L2 in less than a dependent launch costs: ask hd_bn_fold_ok (1 / 0);
- * callers fall back to the two calls otherwise.  hd_bn_bwd_apply applies the same rule to its coefficient launch by itself. */
-int hd_bn_fold_ok(int rows, int C);
-int hd_bn_fold_limit(int floats); /* test / tuning hook: -1 = the built-in rule, 0 = never fold, n = fold while rows * 2C <= n */
-int hd_bn_finalize_apply(const float* part, int rows, int C, double count, const float* gamma, const float* beta,
-                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                         float* scale, float* shift, const void* y, const void* res, void* z, int64_t n, int relu, void* stream);
 /* backward of z = relu(bn(y) (+ res)):  part[rows][2][C] <- (sum g, sum g*xhat) with g = dz*(z>0).
  * z == NULL (non-residual unit): the mask is recomputed as (f16)(y*gamma*invstd + beta - mean*gamma*invstd) > 0,
  * bit-identical to the forward's activation. */
@@ -248,8 +238,7 @@ int hd_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* 
                      const float* gamma, const float* beta, float* part, int rows, int64_t npix, int C, int relu, void* stream);
 /* dy = gamma*invstd*(g - sum_g/M - xhat*sum_gx/M); dres = g (optional); also emits dgamma/dbeta (fp32, scaled by gscale).
  * part[rows][2][C] (any number of rows) are the partial rows of hd_bn_bwd_reduce: a coefficient launch sums them once (fixed
- * order) into coef_ws [5][C] (caller-owned scratch), the apply launch streams the tensor; where hd_bn_fold_ok(rows, C) the blocks of
- * the apply launch re-derive the coefficients themselves (same order, bit-identical) and the coefficient launch is not issued. */
+ * order) into coef_ws [5][C] (caller-owned scratch), the apply launch streams the tensor. */
 int hd_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* invstd,
                     const float* gamma, const float* beta, const float* part, int rows, float* coef_ws, void* dy, void* dres,
                     float* dgamma, float* dbeta, float gscale, int accumulate, int64_t npix, int C, int relu, void* stream);
@@ -533,11 +522,6 @@ int hd_wgrad_f32(const hd_wgrad_args* a, void* stream);
 int hd_weight_prep_f32(const float* w_oihw, const float* out_scale, void* w_fwd, void* w_dgrad, int Cout, int Cin, int KH, int KW,
                        int Cin_pad, int Cout_pad, void* stream);
 int hd_bn_apply_f32(const void* y, const void* res, const float* scale, const float* shift, void* z, int64_t n, int C, int relu, void* stream);
-int hd_bn_fold_ok_f32(int rows, int C);
-int hd_bn_fold_limit_f32(int floats);
-int hd_bn_finalize_apply_f32(const float* part, int rows, int C, double count, const float* gamma, const float* beta, float* running_mean,
-                             float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                             const void* y, const void* res, void* z, int64_t n, int relu, void* stream);
 int hd_bn_bwd_reduce_f32(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, float* part, int rows, int64_t npix, int C, int relu, void* stream);
 int hd_bn_bwd_apply_f32(const void* dz, const void* z, const void* y, const float* mean, const float* invstd, const float* gamma,

@@ -208,53 +208,6 @@ def test_gemm_w8_matches_the_igemm_family_bit_for_bit(dev, bn):
         lib.hd_gemm_w8_mode(-1)
 
 
-@pytest.mark.parametrize("case", [(20, 512, 2560, True, True), (80, 256, 10240, False, True), (160, 128, 5000, True, False), (256, 64, 20480, False, True),
-                                  (7, 64, 300, False, False), (330, 32, 9000, True, True)])
-def test_batchnorm_fold_is_bit_identical_to_the_separate_launches(dev, case):
-    """hd_bn_finalize_apply (statistics re-derived in every block of the apply pass) against hd_bn_finalize + hd_bn_apply, and
-    hd_bn_bwd_apply with / without its coefficient launch (hd_bn_fold_limit switches the fold off for the reference side): mean, invstd,
-    scale, shift, running statistics, z, dy, dres, dgamma, dbeta bit for bit -- row counts on both sides of the 64-lane and 256-row
-    strides of the canonical summation order, with and without residual / ReLU."""
-    from hallucidet_amd import ops, _abi
-    lib = _abi.load()
-    rows, C_, npix, use_res, relu = case
-    g = torch.Generator().manual_seed(rows * 131 + C_)
-    y = (torch.randn(npix, C_, generator=g) * 0.7 + 0.2).half().to(dev)
-    res = torch.randn(npix, C_, generator=g).half().to(dev) if use_res else None
-    part = torch.randn(rows, 2, C_, generator=g).to(dev)
-    part[:, 1] = part[:, 1].abs() * 3 + 1.0                         # sums of squares
-    gamma, beta = (torch.rand(C_, generator=g) + 0.5).to(dev), torch.randn(C_, generator=g).to(dev)
-    rm0, rv0 = torch.randn(C_, generator=g).to(dev), (torch.rand(C_, generator=g) + 0.5).to(dev)
-    count = float(npix)
-    try:
-        lib.hd_bn_fold_limit(0)
-        rm_a, rv_a = rm0.clone(), rv0.clone()
-        ma, ia, sa, ha = ops.bn_finalize(part, count, gamma, beta, rm_a, rv_a, 0.1, 1e-5)
-        za = ops.bn_apply(y, sa, ha, res=res, relu=relu)
-        lib.hd_bn_fold_limit(1 << 30)
-        rm_b, rv_b = rm0.clone(), rv0.clone()
-        mb, ib, sb, hb, zb = ops.bn_finalize_apply(part, count, gamma, beta, rm_b, rv_b, 0.1, 1e-5, y, res=res, relu=relu)
-        torch.cuda.synchronize()
-        for a, b in ((ma, mb), (ia, ib), (sa, sb), (ha, hb), (rm_a, rm_b), (rv_a, rv_b), (za, zb)):
-            assert torch.equal(a, b)
-        assert not torch.equal(rm_a, rm0)
-        # backward: same partial rows read as (sum g, sum g * xhat)
-        dz = torch.randn(npix, C_, generator=g).half().to(dev)
-        outs = []
-        for lim in (0, 1 << 30):
-            lib.hd_bn_fold_limit(lim)
-            dg, db = torch.full((C_,), 0.25, device=dev), torch.full((C_,), -0.5, device=dev)
-            dy, dres, dg, db = ops.bn_backward(dz, za if use_res else None, y, ma, ia, gamma, beta, relu=relu, want_dres=use_res, gscale=0.5,
-                                               dgamma=dg, dbeta=db, accumulate=True, part=part.reshape(rows, 2 * C_))
-            torch.cuda.synchronize()
-            outs.append((dy, dres, dg, db))
-        for a, b in zip(*outs):
-            assert (a is None and b is None) or torch.equal(a, b)
-        assert torch.isfinite(outs[1][0].float()).all()
-    finally:
-        lib.hd_bn_fold_limit(-1)
-
-
 def test_conv2d_nchw_f32_output(dev):
     from hallucidet_amd import ops
     x = rnd(2, 12, 16, 16, seed=1)
