@@ -1,6 +1,6 @@
 # Kernel-trace summaries + steady-state table + bench line of the current build (no PMC passes).  On the GPU box, from the repo root:
-#   bash tools/collect_profiles_short.sh r04 v0
-R=${1:-r04}; V=${2:-v0}
+#   bash tools/collect_profiles_short.sh r05 v0
+R=${1:-r05}; V=${2:-v0}
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out
 STEPS=20 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_step --output-format csv -- python3 tools/bench_step.py > gpurun_out/prof_step.log 2>&1 < /dev/null
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench --output-format csv -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/prof_bench.log 2>&1 < /dev/null
