@@ -28,6 +28,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_F16_PEAK_TFLOPS = 2500.0     # dense fp16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F32_PEAK_TFLOPS = 157.3      # f32-input MFMA (v_mfma_f32_32x32x2_f32) = the f32 vector rate, same guide ("Peak FP32 (matrix)")
 BATCH_PER_GPU = 8
 H, W = 512, 640
 
@@ -84,11 +85,13 @@ def _cpu_model():
     return "unknown CPU"
 
 
-def conv_roofline(lit, batch, reps=5):
+def conv_roofline(lit, batch, reps=5, peak=None):
     """Record every hd_conv2d launch of one (eager) training step, then time the recorded launches back to back."""
     import ctypes as C
     from hallucidet_amd import _abi, ops
     lib = _abi.load()
+    PEAK = peak or MFMA_F16_PEAK_TFLOPS
+    f32_mode = PEAK != MFMA_F16_PEAK_TFLOPS
     rec = []
     orig = ops.conv2d
 
@@ -105,8 +108,9 @@ def conv_roofline(lit, batch, reps=5):
         # algorithmic FLOPs: a data-gradient over a zero-dilated input only multiplies the non-zero taps
         flops = 2.0 * n * ho * wo * co * KH * KW * (C1 + C2) / (dil * dil)
         # algorithmic bytes: every operand once (x, x2, w, y, residual, mask)
-        by = x.numel() * 2 + (0 if kw.get("x2") is None else kw["x2"].numel() * 2) + w.numel() * 2 + y.numel() * y.element_size()
-        by += sum(t.numel() * 2 for t in (kw.get("res"), kw.get("mask")) if t is not None)
+        es = x.element_size()          # 2 (fp16 storage) or 4 (--precision 32)
+        by = x.numel() * es + (0 if kw.get("x2") is None else kw["x2"].numel() * es) + w.numel() * es + y.numel() * y.element_size()
+        by += sum(t.numel() * es for t in (kw.get("res"), kw.get("mask")) if t is not None)
         rec.append(({k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, (x, w, KH, KW), flops, by, where[0]))
         return out
 
@@ -202,8 +206,8 @@ def conv_roofline(lit, batch, reps=5):
     grp = {"unet": [0.0, 0.0], "detector": [0.0, 0.0]}
     for kw, (x, w, KH, KW), fl, by, origin in rec:
         tot_by += by
-        roof_ms += max(fl / (MFMA_F16_PEAK_TFLOPS * 1e12), by / 8e12) * 1e3
-        hbm_bound += int(by / 8e12 > fl / (MFMA_F16_PEAK_TFLOPS * 1e12))
+        roof_ms += max(fl / (PEAK * 1e12), by / 8e12) * 1e3
+        hbm_bound += int(by / 8e12 > fl / (PEAK * 1e12))
         kw = {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}                                 # same epilogue (bias / res / mask / BN statistics) as in the step
         ms = iso_time(lambda: orig(x, w, KH, KW, **kw))
         tot_ms += ms
@@ -233,17 +237,19 @@ def conv_roofline(lit, batch, reps=5):
     groups = {
         "unet_conv_fwd_dgrad": {"ms": round(grp_step["unet"], 3), "tflops": tf(grp["unet"][1], grp_step["unet"]), "isolated_ms": round(grp["unet"][0], 3)},
         "unet_wgrad": {"ms": round(wg_s, 3), "tflops": tf(wg_fl, wg_s), "isolated_ms": round(wg_ms, 3), "kernel": "wgrad_kernel"},
-        "unet_conv_blocks_total": {"ms": round(u_ms, 3), "tflops": tf(u_fl, u_ms), "frac": round(u_fl / (u_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4) if u_ms else None,
+        "unet_conv_blocks_total": {"ms": round(u_ms, 3), "tflops": tf(u_fl, u_ms), "frac": round(u_fl / (u_ms * 1e-3) / 1e12 / PEAK, 4) if u_ms else None,
                                    "gflop_per_image": round(u_fl / 1e9 / BATCH_PER_GPU, 1)},
         "detector_conv": {"ms": round(grp_step["detector"], 3), "tflops": tf(grp["detector"][1], grp_step["detector"]), "isolated_ms": round(grp["detector"][0], 3)},
     }
-    return {"bound": "mfma", "groups": groups, "achieved": round(achieved, 2), "achieved_isolated": round(iso, 2), "peak": MFMA_F16_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(achieved / MFMA_F16_PEAK_TFLOPS, 4), "frac_isolated": round(iso / MFMA_F16_PEAK_TFLOPS, 4),
+    return {"bound": "mfma", "groups": groups, "achieved": round(achieved, 2), "achieved_isolated": round(iso, 2), "peak": PEAK,
+            "unit": "TFLOP/s", "frac": round(achieved / PEAK, 4), "frac_isolated": round(iso / PEAK, 4),
             "timing": "step-order replay: the 257 hd_conv2d launches of one training step, each once, in step order, captured in one hipGraph and "
                       "replayed between HIP events on the launch stream (3 passes); `*_isolated`: each launch 5x back to back",
-            "mfma_util": _pmc_mfma_util(), "traffic": _pmc_traffic()[0], "traffic_provenance": _pmc_traffic()[1], "traffic_unit": "HBM bytes per launch (PMC)",
+            "mfma_util": None if f32_mode else _pmc_mfma_util(), "traffic": None if f32_mode else _pmc_traffic()[0],
+            "traffic_provenance": "not collected for the fp32 mode" if f32_mode else _pmc_traffic()[1], "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
-            "kernel": "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + gemm_w8_kernel (8-wave 256-row GEMM tiles: box head) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + "
+            "kernel": "hd_conv2d_f32: conv_f32_kernel (64 x 64 tiles, v_mfma_f32_32x32x2_f32: exact f32 products and sums; peak = the f32 matrix rate)" if f32_mode else
+                      "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + gemm_w8_kernel (8-wave 256-row GEMM tiles: box head) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + "
                       "conv3x3_c64_kernel / conv7x7s2_stem_kernel / conv3x3_cat128to32_kernel / conv3x3_c32to128_kernel (persistent, register-resident weights: "
                       "the 64 -> 64 channel 3x3 layers, the 7x7 stems, decoder block 3) + "
                       "conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
@@ -413,8 +419,6 @@ def main():
                     help="16 = BASELINE configs[1] (the headline); 32 = the reference's default --precision 32: fp32 storage and VALU "
                          "arithmetic end to end (the parity mode, untuned).  Its own JSON line, without the fp16 roofline")
     args = ap.parse_args()
-    if args.precision == 32:
-        args.no_roofline = True
     global BATCH_PER_GPU
     if args.config == "retinanet16":
         args.detector, args.batch = "retinanet", args.batch or 16
@@ -607,7 +611,7 @@ def main():
             # words the metric H2D-inclusive -- that rate is the key above, never `value`
             out["value_protocol"] = "inputs resident in HBM (bench contract); H2D-inclusive rate of SURVEY 8d: pcie_inclusive_images_per_s"
         if not args.no_roofline and args.detector == "fasterrcnn" and BATCH_PER_GPU == 8:
-            out["roofline"] = conv_roofline(lit, batch)
+            out["roofline"] = conv_roofline(lit, batch, peak=MFMA_F32_PEAK_TFLOPS if args.precision == 32 else None)
         if world == 1 and not args.no_cpu_baseline and not args.config:
             out["cpu_baseline"] = cpu_baseline(args.cpu_protocol)
         print(json.dumps(out), flush=True)

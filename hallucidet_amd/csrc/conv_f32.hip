@@ -12,14 +12,27 @@
 // concat(up1 ? nearest2x(x) : x, x2), zero-dilated by in_dil; v = acc + res + bias; v = 0 where mask <= 0; statistics of v per
 // M tile ([rows][2][Cout]); y = act(v); consumer-side BatchNorm of the x source (in_scale / in_shift / in_relu).
 //
-// Kernel: implicit GEMM on the vector ALU, 64 x 64 output tile per 256-thread block, 16-deep K steps through LDS, 4 x 4 outputs per
-// thread; K order k = tap * Cin + ci (the layout of the weights); one thread gathers four consecutive channels of one pixel at one tap
-// (channel counts are multiples of 8, so a quad never straddles a tap or the concat boundary).
+// Kernel: implicit GEMM on the MATRIX cores in fp32 (round 5): v_mfma_f32_32x32x2_f32 -- f32 operands, f32 accumulate, and by the
+// ISA's definition bit for bit the k-ordered fmaf chain D = fma(a_k1, b_k1, fma(a_k0, b_k0, C)) that the vector-ALU form of rounds 3-4
+// evaluated, so the convolution outputs of this mode did not change by a bit when the inner loop moved (the reference's default
+// precision is an fp32 one: src/config/config.py:149).  64 x 64 output tile per 256-thread block = four waves of 32 x 32, 16-deep K
+// steps through LDS ([k][row] images: a lane's operand is one conflict-free dword), eight MFMAs per wave and step; K order
+// k = tap * Cin + ci (the layout of the weights); one thread gathers four consecutive channels of one pixel at one tap (channel
+// counts are multiples of 8, so a quad never straddles a tap or the concat boundary).  Peak of this path: 157 TFLOP/s (the f32 MFMA
+// rate equals the f32 vector rate; what the matrix form buys is one instruction per 2 048 FMAs instead of 32, the accumulators out
+// of the VALU's way, and a free vector pipe for the gather).
 #include "hd_common.h"
 
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16;
+
+// one 16-deep step of a wave's 32 x 32 sub-tile: rows from sa[k][r0 + (lane & 31)], columns from sb[k][c0 + (lane & 31)], k pairs in order
+__device__ __forceinline__ void mfma_step16(const float (*sa)[BM + 4], const float (*sb)[BN + 4], int r0, int c0, int lane, f32x16& acc) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int kk = 0; kk < BK / 2; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[2 * kk + h][r0 + l31], sb[2 * kk + h][c0 + l31], acc, 0, 0, 0);
+}
 
 struct CP {
   const float* x;
@@ -64,99 +77,169 @@ __device__ __forceinline__ f32x4 gather4(const CP& p, int n, int ho, int wo, int
   return *reinterpret_cast<const f32x4*>(p.x2 + ((size_t)(n * p.Hin + hi) * p.Win + wi) * p.C2 + (ci - p.C1));
 }
 
+// TM x TN output tile, four waves as 2 x 2, a wave owns (TM / 2) x (TN / 2) = up to 2 x 2 MFMA tiles (pick_tile_f32 below: 64 x 64 is
+// the instance that is built).
+template <int TM, int TN>
 __global__ __launch_bounds__(256) void conv_f32_kernel(CP p) {
-  __shared__ float sa[BK][BM + 4];      // [k][pixel]
-  __shared__ float sb[BK][BN + 4];      // [k][cout]
-  __shared__ float sred[4][BN][2];
+  constexpr int RA = TM / 64, RB = TN / 64;     // operand rows per loader thread
+  constexpr int MA = TM / 64, MB = TN / 64;     // 32 x 32 MFMA tiles per wave along rows / columns
+  __shared__ float sa[2][BK][TM + 4];   // [stage][k][pixel]
+  __shared__ float sb[2][BK][TN + 4];   // [stage][k][cout]
+  __shared__ float sred[2][TN][2];
   const int tid = threadIdx.x;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  // loader role: row lr (pixel / cout) and channel quad lq of the 16-deep K step
+  const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+  // loader role: rows lr + 64 i (pixel / cout) and channel quad lq of the 16-deep K step
   const int lr = tid >> 2, lq = tid & 3;
   const int HoWo = p.Ho * p.Wo;
-  const int pm = m0 + lr;
-  const bool plive = pm < p.M;
-  const int pn = plive ? pm / HoWo : 0, prem = plive ? pm - pn * HoWo : 0, pho = prem / p.Wo, pwo = prem - pho * p.Wo;
-  const int wco = n0 + lr;
-  // compute role: 4 pixels x 4 couts
-  const int tx = tid & 15, ty = tid >> 4;
-  float acc[4][4];
+  int pn[RA], pho[RA], pwo[RA];
+  bool plive[RA];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < RA; ++i) {
+    const int pm = m0 + lr + 64 * i;
+    plive[i] = pm < p.M;
+    pn[i] = plive[i] ? pm / HoWo : 0;
+    const int prem = plive[i] ? pm - pn[i] * HoWo : 0;
+    pho[i] = prem / p.Wo;
+    pwo[i] = prem - pho[i] * p.Wo;
+  }
+  const float* wrow[RB];
+  bool wlive[RB];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int i = 0; i < RB; ++i) {
+    const int wco = n0 + lr + 64 * i;
+    wlive[i] = wco < p.Cout;
+    wrow[i] = p.w + (size_t)(wlive[i] ? wco : 0) * p.Ktot;
+  }
+  // compute role: wave (wm, wn) owns rows wm * TM/2 .. (pixels) x columns wn * TN/2 .. (couts) of the tile
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc[MA][MB];
+#pragma unroll
+  for (int a = 0; a < MA; ++a)
+#pragma unroll
+    for (int b = 0; b < MB; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  for (int k0 = 0; k0 < p.Ktot; k0 += BK) {
+  // this thread's K position (tap, channel quad) is stepped, not re-divided: the two integer divisions per 16-deep step were
+  // ~80 of the ~150 vector instructions of a step, and with the products on the matrix cores the vector ALU is the busier pipe
+  int ci = lq * 4, kh = 0, kw = 0;
+  while (ci >= p.Cin) {
+    ci -= p.Cin;
+    if (++kw == p.KW) { kw = 0; ++kh; }
+  }
+  // Software pipeline: the operands of step i + 1 are requested into registers BEFORE the MFMAs of step i are issued and go to the
+  // other LDS stage behind them -- one barrier per step, the global round trip of a step under the matrix work of the previous one.
+  f32x4 av[RA], bv[RB];
+  auto fetch = [&](int k0) {
     const int k = k0 + lq * 4;
-    f32x4 av = {0.f, 0.f, 0.f, 0.f}, bv = av;
-    if (k < p.Ktot) {
-      const int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.KW, kw = tap - kh * p.KW;
-      av = gather4(p, pn, pho, pwo, kh, kw, ci, plive);
-      if (wco < p.Cout) bv = *reinterpret_cast<const f32x4*>(p.w + (size_t)wco * p.Ktot + k);
+    const bool klive = k < p.Ktot;
+#pragma unroll
+    for (int i = 0; i < RA; ++i) av[i] = gather4(p, pn[i], pho[i], pwo[i], kh, kw, ci, plive[i] && klive);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+      bv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (klive && wlive[i]) bv[i] = *reinterpret_cast<const f32x4*>(wrow[i] + k);
     }
+    ci += BK;
+    while (ci >= p.Cin) {
+      ci -= p.Cin;
+      if (++kw == p.KW) { kw = 0; ++kh; }
+    }
+  };
+  auto stash = [&](int st) {
+#pragma unroll
+    for (int i = 0; i < RA; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sa[st][lq * 4 + q][lr + 64 * i] = av[i][q];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sb[st][lq * 4 + q][lr + 64 * i] = bv[i][q];
+  };
+  auto mfma_step = [&](int st) {
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      float fa[MA], fb[MB];
+#pragma unroll
+      for (int a = 0; a < MA; ++a) fa[a] = sa[st][2 * kk + lh][wm * (TM / 2) + a * 32 + l31];
+#pragma unroll
+      for (int b = 0; b < MB; ++b) fb[b] = sb[st][2 * kk + lh][wn * (TN / 2) + b * 32 + l31];
+#pragma unroll
+      for (int a = 0; a < MA; ++a)
+#pragma unroll
+        for (int b = 0; b < MB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+    }
+  };
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  int st = 0;
+  for (int k0 = 0; k0 < p.Ktot; k0 += BK) {
+    const bool more = k0 + BK < p.Ktot;
+    if (more) fetch(k0 + BK);
+    mfma_step(st);
+    if (more) stash(st ^ 1);
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      sa[lq * 4 + q][lr] = av[q];
-      sb[lq * 4 + q][lr] = bv[q];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kk = 0; kk < BK; ++kk) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sa[kk][ty * 4]);
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sb[kk][tx * 4]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(a4[i], b4[j], acc[i][j]);
-    }
+    st ^= 1;
   }
 
-  // ---- epilogue: rows ty*4 + i (pixels), columns tx*4 + j (couts)
-  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- epilogue: acc[a][b][r] = (pixel row wm * TM/2 + 32 a + (r & 3) + 8 (r >> 2) + 4 lh, cout column wn * TN/2 + 32 b + l31)
+  float s1[MB], s2[MB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= p.M) continue;
-    const int n = m / HoWo, rem = m - n * HoWo;
+  for (int b = 0; b < MB; ++b) {
+    const int co = n0 + wn * (TN / 2) + b * 32 + l31;
+    const bool cok = co < p.Cout;
+    const float bias = (p.bias && cok) ? p.bias[co] : 0.f;
+    s1[b] = s2[b] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int co = n0 + tx * 4 + j;
-      if (co >= p.Cout) continue;
-      float v = acc[i][j];
-      if (p.res) v += p.res[(size_t)m * p.Cout + co];
-      if (p.bias) v += p.bias[co];
-      if (p.mask && !(p.mask[(size_t)m * p.Cout + co] > 0.f)) v = 0.f;
-      s1[j] += v;
-      s2[j] += v * v;
-      if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
-      else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
-      if (p.out_mode == HD_OUT_NCHW_F32) p.y[((size_t)n * p.Cout + co) * HoWo + rem] = v;
-      else p.y[(size_t)m * p.Cout + co] = v;
-    }
+    for (int a = 0; a < MA; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * (TM / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= p.M || !cok) continue;
+        float v = acc[a][b][r];
+        if (p.res) v += p.res[(size_t)m * p.Cout + co];
+        v += bias;
+        if (p.mask && !(p.mask[(size_t)m * p.Cout + co] > 0.f)) v = 0.f;
+        s1[b] += v;
+        s2[b] += v * v;
+        if (p.act == HD_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (p.act == HD_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        if (p.out_mode == HD_OUT_NCHW_F32) {
+          const int n = m / HoWo, rem = m - n * HoWo;
+          p.y[((size_t)n * p.Cout + co) * HoWo + rem] = v;
+        } else {
+          p.y[(size_t)m * p.Cout + co] = v;
+        }
+      }
   }
   if (p.stats) {
-    // fold the 16 pixel groups (ty) in a fixed order: 16 -> 4 by lane exchange inside a 64-lane wave (ty = wave*4 + (lane>>4)), then LDS
+    // per cout: the two lane halves of a wave, then the two waves that share the column range -- a fixed order
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s1[j] += __shfl_xor(s1[j], 16);
-      s1[j] += __shfl_xor(s1[j], 32);
-      s2[j] += __shfl_xor(s2[j], 16);
-      s2[j] += __shfl_xor(s2[j], 32);
-    }
-    if ((tid & 63) < 16) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        sred[tid >> 6][tx * 4 + j][0] = s1[j];
-        sred[tid >> 6][tx * 4 + j][1] = s2[j];
+    for (int b = 0; b < MB; ++b) {
+      const float t1 = s1[b] + __shfl_xor(s1[b], 32), t2 = s2[b] + __shfl_xor(s2[b], 32);
+      if (lh == 0) {
+        sred[wm][wn * (TN / 2) + b * 32 + l31][0] = t1;
+        sred[wm][wn * (TN / 2) + b * 32 + l31][1] = t2;
       }
     }
     __syncthreads();
-    if (tid < 2 * BN) {
+    if (tid < 2 * TN) {
       const int c = tid >> 1, which = tid & 1;
-      const float s = (sred[0][c][which] + sred[1][c][which]) + (sred[2][c][which] + sred[3][c][which]);
-      if (n0 + c < p.Cout) p.stats[((size_t)blockIdx.x * 2 + which) * p.Cout + n0 + c] = s;
+      const float t = sred[0][c][which] + sred[1][c][which];
+      if (n0 + c < p.Cout) p.stats[((size_t)blockIdx.x * 2 + which) * p.Cout + n0 + c] = t;
     }
   }
+}
+
+// Tile of a problem.  The kernel is written for 64 / 128 rows x 64 / 128 columns; measured on the training step (bench.py --precision 32,
+// same box): 64 x 64 everywhere 60 TFLOP/s over the step's convolutions, 128-wide tiles where the grid allows 53 -- the larger tiles
+// take a CU from eight co-resident blocks to two or four and this kernel hides its LDS round trips with blocks, not with a pipeline.
+// One instance is built.
+void pick_tile_f32(int M, int Cout, int& tm, int& tn) {
+  (void)M; (void)Cout;
+  tm = 64;
+  tn = 64;
 }
 
 int fill(const hd_conv_args* a, CP& p) {
@@ -194,8 +277,8 @@ struct WP {
 
 // slab[s][co][k] = sum over the pixels of slice s of dY[pix][co] * X[pix @ tap(k)][ci(k)]; tile 64 (co) x 64 (k), 16 pixels per step
 __global__ __launch_bounds__(256) void wgrad_f32_kernel(WP p) {
-  __shared__ float sd[BK][BM + 4];      // [pixel][cout]
-  __shared__ float sx[BK][BN + 4];      // [pixel][k]
+  __shared__ float sd[2][BK][BM + 4];   // [stage][pixel][cout]
+  __shared__ float sx[2][BK][BN + 4];   // [stage][pixel][k]
   const int tid = threadIdx.x;
   const int co0 = blockIdx.x * BM, k0 = blockIdx.y * BN, s = blockIdx.z;
   const int p0 = s * p.per, p1 = min(p.M, p0 + p.per);
@@ -209,53 +292,66 @@ __global__ __launch_bounds__(256) void wgrad_f32_kernel(WP p) {
   g.x = p.x; g.x2 = p.x2; g.in_scale = p.in_scale; g.in_shift = p.in_shift; g.in_relu = p.in_relu;
   g.Hsrc = p.Hsrc; g.Wsrc = p.Wsrc; g.Hin = p.Hin; g.Win = p.Win; g.C1 = p.C1; g.C2 = p.C2; g.stride = p.stride; g.pad = p.pad;
   g.up1 = p.up1; g.in_dil = 1;
-  const int tx = tid & 15, ty = tid >> 4;
-  float acc[4][4];
+  // compute role: wave (wm, wn) owns couts wm * 32 .. + 31 x K columns wn * 32 .. + 31 of the tile; the reduction index is the pixel
+  const int lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lh = lane >> 5;
+  f32x16 acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int pb = p0; pb < p1; pb += BK) {
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  // the loader's pixel (n, ho, wo) is stepped by 16 per iteration instead of being divided out of the flat index every time
+  int pn, pho, pwo;
+  {
+    const int pix0 = p0 + lp;
+    pn = pix0 / HoWo;
+    const int rem = pix0 - pn * HoWo;
+    pho = rem / p.Wo;
+    pwo = rem - pho * p.Wo;
+  }
+  f32x4 dv, xv;
+  auto fetch = [&](int pb) {
     const int pix = pb + lp;
     const bool live = pix < p1;
-    f32x4 dv = {0.f, 0.f, 0.f, 0.f}, xv = dv;
+    dv = f32x4{0.f, 0.f, 0.f, 0.f};
+    xv = dv;
     if (live) {
       const int co = co0 + lq * 4;
       if (co + 3 < p.Cout) dv = *reinterpret_cast<const f32x4*>(p.dy + (size_t)pix * p.Cout + co);
       else
         for (int q = 0; q < 4; ++q)
           if (co + q < p.Cout) dv[q] = p.dy[(size_t)pix * p.Cout + co + q];
-      if (klive) {
-        const int n = pix / HoWo, rem = pix - n * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        xv = gather4(g, n, ho, wo, kh, kw, ci, true);
-      }
+      if (klive) xv = gather4(g, pn, pho, pwo, kh, kw, ci, true);
     }
-    __syncthreads();
+    pwo += BK;
+    while (pwo >= p.Wo) {
+      pwo -= p.Wo;
+      if (++pho == p.Ho) { pho = 0; ++pn; }
+    }
+  };
+  auto stash = [&](int st) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      sd[lp][lq * 4 + q] = dv[q];
-      sx[lp][lq * 4 + q] = xv[q];
+      sd[st][lp][lq * 4 + q] = dv[q];
+      sx[st][lp][lq * 4 + q] = xv[q];
     }
-    __syncthreads();
-#pragma unroll
-    for (int pp = 0; pp < BK; ++pp) {
-      const f32x4 a4 = *reinterpret_cast<const f32x4*>(&sd[pp][ty * 4]);
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sx[pp][tx * 4]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(a4[i], b4[j], acc[i][j]);
-    }
+  };
+  if (p0 < p1) {      // (same pipeline as the convolution: next step's operands in flight under this step's MFMAs)
+    fetch(p0);
+    stash(0);
   }
+  __syncthreads();
+  int st = 0;
+  for (int pb = p0; pb < p1; pb += BK) {
+    const bool more = pb + BK < p1;
+    if (more) fetch(pb + BK);
+    mfma_step16(sd[st], sx[st], wm * 32, wn * 32, lane, acc);
+    if (more) stash(st ^ 1);
+    __syncthreads();
+    st ^= 1;
+  }
+  const int k = k0 + wn * 32 + l31;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int co = co0 + ty * 4 + i;
-    if (co >= p.Cout) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + tx * 4 + j;
-      if (k < p.Ktot) p.slab[((size_t)s * p.Cout + co) * p.Ktot + k] = acc[i][j];
-    }
+  for (int r = 0; r < 16; ++r) {
+    const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    if (co < p.Cout && k < p.Ktot) p.slab[((size_t)s * p.Cout + co) * p.Ktot + k] = acc[r];
   }
 }
 
@@ -295,16 +391,20 @@ extern "C" int hd_conv2d_stats_rows_f32(const hd_conv_args* a) {
   CP p;
   int rc = fill(a, p);
   if (rc) return rc;
-  return hd_cdiv(p.M, BM);
+  int tm, tn;
+  pick_tile_f32(p.M, p.Cout, tm, tn);
+  return hd_cdiv(p.M, tm);
 }
 
 extern "C" int hd_conv2d_f32(const hd_conv_args* a, void* stream) {
   CP p;
   int rc = fill(a, p);
   if (rc) return rc;
-  dim3 grid(hd_cdiv(p.M, BM), hd_cdiv(p.Cout, BN));
+  int tm, tn;
+  pick_tile_f32(p.M, p.Cout, tm, tn);
+  dim3 grid(hd_cdiv(p.M, tm), hd_cdiv(p.Cout, tn));
   HD_CHECK_ARG(grid.y <= 65535, "hd_conv2d_f32: Cout %d too large", p.Cout);
-  hipLaunchKernelGGL(conv_f32_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL((conv_f32_kernel<64, 64>), grid, dim3(256), 0, (hipStream_t)stream, p);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }
