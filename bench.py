@@ -542,6 +542,7 @@ def main():
     if rank == 0:
         # everything below is rank-0-only measurement: no collective may be issued from here on (the other ranks are
         # already waiting at the final barrier), so the gradient averager is detached for the extra steps
+        overlap_used = bool(lit.overlap_allreduce)      # what the TIMED steps ran with (reported below; the extra steps run detached)
         lit.averager.start = lambda g: None
         lit.averager.finish = lambda g: None
         lit.averager.bucket_ready = lambda lo, hi: None
@@ -577,7 +578,7 @@ def main():
                 rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
             except Exception as exc:                     # never let a diagnostic cost the line
                 rccl_version = "unavailable (%s)" % exc
-            out["allreduce"] = {"payload_bytes": int(lit.encoder_decoder.runner.flat_grads.numel()) * 4, "overlap": bool(lit.overlap_allreduce),
+            out["allreduce"] = {"payload_bytes": int(lit.encoder_decoder.runner.flat_grads.numel()) * 4, "overlap": overlap_used,
                                 "note": overlap_note, "rccl_version": rccl_version, "ms_per_step_by_rank": per_rank_ms,
                                 "env": {k: os.environ.get(k) for k in ("NCCL_DEBUG", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_P2P_DISABLE", "RCCL_MSCCL_ENABLE") if os.environ.get(k) is not None},
                                 # per bucket, issue order: the part of its all-reduce the backward pass did not hide (HIP events on

@@ -115,6 +115,7 @@ PROTOTYPES = {
     "hd_f32_to_f16": (C.c_int, [vp, vp, c_i64, c_f, vp]),
     "hd_f16_to_f32": (C.c_int, [vp, vp, c_i64, c_f, vp]),
     "hd_pad_cast_f32_f16": (C.c_int, [vp, vp, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_int64, vp]),
+    "hd_pad_cast_f32_f16_multi": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]),
     "hd_channel_sum_f16": (C.c_int, [vp, c_i64, C.c_int, vp, C.c_int, vp]),
     "hd_scale_store": (C.c_int, [vp, vp, C.c_int, c_f, C.c_int, vp]),
     "hd_nms_sorted_batched": (C.c_int, [vp, vp, C.c_int, C.c_int, c_f, vp, vp, vp]),
@@ -161,7 +162,7 @@ F32_TWINS = ["hd_conv2d", "hd_conv2d_stats_rows", "hd_wgrad", "hd_weight_prep", 
              "hd_maxpool3x3s2", "hd_maxpool3x3s2_bwd", "hd_maxpool3x3s2_idx", "hd_maxpool3x3s2_bwd_idx", "hd_maxpool3x3s2_bwd_idx_add", "hd_concat_up_bwd", "hd_subsample2", "hd_subsample2_bwd",
              "hd_nchw_to_nhwc_resize", "hd_nchw_to_nhwc_resize_strided", "hd_nchw_to_nhwc_resize_bwd", "hd_nhwc_to_nchw", "hd_upsample_add",
              "hd_upsample_add_bwd", "hd_upsample2_bwd", "hd_add_f16", "hd_slice_channels", "hd_sigmoid_bwd_nchw_to_nhwc", "hd_relu_bwd",
-             "hd_f32_to_f16", "hd_f16_to_f32", "hd_pad_cast_f32_f16", "hd_channel_sum_f16", "hd_roi_align", "hd_roi_align_bwd",
+             "hd_f32_to_f16", "hd_f16_to_f32", "hd_pad_cast_f32_f16", "hd_pad_cast_f32_f16_multi", "hd_channel_sum_f16", "hd_roi_align", "hd_roi_align_bwd",
              "hd_roi_align_ml", "hd_roi_align_ml_bwd", "hd_roi_align_ml_bwd_gather", "hd_groupnorm8_relu", "hd_groupnorm8_relu_bwd",
              "hd_groupnorm8_param_grad"]
 for _n in F32_TWINS:

@@ -824,6 +824,33 @@ __global__ void pad_cast_kernel(const float* __restrict__ x, f16* __restrict__ y
   }
 }
 
+// several pad_cast problems in ONE launch (the ten head gradients of an RPN backward pass: five levels x {objectness, box deltas},
+// each a 2-30 KB tensor that paid a launch of its own): the descriptor table travels in the kernel arguments, block ranges -> entries
+constexpr int PAD_CAST_MAX = 16;
+struct PadCastTab {
+  const float* x[PAD_CAST_MAX];
+  f16* y[PAD_CAST_MAX];
+  int64_t P[PAD_CAST_MAX], rows_per_image[PAD_CAST_MAX], image_stride[PAD_CAST_MAX];
+  int C[PAD_CAST_MAX], Cp[PAD_CAST_MAX], first[PAD_CAST_MAX + 1];
+  int n;
+};
+__global__ void pad_cast_multi_kernel(PadCastTab t) {
+  int e = 0;
+  for (int i = 1; i < t.n; ++i)
+    if ((int)blockIdx.x >= t.first[i]) e = i;
+  const float* __restrict__ x = t.x[e];
+  f16* __restrict__ y = t.y[e];
+  const int C = t.C[e], Cp = t.Cp[e];
+  const int64_t total = t.P[e] * Cp, rpi = t.rows_per_image[e], istr = t.image_stride[e];
+  const int nb = t.first[e + 1] - t.first[e];
+  for (int64_t i = (int64_t)((int)blockIdx.x - t.first[e]) * blockDim.x + threadIdx.x; i < total; i += (int64_t)nb * blockDim.x) {
+    const int64_t p = i / Cp;
+    const int c = (int)(i - p * Cp);
+    const int64_t n = p / rpi;
+    y[i] = c < C ? (f16)x[n * istr + (p - n * rpi) * C + c] : (f16)0.f;
+  }
+}
+
 __global__ void channel_sum_kernel(const f16* __restrict__ x, int64_t npix, int C, float* __restrict__ part) {
   extern __shared__ float sm[];  // [256][8]
   const int vecs = C / 8;
@@ -1121,6 +1148,29 @@ extern "C" int HD_API(hd_pad_cast_f32_f16)(const float* x, void* y, int64_t P, i
   HD_CHECK_ARG(x && y && P >= 0 && C > 0 && Cp >= C && rows_per_image > 0 && image_stride >= rows_per_image * C, "hd_pad_cast_f32_f16: bad args");
   if (P == 0) return HD_OK;
   hipLaunchKernelGGL(pad_cast_kernel, dim3(grid_for(P * Cp)), dim3(TB), 0, S_, x, (f16*)y, P, C, Cp, rows_per_image, image_stride);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+extern "C" int HD_API(hd_pad_cast_f32_f16_multi)(const float* const* x, void* const* y, const int64_t* P, const int* C, const int* Cp,
+                                                 const int64_t* rows_per_image, const int64_t* image_stride, int n, void* stream) {
+  HD_CHECK_ARG(x && y && P && C && Cp && rows_per_image && image_stride && n >= 1 && n <= PAD_CAST_MAX, "hd_pad_cast_f32_f16_multi: 1 .. %d tensors", PAD_CAST_MAX);
+  PadCastTab t;
+  int total = 0, m = 0;
+  for (int i = 0; i < n; ++i) {
+    HD_CHECK_ARG(x[i] && y[i] && P[i] >= 0 && C[i] > 0 && Cp[i] >= C[i] && rows_per_image[i] > 0 && image_stride[i] >= rows_per_image[i] * C[i],
+                 "hd_pad_cast_f32_f16_multi: bad entry %d", i);
+    if (P[i] == 0) continue;
+    t.x[m] = x[i]; t.y[m] = (f16*)y[i]; t.P[m] = P[i]; t.C[m] = C[i]; t.Cp[m] = Cp[i];
+    t.rows_per_image[m] = rows_per_image[i]; t.image_stride[m] = image_stride[i];
+    t.first[m] = total;
+    total += grid_for(P[i] * Cp[i], TB, 256);
+    ++m;
+  }
+  if (m == 0) return HD_OK;
+  t.first[m] = total;
+  t.n = m;
+  hipLaunchKernelGGL(pad_cast_multi_kernel, dim3(total), dim3(TB), 0, S_, t);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

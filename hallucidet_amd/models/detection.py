@@ -176,6 +176,24 @@ def _head_grad_nhwc16(g, H, W, cout_p, dtype=None):
     return ops.nchw_to_nhwc_resize(g.contiguous().float(), H, W, cout_p, dtype=dtype)
 
 
+def _head_grads_nhwc16_many(gs, hws, cout_ps, dtype=None):
+    """`_head_grad_nhwc16` for a list of head-output gradients: the dense ones (the training step's: slices of the flat [N, HWA, C]
+    gradient) leave in ONE pad-and-cast launch (ops.pad_cast_f32_f16_many), anything else one by one."""
+    outs = [None] * len(gs)
+    dense, where = [], []
+    for i, (g, (H, W), cp) in enumerate(zip(gs, hws, cout_ps)):
+        v = g.permute(0, 2, 3, 1)
+        if g.dtype == torch.float32 and v.stride()[1:] == (v.shape[2] * v.shape[3], v.shape[3], 1):
+            dense.append(v)
+            where.append(i)
+        else:
+            outs[i] = _head_grad_nhwc16(g, H, W, cp, dtype)
+    if dense:
+        for i, y in zip(where, ops.pad_cast_f32_f16_many(dense, [cout_ps[i] for i in where], dtype=dtype)):
+            outs[i] = y
+    return outs
+
+
 def _dgrad(e, dy, in_hw, *, res=None, mask=None):
     return ops.conv2d(dy, e["wd"], e["k"], e["k"], stride=1, pad=e["k"] - 1 - e["pad"], in_dil=e["stride"], out_hw=in_hw,
                       cout=e["cin_p"], res=res, mask=mask)
@@ -713,8 +731,9 @@ class _RPNHeadFn(torch.autograd.Function):
             # frozen head, every level has both gradients (the training step): the three data-gradient convs of ALL levels as three
             # grids -- cls, then box (+ cls result as residual, ReLU mask), then the shared 3x3 conv -- instead of 3 x levels launches
             hws = [(t.shape[1], t.shape[2]) for t in ctx.ts]
-            gls = [_head_grad_nhwc16(grads[2 * i][:na], hws[i][0], hws[i][1], P["cls"]["cout_p"], P["cls"]["wf"].dtype) for i in range(nl)]
-            grs = [_head_grad_nhwc16(grads[2 * i + 1][:na], hws[i][0], hws[i][1], P["box"]["cout_p"], P["box"]["wf"].dtype) for i in range(nl)]
+            both = _head_grads_nhwc16_many([grads[2 * i][:na] for i in range(nl)] + [grads[2 * i + 1][:na] for i in range(nl)], hws + hws,
+                                           [P["cls"]["cout_p"]] * nl + [P["box"]["cout_p"]] * nl, P["cls"]["wf"].dtype)
+            gls, grs = both[:nl], both[nl:]
             dts = _dgrad_many([P["cls"]] * nl, gls, hws)
             dts = _dgrad_many([P["box"]] * nl, grs, hws, ress=dts, masks=list(ctx.ts))
             dfeats = _dgrad_many([P["conv"]] * nl, dts, hws)

@@ -472,6 +472,30 @@ def pad_cast_f32_f16(x, cp, dtype=None):
     return y
 
 
+def pad_cast_f32_f16_many(xs, cps, dtype=None):
+    """`pad_cast_f32_f16` for several tensors in ONE launch (hd_pad_cast_f32_f16_multi; <= 16 per launch) -> list of outputs."""
+    if len(xs) == 1:
+        return [pad_cast_f32_f16(xs[0], cps[0], dtype=dtype)]
+    _need_cuda(*xs)
+    outs = []
+    for lo in range(0, len(xs), 16):
+        part = xs[lo:lo + 16]
+        n = len(part)
+        ys, Ps, Cs, Cps, rpis, strides = [], [], [], [], [], []
+        for x, cp in zip(part, cps[lo:lo + 16]):
+            b, H, W, C_ = x.shape
+            assert x.dtype == torch.float32 and (x.stride()[1:] == (W * C_, C_, 1) or b * H * W == 0)
+            y = torch.empty((b, H, W, cp), dtype=dtype or act_dtype(), device=x.device)
+            ys.append(y); Ps.append(b * H * W); Cs.append(C_); Cps.append(cp); rpis.append(max(H * W, 1))
+            strides.append(max(x.stride(0) if b > 1 else H * W * C_, H * W * C_))
+        arr = lambda ctype, vals: (ctype * n)(*vals)
+        check(_abi.fn("hd_pad_cast_f32_f16_multi", ys[0])(arr(C.c_void_p, [x.data_ptr() for x in part]), arr(C.c_void_p, [y.data_ptr() for y in ys]),
+                                                          arr(C.c_int64, Ps), arr(C.c_int, Cs), arr(C.c_int, Cps), arr(C.c_int64, rpis),
+                                                          arr(C.c_int64, strides), n, _stream()), "hd_pad_cast_f32_f16_multi")
+        outs += ys
+    return outs
+
+
 def maxpool3x3s2(x):
     N, H, W, C_ = x.shape
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1

@@ -300,6 +300,10 @@ int hd_f16_to_f32(const void* x, float* y, int64_t n, float scale, void* stream)
  * data-gradient conv); row p of x lives at (p / rows_per_image) * image_stride + (p % rows_per_image) * C floats (a slice of a larger
  * buffer; image_stride == rows_per_image * C for a dense source) */
 int hd_pad_cast_f32_f16(const float* x, void* y, int64_t P, int C, int Cp, int64_t rows_per_image, int64_t image_stride, void* stream);
+/* n <= 16 such problems in one launch (arrays of the scalar call's arguments): the per-level head gradients of an RPN / RetinaNet
+ * backward pass */
+int hd_pad_cast_f32_f16_multi(const float* const* x, void* const* y, const int64_t* P, const int* C, const int* Cp,
+                              const int64_t* rows_per_image, const int64_t* image_stride, int n, void* stream);
 /* per-channel sums of an NHWC f16 tensor -> part[rows][C] (bias gradients); reduce with hd_colsum */
 int hd_channel_sum_f16(const void* x, int64_t npix, int C, float* part, int rows, void* stream);
 /* out[i] (=|+=) in[i]*scale, small fp32 vectors */
@@ -551,6 +555,8 @@ int hd_relu_bwd_f32(const void* dy, const void* z, void* dx, int64_t n, void* st
 int hd_f32_to_f16_f32(const float* x, void* y, int64_t n, float scale, void* stream);
 int hd_f16_to_f32_f32(const void* x, float* y, int64_t n, float scale, void* stream);
 int hd_pad_cast_f32_f16_f32(const float* x, void* y, int64_t P, int C, int Cp, int64_t rows_per_image, int64_t image_stride, void* stream);
+int hd_pad_cast_f32_f16_multi_f32(const float* const* x, void* const* y, const int64_t* P, const int* C, const int* Cp,
+                                  const int64_t* rows_per_image, const int64_t* image_stride, int n, void* stream);
 int hd_channel_sum_f16_f32(const void* x, int64_t npix, int C, float* part, int rows, void* stream);
 int hd_roi_align_f32(const void* feat, const float* rois, void* out, int R, int N, int H, int W, int C, int PH, int PW, float spatial_scale,
                      int sampling_ratio, void* stream);

@@ -208,6 +208,30 @@ def test_gemm_w8_matches_the_igemm_family_bit_for_bit(dev, bn):
         lib.hd_gemm_w8_mode(-1)
 
 
+def test_pad_cast_many_equals_the_single_launches(dev):
+    """hd_pad_cast_f32_f16_multi (the ten head gradients of an RPN backward pass in one launch) against hd_pad_cast_f32_f16 per tensor
+    and the definition: dense sources, slices of a larger buffer (image stride > H * W * C), an empty tensor, 17 tensors (two launches)."""
+    from hallucidet_amd import ops
+    g = torch.Generator().manual_seed(5)
+    xs, cps = [], []
+    for i, (n, H, W, C_, cp) in enumerate([(8, 75, 75, 3, 8), (8, 38, 38, 12, 16), (8, 19, 19, 3, 8), (8, 10, 10, 12, 16), (8, 5, 5, 3, 8), (0, 5, 5, 3, 8), (1, 1, 1, 1, 8)] +
+                                          [(2, 3 + k, 4, 5, 8) for k in range(10)]):
+        if i % 3 == 1 and n:                      # a slice [:n] of a buffer holding more rows per image
+            big = torch.randn(n, (H * W + 7) * C_, generator=g).to(dev)
+            x = big[:, :H * W * C_].view(n, H, W, C_)
+        else:
+            x = torch.randn(n, H, W, C_, generator=g).to(dev)
+        xs.append(x)
+        cps.append(cp)
+    many = ops.pad_cast_f32_f16_many(xs, cps)
+    torch.cuda.synchronize()
+    assert len(many) == 17
+    for x, cp, y in zip(xs, cps, many):
+        one = ops.pad_cast_f32_f16(x, cp) if x.numel() else torch.empty((0,) + tuple(x.shape[1:3]) + (cp,), dtype=torch.float16, device=dev)
+        assert y.shape == x.shape[:3] + (cp,) and torch.equal(y, one)
+        assert torch.equal(y[..., :x.shape[3]], x.half()) and not bool(y[..., x.shape[3]:].any())
+
+
 def test_conv2d_nchw_f32_output(dev):
     from hallucidet_amd import ops
     x = rnd(2, 12, 16, 16, seed=1)
