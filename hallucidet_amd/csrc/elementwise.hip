@@ -1158,9 +1158,10 @@ extern "C" int HD_API(hd_pad_cast_f32_f16_multi)(const float* const* x, void* co
   PadCastTab t;
   int total = 0, m = 0;
   for (int i = 0; i < n; ++i) {
-    HD_CHECK_ARG(x[i] && y[i] && P[i] >= 0 && C[i] > 0 && Cp[i] >= C[i] && rows_per_image[i] > 0 && image_stride[i] >= rows_per_image[i] * C[i],
+    HD_CHECK_ARG(P[i] >= 0 && C[i] > 0 && Cp[i] >= C[i] && rows_per_image[i] > 0 && image_stride[i] >= rows_per_image[i] * C[i],
                  "hd_pad_cast_f32_f16_multi: bad entry %d", i);
-    if (P[i] == 0) continue;
+    if (P[i] == 0) continue;                       // (an empty tensor has no storage: its pointers may be null)
+    HD_CHECK_ARG(x[i] && y[i], "hd_pad_cast_f32_f16_multi: null pointer in entry %d", i);
     t.x[m] = x[i]; t.y[m] = (f16*)y[i]; t.P[m] = P[i]; t.C[m] = C[i]; t.Cp[m] = Cp[i];
     t.rows_per_image[m] = rows_per_image[i]; t.image_stride[m] = image_stride[i];
     t.first[m] = total;
