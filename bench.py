@@ -52,7 +52,7 @@ def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in two separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py) committed under profiles/ for this round.
     bench.py itself cannot collect PMCs (they need rocprofv3 around the process): null if the file is absent."""
-    for name in ("r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
+    for name in ("r05_conv_traffic.json", "r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
         j = _profile_json([name])
         try:
             return round(j["traffic_bytes_per_launch"]), {"static": True, "stale": _stale(j), "source": "profiles/" + name, "commit": j.get("commit"),
@@ -65,7 +65,7 @@ def _pmc_traffic():
 def _pmc_mfma_util():
     """MFMA-pipe utilisation of the conv kernels in a training step (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy
     clocks), tools/pmc_mfma.py on a `rocprofv3 --pmc` run of tools/bench_step.py), committed under profiles/."""
-    for name in ("r04_conv_mfma_util.json", "r03_conv_mfma_util.json", "r02_conv_mfma_util.json"):
+    for name in ("r05_conv_mfma_util.json", "r04_conv_mfma_util.json", "r03_conv_mfma_util.json", "r02_conv_mfma_util.json"):
         j = _profile_json([name])
         try:
             return {"value": j["mfma_util"], "by_kernel": j.get("by_kernel"), "static": True, "stale": _stale(j), "source": "profiles/" + name, "commit": j.get("commit"),

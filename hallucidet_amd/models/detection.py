@@ -176,6 +176,9 @@ def _head_grad_nhwc16(g, H, W, cout_p, dtype=None):
     return ops.nchw_to_nhwc_resize(g.contiguous().float(), H, W, cout_p, dtype=dtype)
 
 
+_PAD_CAST_MULTI = os.environ.get("HD_PAD_CAST_MULTI", "1") != "0"      # A/B knob: 0 = one launch per tensor
+
+
 def _head_grads_nhwc16_many(gs, hws, cout_ps, dtype=None):
     """`_head_grad_nhwc16` for a list of head-output gradients: the dense ones (the training step's: slices of the flat [N, HWA, C]
     gradient) leave in ONE pad-and-cast launch (ops.pad_cast_f32_f16_many), anything else one by one."""
@@ -183,7 +186,7 @@ def _head_grads_nhwc16_many(gs, hws, cout_ps, dtype=None):
     dense, where = [], []
     for i, (g, (H, W), cp) in enumerate(zip(gs, hws, cout_ps)):
         v = g.permute(0, 2, 3, 1)
-        if g.dtype == torch.float32 and v.stride()[1:] == (v.shape[2] * v.shape[3], v.shape[3], 1):
+        if _PAD_CAST_MULTI and g.dtype == torch.float32 and v.stride()[1:] == (v.shape[2] * v.shape[3], v.shape[3], 1):
             dense.append(v)
             where.append(i)
         else:
