@@ -442,3 +442,140 @@ def test_anchor_generator_at_the_llvip_grid_sizes():
     il = od.ImageList(torch.zeros(1, 3, 300, 300), [(300, 300)])
     got = ag2(il, [torch.zeros(1, 1, gh, gw) for gh, gw in grids])
     assert np.array_equal(got[0].numpy(), brute_anchors((300, 300), grids, rs, ratios))
+
+
+# ----------------------------------------------------------------------------------------------------------------------------------
+# Round 5, second batch: the REDUCTION FORMS of the two Faster R-CNN losses, FCOS's centre-sampling assignment and the P6 / P7 block,
+# again from torchvision 0.12's published code as python loops in float64 (roi_heads.py `fastrcnn_loss`, rpn.py `compute_loss`,
+# fcos.py `FCOS.forward` matching block, feature_pyramid_network.py `LastLevelP6P7`).
+
+
+def _smooth_l1(d, beta):
+    d = abs(d)
+    return 0.5 * d * d / beta if d < beta else d - 0.5 * beta
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), n_cls=st.integers(2, 5), rows=st.lists(st.integers(0, 9), min_size=1, max_size=3))
+def test_fastrcnn_loss_reduction_form(seed, n_cls, rows):
+    """classification: mean over ALL sampled rows of -log softmax(logits)[label]; box: smooth-L1 (beta 1/9) of the 4 deltas of the
+    LABEL's class, summed over the foreground rows only, divided by the number of ALL rows."""
+    g = torch.Generator().manual_seed(seed)
+    if sum(rows) == 0:
+        rows = [1]
+    N = sum(rows)
+    logits = torch.randn(N, n_cls, generator=g) * 2
+    reg = torch.randn(N, n_cls * 4, generator=g)
+    labels = [torch.randint(0, n_cls, (r,), generator=g) for r in rows]
+    tgt = [torch.randn(r, 4, generator=g) * 0.3 for r in rows]
+    got_c, got_b = od.fastrcnn_loss(logits, reg, labels, tgt)
+    lab = [int(v) for l in labels for v in l.tolist()]
+    t = [row for tt in tgt for row in tt.tolist()]
+    lc = lb = 0.0
+    for i in range(N):
+        z = [float(v) for v in logits[i].tolist()]
+        m = max(z)
+        lse = m + math.log(sum(math.exp(v - m) for v in z))
+        lc += lse - z[lab[i]]
+        if lab[i] > 0:
+            for k in range(4):
+                lb += _smooth_l1(float(reg[i, 4 * lab[i] + k]) - t[i][k], 1.0 / 9)
+    assert abs(float(got_c) - lc / N) <= 2e-6 * max(1.0, abs(lc / N))
+    assert abs(float(got_b) - lb / N) <= 2e-6 * max(1.0, abs(lb / N))
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), n_img=st.integers(1, 3), batch=st.integers(2, 12))
+def test_rpn_loss_reduction_form(seed, n_img, batch):
+    """objectness: mean binary cross-entropy with logits over the SAMPLED anchors (positives then negatives of the whole batch); box:
+    smooth-L1 (beta 1/9) summed over the sampled positives, divided by the number of sampled anchors.  The sampler is injected (first
+    entries of fixed permutations) so that the brute force can name the sampled set."""
+    g = torch.Generator().manual_seed(seed)
+    A = 17
+    labels = [torch.tensor([[-1.0, 0.0, 0.0, 1.0][int(v)] for v in torch.randint(0, 4, (A,), generator=g).tolist()]) for _ in range(n_img)]
+    reg_t = [torch.randn(A, 4, generator=g) * 0.4 for _ in range(n_img)]
+    obj = torch.randn(n_img * A, 1, generator=g) * 2
+    deltas = torch.randn(n_img * A, 4, generator=g)
+    rpn = od.RegionProposalNetwork(randperm_fn=lambda n: torch.arange(n))       # identity "permutation": the first candidates are drawn
+    rpn.fg_bg_sampler = od.BalancedPositiveNegativeSampler(batch, 0.5, lambda n: torch.arange(n))
+    got_o, got_b = rpn.compute_loss(obj, deltas, labels, reg_t)
+    pos_all, neg_all = [], []
+    for i, l in enumerate(labels):
+        P = [j for j, v in enumerate(l.tolist()) if v >= 1]
+        Ng = [j for j, v in enumerate(l.tolist()) if v == 0]
+        n_pos = min(len(P), int(batch * 0.5))
+        n_neg = min(len(Ng), batch - n_pos)
+        pos_all += [i * A + j for j in P[:n_pos]]
+        neg_all += [i * A + j for j in Ng[:n_neg]]
+    sampled = pos_all + neg_all
+    if not sampled:
+        return
+    flat_l = [v for l in labels for v in l.tolist()]
+    flat_t = [row for t_ in reg_t for row in t_.tolist()]
+    lo = 0.0
+    for j in sampled:
+        x, y = float(obj[j, 0]), flat_l[j]
+        lo += max(x, 0.0) - x * y + math.log1p(math.exp(-abs(x)))
+    lb = sum(_smooth_l1(float(deltas[j, k]) - flat_t[j][k], 1.0 / 9) for j in pos_all for k in range(4))
+    assert abs(float(got_o) - lo / len(sampled)) <= 2e-6 * max(1.0, lo / len(sampled))
+    assert abs(float(got_b) - lb / len(sampled)) <= 2e-6 * max(1.0, lb / len(sampled))
+
+
+@settings(max_examples=80, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), n_gt=st.integers(0, 4))
+def test_fcos_centre_sampling_assignment_against_its_definition(seed, n_gt):
+    """A location (the centre of its stride-sized anchor) is a candidate for a ground-truth box when (1) it lies within 1.5 strides of
+    the box centre in both axes, (2) strictly inside the box, (3) its largest side distance is inside the level's range (4 s, 8 s), the
+    first level starting at 0 and the last open-ended; among the candidates the box of the SMALLEST area wins (ties: the first), no
+    candidate: -1.  Half-integer geometry, so that every comparison is exact in fp32."""
+    from oracle import fcos as ofc
+    g = torch.Generator().manual_seed(seed)
+    strides, grids = [8, 16, 32], [(6, 6), (3, 3), (2, 2)]
+    anchors, per_level = [], []
+    for s, (gh, gw) in zip(strides, grids):
+        for y in range(gh):
+            for x in range(gw):
+                cx, cy = x * s + s // 2, y * s + s // 2
+                anchors.append([cx - s / 2, cy - s / 2, cx + s / 2, cy + s / 2])
+        per_level.append(gh * gw)
+    anchors = torch.tensor(anchors, dtype=torch.float32)
+    xy = torch.randint(0, 60, (n_gt, 2), generator=g).float() / 2
+    wh = torch.randint(2, 120, (n_gt, 2), generator=g).float() / 2
+    gt = torch.cat([xy, xy + wh], dim=1)
+    model = types.SimpleNamespace(center_sampling_radius=1.5)
+    got = ofc.FCOS.match(model, anchors, {"boxes": gt}, per_level).tolist()
+    want = []
+    lvl_of = [li for li, n in enumerate(per_level) for _ in range(n)]
+    for a, li in zip(anchors.tolist(), lvl_of):
+        cx, cy, size = (a[0] + a[2]) / 2, (a[1] + a[3]) / 2, a[2] - a[0]
+        lower = 0.0 if li == 0 else 4 * size
+        upper = float("inf") if li == len(per_level) - 1 else 8 * size
+        best, best_area = -1, None
+        for j, b in enumerate(gt.tolist()):
+            gx, gy = (b[0] + b[2]) / 2, (b[1] + b[3]) / 2
+            d = [cx - b[0], cy - b[1], b[2] - cx, b[3] - cy]
+            ok = max(abs(cx - gx), abs(cy - gy)) < 1.5 * size and min(d) > 0 and lower < max(d) < upper
+            area = (b[2] - b[0]) * (b[3] - b[1])
+            if ok and (best_area is None or area < best_area):
+                best, best_area = j, area
+        want.append(best)
+    assert got == want
+
+
+def test_last_level_p6p7_block():
+    """P6 = conv3x3 / stride 2 / pad 1 of P5 (in == out channels: `use_P5`), P7 = the same kind of conv of relu(P6): checked against
+    ATen convolutions composed here; the extents of the detector's 300 x 300 input: 10 -> 5 -> 3."""
+    from oracle import retinanet as orr
+    torch.manual_seed(3)
+    fpn = orr.FPN3(in_channels=(8, 16, 24), out_channels=8)
+    xs = [torch.randn(2, 8, 38, 38), torch.randn(2, 16, 19, 19), torch.randn(2, 24, 10, 10)]
+    out = fpn(xs, lambda t: t)
+    assert fpn.extra_blocks.use_P5 and [tuple(out[k].shape[-2:]) for k in ("0", "1", "2", "p6", "p7")] == [(38, 38), (19, 19), (10, 10), (5, 5), (3, 3)]
+    p5 = out["2"]
+    p6 = torch.nn.functional.conv2d(p5, fpn.extra_blocks.p6.weight, fpn.extra_blocks.p6.bias, stride=2, padding=1)
+    p7 = torch.nn.functional.conv2d(torch.relu(p6), fpn.extra_blocks.p7.weight, fpn.extra_blocks.p7.bias, stride=2, padding=1)
+    assert torch.equal(out["p6"], p6) and torch.equal(out["p7"], p7)
+    # top-down pathway: P4 = layer(lateral(C4) + nearest-upsampled inner P5) -- the inner map, not the smoothed output, is passed down
+    inner5 = fpn.inner_blocks[2](xs[2])
+    inner4 = fpn.inner_blocks[1](xs[1]) + torch.nn.functional.interpolate(inner5, size=(19, 19), mode="nearest")
+    assert torch.allclose(out["1"], fpn.layer_blocks[1](inner4), atol=1e-6)
