@@ -579,3 +579,38 @@ def test_last_level_p6p7_block():
     inner5 = fpn.inner_blocks[2](xs[2])
     inner4 = fpn.inner_blocks[1](xs[1]) + torch.nn.functional.interpolate(inner5, size=(19, 19), mode="nearest")
     assert torch.allclose(out["1"], fpn.layer_blocks[1](inner4), atol=1e-6)
+
+
+@settings(max_examples=60, deadline=None)
+@given(seed=st.integers(0, 10 ** 6), sr=st.sampled_from([1, 2, 3]), P=st.sampled_from([1, 2, 7]), scale=st.sampled_from([1.0, 0.5, 0.25]))
+def test_roi_align_on_a_linear_ramp_has_a_closed_form(seed, sr, P, scale):
+    """A known answer that needs no implementation at all: bilinear interpolation reproduces a LINEAR feature f(y, x) = a y + b x + c
+    exactly, and the sampling points of a bin are symmetric about its centre, so RoIAlign (aligned=False, any sampling ratio) of a
+    RoI that stays inside [0, H-1] x [0, W-1] is f at the bin centres: a (y0 + (ph + 1/2) bh) + b (x0 + (pw + 1/2) bw) + c with
+    (x0, y0) the scaled RoI corner and bh, bw = max(extent, 1) / P.  Both oracle forms (the scalar loop and the vectorised gather the
+    detector uses) must reproduce it."""
+    g = torch.Generator().manual_seed(seed)
+    H, W = 24, 31
+    a, b, c = [float(v) for v in torch.randn(3, generator=g)]
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    feat = torch.stack([a * yy + b * xx + c, -b * yy + a * xx - c]).float()[None]            # two channels, one image
+    R = 5
+    x0 = torch.rand(R, generator=g) * (W - 12) / scale
+    y0 = torch.rand(R, generator=g) * (H - 12) / scale
+    w = (torch.rand(R, generator=g) * 9 + 0.2) / scale                                       # some narrower than one pixel after scaling
+    h = (torch.rand(R, generator=g) * 9 + 0.2) / scale
+    rois = torch.stack([torch.zeros(R), x0, y0, x0 + w, y0 + h], dim=1)
+    want = torch.zeros(R, 2, P, P, dtype=torch.float64)
+    for r in range(R):
+        sx0, sy0, sx1, sy1 = [float(torch.tensor(float(v) * scale, dtype=torch.float32)) for v in rois[r, 1:]]
+        bw, bh = max(sx1 - sx0, 1.0) / P, max(sy1 - sy0, 1.0) / P
+        for ph in range(P):
+            for pw in range(P):
+                cy, cx = sy0 + (ph + 0.5) * bh, sx0 + (pw + 0.5) * bw
+                want[r, 0, ph, pw] = a * cy + b * cx + c
+                want[r, 1, ph, pw] = -b * cy + a * cx - c
+    got_scalar = ok.roi_align_nchw(feat, rois, P, P, scale, sr)
+    got_vec = od.roi_align_autograd(feat, rois, P, scale, sr)
+    tol = 2e-4 * (abs(a) + abs(b)) * max(H, W) + 1e-5
+    assert float((got_scalar.double() - want).abs().max()) <= tol
+    assert float((got_vec.double() - want).abs().max()) <= tol
