@@ -1236,6 +1236,44 @@ def test_nms_on_a_coarse_grid_ties_at_the_threshold_and_degenerate_boxes(dev, se
             assert not keep[b, n:].any()
 
 
+def test_roi_align_kernels_reproduce_the_linear_ramp_closed_form(dev):
+    """The analytic known answer of tests/test_third_party_pins.py held against the PRODUCT kernels (not the oracle): on a linear
+    feature RoIAlign is the ramp at the bin centres.  fp32 storage (hd_roi_align_ml_f32: exact up to fp32 rounding) and fp16 storage
+    (the fused-tap kernel of the detector's 7 x 7 / sampling-ratio-2 pooler: the ramp itself is rounded to fp16), two pyramid levels."""
+    from hallucidet_amd import ops
+    g = torch.Generator().manual_seed(11)
+    a, b, c = 0.031, -0.017, 0.4
+    feats32, scales, dims = [], [0.25, 0.125], [(40, 52), (20, 26)]
+    for (H, W) in dims:
+        yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+        ch = [(a * (k + 1)) * yy + (b * (k % 3 - 1)) * xx + c * k for k in range(16)]
+        feats32.append(torch.stack(ch, dim=-1).float()[None].repeat(2, 1, 1, 1).contiguous())
+    R = 40
+    lv = torch.randint(0, 2, (R,), generator=g).to(torch.int32)
+    rois = torch.zeros(R, 5)
+    want = torch.zeros(R, 7, 7, 16, dtype=torch.float64)
+    for r in range(R):
+        H, W = dims[int(lv[r])]
+        sc = scales[int(lv[r])]
+        x0, y0 = float(torch.rand(1, generator=g)) * (W - 14) / sc, float(torch.rand(1, generator=g)) * (H - 14) / sc
+        w, h = (float(torch.rand(1, generator=g)) * 11 + 0.3) / sc, (float(torch.rand(1, generator=g)) * 11 + 0.3) / sc
+        rois[r] = torch.tensor([r % 2, x0, y0, x0 + w, y0 + h])
+        sx0, sy0, sx1, sy1 = [float(torch.tensor(float(v) * sc, dtype=torch.float32)) for v in rois[r, 1:]]
+        bw, bh = max(sx1 - sx0, 1.0) / 7, max(sy1 - sy0, 1.0) / 7
+        for ph in range(7):
+            for pw in range(7):
+                cy, cx = sy0 + (ph + 0.5) * bh, sx0 + (pw + 0.5) * bw
+                for k in range(16):
+                    want[r, ph, pw, k] = (a * (k + 1)) * cy + (b * (k % 3 - 1)) * cx + c * k
+    rois_d, lv_d = rois.to(dev), lv.to(dev)
+    with ops.storage(torch.float32):
+        got32 = ops.roi_align_ml([f.to(dev) for f in feats32], scales, rois_d, lv_d, 7, 7, 2)
+    got16 = ops.roi_align_ml([f.half().to(dev) for f in feats32], scales, rois_d, lv_d, 7, 7, 2)
+    torch.cuda.synchronize()
+    assert float((got32.double().cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((got16.double().cpu() - want).abs().max()) <= 3e-3 * float(want.abs().max())
+
+
 def test_roi_align_degenerate_and_outside_rois(dev):
     """RoIAlign(aligned=False, sampling_ratio 2) on the RoIs the reference's own path can produce at the edges: zero width / height
     (roi size clamps to 1), inverted, entirely outside the map on every side (samples beyond [-1, H] contribute zero), a single-pixel
