@@ -107,28 +107,30 @@ bool use_cat(const ConvP& p) {
   return on && g_small_ok && hd_conv_cat128to32_eligible(p);
 }
 
-// Large-tile GEMM (gemm_w8.hip) for the plain-GEMM problems that are big enough to fill the chip with 256-row tiles: the box head's
-// fc6 / fc7 and fc6's data gradient.  Bit-identical to the igemm family (same products, same K order), so the choice may look at
-// the batch.  Tiles: 256 x 128 when that grid is one (nearly) full round of the 256 CUs, 256 x 256 from ~1.75 rounds up
-// (tools/probe_gemm8.py: fc6 forward 256 -> 212 us, its data gradient 197 -> 138, fc7 43.5 -> 25.3; 128-tile grids lose to the
-// 4-wave family's 256 smaller tiles, e.g. fc6 on 4 096 rows 148 vs 171).
-// hd_gemm_w8_mode (tests / tools): -1 = this rule, 0 = never, 128 / 256 = that tile wherever eligible.  HD_GEMM8=0: off (A/B).
+// Large-tile GEMM (gemm_w8.hip) for the plain-GEMM problems that are K-heavy and big enough to fill the chip with its tiles: the box
+// head's fc6 / fc7 and their data gradients.  Bit-identical to the igemm family (same products, same K order), so the choice may
+// look at the batch.  Tiles: 256 x 128 (8 waves) when that grid is one (nearly) full round of the 256 CUs, else 128 x 128 (4 waves,
+// two blocks per CU) from 200 tiles up (tools/probe_gemm8.py, one box: fc6 forward on 8 192 rows 254 -> 210 us, on 4 096 rows 156 -> 140,
+// its data gradient 197 -> 135, fc7 43.7 -> 26.1; a 256 x 256 instance was built too and never won: 144 us on the data gradient).
+// Not for the output-bound 1x1 layers: with K <= 256 or a residual the 4-wave family's LDS-transposed epilogue (16-byte coalesced
+// loads / stores) beats this kernel's 8-byte-per-row register epilogue (bottleneck conv3 at 24 x 19 x 19: 18.2 vs 26.8 us).
+// hd_gemm_w8_mode (tests / tools): -1 = this rule, 0 = never, 128 / 1128 = that tile wherever eligible.  HD_GEMM8=0: off (A/B).
 static int g_gemm8_mode = -1;
 extern "C" int hd_gemm_w8_mode(int mode) {
-  HD_CHECK_ARG(mode == -1 || mode == 0 || mode == 128 || mode == 256, "hd_gemm_w8_mode: mode in {-1, 0, 128, 256}");
+  HD_CHECK_ARG(mode == -1 || mode == 0 || mode == 128 || mode == 1128, "hd_gemm_w8_mode: mode in {-1, 0, 128, 1128}");
   g_gemm8_mode = mode;
   return HD_OK;
 }
 bool hd_gemm_w8_eligible(const ConvP& p);
-void hd_gemm_w8_launch(ConvP& p, int bn, hipStream_t s);
+void hd_gemm_w8_launch(ConvP& p, int tile, hipStream_t s);
 static int choose_gemm8(const ConvP& p) {
   static const int on = env_int("HD_GEMM8", 1);
   if (!on || g_gemm8_mode == 0 || !g_small_ok || !hd_gemm_w8_eligible(p)) return 0;
   if (g_gemm8_mode > 0) return g_gemm8_mode;
-  if (p.M < 2048 || p.Cout < 512 || p.Ktot < 512) return 0;
-  const int64_t t128 = (int64_t)hd_cdiv(p.M, 256) * hd_cdiv(p.Cout, 128), t256 = (int64_t)hd_cdiv(p.M, 256) * hd_cdiv(p.Cout, 256);
+  if (p.res || p.M < 2048 || p.Cout < 512 || p.Ktot < 512) return 0;
+  const int64_t t128 = (int64_t)hd_cdiv(p.M, 256) * hd_cdiv(p.Cout, 128), t1128 = (int64_t)hd_cdiv(p.M, 128) * hd_cdiv(p.Cout, 128);
   if (t128 >= 160 && t128 <= 256) return 128;
-  if (t256 >= 448) return 256;
+  if (t1128 >= 200) return 1128;
   return 0;
 }
 

@@ -8,8 +8,8 @@
 // tools/probe_tile_order.py) while its MFMA pipes retire 4096 FLOP/clk: a BM x BN x 64 K step moves (BM + BN) * 128 bytes for
 // BM * BN / 32 MFMA clocks, so 128x64 is fill-bound at 34 % MFMA utilisation, 128x128 at 52 %, 256x128 at 69 % and only 256x256
 // balances the two.  The 4-wave kernels stop at 128x128 (fc6: 0.85 PFLOP/s forward, 0.44 data gradient = 6 272 tiles of 128x64, each
-// re-filling 393 KB for 16 K steps).  This kernel: 8 waves, 256 x 256 (or 256 x 128) tile, 64-deep K steps, two / three LDS stages of
-// 64 / 48 KB filled by LDS-DMA exactly as conv_igemm_bk64.hip fills its (same piece shape, same source-side swizzle, zero-fill by
+// re-filling 393 KB for 16 K steps).  This kernel: 256 x 128 tile on 8 waves (three 48-KB LDS stages) or 128 x 128 on 4 waves (two 32-KB
+// stages, two blocks per CU), 64-deep K steps, filled by LDS-DMA exactly as conv_igemm_bk64.hip fills its (same piece shape, same source-side swizzle, zero-fill by
 // out-of-range buffer offsets), one barrier per K step.
 //   * The WEIGHTS are the MFMA A operand (rows of the 32x32 result = output channels), the activations the B operand (columns =
 //     GEMM rows): a lane then owns 4 consecutive channels of one output row per register group, `v_permlane32_swap` pairs two groups
@@ -34,22 +34,25 @@ __device__ __forceinline__ void gdma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, u
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_g*)lds_dst, 16, voff, 0, 0, 0);
 }
 
-// BM: rows of x (GEMM M) per tile, BN: rows of w (output channels) per tile.  8 waves = 2 (channels) x 4 (rows): a wave owns
-// BN / 2 channels x 64 rows.
+// BM: rows of x (GEMM M) per tile, BN: rows of w (output channels) per tile.  Waves = 2 (channels) x BM / 64 (rows): a wave owns
+// BN / 2 channels x 64 rows -- 8 waves at BM = 256, 4 at BM = 128 (the 128 x 128 tile: two blocks per CU, for the short-K 1x1 layers
+// whose time is the per-tile set-up and epilogue of the 4-wave family, not its K loop).
 template <int BM, int BN, int NSTAGE>
-__global__ __launch_bounds__(512) void gemm_w8_kernel(ConvP p) {
-  static_assert(BM == 256 && (BN == 256 || BN == 128), "tile");
+__global__ __launch_bounds__(128 * (BM / 64)) void gemm_w8_kernel(ConvP p) {
+  static_assert((BM == 256 || BM == 128) && BN == 128, "tile");
+  constexpr int NWM = BM / 64, NT = 128 * NWM, RP = NT / 8;      // waves along the rows, threads, rows per DMA pass
   constexpr int NA = BN / 64;                    // 32-channel blocks per wave (MFMA A operand)
   constexpr int NB = 2;                          // 32-row blocks per wave (MFMA B operand)
   constexpr int STAGE = (BM + BN) * GROW;        // halves per stage: [BN weight rows][BM activation rows]
-  constexpr int W_PASS = BN / 64, X_PASS = BM / 64;   // DMA instructions per wave per K step: 64 rows (8 per wave) per pass
+  constexpr int W_PASS = BN / RP, X_PASS = BM / RP;   // DMA instructions per wave per K step: RP rows (8 per wave) per pass
   constexpr int L_TILE = W_PASS + X_PASS;
   static_assert(NSTAGE * STAGE * 2 <= 160 * 1024, "LDS");
+  static_assert(W_PASS >= 1 && X_PASS >= 1, "a DMA pass covers RP rows");
   __shared__ __attribute__((aligned(1024))) f16 lds[NSTAGE * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 2, wm = wave & 3;
+  const int wn = wave / NWM, wm = wave - wn * NWM;
 
   int bid = blockIdx.x;
   {
@@ -71,13 +74,13 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(ConvP p) {
   bool wok[W_PASS], xok[X_PASS];
 #pragma unroll
   for (int i = 0; i < W_PASS; ++i) {
-    const int row = n0 + i * 64 + (tid >> 3);
+    const int row = n0 + i * RP + (tid >> 3);
     wok[i] = row < p.Cout;
     wbase[i] = (unsigned)(wok[i] ? row : 0) * (unsigned)K * 2u + (unsigned)j * 16u;
   }
 #pragma unroll
   for (int i = 0; i < X_PASS; ++i) {
-    const int row = m0 + i * 64 + (tid >> 3);
+    const int row = m0 + i * RP + (tid >> 3);
     xok[i] = row < p.M;
     xbase[i] = (unsigned)(xok[i] ? row : 0) * (unsigned)K * 2u + (unsigned)j * 16u;
   }
@@ -89,9 +92,9 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(ConvP p) {
     const bool kv = kt_issue * GK + j * 8 < K;           // K % 8 == 0: a 16-byte chunk is inside or outside as a whole
     const unsigned ko = (unsigned)kt_issue * (GK * 2);
 #pragma unroll
-    for (int i = 0; i < W_PASS; ++i) gdma16(rw, sw + i * (64 * GROW), (wok[i] && kv) ? wbase[i] + ko : GOOB);
+    for (int i = 0; i < W_PASS; ++i) gdma16(rw, sw + i * (RP * GROW), (wok[i] && kv) ? wbase[i] + ko : GOOB);
 #pragma unroll
-    for (int i = 0; i < X_PASS; ++i) gdma16(rx, sx + i * (64 * GROW), (xok[i] && kv) ? xbase[i] + ko : GOOB);
+    for (int i = 0; i < X_PASS; ++i) gdma16(rx, sx + i * (RP * GROW), (xok[i] && kv) ? xbase[i] + ko : GOOB);
     ++kt_issue;
   };
 
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(ConvP p) {
   // acc[a][b][4 g + i] = channel n0 + wn * BN/2 + 32 a + 8 g + 4 h + i of row m0 + 64 wm + 32 b + (lane & 31)
   f16* __restrict__ yp = reinterpret_cast<f16*>(p.y);
   const f16* __restrict__ maskp = p.mask;
+  const f16* __restrict__ resp = p.res;
   const float* __restrict__ biasp = p.bias;
   const bool relu = p.act == HD_ACT_RELU;
   const int N = p.Cout;
@@ -173,9 +177,16 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(ConvP p) {
 #pragma unroll
         for (int gg = 0; gg < 2; ++gg) {
           float v[4];
+          f16x4 rv = {(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+          if (resp) {                                   // the residual joins in fp32, before the bias (the igemm epilogue's order)
+            const int c = cb + 8 * (gp + gg) + 4 * fh;
+            if (m < p.M && c < N) rv = *reinterpret_cast<const f16x4*>(resp + (size_t)m * N + c);
+          }
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            v[i] = acc[a][b][4 * (gp + gg) + i] + bv[gg][i];
+            v[i] = acc[a][b][4 * (gp + gg) + i];
+            if (resp) v[i] += (float)rv[i];
+            v[i] += bv[gg][i];
             if (relu) v[i] = fmaxf(v[i], 0.f);
           }
           const f16x2 o01 = {(f16)v[0], (f16)v[1]}, o23 = {(f16)v[2], (f16)v[3]};
@@ -207,15 +218,16 @@ __global__ __launch_bounds__(512) void gemm_w8_kernel(ConvP p) {
 bool hd_gemm_w8_eligible(const ConvP& p) {
   const bool flat = (p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0) ||
                     (p.KH == p.Hsrc && p.KW == p.Wsrc && p.pad == 0 && p.Ho == 1 && p.Wo == 1);
-  return flat && !p.x2 && !p.up1 && p.in_dil == 1 && !p.res && !p.stats && !p.in_scale && !p.bs_y && p.out_mode == HD_OUT_NHWC_F16 &&
+  return flat && !p.x2 && !p.up1 && p.in_dil == 1 && !p.stats && !p.in_scale && !p.bs_y && p.out_mode == HD_OUT_NHWC_F16 &&
          (p.act == HD_ACT_NONE || p.act == HD_ACT_RELU) && (p.Cout % 8) == 0 && (p.Ktot % 64) == 0 && (p.Hin == p.Hsrc && p.Win == p.Wsrc);
 }
 
-// bn = 256 or 128 (channels per tile)
-void hd_gemm_w8_launch(ConvP& p, int bn, hipStream_t s) {
-  p.gm = hd_cdiv(p.M, 256);
-  p.gn = hd_cdiv(p.Cout, bn);
+// tile: 128 = 256 x 128 (rows x channels, 8 waves), 1128 = 128 x 128 (4 waves, two blocks per CU)
+void hd_gemm_w8_launch(ConvP& p, int tile, hipStream_t s) {
+  const int bm = tile == 1128 ? 128 : 256;
+  p.gm = hd_cdiv(p.M, bm);
+  p.gn = hd_cdiv(p.Cout, 128);
   p.tgroup = hd_conv_tile_order(p);
-  if (bn == 256) hipLaunchKernelGGL((gemm_w8_kernel<256, 256, 2>), dim3(p.gm * p.gn), dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((gemm_w8_kernel<256, 128, 3>), dim3(p.gm * p.gn), dim3(512), 0, s, p);
+  if (tile == 128) hipLaunchKernelGGL((gemm_w8_kernel<256, 128, 3>), dim3(p.gm * p.gn), dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((gemm_w8_kernel<128, 128, 2>), dim3(p.gm * p.gn), dim3(256), 0, s, p);
 }

@@ -125,8 +125,8 @@ int hd_conv_tune_override(int bm, int bn, int bk, int deep);
  * family with split-K that used it was measured no faster than the 4-wave kernels on any shape and removed in round 3). */
 int hd_conv_tune_w8(int cfg, int nslices);
 /* test / tuning hook of the large-tile GEMM path (gemm_w8.hip: the plain-GEMM problems of hd_conv2d -- 1x1 / stride-1 convolutions
- * and fully connected layers -- on 256 x 256 / 256 x 128 tiles, 8 waves, register-only epilogue; bit-identical to the implicit-GEMM
- * family): -1 = the built-in rule, 0 = never, 128 / 256 = that tile wherever the problem is eligible.  Process-wide. */
+ * and fully connected layers -- on 256 x 128 (8 waves) / 128 x 128 (4 waves) tiles, register-only epilogue; bit-identical to the
+ * implicit-GEMM family): -1 = the built-in rule, 0 = never, 128 / 1128 = that tile wherever the problem is eligible.  Process-wide. */
 int hd_gemm_w8_mode(int mode);
 
 /* ------------------------------------------------------------------------

@@ -161,9 +161,9 @@ GEMM8_CASES = [
 ]
 
 
-@pytest.mark.parametrize("bn", [128, 256])
+@pytest.mark.parametrize("bn", [128, 1128])
 def test_gemm_w8_matches_the_igemm_family_bit_for_bit(dev, bn):
-    """gemm_w8.hip (8 waves, 256 x bn tiles, register-only epilogue) forced through hd_gemm_w8_mode wherever hd_conv2d's problem is a
+    """gemm_w8.hip (256 x 128 tiles on 8 waves / 128 x 128 on 4, register-only epilogue) forced through hd_gemm_w8_mode wherever hd_conv2d's problem is a
     plain GEMM over stored tensors, against (a) the oracle and (b) the 4-wave implicit-GEMM family on the same inputs BIT FOR BIT: the
     products and the fp32 summation order over K are the same, so which path a problem takes may depend on the batch size without
     breaking batch invariance (image n of a batch == the image alone: asserted here across the two paths)."""
@@ -194,16 +194,19 @@ def test_gemm_w8_matches_the_igemm_family_bit_for_bit(dev, bn):
             if bias_relu:
                 want = want.clamp_min(0)
             close(got, want.half())
-        # what the large-tile path does not implement stays where it was (residual, BatchNorm sums, strides, fp32 outputs) -- same call,
-        # same answer as with the path switched off
+        # a residual joins in fp32 before the bias, as in the 4-wave family's epilogue (bit-identical); what the path does not
+        # implement stays where it was (BatchNorm sums, strides, fp32 outputs) -- same call, same answer as with the path switched off
         x = rnd(600, 1, 1, 512, seed=1).to(dev)
-        w = rnd(512, 512, scale=1.0 / math.sqrt(512), seed=3).to(dev)
-        res = rnd(600, 1, 1, 512, seed=5).to(dev)
+        w = rnd(520, 512, scale=1.0 / math.sqrt(512), seed=3).to(dev)
+        res = rnd(600, 1, 1, 520, seed=5).to(dev)
+        bias = torch.randn(520, generator=torch.Generator().manual_seed(9)).to(dev)
         lib.hd_gemm_w8_mode(bn)
+        r1 = ops.conv2d(x, w, 1, 1, res=res, bias=bias, act=1)
         a, sa = ops.conv2d(x, w, 1, 1, res=res, want_stats=True)
         lib.hd_gemm_w8_mode(0)
+        r0 = ops.conv2d(x, w, 1, 1, res=res, bias=bias, act=1)
         b, sb = ops.conv2d(x, w, 1, 1, res=res, want_stats=True)
-        assert torch.equal(a, b) and torch.equal(sa, sb)
+        assert torch.equal(r1, r0) and torch.equal(a, b) and torch.equal(sa, sb)
     finally:
         lib.hd_gemm_w8_mode(-1)
 

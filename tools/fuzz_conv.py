@@ -131,15 +131,15 @@ def run_gemm8(ops, c, gen):
         lib.hd_gemm_w8_mode(0)
         ref = ops.conv2d(x, w, 1, 1, **kw)
         outs = []
-        for bn in (128, 256):
+        for bn in (128, 1128):
             lib.hd_gemm_w8_mode(bn)
             outs.append(ops.conv2d(x, w, 1, 1, **kw))
         torch.cuda.synchronize()
     finally:
         lib.hd_gemm_w8_mode(-1)
-    for bn, o in zip((128, 256), outs):
+    for bn, o in zip((128, 1128), outs):
         if not torch.equal(o, ref):
-            return "gemm_w8 tile 256x%d differs from the igemm family (%d elements)" % (bn, int((o != ref).sum()))
+            return "gemm_w8 tile %d differs from the igemm family (%d elements)" % (bn, int((o != ref).sum()))
     want = x.reshape(-1, C1).float() @ w.float().t()
     if bias is not None:
         want = want + bias
