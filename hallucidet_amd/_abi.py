@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
         ("C1", c_i32), ("C2", c_i32), ("Ho", c_i32), ("Wo", c_i32), ("Cout", c_i32),
         ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32),
         ("up1", c_i32), ("in_dil", c_i32), ("act", c_i32), ("out_mode", c_i32),
-        ("in_scale", vp), ("in_shift", vp), ("in_relu", c_i32), ("reserved0", c_i32),
+        ("in_scale", vp), ("in_shift", vp), ("in_relu", c_i32), ("out_pool2", c_i32),
         ("bs_y", vp), ("bs_z", vp), ("bs_mean", vp), ("bs_invstd", vp), ("bs_gamma", vp), ("bs_beta", vp), ("bs_relu", c_i32), ("reserved1", c_i32),
     ]
 
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "hd_arch": (C.c_char_p, []),
     "hd_conv2d": (C.c_int, [C.POINTER(ConvArgs), vp]),
     "hd_conv2d_stats_rows": (C.c_int, [C.POINTER(ConvArgs)]),
+    "hd_conv2d_pool2_ok": (C.c_int, [C.POINTER(ConvArgs)]),
     "hd_conv2d_bstat_ok": (C.c_int, [C.POINTER(ConvArgs)]),
     "hd_conv7x7s2_dgrad_thin": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "hd_conv_tune_override": (C.c_int, [C.c_int] * 4),

@@ -180,6 +180,31 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvP p) {
       }
       continue;
     }
+    if (p.pool2) {
+      // out_pool2 (round 5): this launch is the data gradient of a decoder block's first convolution whose whole input is the
+      // nearest-2x upsampled tensor (no skip: decoders/unet/decoder.py:38-41 with skip = None), so the gradient the block below
+      // receives is the 2 x 2 SUM of what this kernel would write -- formed here, in fp32, from the two tile rows a lane already
+      // holds (t, t + 2) and its column neighbour (lane ^ 1): the full-resolution tensor (168 MB at 8 x 512 x 640 x 32) is neither
+      // written nor read back by a pooling launch.
+      f16* yb2 = reinterpret_cast<f16*>(p.y) + (size_t)n * (p.Ho >> 1) * (p.Wo >> 1) * COUT;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int oy = y0 + wave * 2, ox = x0 + t * 16 + pl;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          f16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[t][m][r] + acc[t + 2][m][r];
+            v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]: lane ^ 1
+            o[r] = (f16)v;
+          }
+          if (!(pl & 1) && oy < p.Ho && ox < p.Wo)
+            *reinterpret_cast<f16x4*>(yb2 + ((size_t)(oy >> 1) * (p.Wo >> 1) + (ox >> 1)) * COUT + m * 16 + g * 4) = o;
+        }
+      }
+      continue;
+    }
     f16* yb = reinterpret_cast<f16*>(p.y) + (size_t)n * p.Ho * p.Wo * COUT;
     float ssum[MT][4], ssq[MT][4];
 #pragma unroll
@@ -248,6 +273,11 @@ bool hd_conv_small_eligible(const ConvP& p) {
   if (p.out_mode == HD_OUT_NHWC_F32) return false;
   if (p.out_mode == HD_OUT_NCHW_F32) return p.Cout <= 16 && !p.stats;                       // head: bias + activation allowed
   return (p.Cout == 16 || p.Cout == 32) && !p.bias && p.act == HD_ACT_NONE;                   // conv -> BN units, data gradients
+}
+
+// out_pool2: the 2 x 2 sum-pooled output form (plain NHWC f16 output, no statistics, even extent)
+bool hd_conv_small_pool2_ok(const ConvP& p) {
+  return hd_conv_small_eligible(p) && p.out_mode == HD_OUT_NHWC_F16 && !p.stats && !p.in_scale && (p.Ho % 2) == 0 && (p.Wo % 2) == 0;
 }
 
 int hd_conv_small_tiles(const ConvP& p) { return p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW); }

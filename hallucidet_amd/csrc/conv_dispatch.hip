@@ -40,6 +40,7 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   p.act = a->act; p.out_mode = a->out_mode;
   HD_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "hd_conv2d: in_scale / in_shift must be given together");
   p.in_scale = a->in_scale; p.in_shift = a->in_shift; p.in_relu = a->in_relu;
+  p.pool2 = a->out_pool2;
   p.bs_y = (const f16*)a->bs_y; p.bs_z = (const f16*)a->bs_z;
   p.bs_mean = a->bs_mean; p.bs_invstd = a->bs_invstd; p.bs_gamma = a->bs_gamma; p.bs_beta = a->bs_beta; p.bs_relu = a->bs_relu;
   HD_CHECK_ARG(!p.bs_y || (p.stats && p.bs_mean && p.bs_invstd && !a->mask && a->act == HD_ACT_NONE && a->out_mode == HD_OUT_NHWC_F16 && !a->bias),
@@ -276,6 +277,13 @@ static bool bstat_kernel(const ConvP& p) {
   return choose_tile(p).p8cfg >= 0;
 }
 
+// does hd_conv2d implement out_pool2 for this problem?  (the small-channel 3x3 kernel: plain f16 output, even extent)
+extern "C" int hd_conv2d_pool2_ok(const hd_conv_args* a) {
+  ConvP p;
+  if (!a || fill_params(a, p)) return 0;
+  return (use_small(p) && hd_conv_small_pool2_ok(p)) ? 1 : 0;
+}
+
 extern "C" int hd_conv2d_bstat_ok(const hd_conv_args* a) {
   ConvP p;
   if (fill_params(a, p)) return 0;
@@ -324,7 +332,7 @@ extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
     ConvP& p = mp.p[i];
     int rc = fill_params(&args[i], p);
     if (rc) return rc;
-    if (use_small(p) || use_c64(p) || use_stem(p) || use_c32(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y || choose_gemm8(p)) { ok = false; break; }
+    if (use_small(p) || use_c64(p) || use_stem(p) || use_c32(p) || p.in_scale || p.x2 || p.in_dil != 1 || p.bs_y || p.pool2 || choose_gemm8(p)) { ok = false; break; }
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) { ok = false; break; }
     if (i == 0) c0 = c;
@@ -361,6 +369,8 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
 #endif
   HD_CHECK_ARG(!p.bs_y || bstat_kernel(p), "hd_conv2d: bs_* (BatchNorm backward sums) are implemented by the 8-wave and the 64-channel 3x3 kernels only; "
                                            "ask hd_conv2d_bstat_ok first");
+  HD_CHECK_ARG(!p.pool2 || (use_small(p) && hd_conv_small_pool2_ok(p)), "hd_conv2d: out_pool2 is implemented by the small-channel 3x3 kernel only (plain "
+                                                                        "f16 output, no statistics, even extent); ask hd_conv2d_pool2_ok first");
   if (use_small(p)) {
     hd_conv_launch_small(p, s);
     HD_CHECK_LAUNCH();

@@ -23,6 +23,7 @@ struct ConvP {
   // only sees the taps with kh = (pad - ph) mod 2 (+2, +4, ...) -- the others hit the zeros of the dilated input -- so a class
   // walks a quarter of the taps (none at all for three classes of a 1x1).  `par` is set by the dispatcher, the rest by the kernel.
   int par, ph, pw, Hc, Wc, t0h, t0w;
+  int pool2;           // hd_conv_args.out_pool2: write the 2 x 2 sum-pooled output (small-channel kernel only)
   int prio;            // 8-wave families: s_setprio policy (experiment knob HD_W8_PRIO: 0 none, 1 MFMA phase, 2 MEM phase)
   const float* in_scale;   // consumer-side BatchNorm of the x operand (hd_conv_args.in_scale / in_shift / in_relu): small-channel kernel only
   const float* in_shift;
@@ -163,6 +164,7 @@ void hd_conv_launch_p8_wgrad(ConvP& p, int cfg, const hd_wgrad_args* wa, hipStre
 bool hd_wgrad_takes_w8(const hd_wgrad_args* a);
 // conv3x3_small.hip: 3x3 / stride 1 / pad 1, Cin in {8,16,32}, Cout in {16,32}, plain NHWC f16 output (+ BN partial sums)
 bool hd_conv_small_eligible(const ConvP& p);
+bool hd_conv_small_pool2_ok(const ConvP& p);
 int hd_conv_small_tiles(const ConvP& p);
 void hd_conv_launch_small(ConvP& p, hipStream_t s);
 // conv3x3_c64.hip: 3x3 / stride 1 / pad 1, 64 -> 64 channels, weights resident in registers, persistent blocks; rows = partial-sum rows

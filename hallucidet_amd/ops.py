@@ -58,12 +58,16 @@ def conv_out_size(h, k, stride, pad):
 
 def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, pad=0, up1=False, in_dil=1, act=ACT_NONE,
            out_nchw_f32=False, out_nhwc_f32=False, want_stats=False, out_hw=None, cout=None, out=None,
-           in_scale=None, in_shift=None, in_relu=True, bstat=None, _defer=None):
+           in_scale=None, in_shift=None, in_relu=True, bstat=None, pool2=None, _defer=None):
     """Implicit-GEMM convolution.  x: [N,Hs,Ws,C1] f16, w: [Cout, KH*KW*(C1+C2)] f16.
 
     ``bstat`` (dict y, z|None, mean, invstd, gamma, beta, relu): the output of this call is the incoming gradient of a BatchNorm unit
     with raw conv output ``y``; where the kernel supports it (hd_conv2d_bstat_ok) the unit's backward sums leave with the call and
     ``bstat["part"]`` receives the [rows, 2*Cout] tensor `bn_backward(part=...)` takes; otherwise ``bstat["part"]`` is None.
+
+    ``pool2`` (dict): ask for the 2 x 2 SUM-POOLED output [N, Ho/2, Wo/2, Cout] (hd_conv_args.out_pool2: the data gradient of a decoder
+    convolution whose whole input is the nearest-2x upsampled tensor); ``pool2["done"]`` says whether the kernel did it (else the
+    plain output is returned and the caller pools).
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
     ``in_scale`` / ``in_shift`` ([C1] fp32): consumer-side BatchNorm -- x holds the RAW output of the producing conv and the kernel
@@ -101,6 +105,16 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
                  N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
                  1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0),
                  ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
+    if pool2 is not None:
+        pool2["done"] = False
+        if x.dtype == torch.float16 and out is None and not want_stats and bstat is None:
+            a.out_pool2 = 1
+            if lib.hd_conv2d_pool2_ok(C.byref(a)) == 1:
+                y = torch.empty((N, Ho // 2, Wo // 2, Cout), dtype=x.dtype, device=x.device)
+                a.y = ptr(y)
+                pool2["done"] = True
+            else:
+                a.out_pool2 = 0
     stats = None
     if bstat is not None:
         bstat["part"] = None

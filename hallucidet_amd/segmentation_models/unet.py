@@ -184,6 +184,7 @@ def initialize_head(module):
 
 
 _WRED_MULTI = os.environ.get("HD_WRED_MULTI", "1") != "0"     # A/B knob: one slab-reduction launch per backward segment
+_POOL2 = os.environ.get("HD_POOL2", "1") != "0"               # A/B knob: 2x2 sum-pool of the last decoder block's data gradient in its epilogue
 
 _ENCODERS = {
     "resnet18": dict(layers=(2, 2, 2, 2), out_channels=(3, 64, 64, 128, 256, 512)),
@@ -611,7 +612,7 @@ class UnetRunner:
             return None
         return dict(y=r["y"], z=r["z"] if r["has_res"] else None, mean=r["mean"], invstd=r["invstd"], gamma=v.bn.weight, beta=v.bn.bias, relu=v.relu)
 
-    def _unit_bwd(self, u, dz, S, *, want_dres=False, need_dx=True, dx_res=None, part=None, dx_is_dz_of=None):
+    def _unit_bwd(self, u, dz, S, *, want_dres=False, need_dx=True, dx_res=None, part=None, dx_is_dz_of=None, pool2=None):
         """Backward through z = relu(bn(conv(x)) (+res)).  Writes dW/dgamma/dbeta into the flat gradient arena.
         `part`: the BatchNorm reduction rows of THIS unit when the kernel that produced dz emitted them; `dx_is_dz_of`: the unit whose
         output is this convolution's input and receives no other gradient -- its reduction rows are requested from the data-gradient
@@ -637,7 +638,8 @@ class UnetRunner:
                 hw = (x.shape[1], x.shape[2])
             bstat = self._bstat_of(dx_is_dz_of) if (u.stride == 1 and not r["up1"] and r["x2"] is None) else None
             slab, dx = ops.wgrad_dgrad(xt, dy, u.k, u.k, wd, dgrad=dict(stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res,
-                                                                        **(dict(bstat=bstat) if bstat is not None else {})), **wkw)
+                                                                        **(dict(bstat=bstat) if bstat is not None else {}),
+                                                                        **(dict(pool2=pool2) if pool2 is not None else {})), **wkw)
         else:
             slab = ops.wgrad(xt, dy, u.k, u.k, **wkw)
         self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
@@ -667,7 +669,13 @@ class UnetRunner:
         for i in range(len(self.dec) - 1, -1, -1):
             u1, u2, cin, cskip = self.dec[i]
             dz1, _, rows1 = self._unit_bwd(u2, dz, S, dx_is_dz_of=u1)
-            dcat, _, _ = self._unit_bwd(u1, dz1, S, part=rows1)
+            # a block without a skip (the last one): the gradient of the low-resolution input is the 2x2 sum of the data gradient -- asked
+            # from the data-gradient kernel's epilogue (ops.conv2d pool2); the full-resolution tensor is then never written
+            pool = {} if (cskip == 0 and _POOL2) else None
+            dcat, _, _ = self._unit_bwd(u1, dz1, S, part=rows1, pool2=pool)
+            if pool is not None and pool.get("done"):
+                dz = dcat
+                continue
             dz, dskip[i] = ops.concat_up_bwd(dcat, cin)        # 2x2 sum-pool of the upsampled half + the skip's slice, one launch
         self._segment_done(0)                  # head + decoder parameter gradients are final
         # dz is now the gradient of f5; dskip[0..3] belong to f4, f3, f2, f1

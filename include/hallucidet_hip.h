@@ -85,7 +85,13 @@ typedef struct hd_conv_args {
    * Implemented where the operand passes through registers: the small-channel 3x3 kernel (C1 in {8,16,32}); other shapes -> HD_E_ARG. */
   const float* in_scale; /* [C1] or NULL */
   const float* in_shift; /* [C1] or NULL */
-  int32_t in_relu, reserved0;
+  int32_t in_relu;
+  /* out_pool2 != 0: y receives the 2 x 2 SUM-POOLED result [N, Ho/2, Wo/2, Cout] instead of [N, Ho, Wo, Cout] -- the data gradient of a
+   * decoder block's first convolution whose whole input is the nearest-2x upsampled tensor (skip = None,
+   * src/segmentation_models/decoders/unet/decoder.py:38-41): the gradient w.r.t. the low-resolution tensor is the 2 x 2 sum of the
+   * gradient w.r.t. the upsampled one, formed in the epilogue in fp32; the full-resolution tensor is never written.  Implemented by the
+   * small-channel 3x3 kernel (hd_conv2d_pool2_ok says whether this problem qualifies); other problems -> HD_E_ARG. */
+  int32_t out_pool2;
   /* Producer-side sums of a BatchNorm's backward pass (bs_y NULL: off).  The tensor this call writes (y, f16 NHWC) is then the incoming
    * gradient dz of a Conv2dReLU unit (src/segmentation_models/base/modules.py:10-47) whose raw convolution output is bs_y, and `stats`
    * receives, per M tile, the rows hd_bn_bwd_reduce would produce from the stored dz: [gridM][2][Cout] = (sum dz*m, sum dz*m*xhat) with
@@ -107,6 +113,8 @@ int hd_conv2d(const hd_conv_args* a, void* stream);
 /* 1 if hd_conv2d / hd_conv2d_wgrad route this problem to a kernel that implements the bs_* sums (the answer does not depend on the
  * bs_* fields themselves), else 0: the caller then runs hd_bn_bwd_reduce as before */
 int hd_conv2d_bstat_ok(const hd_conv_args* a);
+/* 1 if hd_conv2d implements out_pool2 for this problem, else 0 */
+int hd_conv2d_pool2_ok(const hd_conv_args* a);
 /* number of M tiles (rows of `stats`) hd_conv2d will use for this problem */
 int hd_conv2d_stats_rows(const hd_conv_args* a);
 /* Data gradient of a 7x7 / stride-2 / pad-3 convolution with 64 output and <= 4 input channels (torchvision ResNet.conv1 [EXT] of the

@@ -235,6 +235,35 @@ def test_pad_cast_many_equals_the_single_launches(dev):
         assert torch.equal(y[..., :x.shape[3]], x.half()) and not bool(y[..., x.shape[3]:].any())
 
 
+@pytest.mark.parametrize("case", [(2, 16, 64, 16, 32), (1, 24, 40, 32, 32), (3, 8, 32, 8, 16), (2, 10, 36, 16, 16)])
+def test_conv2d_pooled_output_is_the_2x2_sum_of_the_plain_output(dev, case):
+    """hd_conv_args.out_pool2 (the small-channel 3x3 kernel's epilogue forms the 2 x 2 sum of its tile in fp32: the data gradient of a
+    decoder block without a skip, decoders/unet/decoder.py:38-41) against the plain call followed by hd_concat_up_bwd -- equal up to the
+    one fp16 rounding the fused form does not make (the plain path rounds the four addends first) -- and against the oracle's fp32
+    convolution pooled on the host; ragged tiles, every Cin / Cout the kernel has."""
+    from hallucidet_amd import ops
+    N, H, W, Cin, Cout = case
+    x = rnd(N, H, W, Cin, seed=1).to(dev)
+    w = rnd(Cout, 9 * Cin, scale=1.0 / math.sqrt(9 * Cin), seed=3).to(dev)
+    info = {}
+    got = ops.conv2d(x, w, 3, 3, pad=1, pool2=info)
+    assert info["done"] and got.shape == (N, H // 2, W // 2, Cout)
+    plain = ops.conv2d(x, w, 3, 3, pad=1)
+    two, none = ops.concat_up_bwd(plain, Cout)
+    torch.cuda.synchronize()
+    assert none is None
+    want, _ = ok.conv2d_nhwc(x.cpu(), w.cpu(), 3, 3, pad=1)
+    want = want.reshape(N, H // 2, 2, W // 2, 2, Cout).sum(dim=(2, 4))
+    close(got, want.half())
+    assert float((got.float() - two.float()).abs().max()) <= 4e-3 * max(1.0, float(two.float().abs().max()))
+    again = ops.conv2d(x, w, 3, 3, pad=1, pool2={})
+    assert torch.equal(got, again)
+    # not implemented elsewhere: the request is declined (the caller pools), never silently ignored by the kernel
+    big = {}
+    y = ops.conv2d(rnd(1, 8, 8, 64, seed=2).to(dev), rnd(64, 9 * 64, scale=0.05, seed=4).to(dev), 3, 3, pad=1, pool2=big)
+    assert big["done"] is False and y.shape == (1, 8, 8, 64)
+
+
 def test_conv2d_nchw_f32_output(dev):
     from hallucidet_amd import ops
     x = rnd(2, 12, 16, 16, seed=1)
