@@ -38,6 +38,7 @@ class ConvArgs(C.Structure):
         ("up1", c_i32), ("in_dil", c_i32), ("act", c_i32), ("out_mode", c_i32),
         ("in_scale", vp), ("in_shift", vp), ("in_relu", c_i32), ("out_pool2", c_i32),
         ("bs_y", vp), ("bs_z", vp), ("bs_mean", vp), ("bs_invstd", vp), ("bs_gamma", vp), ("bs_beta", vp), ("bs_relu", c_i32), ("reserved1", c_i32),
+        ("y2", vp),
     ]
 
 

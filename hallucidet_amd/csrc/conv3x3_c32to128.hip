@@ -105,6 +105,12 @@ __global__ __launch_bounds__(256) void conv3x3_c32to128_kernel(ConvP p, int tile
     for (int c = 0; c < 2; ++c) ab[kw][c] = (y0l * PW + xk) * 64 + (((2 * c + h) ^ ((xk >> 2) & 3)) & 3) * 16;
   }
   f16* __restrict__ yp = reinterpret_cast<f16*>(p.y);
+  // out_pool2 = 64 (round 5): this launch is the data gradient of decoder block 3's first convolution over cat([nearest_2x(a), skip]):
+  // channels 0..63 belong to the upsampled half -- their 2 x 2 SUM is the gradient of `a` and goes, pooled in fp32 in the epilogue, to
+  // y [N, Ho/2, Wo/2, 64]; channels 64..127 are the skip's gradient and go straight to y2 [N, Ho, Wo, 64].  The 168 MB concatenated
+  // gradient is never written and hd_concat_up_bwd (273 MB of traffic) is not launched.
+  const bool pool = p.pool2 != 0;
+  f16* __restrict__ y2p = reinterpret_cast<f16*>(p.y2);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   for (int t = t_begin; t < t_end; ++t) {
@@ -156,6 +162,13 @@ __global__ __launch_bounds__(256) void conv3x3_c32to128_kernel(ConvP p, int tile
             float v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = b ? acc1[4 * g + i] : acc0[4 * g + i];
+            if (pool && pass == 0) {          // this lane's pixel + its column neighbour (lane ^ 1) + the row below / above (lane ^ 16)
+#pragma unroll
+              for (int i = 0; i < 4; ++i) {
+                v[i] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v[i]), 0xB1, 0xF, 0xF, true));
+                v[i] += __shfl_xor(v[i], 16);
+              }
+            }
             const f16x2 o01 = {(f16)v[0], (f16)v[1]}, o23 = {(f16)v[2], (f16)v[3]};
             pk[gg][0] = __builtin_bit_cast(unsigned, o01);
             pk[gg][1] = __builtin_bit_cast(unsigned, o23);
@@ -163,7 +176,13 @@ __global__ __launch_bounds__(256) void conv3x3_c32to128_kernel(ConvP p, int tile
           const auto q0 = __builtin_amdgcn_permlane32_swap(pk[0][0], pk[1][0], false, false);
           const auto q1 = __builtin_amdgcn_permlane32_swap(pk[0][1], pk[1][1], false, false);
           const u32x4 o = {q0[0], q1[0], q0[1], q1[1]};
-          if (okp) *reinterpret_cast<u32x4*>(yp + eoff + 64 * pass + 32 * b + 8 * (gp + h)) = o;
+          if (!pool) {
+            if (okp) *reinterpret_cast<u32x4*>(yp + eoff + 64 * pass + 32 * b + 8 * (gp + h)) = o;
+          } else if (pass == 1) {
+            if (okp) *reinterpret_cast<u32x4*>(y2p + (eoff >> 1) + 32 * b + 8 * (gp + h)) = o;        // [pixel][64]
+          } else if (okp && !(lane & 17)) {   // even column, even row: the 2 x 2 block's owner (Ho, Wo even: the block is complete)
+            *reinterpret_cast<u32x4*>(yp + (unsigned)(((cn * (p.Ho >> 1) + (oy >> 1)) * (p.Wo >> 1) + (ox >> 1)) * 64) + 32 * b + 8 * (gp + h)) = o;
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -184,6 +203,7 @@ bool hd_conv_c32to128_eligible(const ConvP& p) {
   if (p.act != HD_ACT_NONE || p.bias || p.res || p.mask) return false;
   if (p.xbytes & 0xC0000000u) return false;
   if ((int64_t)p.N * p.Ho * p.Wo * 128 >= (int64_t)1 << 31) return false;
+  if (p.pool2 && !(p.pool2 == 64 && p.y2 && (p.Ho % 2) == 0 && (p.Wo % 2) == 0)) return false;
   return true;
 }
 

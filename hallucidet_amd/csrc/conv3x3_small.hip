@@ -277,7 +277,8 @@ bool hd_conv_small_eligible(const ConvP& p) {
 
 // out_pool2: the 2 x 2 sum-pooled output form (plain NHWC f16 output, no statistics, even extent)
 bool hd_conv_small_pool2_ok(const ConvP& p) {
-  return hd_conv_small_eligible(p) && p.out_mode == HD_OUT_NHWC_F16 && !p.stats && !p.in_scale && (p.Ho % 2) == 0 && (p.Wo % 2) == 0;
+  return hd_conv_small_eligible(p) && p.out_mode == HD_OUT_NHWC_F16 && !p.stats && !p.in_scale && (p.Ho % 2) == 0 && (p.Wo % 2) == 0 &&
+         (p.pool2 == 0 || (p.pool2 == p.Cout && !p.y2));
 }
 
 int hd_conv_small_tiles(const ConvP& p) { return p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW); }

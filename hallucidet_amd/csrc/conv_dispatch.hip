@@ -41,6 +41,7 @@ int fill_params(const hd_conv_args* a, ConvP& p) {
   HD_CHECK_ARG((a->in_scale == nullptr) == (a->in_shift == nullptr), "hd_conv2d: in_scale / in_shift must be given together");
   p.in_scale = a->in_scale; p.in_shift = a->in_shift; p.in_relu = a->in_relu;
   p.pool2 = a->out_pool2;
+  p.y2 = a->y2;
   p.bs_y = (const f16*)a->bs_y; p.bs_z = (const f16*)a->bs_z;
   p.bs_mean = a->bs_mean; p.bs_invstd = a->bs_invstd; p.bs_gamma = a->bs_gamma; p.bs_beta = a->bs_beta; p.bs_relu = a->bs_relu;
   HD_CHECK_ARG(!p.bs_y || (p.stats && p.bs_mean && p.bs_invstd && !a->mask && a->act == HD_ACT_NONE && a->out_mode == HD_OUT_NHWC_F16 && !a->bias),
@@ -281,7 +282,10 @@ static bool bstat_kernel(const ConvP& p) {
 extern "C" int hd_conv2d_pool2_ok(const hd_conv_args* a) {
   ConvP p;
   if (!a || fill_params(a, p)) return 0;
-  return (use_small(p) && hd_conv_small_pool2_ok(p)) ? 1 : 0;
+  if (!p.pool2) return 0;
+  if (use_small(p)) return hd_conv_small_pool2_ok(p) ? 1 : 0;
+  if (use_c64(p) || use_stem(p)) return 0;
+  return use_c32(p) ? 1 : 0;       // (eligibility includes the out_pool2 = 64 / y2 form)
 }
 
 extern "C" int hd_conv2d_bstat_ok(const hd_conv_args* a) {
@@ -369,8 +373,9 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
 #endif
   HD_CHECK_ARG(!p.bs_y || bstat_kernel(p), "hd_conv2d: bs_* (BatchNorm backward sums) are implemented by the 8-wave and the 64-channel 3x3 kernels only; "
                                            "ask hd_conv2d_bstat_ok first");
-  HD_CHECK_ARG(!p.pool2 || (use_small(p) && hd_conv_small_pool2_ok(p)), "hd_conv2d: out_pool2 is implemented by the small-channel 3x3 kernel only (plain "
-                                                                        "f16 output, no statistics, even extent); ask hd_conv2d_pool2_ok first");
+  HD_CHECK_ARG(!p.pool2 || (use_small(p) ? hd_conv_small_pool2_ok(p) : (!use_c64(p) && !use_stem(p) && use_c32(p))),
+               "hd_conv2d: out_pool2 is implemented by the small-channel 3x3 kernel (all channels pooled) and the 32 -> 128 channel kernel "
+               "(64 pooled channels + y2); ask hd_conv2d_pool2_ok first");
   if (use_small(p)) {
     hd_conv_launch_small(p, s);
     HD_CHECK_LAUNCH();

@@ -12,6 +12,7 @@ struct ConvP {
   const f16* res;
   const f16* mask;
   void* y;
+  void* y2;            // hd_conv_args.y2 (out_pool2 with a skip half: conv3x3_c32to128.hip)
   float* stats;
   unsigned xbytes, x2bytes, wbytes;
   int N, Hsrc, Wsrc, Hin, Win, C1, C2, Cin, Ho, Wo, Cout, KH, KW, stride, pad, up1, in_dil, act, out_mode;
@@ -23,7 +24,7 @@ struct ConvP {
   // only sees the taps with kh = (pad - ph) mod 2 (+2, +4, ...) -- the others hit the zeros of the dilated input -- so a class
   // walks a quarter of the taps (none at all for three classes of a 1x1).  `par` is set by the dispatcher, the rest by the kernel.
   int par, ph, pw, Hc, Wc, t0h, t0w;
-  int pool2;           // hd_conv_args.out_pool2: write the 2 x 2 sum-pooled output (small-channel kernel only)
+  int pool2;           // hd_conv_args.out_pool2: leading output channels that leave 2 x 2 sum-pooled (0 = off)
   int prio;            // 8-wave families: s_setprio policy (experiment knob HD_W8_PRIO: 0 none, 1 MFMA phase, 2 MEM phase)
   const float* in_scale;   // consumer-side BatchNorm of the x operand (hd_conv_args.in_scale / in_shift / in_relu): small-channel kernel only
   const float* in_shift;

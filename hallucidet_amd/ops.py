@@ -65,9 +65,10 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
     with raw conv output ``y``; where the kernel supports it (hd_conv2d_bstat_ok) the unit's backward sums leave with the call and
     ``bstat["part"]`` receives the [rows, 2*Cout] tensor `bn_backward(part=...)` takes; otherwise ``bstat["part"]`` is None.
 
-    ``pool2`` (dict): ask for the 2 x 2 SUM-POOLED output [N, Ho/2, Wo/2, Cout] (hd_conv_args.out_pool2: the data gradient of a decoder
-    convolution whose whole input is the nearest-2x upsampled tensor); ``pool2["done"]`` says whether the kernel did it (else the
-    plain output is returned and the caller pools).
+    ``pool2`` (dict, optional key c_up = Cout): ask for the first c_up output channels 2 x 2 SUM-POOLED, [N, Ho/2, Wo/2, c_up] (returned),
+    and the rest unpooled in ``pool2["skip"]`` (hd_conv_args.out_pool2 / y2: the data gradient of a decoder convolution over
+    cat([nearest_2x(a), skip])); ``pool2["done"]`` says whether the kernel did it (else the plain output is returned and the caller
+    runs concat_up_bwd).
 
     ``out_hw`` overrides the output extent (required with in_dil>1: data-gradient of strided convs).
     ``in_scale`` / ``in_shift`` ([C1] fp32): consumer-side BatchNorm -- x holds the RAW output of the producing conv and the kernel
@@ -105,16 +106,19 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
                  N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
                  1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0),
                  ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
+    y2 = None
     if pool2 is not None:
         pool2["done"] = False
-        if x.dtype == torch.float16 and out is None and not want_stats and bstat is None:
-            a.out_pool2 = 1
+        c_up = int(pool2.get("c_up", Cout))
+        if x.dtype == torch.float16 and out is None and not want_stats and bstat is None and Ho % 2 == 0 and Wo % 2 == 0:
+            yp = torch.empty((N, Ho // 2, Wo // 2, c_up), dtype=x.dtype, device=x.device)
+            y2 = torch.empty((N, Ho, Wo, Cout - c_up), dtype=x.dtype, device=x.device) if Cout > c_up else None
+            a.out_pool2, a.y, a.y2 = c_up, ptr(yp), ptr(y2)
             if lib.hd_conv2d_pool2_ok(C.byref(a)) == 1:
-                y = torch.empty((N, Ho // 2, Wo // 2, Cout), dtype=x.dtype, device=x.device)
-                a.y = ptr(y)
-                pool2["done"] = True
+                y = yp
+                pool2["done"], pool2["skip"] = True, y2
             else:
-                a.out_pool2 = 0
+                a.out_pool2, a.y, a.y2, y2 = 0, ptr(y), None, None
     stats = None
     if bstat is not None:
         bstat["part"] = None
@@ -134,7 +138,7 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=x.device)
         a.stats = ptr(stats)
     if _defer is not None:          # wgrad_dgrad: the caller launches (the argument block and its tensors are kept by the list)
-        _defer.append((a, (x, x2, w, bias, res, mask, y, stats, in_scale, in_shift, bstat)))
+        _defer.append((a, (x, x2, w, bias, res, mask, y, y2, stats, in_scale, in_shift, bstat)))
     else:
         check(_abi.fn("hd_conv2d", x)(C.byref(a), _stream()), "hd_conv2d")
     return (y, stats) if want_stats else y

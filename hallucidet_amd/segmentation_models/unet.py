@@ -669,12 +669,14 @@ class UnetRunner:
         for i in range(len(self.dec) - 1, -1, -1):
             u1, u2, cin, cskip = self.dec[i]
             dz1, _, rows1 = self._unit_bwd(u2, dz, S, dx_is_dz_of=u1)
-            # a block without a skip (the last one): the gradient of the low-resolution input is the 2x2 sum of the data gradient -- asked
-            # from the data-gradient kernel's epilogue (ops.conv2d pool2); the full-resolution tensor is then never written
-            pool = {} if (cskip == 0 and _POOL2) else None
+            # the gradient of the block's low-resolution input is the 2x2 sum of the upsampled half's data gradient -- asked from the
+            # data-gradient kernel's epilogue (ops.conv2d pool2); the full-resolution concatenated gradient is then never written
+            # (with a skip: the 32 -> 128-channel kernel of block 3 writes the pooled half and the skip's half itself; elsewhere the
+            #  request is declined and hd_concat_up_bwd runs as before)
+            pool = dict(c_up=cin) if _POOL2 else None
             dcat, _, _ = self._unit_bwd(u1, dz1, S, part=rows1, pool2=pool)
             if pool is not None and pool.get("done"):
-                dz = dcat
+                dz, dskip[i] = dcat, pool.get("skip")
                 continue
             dz, dskip[i] = ops.concat_up_bwd(dcat, cin)        # 2x2 sum-pool of the upsampled half + the skip's slice, one launch
         self._segment_done(0)                  # head + decoder parameter gradients are final

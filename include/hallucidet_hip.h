@@ -86,11 +86,13 @@ typedef struct hd_conv_args {
   const float* in_scale; /* [C1] or NULL */
   const float* in_shift; /* [C1] or NULL */
   int32_t in_relu;
-  /* out_pool2 != 0: y receives the 2 x 2 SUM-POOLED result [N, Ho/2, Wo/2, Cout] instead of [N, Ho, Wo, Cout] -- the data gradient of a
-   * decoder block's first convolution whose whole input is the nearest-2x upsampled tensor (skip = None,
-   * src/segmentation_models/decoders/unet/decoder.py:38-41): the gradient w.r.t. the low-resolution tensor is the 2 x 2 sum of the
-   * gradient w.r.t. the upsampled one, formed in the epilogue in fp32; the full-resolution tensor is never written.  Implemented by the
-   * small-channel 3x3 kernel (hd_conv2d_pool2_ok says whether this problem qualifies); other problems -> HD_E_ARG. */
+  /* out_pool2 = c > 0: the first c output channels leave 2 x 2 SUM-POOLED, y = [N, Ho/2, Wo/2, c]; the remaining Cout - c channels (if
+   * any) go unpooled to y2 = [N, Ho, Wo, Cout - c] -- the data gradient of a decoder block's first convolution over
+   * cat([nearest_2x(a), skip]) (src/segmentation_models/decoders/unet/decoder.py:38-41): the gradient of `a` is the 2 x 2 sum of the
+   * upsampled half's gradient (formed in the epilogue in fp32), the skip's gradient is the other half; the concatenated full-resolution
+   * gradient is never written and hd_concat_up_bwd is not needed.  Implemented by the small-channel 3x3 kernel (c == Cout, no y2: a
+   * block without a skip) and by the 32 -> 128-channel kernel (c == 64, y2 given); hd_conv2d_pool2_ok says whether a problem
+   * qualifies, other problems -> HD_E_ARG. */
   int32_t out_pool2;
   /* Producer-side sums of a BatchNorm's backward pass (bs_y NULL: off).  The tensor this call writes (y, f16 NHWC) is then the incoming
    * gradient dz of a Conv2dReLU unit (src/segmentation_models/base/modules.py:10-47) whose raw convolution output is bs_y, and `stats`
@@ -107,6 +109,7 @@ typedef struct hd_conv_args {
   const float* bs_gamma;  /* [Cout] or NULL (1) */
   const float* bs_beta;   /* [Cout] or NULL (0) */
   int32_t bs_relu, reserved1;
+  void* y2;               /* out_pool2: f16 NHWC [N,Ho,Wo,Cout - out_pool2] or NULL */
 } hd_conv_args;
 
 int hd_conv2d(const hd_conv_args* a, void* stream);

@@ -49,7 +49,7 @@ def test_struct_layout_matches_c(tmp_path):
     import os
     import subprocess
     from hallucidet_amd._abi import ConvArgs, WgradArgs
-    fields = {"hd_conv_args": (ConvArgs, ["x", "y", "stats", "N", "out_mode", "in_scale", "in_shift", "in_relu", "out_pool2", "bs_y", "bs_z", "bs_mean", "bs_invstd", "bs_gamma", "bs_beta", "bs_relu"]),
+    fields = {"hd_conv_args": (ConvArgs, ["x", "y", "stats", "N", "out_mode", "in_scale", "in_shift", "in_relu", "out_pool2", "bs_y", "bs_z", "bs_mean", "bs_invstd", "bs_gamma", "bs_beta", "bs_relu", "y2"]),
               "hd_wgrad_args": (WgradArgs, ["x", "slab", "N", "nsplit", "in_scale", "in_shift", "in_relu"])}
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "hallucidet_hip.h"\nint main(void) {\n'
     for st, (_, fs) in fields.items():
@@ -67,7 +67,7 @@ def test_struct_layout_matches_c(tmp_path):
         assert int(got[st]) == ctypes.sizeof(cls), st
         for f in fs:
             assert int(got["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
-    assert ctypes.sizeof(ConvArgs) == 8 * 8 + 18 * 4 + 2 * 8 + 2 * 4 + 6 * 8 + 2 * 4 and ConvArgs.N.offset == 64
+    assert ctypes.sizeof(ConvArgs) == 8 * 8 + 18 * 4 + 2 * 8 + 2 * 4 + 6 * 8 + 2 * 4 + 8 and ConvArgs.N.offset == 64
 
 
 def test_bad_arguments_return_status_codes(lib):

@@ -264,6 +264,29 @@ def test_conv2d_pooled_output_is_the_2x2_sum_of_the_plain_output(dev, case):
     assert big["done"] is False and y.shape == (1, 8, 8, 64)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32), (1, 24, 48), (3, 10, 20)])
+def test_conv2d_c32to128_pooled_half_and_skip_half(dev, case):
+    """Decoder block 3's data gradient (32 -> 128 channels, conv3x3_c32to128.hip) with out_pool2 = 64: channels 0..63 leave 2 x 2
+    sum-pooled (the gradient of the upsampled source), channels 64..127 unpooled in a second tensor (the skip's gradient) -- against the
+    plain call + hd_concat_up_bwd (the skip half bit for bit, the pooled half up to the one rounding the fused form saves) and the
+    oracle; ragged 8 x 16 tiles."""
+    from hallucidet_amd import ops
+    N, H, W = case
+    x = rnd(N, H, W, 32, seed=1).to(dev)
+    w = rnd(128, 9 * 32, scale=1.0 / math.sqrt(9 * 32), seed=3).to(dev)
+    info = dict(c_up=64)
+    got = ops.conv2d(x, w, 3, 3, pad=1, pool2=info)
+    assert info["done"] and got.shape == (N, H // 2, W // 2, 64) and info["skip"].shape == (N, H, W, 64)
+    plain = ops.conv2d(x, w, 3, 3, pad=1)
+    da, ds = ops.concat_up_bwd(plain, 64)
+    torch.cuda.synchronize()
+    assert torch.equal(info["skip"], ds)
+    assert float((got.float() - da.float()).abs().max()) <= 4e-3 * max(1.0, float(da.float().abs().max()))
+    want, _ = ok.conv2d_nhwc(x.cpu(), w.cpu(), 3, 3, pad=1)
+    close(got, want[..., :64].reshape(N, H // 2, 2, W // 2, 2, 64).sum(dim=(2, 4)).half())
+    close(info["skip"], want[..., 64:].half())
+
+
 def test_conv2d_nchw_f32_output(dev):
     from hallucidet_amd import ops
     x = rnd(2, 12, 16, 16, seed=1)
