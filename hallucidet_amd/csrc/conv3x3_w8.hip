@@ -318,6 +318,62 @@ __device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, 
   __syncthreads();
   HD_TRACE(12, clock64());
 
+  if (p.pool2) {
+    // hd_conv_args.out_pool2 (round 5): the data gradient of a decoder block's first convolution over cat([nearest_2x(a), skip]).  A
+    // channel tile lies wholly inside the upsampled half (n0 < pool2: pool2 is a multiple of BN) or wholly inside the skip's:
+    //   * upsampled half: the gradient of `a` is the 2 x 2 SUM of this tile's pixels -- a thread adds the four rows (r, r + 1, r + 8,
+    //     r + 9: the 8-wide tile holds whole 2 x 2 blocks) of all WK partial tiles in fp32 and stores ONE pooled vector to
+    //     y [N, Ho/2, Wo/2, pool2];
+    //   * skip half: the unpooled vector goes to y2 [N, Ho, Wo, Cout - pool2].
+    // No residual / mask / bias / activation / sums on this path (the dispatcher checks); hd_concat_up_bwd is not launched.
+    const int c_up = p.pool2;
+    if (n0 < c_up) {
+      f16* __restrict__ yq = reinterpret_cast<f16*>(p.y);
+      const int Hq = p.Ho >> 1, Wq = p.Wo >> 1;
+      for (int pr = r0; pr < BM / 4; pr += RPI) {
+        const int py = pr >> 2, px = pr & 3;
+        const int row = py * 16 + px * 2;
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+#pragma unroll
+        for (int g = 0; g < WK; ++g)
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int rr = row + (d & 1) + (d >> 1) * 8;
+            s0 += *reinterpret_cast<const f32x4*>(ct + (g * BM + rr) * CP + cch * 8);
+            s1 += *reinterpret_cast<const f32x4*>(ct + (g * BM + rr) * CP + cch * 8 + 4);
+          }
+        const int oy = ty0 + 2 * py, ox = tx0 + 2 * px;
+        if (cvalid && oy < p.Ho && ox < p.Wo) {
+          f16x8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (f16)(k < 4 ? s0[k] : s1[k - 4]);
+          *reinterpret_cast<f16x8*>(yq + (size_t)((n_img * Hq + (oy >> 1)) * Wq + (ox >> 1)) * c_up + co) = o;
+        }
+      }
+    } else {
+      f16* __restrict__ y2 = reinterpret_cast<f16*>(p.y2);
+      const int cs = Cout - c_up;
+#pragma unroll
+      for (int it = 0; it < ITER; ++it) {
+        const int row = r0 + it * RPI;
+        f32x4 s0 = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8), s1 = *reinterpret_cast<const f32x4*>(ct + row * CP + cch * 8 + 4);
+#pragma unroll
+        for (int g = 1; g < WK; ++g) {
+          s0 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8);
+          s1 += *reinterpret_cast<const f32x4*>(ct + (g * BM + row) * CP + cch * 8 + 4);
+        }
+        if (ok[it]) {
+          const int oy = ty0 + (row >> 3), ox = tx0 + (row & 7);
+          f16x8 o;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) o[k] = (f16)(k < 4 ? s0[k] : s1[k - 4]);
+          *reinterpret_cast<f16x8*>(y2 + (size_t)((n_img * p.Ho + oy) * p.Wo + ox) * cs + (co - c_up)) = o;
+        }
+      }
+    }
+    return;
+  }
+
   // Row phase, written as whole-tile passes (one option test per pass, not per row): every thread first pulls ALL of its ITER rows
   // (x WK partial tiles) out of LDS -- 2*ITER*WK independent 16-byte reads in flight, the accumulator registers are free by now --
   // and then runs straight-line fp32 code over ITER x 8 values.  The per-row form (`if (ok[it]) { read; ...; store; }`) exposed
@@ -538,6 +594,13 @@ bool hd_conv_p8_eligible(const ConvP& p) {
   if ((p.xbytes | p.x2bytes | p.wbytes) & 0x80000000u) return false;      // out-of-range lanes are marked by bit 31 of the offset
   if (p.x2) return p.up1 && (p.C1 % 64) == 0 && (p.C2 % 64) == 0;
   return !p.up1 && (p.C1 % 64) == 0;
+}
+
+// out_pool2 on this family: plain data gradient (no residual / mask / bias / activation / sums), even extent, the pooled channel count a
+// multiple of the widest channel tile so that no tile straddles the two halves
+bool hd_conv_p8_pool2_ok(const ConvP& p) {
+  return hd_conv_p8_eligible(p) && !p.res && !p.mask && !p.bias && !p.stats && !p.bs_y && p.act == HD_ACT_NONE && (p.Ho % 2) == 0 && (p.Wo % 2) == 0 &&
+         p.pool2 > 0 && (p.pool2 % 128) == 0 && p.pool2 <= p.Cout && ((p.Cout - p.pool2) % 8) == 0 && (p.pool2 == p.Cout || p.y2 != nullptr);
 }
 
 // cfg: 0 256x128 | 1 128x128 (WK 2) | 2 256x64 (WK 2) | 3 128x64 (WK 4)

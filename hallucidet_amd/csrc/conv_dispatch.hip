@@ -278,14 +278,21 @@ static bool bstat_kernel(const ConvP& p) {
   return choose_tile(p).p8cfg >= 0;
 }
 
-// does hd_conv2d implement out_pool2 for this problem?  (the small-channel 3x3 kernel: plain f16 output, even extent)
+// is this problem (out_pool2 set) routed to a kernel that implements the pooled / split output?
+static bool pool2_kernel(const ConvP& p) {
+  if (!p.pool2) return false;
+  if (use_small(p)) return hd_conv_small_pool2_ok(p);
+  if (use_c64(p) || use_stem(p)) return false;
+  if (use_c32(p)) return true;                         // (its eligibility includes the out_pool2 = 64 / y2 form)
+  if (use_cat(p) || choose_gemm8(p)) return false;
+  return choose_tile(p).p8cfg >= 0 && hd_conv_p8_pool2_ok(p);
+}
+
+// does hd_conv2d implement out_pool2 for this problem?
 extern "C" int hd_conv2d_pool2_ok(const hd_conv_args* a) {
   ConvP p;
   if (!a || fill_params(a, p)) return 0;
-  if (!p.pool2) return 0;
-  if (use_small(p)) return hd_conv_small_pool2_ok(p) ? 1 : 0;
-  if (use_c64(p) || use_stem(p)) return 0;
-  return use_c32(p) ? 1 : 0;       // (eligibility includes the out_pool2 = 64 / y2 form)
+  return pool2_kernel(p) ? 1 : 0;
 }
 
 extern "C" int hd_conv2d_bstat_ok(const hd_conv_args* a) {
@@ -303,6 +310,7 @@ extern "C" int hd_conv2d_wgrad(const hd_conv_args* a, const hd_wgrad_args* wa, v
   ConvP p;
   int rc = fill_params(a, p);
   if (rc) return rc;
+  HD_CHECK_ARG(!p.pool2 || pool2_kernel(p), "hd_conv2d_wgrad: out_pool2 is not implemented for this problem; ask hd_conv2d_pool2_ok first");
   if (fuse_on && !use_small(p) && !use_c64(p) && !use_stem(p) && !p.in_scale && !p.x2 && (!p.stats || p.bs_y) && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
     const TileChoice c = choose_tile(p);
     if (c.p8cfg >= 0) {
@@ -373,9 +381,9 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
 #endif
   HD_CHECK_ARG(!p.bs_y || bstat_kernel(p), "hd_conv2d: bs_* (BatchNorm backward sums) are implemented by the 8-wave and the 64-channel 3x3 kernels only; "
                                            "ask hd_conv2d_bstat_ok first");
-  HD_CHECK_ARG(!p.pool2 || (use_small(p) ? hd_conv_small_pool2_ok(p) : (!use_c64(p) && !use_stem(p) && use_c32(p))),
-               "hd_conv2d: out_pool2 is implemented by the small-channel 3x3 kernel (all channels pooled) and the 32 -> 128 channel kernel "
-               "(64 pooled channels + y2); ask hd_conv2d_pool2_ok first");
+  HD_CHECK_ARG(!p.pool2 || pool2_kernel(p),
+               "hd_conv2d: out_pool2 is implemented by the small-channel 3x3 kernel (all channels pooled), the 32 -> 128 channel kernel "
+               "(64 pooled channels + y2) and the 8-wave 3x3 family (pooled channels a multiple of 128); ask hd_conv2d_pool2_ok first");
   if (use_small(p)) {
     hd_conv_launch_small(p, s);
     HD_CHECK_LAUNCH();

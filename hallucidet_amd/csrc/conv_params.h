@@ -157,6 +157,7 @@ bool hd_conv_launch_bk32_multi(ConvMulti& mp, int bm, int bn, bool deep, hipStre
 bool hd_conv_launch_bk64_multi(ConvMulti& mp, int bm, int bn, bool deep, hipStream_t s);
 // conv3x3_w8.hip: 8-wave family with LDS-staged input patches (3x3 / s1 / p1, Cin % 64 == 0); cfg = tile id
 bool hd_conv_p8_eligible(const ConvP& p);
+bool hd_conv_p8_pool2_ok(const ConvP& p);
 int hd_conv_p8_tiles(const ConvP& p, int cfg);
 void hd_conv_launch_p8(ConvP& p, int cfg, hipStream_t s);
 // the same tile grid with the blocks of an 8-wave weight gradient behind it (one launch; conv3x3_w8.hip)

@@ -264,6 +264,45 @@ def test_conv2d_pooled_output_is_the_2x2_sum_of_the_plain_output(dev, case):
     assert big["done"] is False and y.shape == (1, 8, 8, 64)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 16, 128, 256, 128), (1, 32, 24, 256, 512, 256), (2, 16, 24, 64, 128, 64), (1, 16, 8, 128, 256, 0)])
+def test_conv2d_eight_wave_pooled_half_and_skip_half(dev, case):
+    """out_pool2 in the 8-wave 3x3 family (decoder blocks 0-2: the data gradient of conv1 over cat([nearest_2x(a), skip]) with 512 + 256,
+    256 + 128, 128 + 64 channels): the upsampled half 2 x 2 sum-pooled, the skip half unpooled in y2 -- against the plain call +
+    hd_concat_up_bwd and the oracle; alone and inside the fused data + weight gradient grid (ops.wgrad_dgrad); ragged tiles; a case with
+    no skip half."""
+    from hallucidet_amd import ops
+    N, H, W, Cin, c_up, c_skip = case
+    Cout = c_up + c_skip
+    x = rnd(N, H, W, Cin, seed=1).to(dev)
+    w = rnd(Cout, 9 * Cin, scale=1.0 / math.sqrt(9 * Cin), seed=3).to(dev)
+    info = dict(c_up=c_up)
+    got = ops.conv2d(x, w, 3, 3, pad=1, pool2=info)
+    assert info["done"] and got.shape == (N, H // 2, W // 2, c_up)
+    declined = {}                                 # a map the 8-wide tiles cover badly stays on the 4-wave family: the request is declined
+    y = ops.conv2d(rnd(1, 12, 20, Cin, seed=5).to(dev), w, 3, 3, pad=1, pool2=dict(declined, c_up=c_up))
+    assert y.shape[-1] in (Cout, c_up)
+    plain = ops.conv2d(x, w, 3, 3, pad=1)
+    da, ds = ops.concat_up_bwd(plain, c_up)
+    torch.cuda.synchronize()
+    if c_skip:
+        assert torch.equal(info["skip"], ds)
+    else:
+        assert info["skip"] is None and ds is None
+    assert float((got.float() - da.float()).abs().max()) <= 4e-3 * max(1.0, float(da.float().abs().max()))
+    want, _ = ok.conv2d_nhwc(x.cpu(), w.cpu(), 3, 3, pad=1)
+    close(got, want[..., :c_up].reshape(N, H // 2, 2, W // 2, 2, c_up).sum(dim=(2, 4)).half())
+    # the same request through the one-grid data + weight gradient call (the convolution's x is the layer's dY there)
+    xin = rnd(N, H // 2, W // 2, c_up, seed=7).to(dev)
+    skip = rnd(N, H, W, c_skip, seed=8).to(dev) if c_skip else None
+    wd = rnd(Cout, 9 * Cin, scale=1.0 / math.sqrt(9 * Cin), seed=9).to(dev)
+    info2 = dict(c_up=c_up)
+    slab, dx = ops.wgrad_dgrad(xin, x, 3, 3, wd, x2=skip, pad=1, up1=True, dgrad=dict(pad=1, cout=Cout, pool2=info2))
+    ref_slab = ops.wgrad(xin, x, 3, 3, x2=skip, pad=1, up1=True)
+    ref_dx = ops.conv2d(x, wd, 3, 3, pad=1, cout=Cout, pool2=dict(c_up=c_up))
+    torch.cuda.synchronize()
+    assert info2["done"] and torch.equal(dx, ref_dx) and torch.equal(slab, ref_slab)
+
+
 @pytest.mark.parametrize("case", [(2, 16, 32), (1, 24, 48), (3, 10, 20)])
 def test_conv2d_c32to128_pooled_half_and_skip_half(dev, case):
     """Decoder block 3's data gradient (32 -> 128 channels, conv3x3_c32to128.hip) with out_pool2 = 64: channels 0..63 leave 2 x 2
