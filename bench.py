@@ -104,12 +104,17 @@ def conv_roofline(lit, batch, reps=5, peak=None):
             n, co, ho, wo = y.shape
         else:
             n, ho, wo, co = y.shape
+        pooled = kw.get("pool2") is not None and kw["pool2"].get("done")
+        if pooled:      # out_pool2: y is the 2x2 sum-pooled upsampled half; the convolution still computes every output of the full map
+            ho, wo, co = 2 * ho, 2 * wo, (kw.get("cout") or w.shape[0])
         dil = kw.get("in_dil", 1)
         # algorithmic FLOPs: a data-gradient over a zero-dilated input only multiplies the non-zero taps
         flops = 2.0 * n * ho * wo * co * KH * KW * (C1 + C2) / (dil * dil)
         # algorithmic bytes: every operand once (x, x2, w, y, residual, mask)
         es = x.element_size()          # 2 (fp16 storage) or 4 (--precision 32)
         by = x.numel() * es + (0 if kw.get("x2") is None else kw["x2"].numel() * es) + w.numel() * es + y.numel() * y.element_size()
+        if pooled and kw["pool2"].get("skip") is not None:
+            by += kw["pool2"]["skip"].numel() * es
         by += sum(t.numel() * es for t in (kw.get("res"), kw.get("mask")) if t is not None)
         rec.append(({k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, (x, w, KH, KW), flops, by, where[0]))
         return out

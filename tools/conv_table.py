@@ -71,6 +71,9 @@ for x, w, KH, KW, kw, y, wh in rec:
         n, co, ho, wo = y.shape
     else:
         n, ho, wo, co = y.shape
+    pooled = kw.get("pool2") is not None and kw["pool2"].get("done")
+    if pooled:      # out_pool2: y is the 2x2 sum-pooled upsampled half; the convolution still computes every output of the full map
+        ho, wo, co = 2 * ho, 2 * wo, (kw.get("cout") or w.shape[0])
     dil = kw.get("in_dil", 1)
     flops = 2.0 * n * ho * wo * co * KH * KW * (x.shape[3] + C2) / (dil * dil)
     by = x.numel() * 2 + (0 if kw.get("x2") is None else kw["x2"].numel() * 2) + w.numel() * 2 + y.numel() * y.element_size()
