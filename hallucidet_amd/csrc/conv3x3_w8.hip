@@ -39,33 +39,38 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, un
 __device__ __forceinline__ int swz_of(int y, int x) { return ((x >> 1) + 4 * y) & 7; }
 
 // LDS of one block, in halves: max(main-loop ring, epilogue tile)
-template <int TH, int WN, int WK>
+template <int TH, int WN, int WK, bool TS = false>
 constexpr int p8_lds_halves() {
   constexpr int BM = TH * TW, BN = WN * 64;
   constexpr int NPIECE = ((TH + 2) * PW * 8 + 63) / 64;
-  constexpr int RING = 2 * NPIECE * 512 + 3 * BN * LDS_ROW;
+  constexpr int RING = 2 * NPIECE * 512 + (TS ? 6 : 3) * BN * LDS_ROW;
   constexpr int EPI = WK * BM * (BN + 4) * 2;
   return RING > EPI ? RING : EPI;
 }
 
 // One output tile (block `bid_in` of a grid of `nwg_in` tiles); `lds`: p8_lds_halves<TH, WN, WK>() halves, 1 KiB aligned.  A device
 // function so that the fused data-gradient + weight-gradient launch below can run it in the leading blocks of its grid.
-template <int TH, int WN, int WK, bool DUAL>
+template <int TH, int WN, int WK, bool DUAL, bool TS = false>
 __device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, int nwg_in) {
   constexpr int BM = TH * TW, BN = WN * 64, WM = TH / 8;
   static_assert(WM * WN * WK == 8, "eight waves");
-  constexpr int KSP = 4 / WK;
+  static_assert(!TS || WK >= 2, "the step split needs two K groups");
+  // TS (round 5): the two ping-pong wave groups take ALTERNATE K steps (group g the steps s = g mod 2) and a wave runs all of a step's
+  // sub-steps that its group has not split further (WK 4: two waves of a group halve them) -- 16 (8) MFMAs per phase where the
+  // sub-step split ran 8 (4) between the same two barriers.
+  constexpr int KSP = TS ? 8 / WK : 4 / WK;
+  constexpr int NRING = TS ? 6 : 3;
   constexpr int PH = TH + 2, PPX = PH * PW;
   constexpr int NPIECE = (PPX * 8 + 63) / 64;          // 1-KiB pieces per patch chunk (43 / 23)
   constexpr int PPW = (NPIECE + 7) / 8;                // pieces per wave (6 / 3)
   constexpr int PSTAGE = NPIECE * 512;                 // halves
   constexpr int B_LOADS = BN / 64;
   constexpr int BSTAGE = BN * LDS_ROW;
-  constexpr int RING = 2 * PSTAGE + 3 * BSTAGE;
+  constexpr int RING = 2 * PSTAGE + NRING * BSTAGE;
   constexpr int CP = BN + 4;                            // epilogue tile pitch in floats (16-byte LDS writes conflict-free)
   constexpr int EPI_HALVES = WK * BM * CP * 2;
   constexpr int LDS_HALVES = RING > EPI_HALVES ? RING : EPI_HALVES;
-  static_assert(LDS_HALVES == p8_lds_halves<TH, WN, WK>(), "p8_lds_halves out of date");
+  static_assert(LDS_HALVES == p8_lds_halves<TH, WN, WK, TS>(), "p8_lds_halves out of date");
   f16* const patch0 = lds;
   f16* const bst0 = lds + 2 * PSTAGE;
 
@@ -140,16 +145,21 @@ __device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, 
   // ---- fragment read tables (byte offsets, first 16-deep sub-step of this wave; sub-step q is the same address ^ (q << 5)):
   //        a0[a][tap]: patch pixel of this lane's row at that tap, slot = (kc0 ^ swizzle(pixel)); b0: weight row, slot by row
   const int frow = lane & 31, fh = lane >> 5;
-  const int kc0 = (wk * KSP) * 2 + fh;
+  // TS: entry i of the table is ROUND i of the 9-round period (18 K steps = two channel chunks): this group's step of that round is
+  // 2i + grp, i.e. tap (2i + grp) % 9 of the chunk pair's first (second, once 2i + grp >= 9) chunk -- the patch stage rides in the entry.
+  const int kc0 = TS ? ((wk & (WK / 2 - 1)) * KSP) * 2 + fh : (wk * KSP) * 2 + fh;
   unsigned a0[2][9];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int y = wm * 8 + a * 4 + (frow >> 3) + t / 3, x = (frow & 7) + t % 3;
-      a0[a][t] = (unsigned)((y * PW + x) * 128 + ((kc0 ^ swz_of(y, x)) & 7) * 16);
+      const int e = TS ? 2 * t + grp : t;
+      const int tap = e >= 9 ? e - 9 : e;
+      const int ky = TS ? (tap * 11) >> 5 : t / 3;              // tap / 3 for tap < 9
+      const int y = wm * 8 + a * 4 + (frow >> 3) + ky, x = (frow & 7) + (tap - 3 * ky);
+      a0[a][t] = (unsigned)((y * PW + x) * 128 + ((kc0 ^ swz_of(y, x)) & 7) * 16) + (TS && e >= 9 ? (unsigned)(PSTAGE * 2) : 0u);
     }
-  const unsigned b0 = (unsigned)(2 * PSTAGE * 2 + (wn * 64 + frow) * 128 + ((kc0 ^ ((frow >> 1) & 7)) & 7) * 16);
+  const unsigned b0 = (unsigned)(2 * PSTAGE * 2 + (wn * 64 + frow) * 128 + ((kc0 ^ ((frow >> 1) & 7)) & 7) * 16) + (TS ? (unsigned)(grp * BSTAGE * 2) : 0u);
 
   auto issue_patch_piece = [&](int cc, int k) {          // piece k of this wave, chunk cc -> patch stage cc & 1
     f16* dst = patch0 + (cc & 1) * PSTAGE + (k * 8 + wave) * 512;
@@ -185,6 +195,103 @@ __device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, 
   // least one barrier before the first read of K step s+2 (group 0's LOAD(s+2)); ring stage (s+2) % 3 == (s-1) % 3 was last read
   // in LOAD(s-1), which for both groups ends at least one barrier before any LOAD(s) starts; the patch buffer of chunk c+1 was last
   // read in the LOADs of chunk c-1's tap 8 and is first written in LOAD(c, tap 1).
+  if constexpr (TS) {
+    // ---- step-split main loop.  Round r = K steps 2r (group 0) and 2r + 1 (group 1); phases as above, one barrier apart:
+    //     LOAD(r):  this wave's 4 * KSP fragments of ITS step: LDS -> registers; DMA of the weights of BOTH steps of round r + 2 (ring
+    //               stages (2r + 4) % 6 and (2r + 5) % 6, all eight waves share a stage's pieces as before); rounds 0-2 / 5-7 of the
+    //               period also this wave's patch pieces of the next odd / even channel chunk; s_waitcnt vmcnt(<just issued>)
+    //     MFMA(r):  4 * KSP * 4 MFMAs from registers
+    // Hazards: LOAD(r) of group 1 runs one phase after group 0's and a barrier before group 0's LOAD(r + 1), so while any wave is in
+    // LOAD(r + 1) every read of LOAD(<= r) has completed: the ring stages of round r + 2 are those of round r - 1 (free), and a piece
+    // issued in LOAD(r) by either group has been waited for (end of that wave's LOAD(r + 1)) before LOAD(r + 2) of group 0 begins.
+    // Patch buffer (chunk & 1): the odd chunk 2P + 1 is first read in round 9P + 4 and its buffer was last read in round 9P - 1 ->
+    // issued in rounds 9P + {0, 1, 2}; the even chunk 2P + 2 is first read in round 9P + 9, its buffer last in round 9P + 4 ->
+    // issued in rounds 9P + {5, 6, 7}.
+    constexpr int PPR = (PPW + 2) / 3;                   // patch pieces per wave and round
+    // (an odd number of chunks: group 1's step of the last round is step 9 * ncc, whose weights AND patch are the zero fill of an
+    // out-of-range chunk -- it adds 0 * 0)
+    auto issue_b_ts = [&](int cc, int tap, int stage) {
+      f16* dst = bst0 + stage * BSTAGE + wave * 512;
+      const unsigned koff = cc < ncc ? (unsigned)(tap * p.Cin + cc * 64) * 2u : OOBB;
+#pragma unroll
+      for (int i = 0; i < B_LOADS; ++i) dma16(rw, dst + i * (64 * LDS_ROW), wbase[i] + koff);
+    };
+#pragma unroll
+    for (int k = 0; k < PPW; ++k)
+      if (k * 8 + wave < NPIECE) issue_patch_piece(0, k);
+    issue_b_ts(0, 0, 0);
+    issue_b_ts(0, 1, 1);
+    issue_b_ts(0, 2, 2);
+    issue_b_ts(0, 3, 3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+
+    HD_TRACE(3, clock64());
+#ifdef HD_CONV_TRACE
+    tr_t = clock64();
+#endif
+#define HD_P8_ROUND(I)                                                                                                     \
+      {                                                                                                                    \
+        constexpr int E0 = 2 * (I) + 4, E1 = 2 * (I) + 5;                                                                  \
+        f16x8 af[KSP][2], bf[KSP][2];                                                                                      \
+        {                                                                                                                  \
+          const char* lb = reinterpret_cast<const char*>(lds);                                                             \
+          const unsigned ba0 = a0[0][I], ba1 = a0[1][I], bb = b0 + ((2 * (I)) % 6) * BSTAGE * 2;                            \
+          _Pragma("unroll") for (int q = 0; q < KSP; ++q) {                                                                \
+            af[q][0] = *reinterpret_cast<const f16x8*>(lb + (ba0 ^ (unsigned)(q << 5)));                                   \
+            af[q][1] = *reinterpret_cast<const f16x8*>(lb + (ba1 ^ (unsigned)(q << 5)));                                   \
+            bf[q][0] = *reinterpret_cast<const f16x8*>(lb + (bb ^ (unsigned)(q << 5)));                                    \
+            bf[q][1] = *reinterpret_cast<const f16x8*>(lb + (bb ^ (unsigned)(q << 5)) + 4096);                             \
+          }                                                                                                                \
+        }                                                                                                                  \
+        issue_b_ts(2 * P + E0 / 9, E0 % 9, E0 % 6);                                                                        \
+        issue_b_ts(2 * P + E1 / 9, E1 % 9, E1 % 6);                                                                        \
+        {                                                                                                                  \
+          constexpr bool PODD = (I) <= 2, PEVEN = (I) >= 5 && (I) <= 7;                                                    \
+          constexpr int K0 = (PODD ? (I) : (I) - 5) * PPR;                                                                 \
+          int np = 0;                                                                                                      \
+          if (PODD || PEVEN) {                                                                                             \
+            _Pragma("unroll") for (int k = K0; k < K0 + PPR && k < PPW; ++k)                                               \
+              if (k * 8 + wave < NPIECE) {                                                                                 \
+                issue_patch_piece(2 * P + (PODD ? 1 : 2), k);                                                              \
+                ++np;                                                                                                      \
+              }                                                                                                            \
+          }                                                                                                                \
+          if (np == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_LOADS) : "memory");                                  \
+          else if (np == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_LOADS + 1) : "memory");                         \
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * B_LOADS + 2) : "memory");                                      \
+        }                                                                                                                  \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        TR_MARK(tr_mem);                                                                                                   \
+        __builtin_amdgcn_s_barrier();                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        TR_MARK(tr_b1);                                                                                                    \
+        __builtin_amdgcn_s_setprio(1);                                                                                     \
+        _Pragma("unroll") for (int q = 0; q < KSP; ++q)                                                                    \
+          _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                    \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                  \
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[q][b], af[q][a], acc[a][b], 0, 0, 0);                  \
+        __builtin_amdgcn_s_setprio(0);                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        TR_MARK(tr_mfma);                                                                                                  \
+        __builtin_amdgcn_s_barrier();                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        TR_MARK(tr_b2);                                                                                                    \
+      }
+    // whole periods (two channel chunks each), then the five rounds of a last odd chunk: no exit from the middle of the unrolled body
+    // (nine exits, each carrying the 64 accumulator registers, had the allocator spill 500 VGPRs)
+    const int nper = ncc >> 1;
+    for (int P = 0; P < nper; ++P) {
+      HD_P8_ROUND(0) HD_P8_ROUND(1) HD_P8_ROUND(2) HD_P8_ROUND(3) HD_P8_ROUND(4) HD_P8_ROUND(5) HD_P8_ROUND(6) HD_P8_ROUND(7) HD_P8_ROUND(8)
+    }
+    if (ncc & 1) {
+      const int P = nper;
+      HD_P8_ROUND(0) HD_P8_ROUND(1) HD_P8_ROUND(2) HD_P8_ROUND(3) HD_P8_ROUND(4)
+    }
+#undef HD_P8_ROUND
+  } else {
 #pragma unroll
   for (int k = 0; k < PPW; ++k)
     if (k * 8 + wave < NPIECE) issue_patch_piece(0, k);
@@ -244,6 +351,7 @@ __device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, 
     }
     HD_P8_STEP(0) HD_P8_STEP(1) HD_P8_STEP(2) HD_P8_STEP(3) HD_P8_STEP(4) HD_P8_STEP(5) HD_P8_STEP(6) HD_P8_STEP(7) HD_P8_STEP(8)
 #undef HD_P8_STEP
+  }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -544,10 +652,10 @@ __device__ __forceinline__ void conv3x3_w8_body(ConvP& p, f16* lds, int bid_in, 
   HD_TRACE(7, hw_ids());
 }
 
-template <int TH, int WN, int WK, bool DUAL>
+template <int TH, int WN, int WK, bool DUAL, bool TS>
 __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
-  __shared__ __attribute__((aligned(1024))) f16 lds[p8_lds_halves<TH, WN, WK>()];
-  conv3x3_w8_body<TH, WN, WK, DUAL>(p, lds, blockIdx.x, gridDim.x);
+  __shared__ __attribute__((aligned(1024))) f16 lds[p8_lds_halves<TH, WN, WK, TS>()];
+  conv3x3_w8_body<TH, WN, WK, DUAL, TS>(p, lds, blockIdx.x, gridDim.x);
 }
 
 // Data gradient AND weight gradient of one layer as ONE grid: blocks [0, n_conv) run the convolution tiles, the blocks behind them
@@ -555,33 +663,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_w8_kernel(ConvP p) {
 // the chip idles through every one of those launches, and through the tail of the 256-block weight gradient that follows it; both
 // consume the same dY and are independent, so one grid of 160 + 256 blocks keeps every CU busy until the work of both is done.
 // Same code, same summation orders: results are bit-identical to the two separate launches.
-template <int TH, int WN, int WK>
+template <int TH, int WN, int WK, bool TS>
 __global__ __launch_bounds__(512, 2) void conv3x3_w8_wgrad_kernel(ConvP p, hd_wg8::Wg8P q, int n_conv, int wg_gx) {
-  constexpr int L1 = p8_lds_halves<TH, WN, WK>(), L2 = hd_wg8::LDS_HALVES;
+  constexpr int L1 = p8_lds_halves<TH, WN, WK, TS>(), L2 = hd_wg8::LDS_HALVES;
   __shared__ __attribute__((aligned(1024))) f16 lds[L1 > L2 ? L1 : L2];
   if ((int)blockIdx.x < n_conv) {
-    conv3x3_w8_body<TH, WN, WK, false>(p, lds, blockIdx.x, n_conv);
+    conv3x3_w8_body<TH, WN, WK, false, TS>(p, lds, blockIdx.x, n_conv);
   } else {
     const int w = (int)blockIdx.x - n_conv;
     hd_wg8::wgrad3x3_w8_body(q, lds, w % wg_gx, w / wg_gx);
   }
 }
 
-template <int TH, int WN, int WK>
+template <int TH, int WN, int WK, bool TS = false>
 void launch_p8_wgrad(ConvP& p, const hd_wg8::Wg8P& q, int wg_gx, int wg_gy, hipStream_t s) {
   p.gm = p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW);
   p.gn = hd_cdiv(p.Cout, WN * 64);
   const int n_conv = p.gm * p.gn;
-  hipLaunchKernelGGL((conv3x3_w8_wgrad_kernel<TH, WN, WK>), dim3(n_conv + wg_gx * wg_gy), dim3(512), 0, s, p, q, n_conv, wg_gx);
+  hipLaunchKernelGGL((conv3x3_w8_wgrad_kernel<TH, WN, WK, TS>), dim3(n_conv + wg_gx * wg_gy), dim3(512), 0, s, p, q, n_conv, wg_gx);
 }
 
-template <int TH, int WN, int WK>
+template <int TH, int WN, int WK, bool TS = false>
 void launch_p8(ConvP& p, hipStream_t s) {
   p.gm = p.N * hd_cdiv(p.Ho, TH) * hd_cdiv(p.Wo, TW);
   p.gn = hd_cdiv(p.Cout, WN * 64);
   dim3 grid(p.gm * p.gn);
-  if (p.x2) hipLaunchKernelGGL((conv3x3_w8_kernel<TH, WN, WK, true>), grid, dim3(512), 0, s, p);
-  else hipLaunchKernelGGL((conv3x3_w8_kernel<TH, WN, WK, false>), grid, dim3(512), 0, s, p);
+  if (p.x2) hipLaunchKernelGGL((conv3x3_w8_kernel<TH, WN, WK, true, TS>), grid, dim3(512), 0, s, p);
+  else hipLaunchKernelGGL((conv3x3_w8_kernel<TH, WN, WK, false, TS>), grid, dim3(512), 0, s, p);
 }
 
 }  // namespace
@@ -603,9 +711,9 @@ bool hd_conv_p8_pool2_ok(const ConvP& p) {
          p.pool2 > 0 && (p.pool2 % 128) == 0 && p.pool2 <= p.Cout && ((p.Cout - p.pool2) % 8) == 0 && (p.pool2 == p.Cout || p.y2 != nullptr);
 }
 
-// cfg: 0 256x128 | 1 128x128 (WK 2) | 2 256x64 (WK 2) | 3 128x64 (WK 4)
+// cfg & 3: 0 256x128 | 1 128x128 (WK 2) | 2 256x64 (WK 2) | 3 128x64 (WK 4);  cfg & 4: the step-split main loop (TS) of tiles 1-3
 int hd_conv_p8_tiles(const ConvP& p, int cfg) {
-  const int th = (cfg == 0 || cfg == 2) ? 32 : 16;
+  const int th = ((cfg & 3) == 0 || (cfg & 3) == 2) ? 32 : 16;
   return p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, TW);
 }
 
@@ -615,18 +723,24 @@ void hd_conv_launch_p8_wgrad(ConvP& p, int cfg, const hd_wgrad_args* wa, hipStre
   int gx, gy;
   hd_wg8::fill_params(wa, q, &gx, &gy);
   switch (cfg) {
-    case 0: launch_p8_wgrad<32, 2, 1>(p, q, gx, gy, s); break;
+    case 0: case 4: launch_p8_wgrad<32, 2, 1>(p, q, gx, gy, s); break;
     case 1: launch_p8_wgrad<16, 2, 2>(p, q, gx, gy, s); break;
     case 2: launch_p8_wgrad<32, 1, 2>(p, q, gx, gy, s); break;
-    default: launch_p8_wgrad<16, 1, 4>(p, q, gx, gy, s); break;
+    case 3: launch_p8_wgrad<16, 1, 4>(p, q, gx, gy, s); break;
+    case 5: launch_p8_wgrad<16, 2, 2, true>(p, q, gx, gy, s); break;
+    case 6: launch_p8_wgrad<32, 1, 2, true>(p, q, gx, gy, s); break;
+    default: launch_p8_wgrad<16, 1, 4, true>(p, q, gx, gy, s); break;
   }
 }
 
 void hd_conv_launch_p8(ConvP& p, int cfg, hipStream_t s) {
   switch (cfg) {
-    case 0: launch_p8<32, 2, 1>(p, s); break;
+    case 0: case 4: launch_p8<32, 2, 1>(p, s); break;
     case 1: launch_p8<16, 2, 2>(p, s); break;
     case 2: launch_p8<32, 1, 2>(p, s); break;
-    default: launch_p8<16, 1, 4>(p, s); break;
+    case 3: launch_p8<16, 1, 4>(p, s); break;
+    case 5: launch_p8<16, 2, 2, true>(p, s); break;
+    case 6: launch_p8<32, 1, 2, true>(p, s); break;
+    default: launch_p8<16, 1, 4, true>(p, s); break;
   }
 }

@@ -164,7 +164,13 @@ static int choose_p8(const ConvP& p) {
   if (!on || !hd_conv_p8_eligible(p)) return -1;
   if (p.Cout < 128 && !p.x2) return -1;                     // 64 -> 64 layers: the 4-wave family's 2-3 blocks per CU win
   static const int th[4] = {32, 16, 32, 16}, bn[4] = {128, 128, 64, 64};
-  static const double step[4] = {1270., 790., 800., 540.}, fixed[4] = {11500., 8000., 9000., 7000.};
+  // HD_W8_TS: the step-split main loop (conv3x3_w8.hip, TS) -- 1 (default): for the 128 x 64 tile, whose sub-step split prefetched only
+  // two 540-clock steps ahead (the 512-channel layers waited on their weights: 16x20x512 26.7 -> 21.2 us); 2: for every WK >= 2 tile
+  // (measured equal or slower on the 128-wide tiles: twice the DMA issue per LOAD phase, profiles/r05_probe_w8_ts.txt); 0: off
+  static const int ts = env_int("HD_W8_TS", 1);
+  static const double step_ss[4] = {1270., 790., 800., 540.}, step_ts[4] = {1270., 790., 860., 450.}, fixed[4] = {11500., 8000., 9000., 7000.};
+  double step[4];
+  for (int c = 0; c < 4; ++c) step[c] = ((ts >= 2 && c >= 1) || (ts == 1 && c == 3)) ? step_ts[c] : step_ss[c];
   const int nk = p.nchunks / 8;
   int best = -1;
   double best_t = 1e30;
@@ -183,7 +189,7 @@ static int choose_p8(const ConvP& p) {
       best = c;
     }
   }
-  return best;
+  return ((ts >= 2 && best >= 1) || (ts == 1 && best == 3)) ? best + 4 : best;
 }
 
 struct TileChoice {
@@ -192,12 +198,13 @@ struct TileChoice {
   int p8cfg;             // p8cfg >= 0: the 8-wave input-patch family (conv3x3_w8.hip) with that tile id
 };
 
-// tuning hook of the 8-wave patch-staged family (tools/tune_w8.py): cfg -1 = cost model, -2 = never, 10..13 = force that tile
+// tuning hook of the 8-wave patch-staged family (tools/tune_w8.py): cfg -1 = cost model, -2 = never, 10..13 = force that tile, 15..17 = force
+// the step-split main loop (TS) of tiles 11..13
 // wherever the family is eligible
 static int g_w8_cfg = -1;
 extern "C" int hd_conv_tune_w8(int cfg, int nslices) {
   (void)nslices;
-  HD_CHECK_ARG(cfg == -1 || cfg == -2 || (cfg >= 10 && cfg <= 13), "hd_conv_tune_w8: cfg in {-1, -2, 10..13}");
+  HD_CHECK_ARG(cfg == -1 || cfg == -2 || (cfg >= 10 && cfg <= 13) || (cfg >= 15 && cfg <= 17), "hd_conv_tune_w8: cfg in {-1, -2, 10..13, 15..17}");
   g_w8_cfg = cfg;
   return HD_OK;
 }
