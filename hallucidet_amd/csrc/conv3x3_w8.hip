@@ -20,6 +20,12 @@
 //   * decoder convs gather the patch from two sources in place: channels < C1 from the nearest-2x upsampled low-resolution
 //     tensor (pixel (y>>1, x>>1)), the rest from the skip tensor (reference: decoders/unet/decoder.py:38-41);
 //   * K order: channel chunk (outer) x tap (inner); the patch of chunk c+1 is fetched during taps 1-6 of chunk c.
+//   * TS (round 5, the 128 x 64 tile): the two ping-pong groups take ALTERNATE K steps instead of halves of every step, 6-deep weight
+//     ring, weights requested two ROUNDS (four steps) ahead.  tools/w8_trace.py: the sub-step split of that tile requested its weights
+//     two 540-clock steps ahead -- less than an L2 / Infinity-Cache round trip, so the 512-channel layers (4.7 MB of weights) sat in
+//     s_waitcnt vmcnt; with the step split 16x20x512 runs 26.7 -> 21.2 us.  On the 128-wide tiles the step split measures equal or
+//     slower (the LOAD phase issues two steps' DMA pieces and becomes as long as the 16-MFMA phase: 779 -> 788 clocks per step), so
+//     they keep the sub-step split (HD_W8_TS=2 forces it everywhere; profiles/r05_probe_w8_ts.txt).
 #include "hd_common.h"
 #include "conv_params.h"
 #include "wgrad3x3_w8_body.h"

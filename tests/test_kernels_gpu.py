@@ -105,14 +105,16 @@ W8_CASES = [
     (2, 16, 20, 64, 0, 128, 3, 2, 1, False, 1, True, False, False),    # stride 2 (im2col family only)
     (1, 7, 7, 256, 0, 256, 7, 1, 0, False, 1, True, False, False),     # fc6-like 7x7 valid
     (2, 24, 24, 24, 0, 64, 3, 1, 1, False, 0, False, False, False),    # Cin % 64 != 0: per-lane taps (im2col family only)
+    (1, 18, 22, 320, 0, 136, 3, 1, 1, False, 0, False, True, False),   # 5 chunks: two whole periods + the odd-chunk tail of the step-split loop
+    (1, 16, 20, 512, 0, 128, 3, 1, 1, False, 1, True, False, False),   # 8 chunks = 72 K steps: the layer the step split was built for
 ]
 
 
-@pytest.mark.parametrize("cfg", [10, 11, 12, 13])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 15, 16, 17])
 def test_conv2d_eight_wave_families(dev, cfg):
-    """Every tile of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip: cfg 10-13), forced through hd_conv_tune_w8 wherever it is
-    eligible (the other cases fall through to the 4-wave family), against the oracle: outputs, BN partial sums per tile, bias /
-    residual / ReLU-mask / ReLU."""
+    """Every tile of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip: cfg 10-13; 15-17 = the step-split main loop of 11-13, shipped
+    for 13), forced through hd_conv_tune_w8 wherever it is eligible (the other cases fall through to the 4-wave family), against the
+    oracle: outputs, BN partial sums per tile, bias / residual / ReLU-mask / ReLU."""
     from hallucidet_amd import ops, _abi
     lib = _abi.load()
     try:

@@ -151,6 +151,49 @@ def run_gemm8(ops, c, gen):
     return "" if nbad == 0 else "gemm_w8: %d elements off, max err %.4g" % (nbad, emax)
 
 
+def run_w8_tiles(ops, c, gen):
+    """Every tile of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip), sub-step split (10-13) and step split (15-17), forced on the cases
+    the family is eligible for (3x3 / s1 / p1, channel counts of both sources multiples of 64, Cout % 8 == 0): each against ATen."""
+    if c["K"] != 3 or c["stride"] != 1 or c["pad"] != 1 or c["C1"] % 64 or c["C2"] % 64 or c["Cout"] % 8 or c["up1"] != bool(c["C2"]):
+        return None
+    from hallucidet_amd import _abi
+    lib = _abi.load()
+    N, H, W, C1, C2, Cout = c["N"], c["H"], c["W"], c["C1"], c["C2"], c["Cout"]
+    Hin, Win = (2 * H, 2 * W) if c["up1"] else (H, W)
+    x = rnd(gen, N, H, W, C1)
+    x2 = rnd(gen, N, Hin, Win, C2) if C2 else None
+    Kt = 9 * (C1 + C2)
+    w = rnd(gen, Cout, Kt, scale=1.0 / math.sqrt(Kt))
+    bias = torch.randn(Cout, generator=gen, device="cuda") if c["bias"] else None
+    res = rnd(gen, N, Hin, Win, Cout) if c["res"] else None
+    w_oihw = w.float().view(Cout, 3, 3, C1 + C2).permute(0, 3, 1, 2).contiguous()
+    pre = F.conv2d(gathered_input(x, x2, c["up1"]), w_oihw, bias, padding=1)
+    if res is not None:
+        pre = pre + nchw(res)
+    want = pre.clamp_min(0) if c["act"] == 1 else torch.sigmoid(pre) if c["act"] == 2 else pre
+    msgs = []
+    try:
+        for cfg in (10, 11, 12, 13, 15, 16, 17):
+            lib.hd_conv_tune_w8(cfg, 1)
+            got, stats = ops.conv2d(x, w, 3, 3, x2=x2, bias=bias, res=res, pad=1, up1=c["up1"], act=c["act"], want_stats=True)
+            torch.cuda.synchronize()
+            nbad, emax = err_of(nchw(got), want, 4e-3, 2e-3 + 1e-3 * (1 if c["res"] or c["bias"] else 0))
+            if nbad:
+                msgs.append("tile %d: %d elements off, max err %.4g" % (cfg, nbad, emax))
+                continue
+            s = stats.sum(dim=0)
+            g32 = got.float() if c["act"] == 0 else pre.permute(0, 2, 3, 1).half().float()
+            w1, w2 = g32.sum(dim=(0, 1, 2)), (g32 * g32).sum(dim=(0, 1, 2))
+            npix = N * Hin * Win
+            if not torch.allclose(s[0], w1, rtol=2e-3, atol=2e-3 * npix ** 0.5 + 1e-2):
+                msgs.append("tile %d: stats sum off by %.4g" % (cfg, float((s[0] - w1).abs().max())))
+            elif not torch.allclose(s[1], w2, rtol=3e-3, atol=1e-2 + 1e-3 * npix ** 0.5):
+                msgs.append("tile %d: stats sum of squares off by %.4g" % (cfg, float((s[1] - w2).abs().max())))
+    finally:
+        lib.hd_conv_tune_w8(-1, 1)
+    return "; ".join(msgs)
+
+
 def run_dgrad(ops, c, gen):
     if c["up1"] or c["C2"]:
         return None
@@ -314,7 +357,7 @@ def main():
     from hallucidet_amd import ops
     torch.backends.cudnn.allow_tf32 = False
     torch.backends.cuda.matmul.allow_tf32 = False
-    t0, fails, ran = time.time(), [], {"forward": 0, "dgrad": 0, "wgrad": 0, "fused": 0, "multi": 0, "consumer_bn": 0, "bstat": 0, "stem_subpixel": 0, "gemm8": 0}
+    t0, fails, ran = time.time(), [], {"forward": 0, "dgrad": 0, "wgrad": 0, "fused": 0, "multi": 0, "consumer_bn": 0, "bstat": 0, "stem_subpixel": 0, "gemm8": 0, "w8_tiles": 0}
     for i in range(args.cases):
         if time.time() - t0 > args.max_seconds:
             break
@@ -324,7 +367,7 @@ def main():
         c = draw_case(r)
         legs = [("forward", lambda: run_forward(ops, c, gen)), ("dgrad", lambda: run_dgrad(ops, c, gen)),
                 ("wgrad", lambda: run_wgrad(ops, c, gen, r)), ("fused", lambda: run_fused(ops, c, gen)),
-                ("gemm8", lambda: run_gemm8(ops, c, gen))]
+                ("gemm8", lambda: run_gemm8(ops, c, gen)), ("w8_tiles", lambda: run_w8_tiles(ops, c, gen))]
         if i % 4 == 0:
             legs.append(("multi", lambda: run_multi(ops, r, gen)))
         if i % 4 == 1:
