@@ -61,6 +61,7 @@ class WgradArgs(C.Structure):
         ("KH", c_i32), ("KW", c_i32), ("stride", c_i32), ("pad", c_i32), ("up1", c_i32),
         ("nsplit", c_i32),
         ("in_scale", vp), ("in_shift", vp), ("in_relu", c_i32), ("reserved0", c_i32),
+        ("dw_oihw", vp), ("dw_scale", c_f), ("reserved1", c_i32),
     ]
 
 
@@ -80,6 +81,8 @@ PROTOTYPES = {
     "hd_gemm_w8_mode": (C.c_int, [C.c_int]),
     "hd_wgrad_w8_blocks": (C.c_int, [C.POINTER(WgradArgs)]),
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),
+    "hd_wgrad_multi": (C.c_int, [C.POINTER(WgradArgs), C.c_int, vp]),
+    "hd_wgrad_direct_ok": (C.c_int, [C.POINTER(WgradArgs)]),
     "hd_conv2d_wgrad": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(WgradArgs), vp]),
     "hd_conv2d_multi": (C.c_int, [C.POINTER(ConvArgs), C.c_int, vp]),
     "hd_wgrad_tune_override": (C.c_int, [C.c_int]),

@@ -587,16 +587,24 @@ extern "C" int hd_wgrad_w8_blocks(const hd_wgrad_args* a) {
   return ((a->C1 + a->C2) / 64) * (a->Cout / 64);
 }
 
+extern "C" int hd_wgrad_direct_ok(const hd_wgrad_args* a) {
+  if (!a || a->nsplit != 1 || a->in_scale) return 0;
+  static const char* env8 = getenv("HD_WGRAD_W8");
+  static const bool w8_on = !(env8 && env8[0] == '0');
+  return (w8_on && g_wg_tm < 0 && !hd_wgrad_small_eligible(a) && hd_wgrad_w8_eligible(a)) ? 1 : 0;
+}
+
 bool hd_wgrad_takes_w8(const hd_wgrad_args* a) {
   static const char* env8 = getenv("HD_WGRAD_W8");
   static const bool w8_on = !(env8 && env8[0] == '0');
-  if (!a || !a->x || !a->dy || !a->slab || a->nsplit < 1 || a->in_scale) return false;
+  if (!a || !a->x || !a->dy || !(a->slab || (a->dw_oihw && a->nsplit == 1)) || a->nsplit < 1 || a->in_scale) return false;
   if (g_wg_tm >= 0 || hd_wgrad_small_eligible(a)) return false;
   return w8_on && hd_wgrad_w8_eligible(a);
 }
 
 extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
-  HD_CHECK_ARG(a && a->x && a->dy && a->slab, "hd_wgrad: null pointer");
+  HD_CHECK_ARG(a && a->x && a->dy && (a->slab || a->dw_oihw), "hd_wgrad: null pointer");
+  HD_CHECK_ARG(!a->dw_oihw || hd_wgrad_direct_ok(a), "hd_wgrad: dw_oihw (direct output) needs nsplit == 1 and the 8-wave 3x3 kernel (hd_wgrad_direct_ok)");
   HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->Cout % 8 == 0, "hd_wgrad: channels must be multiples of 8");
   HD_CHECK_ARG((a->C2 == 0) == (a->x2 == nullptr), "hd_wgrad: x2/C2 mismatch");
   HD_CHECK_ARG(a->nsplit >= 1, "hd_wgrad: nsplit");
@@ -645,6 +653,32 @@ extern "C" int hd_wgrad(const hd_wgrad_args* a, void* stream) {
   if (tm == 128) hipLaunchKernelGGL((wgrad_kernel<128, 2, 2>), grid, dim3(256), 0, s, p);
   else if (tm == 64) hipLaunchKernelGGL((wgrad_kernel<64, 2, 2>), grid, dim3(256), 0, s, p);
   else hipLaunchKernelGGL((wgrad_kernel<32, 1, 4>), grid, dim3(256), 0, s, p);
+  HD_CHECK_LAUNCH();
+  return HD_OK;
+}
+
+// n independent weight gradients; ONE grid when every entry runs in the 8-wave patch-staged kernel (wgrad3x3_w8.hip), else n launches
+void hd_wgrad_w8_launch_multi(const hd_wgrad_args* a, int n, hipStream_t s);
+extern "C" int hd_wgrad_multi(const hd_wgrad_args* args, int n, void* stream) {
+  HD_CHECK_ARG(args && n > 0, "hd_wgrad_multi: bad args");
+  static const char* env = getenv("HD_WGRAD_MULTI");
+  bool one = !(env && env[0] == '0') && n >= 2 && n <= HD_WGRAD_MULTI_MAX;
+  for (int i = 0; i < n; ++i)
+    HD_CHECK_ARG(!args[i].dw_oihw || hd_wgrad_direct_ok(args + i), "hd_wgrad_multi: dw_oihw (direct output) needs nsplit == 1 and the 8-wave 3x3 kernel");
+  for (int i = 0; one && i < n; ++i) one = hd_wgrad_takes_w8(args + i);
+  if (!one) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = hd_wgrad(args + i, stream);
+      if (rc) return rc;
+    }
+    return HD_OK;
+  }
+  for (int i = 0; i < n; ++i) {
+    const hd_wgrad_args* a = args + i;
+    HD_CHECK_ARG(a->C1 > 0 && a->C1 % 8 == 0 && a->C2 % 8 == 0 && a->Cout % 8 == 0 && (a->C2 == 0) == (a->x2 == nullptr) && a->nsplit >= 1,
+                 "hd_wgrad_multi: bad entry");
+  }
+  hd_wgrad_w8_launch_multi(args, n, (hipStream_t)stream);
   HD_CHECK_LAUNCH();
   return HD_OK;
 }

@@ -36,6 +36,8 @@ struct Wg8P {
   const f16* x2;
   const f16* dy;
   float* slab;
+  float* dw;        // direct OIHW output (nsplit == 1) or nullptr
+  float dw_scale;
   int N, Hsrc, Wsrc, H, W, C1, C2, Cin, Cout, Ktot;
   int tiles_x, tiles_y, ntiles, per_split, dual;
   unsigned xbytes, x2bytes, dybytes;
@@ -193,16 +195,30 @@ __device__ __forceinline__ void wgrad3x3_w8_body(const Wg8P& p, f16* lds, int bx
   }
   __syncthreads();
   if (wpx == 0) {
-    float* out = p.slab + (size_t)bx * p.Cout * p.Ktot;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
+    if (p.dw) {
+      // hd_wgrad_args.dw_oihw (one pixel split): this block's sums ARE the gradient of its 64 x 64 x 9 weights.  A lane holds all nine taps
+      // of its (co, ci) pairs -- nine consecutive floats of the OIHW tensor, the 32 lanes of a half-wave 32 consecutive ci: a 1 152-byte run
+      // per co row.  scale * sum as hd_wgrad_reduce forms it for one split (one fp32 multiply of the same sum: same bits).
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float v = acc[t][r] + red[((t * 4 + wt) * 16 + r) * 64 + lane];
         const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int ci = ci0 + wci * 32 + (lane & 31);
-        out[(size_t)co * p.Ktot + t * p.Cin + ci] = v;
+        float* o = p.dw + ((size_t)co * p.Cin + ci) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o[t] = (0.f + (acc[t][r] + red[((t * 4 + wt) * 16 + r) * 64 + lane])) * p.dw_scale;   // (0.f +: the reduction's accumulator start, -0 -> +0)
       }
+    } else {
+      float* out = p.slab + (size_t)bx * p.Cout * p.Ktot;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = acc[t][r] + red[((t * 4 + wt) * 16 + r) * 64 + lane];
+          const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int ci = ci0 + wci * 32 + (lane & 31);
+          out[(size_t)co * p.Ktot + t * p.Cin + ci] = v;
+        }
+    }
   }
 }
 
@@ -210,6 +226,7 @@ __device__ __forceinline__ void wgrad3x3_w8_body(const Wg8P& p, f16* lds, int bx
 // host side: kernel parameters and grid of a launch (grid = (nsplit, ci chunks x co chunks))
 inline void fill_params(const hd_wgrad_args* a, Wg8P& p, int* gx, int* gy) {
   p.x = (const f16*)a->x; p.x2 = (const f16*)a->x2; p.dy = (const f16*)a->dy; p.slab = a->slab;
+  p.dw = a->nsplit == 1 ? a->dw_oihw : nullptr; p.dw_scale = a->dw_scale;
   p.N = a->N; p.Hsrc = a->Hsrc; p.Wsrc = a->Wsrc; p.H = a->Hin; p.W = a->Win; p.C1 = a->C1; p.C2 = a->C2;
   p.Cin = a->C1 + a->C2; p.Cout = a->Cout; p.Ktot = 9 * p.Cin;
   p.tiles_x = hd_cdiv(p.W, TW); p.tiles_y = hd_cdiv(p.H, TH);

@@ -144,9 +144,12 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
     return (y, stats) if want_stats else y
 
 
-def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in_scale=None, in_shift=None, in_relu=True, _defer=None):
+def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in_scale=None, in_shift=None, in_relu=True, _defer=None,
+          dw=None, dw_scale=1.0):
     """Returns fp32 slab [nsplit, Cout, KH*KW*(C1+C2)] of partial weight gradients.  ``in_scale`` / ``in_shift``: as in conv2d
-    (x is the raw output of the producing conv; small-channel 3x3 kernel only)."""
+    (x is the raw output of the producing conv; small-channel 3x3 kernel only).  ``dw`` (fp32 OIHW, with nsplit == 1 where
+    hd_wgrad_direct_ok): the kernel writes dw = dw_scale * gradient itself (== wgrad_reduce of the one slab, bit for bit) and None is
+    returned; where the kernel cannot, the slab is returned and the caller reduces as usual."""
     _need_cuda(x, dy, x2)
     lib = _abi.load()
     N, Hs, Ws, C1 = x.shape
@@ -170,11 +173,18 @@ def wgrad(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, nsplit=None, in
             nsplit = 256          # thin-output kernel on the decoder concat (wgrad3x3_small.hip): 125 KB of LDS, one persistent block per CU
         else:
             nsplit = pick_nsplit(M, Cout, K)
-    slab = torch.empty((nsplit, Cout, K), dtype=torch.float32, device=x.device)
+    direct = False
+    if dw is not None and nsplit == 1 and x.dtype == torch.float16:
+        probe = WgradArgs(ptr(x), ptr(x2), ptr(dy), None, N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad, 1 if up1 else 0, 1,
+                          ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
+        direct = lib.hd_wgrad_direct_ok(C.byref(probe)) == 1
+        if direct:
+            assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == Cout * K
+    slab = None if direct else torch.empty((nsplit, Cout, K), dtype=torch.float32, device=x.device)
     a = WgradArgs(ptr(x), ptr(x2), ptr(dy), ptr(slab), N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
-                  1 if up1 else 0, nsplit, ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
+                  1 if up1 else 0, nsplit, ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0, ptr(dw) if direct else None, float(dw_scale), 0)
     if _defer is not None:
-        _defer.append((a, (x, x2, dy, slab, in_scale, in_shift)))
+        _defer.append((a, (x, x2, dy, slab, in_scale, in_shift, dw)))
     else:
         check(_abi.fn("hd_wgrad", x)(C.byref(a), _stream()), "hd_wgrad")
     return slab
@@ -220,6 +230,42 @@ def conv2d_multi(calls):
     arr = (ConvArgs * len(hold))(*[h[0] for h in hold])
     check(_abi.load().hd_conv2d_multi(arr, len(hold), _stream()), "hd_conv2d_multi")
     return outs
+
+
+WGRAD_MULTI_MAX = 24      # HD_WGRAD_MULTI_MAX
+
+
+def wgrad_w8_blocks(x, dy, KH, KW, *, x2=None, stride=1, pad=0, up1=False, **_):
+    """(Cin / 64) * (Cout / 64) if hd_wgrad routes this problem to the 8-wave patch-staged 3x3 kernel, else 0 (hd_wgrad_w8_blocks)."""
+    if x.dtype != torch.float16:
+        return 0
+    N, Hs, Ws, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    _, Ho, Wo, Cout = dy.shape
+    Hin, Win = (Hs * 2, Ws * 2) if up1 else (Hs, Ws)
+    probe = WgradArgs(ptr(x), ptr(x2), ptr(dy), None, N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad, 1 if up1 else 0, 1)
+    return int(_abi.load().hd_wgrad_w8_blocks(C.byref(probe)))
+
+
+def wgrad_takes_w8(x, dy, KH, KW, **kw):
+    return wgrad_w8_blocks(x, dy, KH, KW, **kw) > 0
+
+
+def wgrad_multi(calls):
+    """calls: [(x, dy, KH, KW, kwargs)] -- the arguments of independent `wgrad` calls -> their slabs; ONE grid per <= 16 calls when all of
+    them run in the 8-wave patch-staged 3x3 kernel (hd_wgrad_multi), else one launch each.  Bit-identical to the separate calls."""
+    if not calls:
+        return []
+    if calls[0][0].dtype == torch.float32:
+        return [wgrad(x, dy, KH, KW, **kw) for x, dy, KH, KW, kw in calls]
+    slabs = []
+    for i in range(0, len(calls), WGRAD_MULTI_MAX):
+        hold = []
+        for x, dy, KH, KW, kw in calls[i:i + WGRAD_MULTI_MAX]:
+            slabs.append(wgrad(x, dy, KH, KW, _defer=hold, **kw))
+        arr = (WgradArgs * len(hold))(*[h[0] for h in hold])
+        check(_abi.load().hd_wgrad_multi(arr, len(hold), _stream()), "hd_wgrad_multi")
+    return slabs
 
 
 def wgrad_dgrad(x, dy, KH, KW, wd, *, x2=None, stride=1, pad=0, up1=False, in_scale=None, in_shift=None, in_relu=True, dgrad=None):

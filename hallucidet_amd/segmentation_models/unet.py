@@ -184,7 +184,39 @@ def initialize_head(module):
 
 
 _WRED_MULTI = os.environ.get("HD_WRED_MULTI", "1") != "0"     # A/B knob: one slab-reduction launch per backward segment
+_WGRAD_DEFER = os.environ.get("HD_WGRAD_DEFER", "1") != "0"   # A/B knob: a backward segment's 8-wave weight gradients as one grid at its end
+_WGRAD_MERGE = os.environ.get("HD_WGRAD_MERGE", "1") != "0"     # A/B knob: without an exchange hook, launch the deferred weight gradients of segments 0-2 / 3-4 together
+_WGRAD_DIRECT = os.environ.get("HD_WGRAD_DIRECT", "1") != "0"   # A/B knob: one-split weight gradients written as the OIHW gradient by the kernel
+_WGRAD_DEFER_BLOCKS = int(os.environ.get("HD_WGRAD_DEFER_BLOCKS", "0"))     # > 0: force that grid size (A/B); 0: simulated schedule
 _POOL2 = os.environ.get("HD_POOL2", "1") != "0"               # A/B knob: 2x2 sum-pool of the last decoder block's data gradient in its epilogue
+
+def _plan_wgrad_splits(geo, cus=256):
+    """Pixel splits of the layers of one multi-layer weight-gradient grid.  geo: [(64 x 64 weight tiles, 16 x 8-pixel tiles)] per layer.
+    A block of layer i walks ceil(t_i / s_i) pixel tiles (~2 us each) after ~9 us of fixed cost and writes a 147 KB partial that the
+    reduction reads back; blocks are dispatched in grid order to the next free CU, one block per CU (147 KB of LDS).  Candidates: a
+    common number of pixel tiles per block for grids of 256 ... 1 024 blocks; the cheapest simulated schedule wins (the deep stages'
+    12 x 16 tiles: 192 blocks of 80 tiles leave a quarter of the chip idle, 768 blocks of 20 run three full rounds of a quarter each)."""
+    import heapq
+    work = float(sum(b * t for b, t in geo))
+    best, best_cost = None, None
+    forced = _WGRAD_DEFER_BLOCKS
+    for target in ((forced,) if forced > 0 else range(192, 1025, 64)):
+        per_block = max(4.0, work / target)
+        ss = [max(1, min(int(t / per_block + 0.5), max(1, t // 4))) for b, t in geo]
+        free = [0.0] * cus
+        heapq.heapify(free)
+        end = 0.0
+        for (b, t), ns in zip(geo, ss):
+            d = 9.0 + 2.0 * ((t + ns - 1) // ns)
+            for _ in range(b * ns):
+                t0 = heapq.heappop(free)
+                heapq.heappush(free, t0 + d)
+                end = max(end, t0 + d)
+        cost = end + 0.0735 * sum(b * ns for (b, t), ns in zip(geo, ss) if ns > 1)      # one split: written as the gradient, no reduction
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = ss, cost
+    return best
+
 
 _ENCODERS = {
     "resnet18": dict(layers=(2, 2, 2, 2), out_channels=(3, 64, 64, 128, 256, 512)),
@@ -271,6 +303,8 @@ class UnetRunner:
         self.bucket_hook = None
         self._cut = None
         self._red = None
+        self._wg_pending = None
+        self._wg_ready = []
         enc, dec = module.encoder, module.decoder
         self.stem = _Unit("encoder.conv1", enc.conv1, enc.bn1)
         self.stages = []
@@ -389,6 +423,13 @@ class UnetRunner:
 
     def _segment_done(self, k):
         """Called by backward() at segment boundary k (0 = decoder + head done, 1..3 = layer4..layer2, 4 = everything)."""
+        if self._wg_pending is not None:
+            # deferred 8-wave weight gradients (see _unit_bwd): with a gradient-exchange hook every segment's are launched here, before its
+            # bucket is handed over; without one they wait for segment 2 (decoder + layer4 + layer3) and 4 (layer2 + layer1): a grid of two
+            # or three stages' layers keeps the chip full where one stage's 192 or 384 equal blocks leave a quarter of it idle
+            self._plan_segment_wgrads()
+            if not _WGRAD_MERGE or self._cut is not None or self.bucket_hook is not None or k in (2, 4):
+                self._launch_wgrads()
         if self._red is not None:
             self._red.flush()                   # the segment's gradients are final only after this launch
         if self._cut is not None:
@@ -637,13 +678,47 @@ class UnetRunner:
             else:
                 hw = (x.shape[1], x.shape[2])
             bstat = self._bstat_of(dx_is_dz_of) if (u.stride == 1 and not r["up1"] and r["x2"] is None) else None
-            slab, dx = ops.wgrad_dgrad(xt, dy, u.k, u.k, wd, dgrad=dict(stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res,
-                                                                        **(dict(bstat=bstat) if bstat is not None else {}),
-                                                                        **(dict(pool2=pool2) if pool2 is not None else {})), **wkw)
+            dkw = dict(stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res,
+                       **(dict(bstat=bstat) if bstat is not None else {}), **(dict(pool2=pool2) if pool2 is not None else {}))
+            if self._wg_pending is not None and isc is None and ops.wgrad_takes_w8(xt, dy, u.k, u.k, **wkw):
+                # the weight gradient waits for the end of the backward segment, where all of the segment's 8-wave weight gradients are ONE
+                # grid (ops.wgrad_multi): a block per 64 x 64 weight tile and LAYER walks that layer's pixel tiles and writes one 147 KB
+                # partial, where 256 blocks per layer wrote 256 -- 1 / 16 ... 1 / 256 of the slab bytes, the per-block fixed cost once.
+                dx = ops.conv2d(dy, wd, u.k, u.k, **dkw)
+                self._wg_pending.append((u, xt, dy, wkw, inv))
+                return dx, dres, (bstat["part"] if bstat is not None else None)
+            slab, dx = ops.wgrad_dgrad(xt, dy, u.k, u.k, wd, dgrad=dkw, **wkw)
         else:
             slab = ops.wgrad(xt, dy, u.k, u.k, **wkw)
         self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
         return dx, dres, (bstat["part"] if bstat is not None else None)
+
+    def _plan_segment_wgrads(self):
+        """Pixel splits for the weight gradients deferred in the segment that just ended -- from THAT segment's layers alone, so a layer's
+        split (and with it the rounding of its gradient) does not depend on how the launches are grouped afterwards."""
+        pend = self._wg_pending
+        if not pend:
+            return
+        self._wg_pending = []
+        geo = []
+        for u, xt, dy, wkw, inv in pend:
+            tiles = dy.shape[0] * ((dy.shape[1] + 15) // 16) * ((dy.shape[2] + 7) // 8)
+            geo.append((ops.wgrad_w8_blocks(xt, dy, u.k, u.k, **wkw), tiles))
+        for item, (b, t), ns in zip(pend, geo, _plan_wgrad_splits(geo)):
+            self._wg_ready.append((item, ns, (t + ns - 1) // ns))
+
+    def _launch_wgrads(self):
+        """The planned weight gradients as one grid per <= 24 layers, longest blocks first.  One pixel split: the kernel writes the scaled
+        OIHW gradient itself (hd_wgrad_args.dw_oihw), no slab, no reduction."""
+        ready, self._wg_ready = self._wg_ready, []
+        ready.sort(key=lambda e: -e[2])
+        for lo in range(0, len(ready), ops.WGRAD_MULTI_MAX):
+            part = ready[lo:lo + ops.WGRAD_MULTI_MAX]
+            calls = [(xt, dy, u.k, u.k, dict(nsplit=ns, **(dict(dw=u.conv.weight.grad, dw_scale=inv) if (ns == 1 and _WGRAD_DIRECT and u.cin_p == u.cin) else {}), **wkw))
+                     for (u, xt, dy, wkw, inv), ns, _ in part]
+            for ((u, xt, dy, wkw, inv), ns, _), slab in zip(part, ops.wgrad_multi(calls)):
+                if slab is not None:
+                    self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
 
     def backward(self, dout, need_dx=False, keep_saved=False):
         sv = self.saved
@@ -654,6 +729,8 @@ class UnetRunner:
         N, H, Wd = sv["shape"]
         hc = self.head_conv
         self._red = ops.WgradReduceBatch() if _WRED_MULTI else None
+        self._wg_pending = [] if (_WGRAD_DEFER and self.act_dtype == torch.float16) else None
+        self._wg_ready = []
         # head: sigmoid' then conv backward
         dl = ops.sigmoid_bwd_nchw_to_nhwc(dout.float(), sv["out"], 8, 1.0, dtype=self.act_dtype)
         db = ops.channel_sum(dl)

@@ -159,8 +159,23 @@ typedef struct hd_wgrad_args {
   const float* in_scale; /* [C1] or NULL */
   const float* in_shift; /* [C1] or NULL */
   int32_t in_relu, reserved0;
+  /* direct output (round 5, appended): with nsplit == 1 the one partial IS the gradient, so where the 8-wave 3x3 kernel takes the problem
+   * (hd_wgrad_direct_ok) it writes dw_oihw[co][ci][kh][kw] = dw_scale * sum itself -- what hd_wgrad_reduce(slab, dw_oihw, 1, ..., dw_scale,
+   * accumulate = 0) would produce, bit for bit -- and `slab` is neither written nor needed (may be NULL).  NULL: the slab, as before. */
+  float* dw_oihw;
+  float dw_scale;
+  int32_t reserved1;
 } hd_wgrad_args;
 int hd_wgrad(const hd_wgrad_args* a, void* stream);
+/* n independent weight gradients (the Conv2d layers of one ResNet stage / one decoder block in the backward pass of
+ * train_hallucidet.py:448-451 -> autograd) as ONE grid when every entry runs in the 8-wave patch-staged 3x3 kernel, n hd_wgrad launches
+ * otherwise.  Results are bit-identical to n hd_wgrad calls with the same nsplit.  With the layers of a stage in one grid, nsplit = 1
+ * (one block per 64 x 64 weight tile and layer) already fills the chip: 1 / 16 ... 1 / 256 of the fp32 slab bytes of per-layer launches.
+ * n <= HD_WGRAD_MULTI_MAX for the single grid. */
+/* 1 if hd_wgrad / hd_wgrad_multi honour args->dw_oihw for this problem (8-wave 3x3 kernel, nsplit == 1, one source or both of a concat) */
+int hd_wgrad_direct_ok(const hd_wgrad_args* a);
+#define HD_WGRAD_MULTI_MAX 24
+int hd_wgrad_multi(const hd_wgrad_args* args, int n, void* stream);
 /* blocks per pixel slice the 8-wave 3x3 weight-gradient kernel uses for this problem ((Cin/64) * (Cout/64)), 0 if hd_wgrad
  * will not route it there: lets the caller choose `nsplit` so that nsplit * blocks fills the GPU */
 int hd_wgrad_w8_blocks(const hd_wgrad_args* a);

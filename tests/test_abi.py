@@ -50,7 +50,7 @@ def test_struct_layout_matches_c(tmp_path):
     import subprocess
     from hallucidet_amd._abi import ConvArgs, WgradArgs
     fields = {"hd_conv_args": (ConvArgs, ["x", "y", "stats", "N", "out_mode", "in_scale", "in_shift", "in_relu", "out_pool2", "bs_y", "bs_z", "bs_mean", "bs_invstd", "bs_gamma", "bs_beta", "bs_relu", "y2"]),
-              "hd_wgrad_args": (WgradArgs, ["x", "slab", "N", "nsplit", "in_scale", "in_shift", "in_relu"])}
+              "hd_wgrad_args": (WgradArgs, ["x", "slab", "N", "nsplit", "in_scale", "in_shift", "in_relu", "dw_oihw", "dw_scale"])}
     src = '#include <stdio.h>\n#include <stddef.h>\n#include "hallucidet_hip.h"\nint main(void) {\n'
     for st, (_, fs) in fields.items():
         src += '  printf("%s %%zu\\n", sizeof(%s));\n' % (st, st)
