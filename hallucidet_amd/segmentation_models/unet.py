@@ -192,23 +192,22 @@ _POOL2 = os.environ.get("HD_POOL2", "1") != "0"               # A/B knob: 2x2 su
 
 def _plan_wgrad_splits(geo, cus=256):
     """Pixel splits of the layers of one multi-layer weight-gradient grid.  geo: [(64 x 64 weight tiles, 16 x 8-pixel tiles)] per layer.
-    A block of layer i walks ceil(t_i / s_i) pixel tiles (~2 us each) after ~9 us of fixed cost and writes a 147 KB partial that the
-    reduction reads back; blocks are dispatched in grid order to the next free CU, one block per CU (147 KB of LDS).  Candidates: a
-    common number of pixel tiles per block for grids of 256 ... 1 024 blocks; the cheapest simulated schedule wins (the deep stages'
-    12 x 16 tiles: 192 blocks of 80 tiles leave a quarter of the chip idle, 768 blocks of 20 run three full rounds of a quarter each)."""
+    A block of layer i walks ceil(t_i / s_i) pixel tiles (~2.3 us each) after ~9 us of fixed cost; with s_i > 1 it writes a 147 KB partial
+    that the reduction reads back (s_i == 1: the kernel writes the gradient itself).  Blocks are dispatched longest first to the next free
+    CU, one block per CU (147 KB of LDS).  Candidates: a common number of pixel tiles per block for grids of 192 ... 1 536 blocks; the
+    cheapest simulated schedule wins."""
     import heapq
     work = float(sum(b * t for b, t in geo))
     best, best_cost = None, None
     forced = _WGRAD_DEFER_BLOCKS
-    for target in ((forced,) if forced > 0 else range(192, 1025, 64)):
+    for target in ((forced,) if forced > 0 else range(192, 1537, 64)):
         per_block = max(4.0, work / target)
         ss = [max(1, min(int(t / per_block + 0.5), max(1, t // 4))) for b, t in geo]
+        blocks = sorted(((9.0 + 2.3 * ((t + ns - 1) // ns), b * ns) for (b, t), ns in zip(geo, ss)), reverse=True)
         free = [0.0] * cus
-        heapq.heapify(free)
         end = 0.0
-        for (b, t), ns in zip(geo, ss):
-            d = 9.0 + 2.0 * ((t + ns - 1) // ns)
-            for _ in range(b * ns):
+        for d, cnt in blocks:
+            for _ in range(cnt):
                 t0 = heapq.heappop(free)
                 heapq.heappush(free, t0 + d)
                 end = max(end, t0 + d)
@@ -303,7 +302,7 @@ class UnetRunner:
         self.bucket_hook = None
         self._cut = None
         self._red = None
-        self._wg_pending = None
+        self._wg_plan = None
         self._wg_ready = []
         enc, dec = module.encoder, module.decoder
         self.stem = _Unit("encoder.conv1", enc.conv1, enc.bn1)
@@ -423,11 +422,10 @@ class UnetRunner:
 
     def _segment_done(self, k):
         """Called by backward() at segment boundary k (0 = decoder + head done, 1..3 = layer4..layer2, 4 = everything)."""
-        if self._wg_pending is not None:
+        if self._wg_ready:
             # deferred 8-wave weight gradients (see _unit_bwd): with a gradient-exchange hook every segment's are launched here, before its
             # bucket is handed over; without one they wait for segment 2 (decoder + layer4 + layer3) and 4 (layer2 + layer1): a grid of two
             # or three stages' layers keeps the chip full where one stage's 192 or 384 equal blocks leave a quarter of it idle
-            self._plan_segment_wgrads()
             if not _WGRAD_MERGE or self._cut is not None or self.bucket_hook is not None or k in (2, 4):
                 self._launch_wgrads()
         if self._red is not None:
@@ -680,12 +678,14 @@ class UnetRunner:
             bstat = self._bstat_of(dx_is_dz_of) if (u.stride == 1 and not r["up1"] and r["x2"] is None) else None
             dkw = dict(stride=1, pad=u.k - 1 - u.pad, in_dil=u.stride, out_hw=hw, cout=u.cin_p, res=dx_res,
                        **(dict(bstat=bstat) if bstat is not None else {}), **(dict(pool2=pool2) if pool2 is not None else {}))
-            if self._wg_pending is not None and isc is None and ops.wgrad_takes_w8(xt, dy, u.k, u.k, **wkw):
+            if self._wg_plan is not None and u.name in self._wg_plan:
                 # the weight gradient waits for the end of the backward segment, where all of the segment's 8-wave weight gradients are ONE
                 # grid (ops.wgrad_multi): a block per 64 x 64 weight tile and LAYER walks that layer's pixel tiles and writes one 147 KB
                 # partial, where 256 blocks per layer wrote 256 -- 1 / 16 ... 1 / 256 of the slab bytes, the per-block fixed cost once.
                 dx = ops.conv2d(dy, wd, u.k, u.k, **dkw)
-                self._wg_pending.append((u, xt, dy, wkw, inv))
+                ns = self._wg_plan[u.name]
+                tiles = dy.shape[0] * ((dy.shape[1] + 15) // 16) * ((dy.shape[2] + 7) // 8)
+                self._wg_ready.append(((u, xt, dy, wkw, inv), ns, (tiles + ns - 1) // ns))
                 return dx, dres, (bstat["part"] if bstat is not None else None)
             slab, dx = ops.wgrad_dgrad(xt, dy, u.k, u.k, wd, dgrad=dkw, **wkw)
         else:
@@ -693,19 +693,30 @@ class UnetRunner:
         self._reduce(slab, u.conv.weight.grad, u.k, u.k, u.cin_p, Cin_real=u.cin, scale=inv)
         return dx, dres, (bstat["part"] if bstat is not None else None)
 
-    def _plan_segment_wgrads(self):
-        """Pixel splits for the weight gradients deferred in the segment that just ended -- from THAT segment's layers alone, so a layer's
-        split (and with it the rounding of its gradient) does not depend on how the launches are grouped afterwards."""
-        pend = self._wg_pending
-        if not pend:
-            return
-        self._wg_pending = []
-        geo = []
-        for u, xt, dy, wkw, inv in pend:
-            tiles = dy.shape[0] * ((dy.shape[1] + 15) // 16) * ((dy.shape[2] + 7) // 8)
-            geo.append((ops.wgrad_w8_blocks(xt, dy, u.k, u.k, **wkw), tiles))
-        for item, (b, t), ns in zip(pend, geo, _plan_wgrad_splits(geo)):
-            self._wg_ready.append((item, ns, (t + ns - 1) // ns))
+    def _plan_wgrads(self):
+        """{unit name: pixel split} for every convolution whose weight gradient the backward pass defers (3x3 / stride 1, >= 64 channels on
+        both sides, materialised operand: the 8-wave kernel's domain), from the saved forward record -- BEFORE the pass, for the two launch
+        groups (segments 0-2: decoder, layer4, layer3; segments 3-4: layer2, layer1) as whole grids, so that a layer's split, and with it
+        the rounding of its gradient, is the same whether the groups are launched whole (no exchange hook) or segment by segment."""
+        rec = self.saved["rec"]
+        seg_units = [[u for d in self.dec for u in d[:2]]] + [[u for (us, ud) in self.stages[si] for u in us + ([ud] if ud is not None else [])] for si in (3, 2, 1, 0)]
+        plan = {}
+        for group in ((0, 1, 2), (3, 4)):
+            names, geo = [], []
+            for k in group:
+                for u in seg_units[k]:
+                    r = rec[u.name]
+                    xt, isc, _, _ = _operand(r["x"])
+                    if isc is not None or u.k != 3 or u.stride != 1:
+                        continue
+                    y = r["y"]
+                    b = ops.wgrad_w8_blocks(xt, y, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"])
+                    if b > 0:
+                        names.append(u.name)
+                        geo.append((b, y.shape[0] * ((y.shape[1] + 15) // 16) * ((y.shape[2] + 7) // 8)))
+            if names:
+                plan.update(zip(names, _plan_wgrad_splits(geo)))
+        return plan
 
     def _launch_wgrads(self):
         """The planned weight gradients as one grid per <= 24 layers, longest blocks first.  One pixel split: the kernel writes the scaled
@@ -729,7 +740,7 @@ class UnetRunner:
         N, H, Wd = sv["shape"]
         hc = self.head_conv
         self._red = ops.WgradReduceBatch() if _WRED_MULTI else None
-        self._wg_pending = [] if (_WGRAD_DEFER and self.act_dtype == torch.float16) else None
+        self._wg_plan = self._plan_wgrads() if (_WGRAD_DEFER and self.act_dtype == torch.float16) else None
         self._wg_ready = []
         # head: sigmoid' then conv backward
         dl = ops.sigmoid_bwd_nchw_to_nhwc(dout.float(), sv["out"], 8, 1.0, dtype=self.act_dtype)
