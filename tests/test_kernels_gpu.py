@@ -1160,6 +1160,65 @@ def test_wgrad_reduce_multi_is_bit_identical_to_separate_reductions():
             assert torch.allclose(a.double(), ref, rtol=1e-4, atol=1e-3 * (ns ** 0.5))
 
 
+def test_wgrad_multi_is_bit_identical_to_separate_launches_and_direct_output_to_the_reduction():
+    """hd_wgrad_multi (the 8-wave 3x3 weight gradients of several layers as one grid) against hd_wgrad per layer with the same pixel
+    split: slabs bit for bit, mixed shapes, a decoder concat, ragged maps, more entries than one grid holds (HD_WGRAD_MULTI_MAX = 24); a
+    list with an entry the 8-wave kernel does not take falls back to separate launches.  hd_wgrad_args.dw_oihw (one pixel split: the
+    kernel writes the scaled OIHW gradient itself) against hd_wgrad + hd_wgrad_reduce bit for bit, and against the fp32 definition."""
+    from hallucidet_amd import ops
+    dev = "cuda"
+    gen = torch.Generator(device=dev).manual_seed(3)
+    r = lambda *sh: (torch.randn(*sh, device=dev, generator=gen) * 0.5).half()
+    # N, H, W, C1, C2 (skip of a concat; C1 then lives at half resolution), Cout, nsplit
+    shapes = [(2, 16, 24, 64, 0, 64, 1), (2, 16, 24, 128, 0, 64, 3), (1, 19, 21, 64, 0, 128, 2), (2, 16, 16, 128, 64, 64, 1), (3, 8, 8, 256, 0, 256, 1),
+              (1, 32, 40, 64, 0, 64, 7)] * 5                     # 30 entries: two grids
+    calls, refs = [], []
+    for N, H, W, C1, C2, Cout, ns in shapes:
+        x = r(N, H // 2 if C2 else H, W // 2 if C2 else W, C1)
+        x2 = r(N, H, W, C2) if C2 else None
+        dy = r(N, H, W, Cout)
+        kw = dict(x2=x2, pad=1, up1=bool(C2), nsplit=ns)
+        assert ops.wgrad_takes_w8(x, dy, 3, 3, x2=x2, pad=1, up1=bool(C2))
+        calls.append((x, dy, 3, 3, kw))
+        refs.append(ops.wgrad(x, dy, 3, 3, **kw))
+    slabs = ops.wgrad_multi(calls)
+    torch.cuda.synchronize()
+    for (sh, a, b) in zip(shapes, refs, slabs):
+        assert a.shape == b.shape and torch.equal(a, b), sh
+    # fallback: a 1x1 entry in the list
+    x1, dy1 = r(2, 8, 8, 64), r(2, 8, 8, 64)
+    mixed = calls[:3] + [(x1, dy1, 1, 1, dict(nsplit=2))]
+    out = ops.wgrad_multi(mixed)
+    torch.cuda.synchronize()
+    assert torch.equal(out[3], ops.wgrad(x1, dy1, 1, 1, nsplit=2)) and all(torch.equal(a, b) for a, b in zip(out[:3], refs[:3]))
+    # direct OIHW output
+    calls_d, outs_d = [], []
+    for (N, H, W, C1, C2, Cout, ns), (x, dy, _, _, kw), slab in zip(shapes[:6], calls[:6], refs[:6]):
+        dw = torch.full((Cout, C1 + C2, 3, 3), 7.0, device=dev)
+        calls_d.append((x, dy, 3, 3, dict(kw, dw=dw, dw_scale=0.37)))
+        outs_d.append(dw)
+    got = ops.wgrad_multi(calls_d)
+    torch.cuda.synchronize()
+    for (N, H, W, C1, C2, Cout, ns), (x, dy, _, _, kw), slab, dw, g in zip(shapes[:6], calls[:6], refs[:6], outs_d, got):
+        want = torch.empty_like(dw)
+        ops.wgrad_reduce(slab, want, 3, 3, C1 + C2, scale=0.37)
+        if ns == 1:
+            assert g is None and torch.equal(dw, want), (N, H, W, C1, C2, Cout)
+            xin = x.float().permute(0, 3, 1, 2)
+            if C2:
+                xin = torch.cat([xin.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3), kw["x2"].float().permute(0, 3, 1, 2)], dim=1)
+            ref = torch.nn.grad.conv2d_weight(xin, (Cout, C1 + C2, 3, 3), dy.float().permute(0, 3, 1, 2), padding=1) * 0.37
+            assert torch.allclose(dw, ref, rtol=2e-3, atol=2e-2), float((dw - ref).abs().max())
+        else:                                  # more than one split: the slab comes back, dw is untouched
+            assert g is not None and torch.equal(g, slab) and bool((dw == 7.0).all())
+    with pytest.raises(Exception, match="dw_oihw"):
+        from hallucidet_amd import _abi
+        import ctypes as C
+        a = _abi.WgradArgs(x1.data_ptr(), None, dy1.data_ptr(), None, 2, 8, 8, 8, 8, 64, 0, 8, 8, 64, 1, 1, 1, 0, 0, 1, None, None, 1, 0,
+                           torch.empty(64, 64, 1, 1, device=dev).data_ptr(), 1.0, 0)
+        ops.check(_abi.load().hd_wgrad(C.byref(a), None), "hd_wgrad")
+
+
 def test_small_grid_conv_is_batch_invariant_and_run_to_run_identical(dev):
     """Image n of a batched launch equals the same image alone, and two runs agree, bit for bit, on a small-grid long-K layer (the
     property an in-launch split-K must keep; a ticketed split-K of the 64-deep family was built against this test, measured
