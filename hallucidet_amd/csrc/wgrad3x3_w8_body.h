@@ -12,11 +12,16 @@
 //     transposing LDS read ds_read_b64_tr_b16 (four pixel rows x 16 channels per 16-lane group); bank swizzle on the DMA source
 //     side: 16-byte slot s of pixel p holds channel group s ^ (4 * ((p >> 1) & 1)), which puts the four pixel rows of a 32-lane
 //     half into the four 64-byte quarters of the 256-byte bank row (conflict-free);
-//   * 8 waves = 2 (co halves) x 2 (ci halves) x 2 (pixel halves of the tile); a wave keeps its nine 32 x 32 fp32 accumulators (144
-//     registers) across the whole tile range, the two pixel halves meet once, in LDS, at the end;
+//   * 8 waves = 2 (ci halves) x 2 (tap groups: taps 0-4 / 5-8) x 2 (pixel halves of the tile); a wave keeps BOTH co halves of its taps
+//     -- ten (eight) 32 x 32 fp32 accumulators, 160 registers -- across the whole tile range, the two pixel halves meet once, in LDS, at
+//     the end.  (Rounds 2-4: 2 co x 2 ci x 2 pixel halves, nine taps per wave: every MFMA needed its own transposed patch fragment, 80
+//     ds_read_b64_tr_b16 per wave and tile, and the kernel ran at the rate of those reads -- 2.3 us per tile, MFMA utilisation 0.26.  With
+//     both co halves in one wave a patch fragment feeds TWO MFMAs: 56 / 48 reads per wave and tile.  Every output element still sums its
+//     pixels in the same order: results are bit-identical to the old decomposition.)
 //   * one fp32 partial per block -> slab[slice][co][tap*Cin + ci], summed by hd_wgrad_reduce (deterministic, as before).
 #pragma once
 #include "hd_common.h"
+#include <type_traits>
 
 namespace hd_wg8 {
 
@@ -65,7 +70,7 @@ constexpr int LDS_HALVES = 2 * STAGE > 9 * 4 * 1024 * 2 ? 2 * STAGE : 9 * 4 * 10
 __device__ __forceinline__ void wgrad3x3_w8_body(const Wg8P& p, f16* lds, int bx, int by) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wco = wave & 1, wci = (wave >> 1) & 1, wpx = wave >> 2;      // co half, ci half, pixel half of the tile
+  const int wci = wave & 1, wpx = (wave >> 1) & 1, wtap = wave >> 2;     // ci half, pixel half of the tile, tap group (waves w and w + 4 share a SIMD: one of each group)
   const int ci_chunks = p.Cin >> 6;
   const int cchunk = by % ci_chunks, ochunk = by / ci_chunks;
   const int ci0 = cchunk * 64, co0 = ochunk * 64;
@@ -122,104 +127,126 @@ __device__ __forceinline__ void wgrad3x3_w8_body(const Wg8P& p, f16* lds, int bx
   //      g & 1; within the group lane 4q+p addresses pixel q (x = q, second read x = q + 4), columns 4p .. 4p+3
   const int li = lane & 15, g = lane >> 4;
   const int tq = li >> 2, tp = li & 3, th = g >> 1, thalf = g & 1;
-  // byte offsets (within a stage) for K step 0 of this wave's pixel half; K step s adds s * 2 rows
-  unsigned ya[2], xa[9][2];
-#pragma unroll
-  for (int r = 0; r < 2; ++r) {
-    const int y = wpx * (TH / 2) + th, x = tq + 4 * r;
-    const int pix = y * 8 + x;
-    const int cb = wco * 64 + thalf * 32 + tp * 8;                 // byte column within the 128-byte dY row (co half, 16-col half, 4-col group)
-    ya[r] = (unsigned)(XSTAGE * 2 + pix * 128 + (((cb >> 4) ^ swz4(pix)) << 4) + (cb & 15));
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int pp = (y + t / 3) * PW + x + t % 3;
-      const int cx = wci * 64 + thalf * 32 + tp * 8;
-      xa[t][r] = (unsigned)(pp * 128 + (((cx >> 4) ^ swz4(pp)) << 4) + (cx & 15));
-    }
-  }
-
-  f32x16 acc[9];
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
   const int t_begin = bx * p.per_split;
   int t_end = t_begin + p.per_split;
   if (t_end > p.ntiles) t_end = p.ntiles;
   const char* lb = reinterpret_cast<const char*>(lds);
+  float* red = reinterpret_cast<float*>(lds);
+  const int wt2 = wci;                       // (co half, ci half) tile index of the final exchange = coh * 2 + wci
 
-  if (t_begin < t_end) issue_tile(t_begin, 0);
-  for (int t = t_begin; t < t_end; ++t) {
-    const int st = (t - t_begin) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();          // tile t landed everywhere; everyone is done with the other stage
-    __builtin_amdgcn_sched_barrier(0);
-    if (t + 1 < t_end) issue_tile(t + 1, st ^ 1);
-    const unsigned sb = (unsigned)(st * STAGE * 2);
-    // K steps of this wave's pixel half: 2 pixel rows (16 pixels) each; row step = 8 dY pixels (1 KiB) / 10 patch pixels (1 280 B)
-    // The 36 MFMAs of a tile (4 K steps x 9 taps) as ONE software-pipelined stream: the patch fragment of MFMA j + RINGW is requested
-    // right after MFMA j is issued, the dY fragment of the next K step while the current one runs.  Written as the plain loop
-    // "read b; mfma" the compiler kept one register set and put s_waitcnt lgkmcnt(0) in front of EVERY MFMA: an LDS round trip
-    // (~120 clocks) per 32 clocks of matrix work -- the 0.25 MFMA utilisation this kernel was measured at in rounds 2 and 3.
-    constexpr int RINGW = 4, NMM = (TH / 4) * 9;
-    f16x8 bq[RINGW], aq[2];
-#define HD_WG8_B(J) tr_pair(lb + sb + xa[(J) % 9][0] + ((J) / 9) * 2560, lb + sb + xa[(J) % 9][1] + ((J) / 9) * 2560)
-#define HD_WG8_A(S) tr_pair(lb + sb + ya[0] + (S) * 2048, lb + sb + ya[1] + (S) * 2048)
-    aq[0] = HD_WG8_A(0);
+  // The tap group is wave-uniform: two instantiations of the same code (T0 = first tap, NT = taps of this wave).
+  auto run = [&](auto t0c, auto ntc) {
+    constexpr int T0 = decltype(t0c)::value, NT = decltype(ntc)::value;
+    // byte offsets (within a stage) for K step 0 of this wave's pixel half; K step s adds s * 2 rows
+    unsigned ya[2][2], xa[NT][2];
 #pragma unroll
-    for (int j = 0; j < RINGW; ++j) bq[j] = HD_WG8_B(j);
+    for (int r = 0; r < 2; ++r) {
+      const int y = wpx * (TH / 2) + th, x = tq + 4 * r;
+      const int pix = y * 8 + x;
 #pragma unroll
-    for (int j = 0; j < NMM; ++j) {
-      const int s = j / 9, tp9 = j % 9;
-      if (tp9 == 0 && s + 1 < TH / 4) aq[(s + 1) & 1] = HD_WG8_A(s + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[tp9] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s & 1], bq[j % RINGW], acc[tp9], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      if (j + RINGW < NMM) bq[j % RINGW] = HD_WG8_B(j + RINGW);
+      for (int coh = 0; coh < 2; ++coh) {
+        const int cb = coh * 64 + thalf * 32 + tp * 8;               // byte column within the 128-byte dY row (co half, 16-col half, 4-col group)
+        ya[coh][r] = (unsigned)(XSTAGE * 2 + pix * 128 + (((cb >> 4) ^ swz4(pix)) << 4) + (cb & 15));
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int tap = T0 + t;
+        const int pp = (y + tap / 3) * PW + x + tap % 3;
+        const int cx = wci * 64 + thalf * 32 + tp * 8;
+        xa[t][r] = (unsigned)(pp * 128 + (((cx >> 4) ^ swz4(pp)) << 4) + (cx & 15));
+      }
     }
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][coh][r] = 0.f;
+
+    if (t_begin < t_end) issue_tile(t_begin, 0);
+    for (int t = t_begin; t < t_end; ++t) {
+      const int st = (t - t_begin) & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();          // tile t landed everywhere; everyone is done with the other stage
+      __builtin_amdgcn_sched_barrier(0);
+      if (t + 1 < t_end) issue_tile(t + 1, st ^ 1);
+      const unsigned sb = (unsigned)(st * STAGE * 2);
+      // K steps of this wave's pixel half: 2 pixel rows (16 pixels) each; row step = 8 dY pixels (1 KiB) / 10 patch pixels (1 280 B).
+      // The 2 * NT * 4 MFMAs of a tile as ONE software-pipelined stream: MFMA pair j = (K step j / NT, tap j % NT) uses patch fragment j
+      // for both co halves; the patch fragment of pair j + RINGW is requested right after pair j is issued, the two dY fragments of the
+      // next K step while the current one runs (written as "read; mfma" the compiler put s_waitcnt lgkmcnt(0) in front of every MFMA).
+      constexpr int RINGW = 4, NPAIR = (TH / 4) * NT;
+      f16x8 bq[RINGW], aq[2][2];
+#define HD_WG8_B(J) tr_pair(lb + sb + xa[(J) % NT][0] + ((J) / NT) * 2560, lb + sb + xa[(J) % NT][1] + ((J) / NT) * 2560)
+#define HD_WG8_A(S, COH) tr_pair(lb + sb + ya[COH][0] + (S) * 2048, lb + sb + ya[COH][1] + (S) * 2048)
+      aq[0][0] = HD_WG8_A(0, 0);
+      aq[0][1] = HD_WG8_A(0, 1);
+#pragma unroll
+      for (int j = 0; j < RINGW; ++j) bq[j] = HD_WG8_B(j);
+#pragma unroll
+      for (int j = 0; j < NPAIR; ++j) {
+        const int s_ = j / NT, tp9 = j % NT;
+        if (tp9 == 0 && s_ + 1 < TH / 4) {
+          aq[(s_ + 1) & 1][0] = HD_WG8_A(s_ + 1, 0);
+          aq[(s_ + 1) & 1][1] = HD_WG8_A(s_ + 1, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[tp9][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s_ & 1][0], bq[j % RINGW], acc[tp9][0], 0, 0, 0);
+        acc[tp9][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s_ & 1][1], bq[j % RINGW], acc[tp9][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + RINGW < NPAIR) bq[j % RINGW] = HD_WG8_B(j + RINGW);
+      }
 #undef HD_WG8_A
 #undef HD_WG8_B
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- the two pixel halves meet in LDS (9 x 4 wave tiles of 32 x 32 fp32 = 147 KiB), then one coalesced slab write
-  float* red = reinterpret_cast<float*>(lds);
-  const int wt = wave & 3;
-  if (wpx == 1) {
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) red[((t * 4 + wt) * 16 + r) * 64 + lane] = acc[t][r];
-  }
-  __syncthreads();
-  if (wpx == 0) {
-    if (p.dw) {
-      // hd_wgrad_args.dw_oihw (one pixel split): this block's sums ARE the gradient of its 64 x 64 x 9 weights.  A lane holds all nine taps
-      // of its (co, ci) pairs -- nine consecutive floats of the OIHW tensor, the 32 lanes of a half-wave 32 consecutive ci: a 1 152-byte run
-      // per co row.  scale * sum as hd_wgrad_reduce forms it for one split (one fp32 multiply of the same sum: same bits).
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int ci = ci0 + wci * 32 + (lane & 31);
-        float* o = p.dw + ((size_t)co * p.Cin + ci) * 9;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) o[t] = (0.f + (acc[t][r] + red[((t * 4 + wt) * 16 + r) * 64 + lane])) * p.dw_scale;   // (0.f +: the reduction's accumulator start, -0 -> +0)
-      }
-    } else {
-      float* out = p.slab + (size_t)bx * p.Cout * p.Ktot;
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = acc[t][r] + red[((t * 4 + wt) * 16 + r) * 64 + lane];
-          const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          const int ci = ci0 + wci * 32 + (lane & 31);
-          out[(size_t)co * p.Ktot + t * p.Cin + ci] = v;
-        }
     }
-  }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- the two pixel halves meet in LDS (9 x 4 tiles of 32 x 32 fp32 = 147 KiB), then one coalesced slab write
+    if (wpx == 1) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[(((T0 + t) * 4 + coh * 2 + wt2) * 16 + r) * 64 + lane] = acc[t][coh][r];
+    }
+    __syncthreads();
+    if (wpx == 0) {
+      if (p.dw) {
+        // hd_wgrad_args.dw_oihw (one pixel split): this block's sums ARE the gradient of its 64 x 64 x 9 weights.  A lane holds NT
+        // consecutive taps of its (co, ci) pairs -- consecutive floats of the OIHW tensor, the 32 lanes of a half-wave 32 consecutive ci.
+        // scale * sum as hd_wgrad_reduce forms it for one split (0.f + sum: the reduction's accumulator start, -0 -> +0; same bits).
+#pragma unroll
+        for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int ci = ci0 + wci * 32 + (lane & 31);
+            float* o = p.dw + ((size_t)co * p.Cin + ci) * 9 + T0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) o[t] = (0.f + (acc[t][coh][r] + red[(((T0 + t) * 4 + coh * 2 + wt2) * 16 + r) * 64 + lane])) * p.dw_scale;
+          }
+      } else {
+        float* out = p.slab + (size_t)bx * p.Cout * p.Ktot;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+          for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float v = acc[t][coh][r] + red[(((T0 + t) * 4 + coh * 2 + wt2) * 16 + r) * 64 + lane];
+              const int co = co0 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+              const int ci = ci0 + wci * 32 + (lane & 31);
+              out[(size_t)co * p.Ktot + (T0 + t) * p.Cin + ci] = v;
+            }
+      }
+    }
+  };
+  if (wtap == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});
+  else run(std::integral_constant<int, 5>{}, std::integral_constant<int, 4>{});
 }
 
 
