@@ -123,10 +123,25 @@ def conv_roofline(lit, batch, reps=5, peak=None):
     wrec = []
     orig_wg = ops.wgrad
 
+    wg_flops = lambda x, dy, KH, KW, kw: 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * KH * KW * (x.shape[3] + (0 if kw.get("x2") is None else kw["x2"].shape[3]))
+    in_multi = [False]
+
     def spy_wg(x, dy, KH, KW, **kw):
         out = orig_wg(x, dy, KH, KW, **kw)
-        C2 = 0 if kw.get("x2") is None else kw["x2"].shape[3]
-        wrec.append(((x, dy, KH, KW), {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, 2.0 * dy.shape[0] * dy.shape[1] * dy.shape[2] * dy.shape[3] * KH * KW * (x.shape[3] + C2)))
+        if not in_multi[0]:          # (the entries of a multi-layer grid are recorded as ONE launch below)
+            wrec.append(("one", (x, dy, KH, KW), {k_: v_ for k_, v_ in kw.items() if k_ != "_defer"}, wg_flops(x, dy, KH, KW, kw)))
+        return out
+
+    # several layers' weight gradients as one grid (hd_wgrad_multi: the U-Net backward's deferred 3x3 layers) -- replayed as that one grid
+    orig_wgm = ops.wgrad_multi
+
+    def spy_wgm(calls):
+        in_multi[0] = True
+        try:
+            out = orig_wgm(calls)
+        finally:
+            in_multi[0] = False
+        wrec.append(("multi", calls, None, sum(wg_flops(x, dy, KH, KW, kw) for x, dy, KH, KW, kw in calls)))
         return out
 
     where = ["detector"]
@@ -144,6 +159,7 @@ def conv_roofline(lit, batch, reps=5, peak=None):
     rr.forward, rr.backward = tag(o_fwd), tag(o_bwd)
     ops.conv2d = spy
     ops.wgrad = spy_wg
+    ops.wgrad_multi = spy_wgm
     import hallucidet_amd.models.detection as det_mod
     import hallucidet_amd.segmentation_models.unet as unet_mod
     r = lit.encoder_decoder.runner
@@ -156,6 +172,7 @@ def conv_roofline(lit, batch, reps=5, peak=None):
     finally:
         ops.conv2d = orig
         ops.wgrad = orig_wg
+        ops.wgrad_multi = orig_wgm
         rr.forward, rr.backward = o_fwd, o_bwd
         r.enable_graphs(was)
         lit.use_detector_graph = was_det
@@ -205,7 +222,8 @@ def conv_roofline(lit, batch, reps=5, peak=None):
     conv_call = lambda it: orig(it[1][0], it[1][1], it[1][2], it[1][3], **it[0])
     grp_step = {k: replay([r_ for r_ in rec if r_[4] == k], conv_call) for k in ("unet", "detector")}
     step_conv_ms = replay(rec, conv_call)
-    wg_seq_ms = replay(wrec, lambda it: orig_wg(*it[0], **it[1])) if wrec else 0.0
+    wg_call = lambda it: orig_wgm(it[1]) if it[0] == "multi" else orig_wg(*it[1], **it[2])
+    wg_seq_ms = replay(wrec, wg_call) if wrec else 0.0
     dump = os.environ.get("HD_BENCH_DUMP")
     rows = []
     grp = {"unet": [0.0, 0.0], "detector": [0.0, 0.0]}
@@ -232,16 +250,17 @@ def conv_roofline(lit, batch, reps=5, peak=None):
     iso = tot_fl / (tot_ms * 1e-3) / 1e12
     achieved = tot_fl / (step_conv_ms * 1e-3) / 1e12
     wg_ms = wg_fl = 0.0
-    for (x, dy, KH, KW), kw, fl in wrec:
-        wg_ms += iso_time(lambda: orig_wg(x, dy, KH, KW, **kw))
-        wg_fl += fl
+    for it in wrec:
+        wg_ms += iso_time(lambda: wg_call(it))
+        wg_fl += it[3]
     tf = lambda fl, ms: round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None
     # groups are IN-STEP times (isolated re-timing in *_isolated_ms)
     wg_s = wg_seq_ms
     u_ms, u_fl = grp_step["unet"] + wg_s, grp["unet"][1] + wg_fl
     groups = {
         "unet_conv_fwd_dgrad": {"ms": round(grp_step["unet"], 3), "tflops": tf(grp["unet"][1], grp_step["unet"]), "isolated_ms": round(grp["unet"][0], 3)},
-        "unet_wgrad": {"ms": round(wg_s, 3), "tflops": tf(wg_fl, wg_s), "isolated_ms": round(wg_ms, 3), "kernel": "wgrad_kernel"},
+        "unet_wgrad": {"ms": round(wg_s, 3), "tflops": tf(wg_fl, wg_s), "isolated_ms": round(wg_ms, 3), "kernel": "wgrad3x3_w8_multi_kernel (two multi-layer grids per backward pass) + wgrad_kernel / wgrad3x3_small_kernel",
+                       "launches": len(wrec)},
         "unet_conv_blocks_total": {"ms": round(u_ms, 3), "tflops": tf(u_fl, u_ms), "frac": round(u_fl / (u_ms * 1e-3) / 1e12 / PEAK, 4) if u_ms else None,
                                    "gflop_per_image": round(u_fl / 1e9 / BATCH_PER_GPU, 1)},
         "detector_conv": {"ms": round(grp_step["detector"], 3), "tflops": tf(grp["detector"][1], grp_step["detector"]), "isolated_ms": round(grp["detector"][0], 3)},
