@@ -16,7 +16,7 @@ import glob
 import json
 import sys
 
-FAMILIES = ["conv_igemm_kernel", "gemm_w8_kernel", "conv3x3_w8_kernel", "conv3x3_c64_kernel", "conv7x7s2_stem_kernel", "conv3x3_c32to128_kernel", "conv3x3_cat128to32_kernel", "conv3x3_small_kernel", "wgrad3x3_w8_kernel", "wgrad_kernel", "wgrad3x3_small_kernel"]
+FAMILIES = ["conv_igemm_kernel", "gemm_w8_kernel", "conv3x3_w8_kernel", "conv3x3_c64_kernel", "conv7x7s2_stem_kernel", "conv3x3_c32to128_kernel", "conv3x3_cat128to32_kernel", "conv3x3_small_kernel", "wgrad3x3_w8_multi_kernel", "wgrad3x3_w8_kernel", "wgrad_kernel", "wgrad3x3_small_kernel"]
 
 
 def load(d):
