@@ -201,3 +201,20 @@ def test_reduce_lr_on_plateau_drives_the_fused_optimizer_lr():
     lrs = [lit.lr_scheduler_step(1.0) for _ in range(12)]
     assert lrs[0] == 1e-4 and abs(lrs[-1] - 1e-5) < 1e-12          # patience 10 exceeded -> x0.1
     assert lit.lr_scheduler_step(0.5) == lrs[-1]
+
+
+def test_weight_gradient_split_planner_properties():
+    """unet._plan_wgrad_splits (host side of the deferred multi-layer weight-gradient grids): deterministic, every split within
+    [1, tiles // 4], the deep stages (many 64 x 64 weight tiles per layer) get ONE split, the shallow ones enough splits to fill the chip,
+    and the simulated grid is never smaller than ~3/4 of the chip for a whole stage."""
+    from hallucidet_amd.segmentation_models.unet import _plan_wgrad_splits
+    g0 = [(48, 80), (16, 80), (12, 320), (4, 320), (3, 1280), (1, 1280)] + [(64, 24)] * 6 + [(16, 80)] * 12      # decoder + layer4 + layer3 of resnet34 at 8 x 512 x 640
+    g1 = [(4, 320)] * 8 + [(1, 1280)] * 6                                                                          # layer2 + layer1
+    for geo in (g0, g1, [(16, 80)] * 12, [(1, 5)], [(2, 3), (1, 1)]):
+        ss = _plan_wgrad_splits(geo)
+        assert ss == _plan_wgrad_splits(list(geo)) and len(ss) == len(geo)
+        for (b, t), s in zip(geo, ss):
+            assert 1 <= s <= max(1, t // 4), (b, t, s)
+    s0, s1 = _plan_wgrad_splits(g0), _plan_wgrad_splits(g1)
+    assert all(s == 1 for s in s0[6:]), s0                       # layer4 / layer3: one block per weight tile and layer, gradient written directly
+    assert sum(b * s for (b, t), s in zip(g1, s1)) >= 192 and min(s1) > 1, s1

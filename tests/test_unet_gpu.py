@@ -365,3 +365,51 @@ def test_backward_sums_from_epilogues_equal_the_separate_reductions(dev):
     d1 = float((x0 - x1).norm() / x0.norm())
     print("first fused unit (decoder block 2, conv1): dbeta rel-L2 %.2e" % d1)
     assert d1 <= 1e-5
+
+
+def test_deferred_multi_layer_weight_gradients_equal_the_per_layer_launches(dev):
+    """Round 5: the 8-wave weight gradients of a backward segment run as ONE multi-layer grid at its end (hd_wgrad_multi; one pixel split
+    for the deep stages, written as the OIHW gradient by the kernel) instead of one grid per layer behind that layer's data gradient.
+    The data-gradient chain is untouched: every BatchNorm gradient and every non-deferred weight gradient is bit-identical; a deferred
+    layer's weight gradient differs by the grouping of its fp32 pixel sum only.  With and without an exchange hook (per-segment launches
+    vs two groups) the gradients are bit-identical (splits are planned before the pass)."""
+    import hallucidet_amd.segmentation_models.unet as unet_mod
+    net, _ = _pair(dev, seed=7)
+    net.train()
+    x = torch.rand(4, 3, 256, 320, device=dev)
+    g = torch.randn(4, 3, 256, 320, generator=torch.Generator().manual_seed(8)).to(dev) * 1e-3
+    r = net.runner
+    r.enable_graphs(False)
+    bufs = {k: v.clone() for k, v in net.state_dict().items()}
+    was = unet_mod._WGRAD_DEFER
+    named, hooks_seen = {}, []
+    try:
+        for mode in ("per_layer", "deferred", "deferred_hook"):
+            net.load_state_dict(bufs)
+            unet_mod._WGRAD_DEFER = mode != "per_layer"
+            r.bucket_hook = (lambda lo, hi: hooks_seen.append((lo, hi))) if mode == "deferred_hook" else None
+            r.grad_scale = 256.0
+            for p_ in net.parameters():
+                p_.grad = None
+            net(x).backward(g * 256.0)
+            torch.cuda.synchronize()
+            named[mode] = {n_: p_.grad.detach().clone() for n_, p_ in net.named_parameters()}
+    finally:
+        unet_mod._WGRAD_DEFER = was
+        r.bucket_hook = None
+    assert len(hooks_seen) == 5
+    deferred = {n_ for n_ in named["deferred"] if n_.endswith(".weight") and named["deferred"][n_].dim() == 4 and
+                not torch.equal(named["deferred"][n_], named["per_layer"][n_])}
+    print("%d conv weight gradients differ between the schedules" % len(deferred))
+    assert 20 <= len(deferred) <= 40                      # resnet34: 30 encoder + 8 decoder 3x3 layers with >= 64 channels on both sides
+    worst = 0.0
+    for n_, a in named["per_layer"].items():
+        b = named["deferred"][n_]
+        assert torch.equal(named["deferred_hook"][n_], b), n_                 # launch grouping does not change a bit
+        if n_ in deferred:
+            rel = float((a.double() - b.double()).norm() / a.double().norm())
+            worst = max(worst, rel)
+            assert rel <= 2e-6, (n_, rel)
+        else:
+            assert torch.equal(a, b), n_
+    print("deferred vs per-layer weight gradients: worst rel-L2 %.2e" % worst)
