@@ -1,3 +1,6 @@
+"""Durations of the multi-layer weight-gradient grids (M) and slab reductions (R) of ONE steady-state training step, in launch order,
+from a rocprofv3 --kernel-trace CSV of tools/bench_step.py.
+    python tools/list_wgrad_launches.py <kernel_trace.csv>"""
 import csv, sys
 rows=[]
 for r in csv.DictReader(open(sys.argv[1])):
