@@ -85,6 +85,15 @@ def _cpu_model():
     return "unknown CPU"
 
 
+def _flush_c_stdio():
+    """fflush(NULL): text that native libraries (RCCL's banner) wrote through C stdio leaves the process now, not after our JSON line."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def conv_roofline(lit, batch, reps=5, peak=None):
     """Record every hd_conv2d launch of one (eager) training step, then time the recorded launches back to back."""
     import ctypes as C
@@ -639,10 +648,12 @@ def main():
             out["roofline"] = conv_roofline(lit, batch, peak=MFMA_F32_PEAK_TFLOPS if args.precision == 32 else None)
         if world == 1 and not args.no_cpu_baseline and not args.config:
             out["cpu_baseline"] = cpu_baseline(args.cpu_protocol)
+        _flush_c_stdio()               # RCCL's version banner sits in C stdio's buffer when stdout is a pipe: out with it BEFORE the line
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()                 # ranks > 0 wait here while rank 0 finishes its roofline / baseline legs
         dist.destroy_process_group()
+    _flush_c_stdio()
 
 
 if __name__ == "__main__":

@@ -185,6 +185,7 @@ def initialize_head(module):
 
 _WRED_MULTI = os.environ.get("HD_WRED_MULTI", "1") != "0"     # A/B knob: one slab-reduction launch per backward segment
 _WGRAD_DEFER = os.environ.get("HD_WGRAD_DEFER", "1") != "0"   # A/B knob: a backward segment's 8-wave weight gradients as one grid at its end
+_EXCHANGE_BUCKETS = 2 if os.environ.get("HD_EXCHANGE_BUCKETS", "2") != "5" else 5     # gradient-exchange buckets / backward graphs with a hook: 2 (default) or 5 (one per segment)
 _WGRAD_MERGE = os.environ.get("HD_WGRAD_MERGE", "1") != "0"     # A/B knob: without an exchange hook, launch the deferred weight gradients of segments 0-2 / 3-4 together
 _WGRAD_DIRECT = os.environ.get("HD_WGRAD_DIRECT", "1") != "0"   # A/B knob: one-split weight gradients written as the OIHW gradient by the kernel
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("HD_WGRAD_DEFER_BLOCKS", "0"))     # > 0: force that grid size (A/B); 0: simulated schedule
@@ -405,7 +406,12 @@ class UnetRunner:
         total = self._gflat.numel()
         first = lambda mod: min(off[id(p)] for p in mod.parameters())
         enc = self.module.encoder
-        cuts = [first(self.module.decoder)] + [first(getattr(enc, "layer%d" % li)) for li in (4, 3, 2)] + [0]
+        if _EXCHANGE_BUCKETS == 2:
+            # two buckets (round 5): decoder + layer4 + layer3 (94 % of a resnet34 U-Net's parameters, final after 60 % of the pass) and
+            # the rest -- the boundaries at which the deferred weight gradients are launched as whole groups (_segment_done)
+            cuts = [first(enc.layer3), 0]
+        else:
+            cuts = [first(self.module.decoder)] + [first(getattr(enc, "layer%d" % li)) for li in (4, 3, 2)] + [0]
         out, hi = [], total
         for lo in cuts:
             out.append((lo, hi))
@@ -421,19 +427,24 @@ class UnetRunner:
             self._red.add(slab, dw, KH, KW, Cin, **kw)
 
     def _segment_done(self, k):
-        """Called by backward() at segment boundary k (0 = decoder + head done, 1..3 = layer4..layer2, 4 = everything)."""
-        if self._wg_ready:
-            # deferred 8-wave weight gradients (see _unit_bwd): with a gradient-exchange hook every segment's are launched here, before its
-            # bucket is handed over; without one they wait for segment 2 (decoder + layer4 + layer3) and 4 (layer2 + layer1): a grid of two
-            # or three stages' layers keeps the chip full where one stage's 192 or 384 equal blocks leave a quarter of it idle
-            if not _WGRAD_MERGE or self._cut is not None or self.bucket_hook is not None or k in (2, 4):
-                self._launch_wgrads()
-        if self._red is not None:
+        """Called by backward() at segment boundary k (0 = decoder + head done, 1..3 = layer4..layer2, 4 = everything).
+        Deferred 8-wave weight gradients (see _unit_bwd) are launched as two groups, after segment 2 (decoder + layer4 + layer3) and
+        after segment 4 (layer2 + layer1): a grid of three stages' layers keeps the chip full where one stage's 192 or 384 equal blocks
+        leave a quarter of it idle.  A gradient-exchange hook sees the same two boundaries (HD_EXCHANGE_BUCKETS=2: bucket_ranges() has two
+        entries, the backward pass is two hipGraphs); HD_EXCHANGE_BUCKETS=5: one bucket, one launch group and one graph per segment."""
+        hooked = self._cut is not None or self.bucket_hook is not None
+        per_segment = (hooked and _EXCHANGE_BUCKETS != 2) or not _WGRAD_MERGE
+        act = per_segment or k in (2, 4)
+        if self._wg_ready and act:
+            self._launch_wgrads()
+        if self._red is not None and (act or not hooked):
             self._red.flush()                   # the segment's gradients are final only after this launch
+        if not hooked or (_EXCHANGE_BUCKETS == 2 and k not in (2, 4)):
+            return
         if self._cut is not None:
-            self._cut(k)
-        elif self.bucket_hook is not None:
-            self.bucket_hook(*self.bucket_ranges()[k])
+            self._cut(k)                        # (graph capture: a new graph begins behind every boundary but the last)
+        else:
+            self.bucket_hook(*self.bucket_ranges()[(0 if k == 2 else 1) if _EXCHANGE_BUCKETS == 2 else k])
 
     def run_backward(self, dout):
         if not self.use_graphs:

@@ -343,7 +343,7 @@ def test_overlapped_allreduce_buckets_rccl_world1(dev):
             results.append((float(loss), r.flat_grads.clone(), r.flat_params.clone(), list(lit.averager.issued), r.bucket_ranges(), r.flat_grads.numel()))
         (l0, g0, p0, issued0, _, n), (l1, g1, p1, issued1, ranges, _) = results
         assert l0 == l1 and torch.equal(g0, g1) and torch.equal(p0, p1)
-        assert issued1[:5] == ranges and ranges[0][1] == n and ranges[-1][0] == 0
+        assert issued1[:len(ranges)] == ranges and ranges[0][1] == n and ranges[-1][0] == 0 and len(ranges) in (2, 5)
         assert all(a[0] == b[1] for a, b in zip(ranges, ranges[1:])), "buckets must tile the arena from its end"
         assert len(issued0) == 4 and sorted(issued0)[0][0] == 0 and sorted(issued0)[-1][1] == n      # no hooks: four equal slices after backward
     finally:

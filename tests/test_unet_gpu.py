@@ -397,7 +397,7 @@ def test_deferred_multi_layer_weight_gradients_equal_the_per_layer_launches(dev)
     finally:
         unet_mod._WGRAD_DEFER = was
         r.bucket_hook = None
-    assert len(hooks_seen) == 5
+    assert hooks_seen == r.bucket_ranges() and len(hooks_seen) in (2, 5)
     deferred = {n_ for n_ in named["deferred"] if n_.endswith(".weight") and named["deferred"][n_].dim() == 4 and
                 not torch.equal(named["deferred"][n_], named["per_layer"][n_])}
     print("%d conv weight gradients differ between the schedules" % len(deferred))
