@@ -391,6 +391,7 @@ def bench_detector_training(args, dev, rank, world):
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
+        _flush_c_stdio()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -487,7 +488,8 @@ def main():
     torch.cuda.set_device(local)
     force_dist = os.environ.get("HD_FORCE_DIST") == "1"      # exercise the RCCL path on one GPU (world size 1)
     if world > 1 or force_dist:
-        os.environ.setdefault("NCCL_DEBUG", "VERSION")           # one line per rank on stderr: which RCCL build answered
+        # (RCCL writes its NCCL_DEBUG=VERSION banner -- five lines per rank, the pool's images export that variable -- to STDOUT through C
+        #  stdio, i.e. at process exit, behind the JSON line: every rank flushes C stdio after the warm-up steps, see _flush_c_stdio)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -546,6 +548,7 @@ def main():
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
+        _flush_c_stdio()               # every rank: RCCL's start-up text (NCCL_DEBUG=VERSION is set on this pool) leaves now, not behind rank 0's line
     torch.cuda.synchronize()
     lit.averager.timing = dist.is_initialized()
     t0 = time.perf_counter()
