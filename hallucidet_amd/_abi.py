@@ -11,6 +11,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # HD_HIP_LIB: load another build of the same ABI (A/B runs of kernel changes, the profiling build); default = the in-tree library
 LIB_PATH = os.environ.get("HD_HIP_LIB") or os.path.join(_HERE, "lib", "libhallucidet_hip.so")
 
+# hd_abi_version() this binding's struct mirrors and prototypes belong to (include/hallucidet_hip.h); load() refuses any other build
+ABI_VERSION = 6
+
 HD_ACT_NONE, HD_ACT_RELU, HD_ACT_SIGMOID = 0, 1, 2
 HD_OUT_NHWC_F16, HD_OUT_NCHW_F32, HD_OUT_NHWC_F32 = 0, 1, 2
 
@@ -200,6 +203,13 @@ def load():
     # the system copy, and torch's copy would then find no device ("no ROCm-capable device is detected" on the first launch).
     import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
+    lib.hd_abi_version.restype = C.c_int
+    got = lib.hd_abi_version()
+    if got != ABI_VERSION:
+        # a library built from other sources reads structs of another size: fail before the first call passes it one
+        raise HipLibraryMissing(
+            "%s reports hd_abi_version() == %d, this binding is written for %d: rebuild it "
+            "(`python hallucidet_amd/build.py --force`)" % (LIB_PATH, got, ABI_VERSION))
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
         fn.restype = res

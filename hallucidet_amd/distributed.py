@@ -4,10 +4,14 @@ over xGMI, gradients of the 24.4 M U-Net parameters only (the detector is frozen
 All parameters and gradients live in ONE flat fp32 arena (UnetRunner.flatten_parameters), so the exchange is a handful of
 large all-reduces over contiguous slices (xGMI is point-to-point, per-link bound: few big messages beat many small ones).
 OVERLAP: the backward pass completes the arena from its end (head + decoder, then layer4 ... layer1 + stem), and the runner
-calls `bucket_ready(lo, hi)` at each of those five boundaries -- the all-reduce of a bucket is issued while the kernels of the
-following encoder stages still run (the 52 MB layer4 bucket is ready after ~35 % of the backward) and `finish()` waits right
-before the optimizer step.  Without hooks `start()` issues the whole arena after backward (4 buckets).  BatchNorm statistics
-stay per rank (the reference has no SyncBatchNorm).  The same code runs on the gloo backend for CPU tests.
+calls `bucket_ready(lo, hi)` at its exchange boundaries -- by default TWO (UnetRunner.bucket_ranges, unet.py): decoder + layer4 +
+layer3 (92 MB, 94 % of the arena, final after ~60 % of the backward pass: its all-reduce runs under layer2 / layer1 / the stem)
+and the rest (5.6 MB, the only exposed part); they are the boundaries at which the deferred weight-gradient grids run, so the
+data-parallel step keeps the single-GPU launch schedule.  HD_EXCHANGE_BUCKETS=5 restores one bucket per backward segment
+(rounds 2-4).  `finish()` waits right before the optimizer step; the division by the world size rides in the fused Adam's
+inverse scale (`exchange_and_step`: no extra pass over the 97.75 MB arena).  Without hooks `start()` issues the whole arena after
+backward (n_buckets slices).  BatchNorm statistics stay per rank (the reference has no SyncBatchNorm).  The same code runs on the
+gloo backend for CPU tests.
 """
 import os
 
@@ -73,11 +77,14 @@ class GradientAverager:
             for o in range(lo, hi, step):
                 self.bucket_ready(o, min(hi, o + step))
 
-    def finish(self, flat_grads):
-        """Wait and divide by the world size (mean gradient, as DDP)."""
+    def finish(self, flat_grads, defer_mean=False):
+        """Wait for the all-reduces; -> the factor that turns the arena's content into the MEAN gradient (DDP semantics).
+        defer_mean=False: the arena is multiplied here and 1.0 is returned.  defer_mean=True: the arena keeps the SUM over ranks
+        and 1 / world is returned -- the caller hands it to the fused optimizer as its inverse scale (`g * inv_scale` is the first
+        thing hd_adam_step computes per element, so the separate read + write of the whole arena is not needed; same products)."""
         work, self._work, self._flat = self._work, [], None
         if not is_dist():
-            return
+            return 1.0
         if self.timing and flat_grads.is_cuda:
             # w.wait() makes the CURRENT stream wait for the collective (the host does not block): the time between two events
             # recorded on that stream around it is the part of the bucket's all-reduce that the backward pass did not hide
@@ -92,7 +99,11 @@ class GradientAverager:
         else:
             for w in work:
                 w.wait()
-        flat_grads.mul_(1.0 / dist.get_world_size())
+        inv = 1.0 / dist.get_world_size()
+        if defer_mean:
+            return inv
+        flat_grads.mul_(inv)
+        return 1.0
 
     def exposed_wait_ms(self):
         """Mean exposed wait per bucket (issue order) over the steps timed so far: [{'bytes', 'ms'}]; call after a synchronize."""
@@ -108,10 +119,11 @@ class GradientAverager:
 
 def exchange_and_step(averager, flat_grads, scaler, optimizer):
     """What follows backward() in a data-parallel training step (EncoderDecoderLit.fit_step): cover the slices no bucket hook
-    reported, wait for every all-reduce, take the mean, then the (replicated) unscale / overflow check / clip / Adam step and the
-    GradScaler update.  Every rank sees the same averaged gradient -- an inf on one rank is an inf on all -- so the skip decision,
-    the loss scale and the parameters stay identical across ranks without any further communication."""
+    reported, wait for every all-reduce, then the (replicated) overflow check / mean (x 1 / world, inside the fused Adam) / clip /
+    Adam step and the GradScaler update.  Every rank sees the same summed gradient -- an inf on one rank is an inf on all -- so the
+    skip decision, the loss scale and the parameters stay identical across ranks without any further communication.  After the
+    call `flat_grads` holds the SUM over ranks (the mean was never written)."""
     averager.start(flat_grads)
-    averager.finish(flat_grads)
-    scaler.step(optimizer)
+    inv = averager.finish(flat_grads, defer_mean=True)
+    scaler.step(optimizer, inv_scale=inv)
     scaler.update()

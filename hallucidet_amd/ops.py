@@ -252,7 +252,7 @@ def wgrad_takes_w8(x, dy, KH, KW, **kw):
 
 
 def wgrad_multi(calls):
-    """calls: [(x, dy, KH, KW, kwargs)] -- the arguments of independent `wgrad` calls -> their slabs; ONE grid per <= 16 calls when all of
+    """calls: [(x, dy, KH, KW, kwargs)] -- the arguments of independent `wgrad` calls -> their slabs; ONE grid per <= 24 calls (HD_WGRAD_MULTI_MAX) when all of
     them run in the 8-wave patch-staged 3x3 kernel (hd_wgrad_multi), else one launch each.  Bit-identical to the separate calls."""
     if not calls:
         return []

@@ -127,11 +127,12 @@ class LossScaler:
         self.runner.grad_scale = self.scale_value
         return loss * self.scale_value
 
-    def step(self, optimizer):
-        """Parameter gradients were already divided by the scale in-kernel; only inf/nan detection remains."""
+    def step(self, optimizer, inv_scale=1.0):
+        """Parameter gradients were already divided by the scale in-kernel; only inf/nan detection remains.  `inv_scale`: a factor
+        the optimizer applies to every gradient element first (1 / world size of a data-parallel SUM exchange)."""
         self.resolve()
         self._optimizer = optimizer
-        optimizer.step(check_inf=self.enabled)
+        optimizer.step(check_inf=self.enabled, inv_scale=inv_scale)
         return optimizer.found_inf
 
     def update(self, found_inf_host=None):

@@ -40,7 +40,8 @@ extern "C" {
 #define HD_OUT_NHWC_F32 2 /* [N][Ho][Wo][Cout] fp32 (any Cout): head outputs whose [N, HWA, C] view must be free */
 
 /* library identity / diagnostics */
-int hd_abi_version(void);
+int hd_abi_version(void); /* 6: struct layouts of this header (hd_conv_args incl. y2 = 224 bytes, hd_wgrad_args incl. dw_oihw / dw_scale); a binding
+                             must refuse a library that reports another number (hallucidet_amd/_abi.py: ABI_VERSION) */
 const char* hd_last_error(void);
 const char* hd_arch(void); /* "gfx950" */
 
@@ -91,7 +92,8 @@ typedef struct hd_conv_args {
    * cat([nearest_2x(a), skip]) (src/segmentation_models/decoders/unet/decoder.py:38-41): the gradient of `a` is the 2 x 2 sum of the
    * upsampled half's gradient (formed in the epilogue in fp32), the skip's gradient is the other half; the concatenated full-resolution
    * gradient is never written and hd_concat_up_bwd is not needed.  Implemented by the small-channel 3x3 kernel (c == Cout, no y2: a
-   * block without a skip) and by the 32 -> 128-channel kernel (c == 64, y2 given); hd_conv2d_pool2_ok says whether a problem
+   * block without a skip), by the 32 -> 128-channel kernel (c == 64, y2 given) and by the 8-wave 3x3 families (c a multiple of 128, or of
+   * 64 on the 160-pixel tile; y2 given unless c == Cout); hd_conv2d_pool2_ok says whether a problem
    * qualifies, other problems -> HD_E_ARG. */
   int32_t out_pool2;
   /* Producer-side sums of a BatchNorm's backward pass (bs_y NULL: off).  The tensor this call writes (y, f16 NHWC) is then the incoming

@@ -40,7 +40,8 @@ def test_ctypes_table_matches_header():
 
 
 def test_identity(lib):
-    assert lib.hd_abi_version() == 5
+    from hallucidet_amd import _abi
+    assert lib.hd_abi_version() == _abi.ABI_VERSION == 6
     assert lib.hd_arch() == b"gfx950"
 
 
@@ -68,6 +69,58 @@ def test_struct_layout_matches_c(tmp_path):
         for f in fs:
             assert int(got["%s.%s" % (st, f)]) == getattr(cls, f).offset, (st, f)
     assert ctypes.sizeof(ConvArgs) == 8 * 8 + 18 * 4 + 2 * 8 + 2 * 4 + 6 * 8 + 2 * 4 + 8 and ConvArgs.N.offset == 64
+
+
+def _gcc_sizeofs(tmp_path, names):
+    import subprocess
+    src = '#include <stdio.h>\n#include "hallucidet_hip.h"\nint main(void) {\n'
+    for st in names:
+        src += '  printf("%s %%zu\\n", sizeof(%s));\n' % (st, st)
+    src += "  return 0;\n}\n"
+    c = tmp_path / "sizes.c"
+    c.write_text(src)
+    exe = str(tmp_path / "sizes")
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), "-o", exe, str(c)], check=True)
+    return {k: int(v) for k, v in (l.split() for l in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.splitlines())}
+
+
+def test_integration_md_structs_match_the_header(tmp_path):
+    """INTEGRATION.md is the document a maintainer pastes from: every ```python block in it that defines a ctypes Structure is
+    executed (the CDLL / torch lines stubbed out) and each Structure's sizeof must equal what gcc lays out for the struct the
+    snippet says it mirrors.  A header change that is not carried into the document fails here (round 5's review: the pasted
+    hd_conv_args was 136 bytes, the header's 224)."""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    blocks = [b for b in re.findall(r"```python\n(.*?)```", text, flags=re.S) if "C.Structure" in b]
+    assert blocks, "INTEGRATION.md no longer shows the ctypes binding"
+    checked = 0
+    for b in blocks:
+        mirrors = dict(re.findall(r"class\s+(\w+)\(C\.Structure\):\s*#\s*mirrors struct (\w+)", b))
+        assert mirrors, "a Structure in INTEGRATION.md does not say which struct it mirrors"
+        ns = {}
+        # keep only the import and the class statements: nothing that opens the library or touches a device
+        code = "import ctypes as C\n"
+        for m in re.finditer(r"^class\s+\w+\(C\.Structure\):.*?(?=^\S)", b, flags=re.S | re.M):
+            code += m.group(0)
+        exec(compile(code, "INTEGRATION.md", "exec"), ns)
+        sizes = _gcc_sizeofs(tmp_path, sorted(set(mirrors.values())))
+        for cls, st in mirrors.items():
+            assert ctypes.sizeof(ns[cls]) == sizes[st], "INTEGRATION.md's %s is %d bytes, %s is %d" % (cls, ctypes.sizeof(ns[cls]), st, sizes[st])
+            checked += 1
+        m = re.search(r"hd_abi_version\(\)\s*==\s*(\d+)", b)
+        if m:
+            from hallucidet_amd import _abi
+            assert int(m.group(1)) == _abi.ABI_VERSION
+    assert checked >= 1
+    from hallucidet_amd._abi import ConvArgs
+    assert [f[0] for f in ns["ConvArgs"]._fields_] == [f[0] for f in ConvArgs._fields_]
+
+
+def test_load_refuses_a_library_of_another_abi_version(monkeypatch, lib):
+    from hallucidet_amd import _abi
+    monkeypatch.setattr(_abi, "_lib", None)
+    monkeypatch.setattr(_abi, "ABI_VERSION", _abi.ABI_VERSION + 1)
+    with pytest.raises(_abi.HipLibraryMissing, match="rebuild"):
+        _abi.load()
 
 
 def test_bad_arguments_return_status_codes(lib):

@@ -82,13 +82,14 @@ def _model_worker(rank, world, port, inject_inf, q):
             self.found_inf.fill_(0.0 if bool(torch.isfinite(grads).all()) else 1.0)
             self.step_count += 1
             if not (check_inf and float(self.found_inf) != 0.0):
-                gg = grads.clamp(-g_["clip_value"], g_["clip_value"])
+                gg = (grads * inv_scale).clamp(-g_["clip_value"], g_["clip_value"])       # hd_adam_step: g * inv_scale first
                 b1, b2 = g_["betas"]
                 self.exp_avg.mul_(b1).add_(gg, alpha=1 - b1)
                 self.exp_avg_sq.mul_(b2).addcmul_(gg, gg, value=1 - b2)
                 mh = self.exp_avg / (1 - b1 ** self.step_count)
                 vh = self.exp_avg_sq / (1 - b2 ** self.step_count)
                 r.flat_params.addcdiv_(mh, vh.sqrt().add_(g_["eps"]), value=-g_["lr"])
+            self.last_inv_scale = inv_scale
             self._inf_host.copy_(self.found_inf)
             self._inf_pending = True
 
@@ -121,14 +122,16 @@ def _model_worker(rank, world, port, inject_inf, q):
     exchange_and_step(av, g, scaler, opt)
     skipped = scaler.resolve()
     q.put((rank, own.numpy().copy(), g.numpy().copy(), start.numpy().copy(), arena.flat_params.detach().numpy().copy(), issued_by_hooks,
-           list(av.issued), bool(skipped), scaler.scale_value, opt.step_count, buf_start.numpy().copy()))
+           list(av.issued), bool(skipped), scaler.scale_value, opt.step_count, buf_start.numpy().copy(), opt.last_inv_scale,
+           opt.exp_avg.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("inject_inf", [False, True])
-def test_model_level_data_parallel_step_world2(inject_inf):
-    world = 2
+@pytest.mark.parametrize("world,inject_inf", [(2, False), (2, True), (4, False), (4, True)])
+def test_model_level_data_parallel_step(world, inject_inf):
+    """World sizes 2 and 4: the bucket cover, the start-up broadcast and the identical end state do not depend on the world size;
+    the mean does (x 1 / world, applied by the optimizer: exchange_and_step leaves the SUM in the arena)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -142,23 +145,31 @@ def test_model_level_data_parallel_step_world2(inject_inf):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    own0, avg0, start0, after0, hooks0, issued0, skip0, scale0, steps0, buf0 = res[0]
-    own1, avg1, start1, after1, hooks1, issued1, skip1, scale1, steps1, buf1 = res[1]
-    n = own0.size
-    assert (start0 == start1).all() and (buf0 == buf1).all(), "ranks must start from rank 0's parameters and BatchNorm buffers"
+    import numpy as np
+    own = [res[r][0] for r in range(world)]
+    summed0, start0, after0, hooks0, issued0 = res[0][1:6]
+    n = own[0].size
+    for r in range(1, world):
+        _, _, start_r, _, hooks_r, _, _, _, _, buf_r = res[r][:10]
+        assert (start0 == start_r).all() and (res[0][9] == buf_r).all(), "ranks must start from rank 0's parameters and BatchNorm buffers"
+        assert hooks0 == hooks_r
     # buckets: hooks fire from the end of the arena, start() adds what they left, together exactly one cover of [0, n)
-    assert hooks0 == hooks1 and [hi for _, hi in hooks0] == sorted([hi for _, hi in hooks0], reverse=True) and hooks0[0][1] == n
+    assert [hi for _, hi in hooks0] == sorted([hi for _, hi in hooks0], reverse=True) and hooks0[0][1] == n
     cover = sorted(issued0)
     assert cover[0][0] == 0 and cover[-1][1] == n and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
-    if not inject_inf:
-        import numpy as np
-        assert np.allclose(avg0, (own0 + own1) / 2, rtol=1e-6, atol=1e-9) and (avg0 == avg1).all(), "averaged gradient != mean of per-rank gradients"
-        assert not skip0 and not skip1 and steps0 == steps1 == 1
-        assert (after0 == after1).all() and not (after0 == start0).all(), "ranks must hold identical, updated parameters after the step"
-    else:
-        assert skip0 and skip1, "an overflow on one rank must skip the step on every rank"
-        assert (after0 == start0).all() and (after1 == start1).all() and steps0 == steps1 == 0
-        assert scale0 == scale1 == 512.0
+    for r in range(world):
+        summed, _, after, _, _, skip, scale, steps, _, inv, m1 = res[r][1:12]
+        assert inv == 1.0 / world, "the optimizer must receive 1 / world as its inverse scale"
+        if not inject_inf:
+            assert np.allclose(summed, sum(own), rtol=1e-6, atol=1e-9) and (summed == summed0).all(), "exchanged gradient != sum of per-rank gradients"
+            # what Adam consumed is the MEAN: its first moment after one step is (1 - beta1) * clip(mean)
+            assert np.allclose(m1, 0.1 * np.clip(sum(own) / world, -0.5, 0.5), rtol=1e-5, atol=1e-9), "the optimizer did not see the mean gradient"
+            assert not skip and steps == 1
+            assert (after == after0).all() and not (after == start0).all(), "ranks must hold identical, updated parameters after the step"
+        else:
+            assert skip, "an overflow on one rank must skip the step on every rank"
+            assert (after == start0).all() and steps == 0
+            assert scale == 512.0
 
 
 def test_single_process_is_a_noop():
