@@ -1573,14 +1573,10 @@ class _FastRCNNLossFn(torch.autograd.Function):
 
 def rpn_loss_from_samples(st, objectness, deltas):
     pos_f, samp_f, n_sampled = st["pos_f"], st["samp_f"], st["n_sampled"]
-    if objectness.is_cuda and objectness.dtype == torch.float32 and deltas.dtype == torch.float32:
-        return _RPNLossFn.apply(objectness, deltas, st["labels"], st["reg_t"], pos_f, samp_f, n_sampled)
-    l1 = F.smooth_l1_loss(deltas, torch.where(pos_f[:, None], st["reg_t"], deltas.detach()), beta=1 / 9, reduction="none").sum(dim=1)
-    denom = n_sampled.clamp(min=1) if torch.is_tensor(n_sampled) else max(n_sampled, 1)
-    box_loss = torch.where(pos_f, l1, torch.zeros_like(l1)).sum() / denom
-    bce = F.binary_cross_entropy_with_logits(objectness.flatten(), st["labels"], reduction="none")
-    obj_loss = torch.where(samp_f, bce, torch.zeros_like(bce)).sum() / denom
-    return obj_loss, box_loss
+    if not (objectness.is_cuda and objectness.dtype == torch.float32 and deltas.dtype == torch.float32):
+        raise RuntimeError("hallucidet_amd: the RPN loss runs in hd_rpn_loss on fp32 CUDA head outputs (got %s %s on %s); there is no CPU path"
+                           % (objectness.dtype, deltas.dtype, objectness.device))
+    return _RPNLossFn.apply(objectness, deltas, st["labels"], st["reg_t"], pos_f, samp_f, n_sampled)
 
 
 def rpn_targets_loss_batched(rpn, anchors0, gt, gvalid, objectness, deltas, n_loss=None):
@@ -1700,37 +1696,29 @@ def postprocess_detections_padded_rois(rh, class_logits, box_regression, rois, p
     return torch.gather(B, 1, pick[:, :, None].expand(-1, -1, 4)), torch.gather(Sx, 1, pick), torch.gather(Lb, 1, pick), counts
 
 
+def _need_cuda_rois(rois):
+    if not rois.is_cuda:
+        raise RuntimeError("hallucidet_amd: RoI pooling runs on the GPU only (RoIs on %s); there is no CPU path" % rois.device)
+
+
 def roi_pool_rois(pool, feats_dict, rois, image_shape, n_images=None):
     feats = [v for k, v in feats_dict.items() if k in pool.featmap_names]
     device = rois.device
     scales = [pool.infer_scale((f.shape[1], f.shape[2]), image_shape) for f in feats]
     k_min, k_max = int(-math.log2(scales[0])), int(-math.log2(scales[-1]))
     rois = rois.float().contiguous()
-    if rois.is_cuda:               # LevelMapper in one launch (was 12)
-        levels = ops.roi_levels(rois, pool.canonical_scale, pool.canonical_level, pool.eps, k_min, k_max)
-    else:
-        b = rois[:, 1:]
-        s = torch.sqrt(box_area(b).float())
-        t = torch.floor(pool.canonical_level + torch.log2(s / pool.canonical_scale) + pool.eps)   # fp32 scalar add, no H2D copy
-        levels = (torch.clamp(t, min=k_min, max=k_max).to(torch.int64) - k_min).to(torch.int32)
+    _need_cuda_rois(rois)
+    levels = ops.roi_levels(rois, pool.canonical_scale, pool.canonical_level, pool.eps, k_min, k_max)      # LevelMapper in one launch
     acts = _active_views(feats, n_images) if (n_images is not None and n_images < feats[0].shape[0]) else None
     return _RoIAlignFn.apply(rois, levels, (scales, pool.output_size[0], pool.sampling_ratio, n_images), len(feats), *feats, *(acts or ()))
 
 
 def fastrcnn_loss_flat(class_logits, box_regression, labels, regression_targets, n_valid=None):
-    if (class_logits.is_cuda and class_logits.dtype == torch.float32 and box_regression.dtype == torch.float32 and class_logits.shape[0] > 0
+    if not (class_logits.is_cuda and class_logits.dtype == torch.float32 and box_regression.dtype == torch.float32 and class_logits.shape[0] > 0
             and box_regression.shape[1] == 4 * class_logits.shape[1]):
-        return _FastRCNNLossFn.apply(class_logits, box_regression, labels, regression_targets, n_valid)
-    if n_valid is not None:
-        raise RuntimeError("hallucidet_amd: the fixed-size RoI stage runs on the GPU only")
-    cls_loss = F.cross_entropy(class_logits, labels)
-    N = class_logits.shape[0]
-    br = box_regression.reshape(N, box_regression.size(-1) // 4, 4)
-    pos = labels > 0
-    picked = torch.gather(br, 1, labels.clamp(min=0)[:, None, None].expand(-1, 1, 4)).squeeze(1)
-    l1 = F.smooth_l1_loss(picked, torch.where(pos[:, None], regression_targets, picked.detach()), beta=1 / 9, reduction="none").sum(dim=1)
-    box_loss = torch.where(pos, l1, torch.zeros_like(l1)).sum()
-    return cls_loss, box_loss / max(labels.numel(), 1)
+        raise RuntimeError("hallucidet_amd: the Fast R-CNN loss runs in hd_fastrcnn_loss on fp32 CUDA predictor outputs with >= 1 RoI "
+                           "(got logits %s %s on %s); there is no CPU path" % (tuple(class_logits.shape), class_logits.dtype, class_logits.device))
+    return _FastRCNNLossFn.apply(class_logits, box_regression, labels, regression_targets, n_valid)
 
 
 def postprocess_detections_flat(rh, class_logits, box_regression, rois, per, image_shape):

@@ -94,23 +94,27 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
             Ho, Wo = conv_out_size(Hin, KH, stride, pad), conv_out_size(Win, KW, stride, pad)
         else:
             Ho, Wo = out_hw
-    if out is not None:
-        y = out
-    elif out_nchw_f32:
-        y = torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    elif out_nhwc_f32:
-        y = torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
-    else:
-        y = torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
-    a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(mask), ptr(y), None,
+    def alloc_y():
+        if out is not None:
+            return out
+        if out_nchw_f32:
+            return torch.empty((N, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        if out_nhwc_f32:
+            return torch.empty((N, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+        return torch.empty((N, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+
+    a = ConvArgs(ptr(x), ptr(x2), ptr(w), ptr(bias), ptr(res), ptr(mask), None, None,
                  N, Hs, Ws, Hin, Win, C1, C2, Ho, Wo, Cout, KH, KW, stride, pad,
                  1 if up1 else 0, in_dil, act, 1 if out_nchw_f32 else (2 if out_nhwc_f32 else 0),
                  ptr(in_scale), ptr(in_shift), 1 if in_relu else 0, 0)
-    y2 = None
+    y, y2 = None, None
     if pool2 is not None:
         pool2["done"] = False
         c_up = int(pool2.get("c_up", Cout))
         if x.dtype == torch.float16 and out is None and not want_stats and bstat is None and Ho % 2 == 0 and Wo % 2 == 0:
+            # the pooled pair is probed BEFORE the full-resolution output exists: where the kernel takes the request that tensor (168 MB
+            # for the last decoder block at 8 x 512 x 640) is exactly what the feature avoids, and under graph capture even an unused
+            # allocation raises the private pool's high-water mark
             yp = torch.empty((N, Ho // 2, Wo // 2, c_up), dtype=x.dtype, device=x.device)
             y2 = torch.empty((N, Ho, Wo, Cout - c_up), dtype=x.dtype, device=x.device) if Cout > c_up else None
             a.out_pool2, a.y, a.y2 = c_up, ptr(yp), ptr(y2)
@@ -118,7 +122,11 @@ def conv2d(x, w, KH, KW, *, x2=None, bias=None, res=None, mask=None, stride=1, p
                 y = yp
                 pool2["done"], pool2["skip"] = True, y2
             else:
-                a.out_pool2, a.y, a.y2, y2 = 0, ptr(y), None, None
+                a.out_pool2, a.y2, y2 = 0, None, None
+                del yp
+    if y is None:
+        y = alloc_y()
+        a.y = ptr(y)
     stats = None
     if bstat is not None:
         bstat["part"] = None

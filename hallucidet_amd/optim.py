@@ -132,7 +132,10 @@ class LossScaler:
         the optimizer applies to every gradient element first (1 / world size of a data-parallel SUM exchange)."""
         self.resolve()
         self._optimizer = optimizer
-        optimizer.step(check_inf=self.enabled, inv_scale=inv_scale)
+        if inv_scale == 1.0:
+            optimizer.step(check_inf=self.enabled)
+        else:
+            optimizer.step(check_inf=self.enabled, inv_scale=inv_scale)
         return optimizer.found_inf
 
     def update(self, found_inf_host=None):

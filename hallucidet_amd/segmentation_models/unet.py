@@ -711,22 +711,38 @@ class UnetRunner:
         the rounding of its gradient, is the same whether the groups are launched whole (no exchange hook) or segment by segment."""
         rec = self.saved["rec"]
         seg_units = [[u for d in self.dec for u in d[:2]]] + [[u for (us, ud) in self.stages[si] for u in us + ([ud] if ud is not None else [])] for si in (3, 2, 1, 0)]
+        # The plan depends on shapes only (operand extents per unit + which operands are materialised): ~40 ctypes probes and a heap
+        # simulation of 22 candidate grids per group cost ~14 ms of host time (more than a whole graphed step), so it is computed once
+        # per geometry -- the eager runner (use_graphs=False, every test that calls net(x).backward) and every re-capture hit the cache.
+        cand = []
+        for k in range(5):
+            for u in seg_units[k]:
+                r = rec[u.name]
+                xt, isc, _, _ = _operand(r["x"])
+                if isc is not None or u.k != 3 or u.stride != 1:
+                    continue
+                cand.append((k, u, r, xt))
+        key = tuple((u.name, tuple(xt.shape), tuple(r["y"].shape), None if r["x2"] is None else tuple(r["x2"].shape), bool(r["up1"]), xt.dtype)
+                    for _, u, r, xt in cand) + (_WGRAD_DEFER_BLOCKS,)
+        cache = self.__dict__.setdefault("_wg_plan_cache", {})
+        if key in cache:
+            return cache[key]
         plan = {}
         for group in ((0, 1, 2), (3, 4)):
             names, geo = [], []
-            for k in group:
-                for u in seg_units[k]:
-                    r = rec[u.name]
-                    xt, isc, _, _ = _operand(r["x"])
-                    if isc is not None or u.k != 3 or u.stride != 1:
-                        continue
-                    y = r["y"]
-                    b = ops.wgrad_w8_blocks(xt, y, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"])
-                    if b > 0:
-                        names.append(u.name)
-                        geo.append((b, y.shape[0] * ((y.shape[1] + 15) // 16) * ((y.shape[2] + 7) // 8)))
+            for k, u, r, xt in cand:
+                if k not in group:
+                    continue
+                y = r["y"]
+                b = ops.wgrad_w8_blocks(xt, y, u.k, u.k, x2=r["x2"], stride=u.stride, pad=u.pad, up1=r["up1"])
+                if b > 0:
+                    names.append(u.name)
+                    geo.append((b, y.shape[0] * ((y.shape[1] + 15) // 16) * ((y.shape[2] + 7) // 8)))
             if names:
                 plan.update(zip(names, _plan_wgrad_splits(geo)))
+        if len(cache) >= 8:
+            cache.pop(next(iter(cache)))
+        cache[key] = plan
         return plan
 
     def _launch_wgrads(self):
