@@ -159,7 +159,7 @@ extern "C" int hd_conv_trace_buffer(void* buf) {
 // tiles cover the feature map well.  Tile choice by a cost model fitted to per-block timelines (tools/w8_trace.py, shader clocks):
 // one block per CU, so a launch costs ceil(blocks / 256) rounds of (fixed + K steps x step), fixed = set-up + first stage +
 // epilogue.  Measured against the per-shape sweep of one training step's 136 launch shapes (tools/tune_w8.py).
-static int choose_p8(const ConvP& p) {
+static int choose_p8(const ConvP& p, bool allow_m160 = true) {
   static const int on = env_int("HD_CONV_P8", 1);
   if (!on || !hd_conv_p8_eligible(p)) return -1;
   if (p.Cout < 128 && !p.x2) return -1;                     // 64 -> 64 layers: the 4-wave family's 2-3 blocks per CU win
@@ -189,7 +189,28 @@ static int choose_p8(const ConvP& p) {
       best = c;
     }
   }
-  return ((ts >= 2 && best >= 1) || (ts == 1 && best == 3)) ? best + 4 : best;
+  best = ((ts >= 2 && best >= 1) || (ts == 1 && best == 3)) ? best + 4 : best;
+  // Round 6: the 160- / 320-pixel x 64-channel tiles (conv3x3_m160.hip, cfg 8 / 9): 4 x 40- and 8 x 40-pixel tiles divide the U-Net's 32x40 /
+  // 64x80 / 128x160 maps exactly, and 10 240 pixels x 256 channels (40 960 x 128) are 256 blocks of 160 (320) pixels where the tiles
+  // above give 160 / 320.  Same model: rounds x (fixed + K steps x step), constants from per-block stamps (tools/w8_trace.py, CFGS=18,19).
+  // HD_CONV_M160=0: off (A/B).
+  static const int m160_on = env_int("HD_CONV_M160", 1);
+  static const double m160_fixed[2] = {(double)env_int("HD_M160_FIXED", 9000), (double)env_int("HD_M320_FIXED", 13500)};
+  static const double m160_step[2] = {(double)env_int("HD_M160_STEP", 440), (double)env_int("HD_M320_STEP", 800)};
+  if (m160_on && allow_m160 && hd_conv_m160_eligible(p)) {
+    for (int v = 0; v < 2; ++v) {
+      const int th_ = v ? 8 : 4;
+      const int64_t tm = (int64_t)nominal_batch * hd_cdiv(p.Ho, th_) * hd_cdiv(p.Wo, 40);
+      const double eff = (double)((int64_t)nominal_batch * p.Ho * p.Wo) / (double)(tm * th_ * 40);
+      const int64_t blocks = tm * hd_cdiv(p.Cout, 64);
+      const double t = (double)hd_cdiv(blocks, 256) * (m160_fixed[v] + nk * m160_step[v]);
+      if (eff >= 0.999 && t < best_t) {        // exact covers only (the U-Net's maps) until the ragged cases are measured
+        best_t = t;
+        best = 8 + v;
+      }
+    }
+  }
+  return best;
 }
 
 struct TileChoice {
@@ -198,13 +219,14 @@ struct TileChoice {
   int p8cfg;             // p8cfg >= 0: the 8-wave input-patch family (conv3x3_w8.hip) with that tile id
 };
 
-// tuning hook of the 8-wave patch-staged family (tools/tune_w8.py): cfg -1 = cost model, -2 = never, 10..13 = force that tile, 15..17 = force
-// the step-split main loop (TS) of tiles 11..13
+// tuning hook of the 8-wave patch-staged family (tools/tune_w8.py): cfg -1 = cost model, -2 = never, -3 = cost model without the 160-pixel tile
+// (round 5's choice: A/B of conv3x3_m160.hip inside one process, tools/probe_m160.py), 10..13 = force that tile, 15..17 = force
+// the step-split main loop (TS) of tiles 11..13, 18 / 19 = force the 160- / 320-pixel x 64-channel tile (conv3x3_m160.hip)
 // wherever the family is eligible
 static int g_w8_cfg = -1;
 extern "C" int hd_conv_tune_w8(int cfg, int nslices) {
   (void)nslices;
-  HD_CHECK_ARG(cfg == -1 || cfg == -2 || (cfg >= 10 && cfg <= 13) || (cfg >= 15 && cfg <= 17), "hd_conv_tune_w8: cfg in {-1, -2, 10..13, 15..17}");
+  HD_CHECK_ARG(cfg == -1 || cfg == -2 || cfg == -3 || (cfg >= 10 && cfg <= 13) || (cfg >= 15 && cfg <= 19), "hd_conv_tune_w8: cfg in {-1, -2, -3, 10..13, 15..19}");
   g_w8_cfg = cfg;
   return HD_OK;
 }
@@ -255,8 +277,9 @@ static TileChoice choose_tile(const ConvP& p) {
   if (force_deep >= 0) c.deep = force_deep != 0;
   if (g_ov_deep >= 0) c.deep = g_ov_deep != 0;
   c.p8cfg = -1;
-  if (g_w8_cfg >= 10 && hd_conv_p8_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
-  if (g_w8_cfg == -1 && g_small_ok && g_ov_bm < 0 && g_ov_bn < 0 && g_ov_bk < 0) c.p8cfg = choose_p8(p);
+  if (g_w8_cfg >= 10 && g_w8_cfg < 18 && hd_conv_p8_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
+  if (g_w8_cfg >= 18 && hd_conv_m160_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
+  if ((g_w8_cfg == -1 || g_w8_cfg == -3) && g_small_ok && g_ov_bm < 0 && g_ov_bn < 0 && g_ov_bk < 0) c.p8cfg = choose_p8(p, g_w8_cfg == -1);
   return c;
 }
 
@@ -270,6 +293,7 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (use_stem(p)) return hd_conv_stem_rows(p);
   if (use_cat(p)) return hd_conv_cat128to32_rows(p);
   const TileChoice c = choose_tile(p);
+  if (c.p8cfg >= 8) return hd_conv_m160_tiles(p, c.p8cfg == 9 ? 8 : 4);
   if (c.p8cfg >= 0) return hd_conv_p8_tiles(p, c.p8cfg);
   return hd_cdiv(p.M, c.bm);
 }
@@ -292,7 +316,8 @@ static bool pool2_kernel(const ConvP& p) {
   if (use_c64(p) || use_stem(p)) return false;
   if (use_c32(p)) return true;                         // (its eligibility includes the out_pool2 = 64 / y2 form)
   if (use_cat(p) || choose_gemm8(p)) return false;
-  return choose_tile(p).p8cfg >= 0 && hd_conv_p8_pool2_ok(p);
+  const int cfg = choose_tile(p).p8cfg;
+  return cfg >= 8 ? hd_conv_m160_pool2_ok(p) : (cfg >= 0 && hd_conv_p8_pool2_ok(p));
 }
 
 // does hd_conv2d implement out_pool2 for this problem?
@@ -320,7 +345,7 @@ extern "C" int hd_conv2d_wgrad(const hd_conv_args* a, const hd_wgrad_args* wa, v
   HD_CHECK_ARG(!p.pool2 || pool2_kernel(p), "hd_conv2d_wgrad: out_pool2 is not implemented for this problem; ask hd_conv2d_pool2_ok first");
   if (fuse_on && !use_small(p) && !use_c64(p) && !use_stem(p) && !p.in_scale && !p.x2 && (!p.stats || p.bs_y) && p.in_dil == 1 && hd_wgrad_takes_w8(wa)) {
     const TileChoice c = choose_tile(p);
-    if (c.p8cfg >= 0) {
+    if (c.p8cfg >= 0 && c.p8cfg < 8) {             // (the 160- / 320-pixel tiles have no fused weight-gradient grid: two launches below)
       static const int w8_prio = env_int("HD_W8_PRIO", 0);
       p.prio = w8_prio;
 #ifdef HD_CONV_TRACE
@@ -439,7 +464,9 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
   } else {
     p.M = M_full;
   }
-  if (c.p8cfg >= 0) {
+  if (c.p8cfg >= 8) {
+    hd_conv_launch_m160(p, c.p8cfg == 9 ? 8 : 4, s);
+  } else if (c.p8cfg >= 0) {
     hd_conv_launch_p8(p, c.p8cfg, s);
   } else if (use64) hd_conv_launch_bk64(p, bm, bn, deep, s);
   else hd_conv_launch_bk32(p, bm, bn, deep, s);

@@ -160,6 +160,12 @@ bool hd_conv_p8_eligible(const ConvP& p);
 bool hd_conv_p8_pool2_ok(const ConvP& p);
 int hd_conv_p8_tiles(const ConvP& p, int cfg);
 void hd_conv_launch_p8(ConvP& p, int cfg, hipStream_t s);
+// conv3x3_m160.hip: the same family on th x 40-pixel x 64-channel tiles, th in {4, 8} (v_mfma_f32_16x16x32_f16): 256 blocks for the 12-GFLOP
+// U-Net layers; hd_conv_m160_tiles = BatchNorm partial-sum rows (one per 160 pixels)
+bool hd_conv_m160_eligible(const ConvP& p);
+bool hd_conv_m160_pool2_ok(const ConvP& p);
+int hd_conv_m160_tiles(const ConvP& p, int th);
+void hd_conv_launch_m160(ConvP& p, int th, hipStream_t s);
 // the same tile grid with the blocks of an 8-wave weight gradient behind it (one launch; conv3x3_w8.hip)
 void hd_conv_launch_p8_wgrad(ConvP& p, int cfg, const hd_wgrad_args* wa, hipStream_t s);
 // wgrad.hip: would hd_wgrad run this weight gradient in the 8-wave patch-staged kernel?

@@ -110,10 +110,10 @@ W8_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 15, 16, 17])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 15, 16, 17, 18, 19])
 def test_conv2d_eight_wave_families(dev, cfg):
     """Every tile of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip: cfg 10-13; 15-17 = the step-split main loop of 11-13, shipped
-    for 13), forced through hd_conv_tune_w8 wherever it is eligible (the other cases fall through to the 4-wave family), against the
+    for 13; 18 / 19 = the 160- / 320-pixel x 64-channel tiles of conv3x3_m160.hip on v_mfma_f32_16x16x32_f16, round 6), forced through hd_conv_tune_w8 wherever it is eligible (the other cases fall through to the 4-wave family), against the
     oracle: outputs, BN partial sums per tile, bias / residual / ReLU-mask / ReLU."""
     from hallucidet_amd import ops, _abi
     lib = _abi.load()
@@ -150,6 +150,84 @@ def test_conv2d_eight_wave_families(dev, cfg):
                 assert torch.equal(got, again), "run-to-run identical"
     finally:
         lib.hd_conv_tune_w8(-1, 0)
+
+
+M160_CASES = [
+    # N, H, W, C1, C2, Cout, act, bias, res, mask   (3x3 / s1 / p1 through the DEFAULT dispatcher: these maps are exact covers of 4 x 40 tiles)
+    (2, 32, 40, 256, 0, 256, 0, False, False, False),      # ResNet-34 layer3 at 256 x 320 input (the 12-GFLOP shape at batch 8)
+    (2, 32, 40, 256, 0, 256, 1, True, True, True),         # the same with every epilogue option
+    (1, 64, 80, 128, 0, 128, 0, False, True, False),       # layer2: two channel tiles, 32 pixel tiles per image
+    (2, 16, 20, 512, 256, 256, 0, False, False, False),    # decoder block 0's conv1: nearest-2x(512 @16x20) ++ skip(256 @32x40), 12 chunks
+    (1, 32, 40, 192, 0, 136, 1, False, False, False),      # 3 chunks (odd: the five-round tail), Cout not a multiple of 64
+    (1, 8, 40, 64, 0, 128, 0, True, False, False),         # one chunk only (nine K steps: prologue + tail, no whole period)
+    (2, 64, 80, 128, 0, 128, 1, True, True, True),         # layer2 with every epilogue option (the 320-pixel tile: two epilogue halves per block)
+    (1, 32, 40, 256, 128, 128, 0, False, False, False),    # decoder block 1's conv1: nearest-2x(256 @32x40) ++ skip(128 @64x80)
+]
+
+
+@pytest.mark.parametrize("case", M160_CASES)
+def test_conv2d_160_pixel_tile_on_the_unet_maps(dev, case):
+    """conv3x3_m160.hip (round 6) where the dispatcher itself picks it: the U-Net's 32x40 / 64x80 maps are cut into 4 x 40- or 8 x 40-pixel x
+    64-channel tiles (the BatchNorm partial-sum rows prove which kernel ran: one row per 160 pixels) -- outputs, sums and every epilogue option against
+    the oracle, run-to-run identical."""
+    from hallucidet_amd import ops
+    N, H, W, C1, C2, Cout, act, use_bias, use_res, use_mask = case
+    up1 = C2 > 0
+    x = rnd(N, H, W, C1, seed=1)
+    Hin, Win = (2 * H, 2 * W) if up1 else (H, W)
+    x2 = rnd(N, Hin, Win, C2, seed=2) if C2 else None
+    Kt = 9 * (C1 + C2)
+    w = rnd(Cout, Kt, scale=1.0 / math.sqrt(Kt), seed=3)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(4)) if use_bias else None
+    res = rnd(N, Hin, Win, Cout, seed=5) if use_res else None
+    mask = (torch.rand(N, Hin, Win, Cout, generator=torch.Generator().manual_seed(6)) > 0.4).half() if use_mask else None
+    want, wstats = ok.conv2d_nhwc(x, w, 3, 3, x2=x2, bias=bias, res=res, pad=1, up1=up1, act=0)
+    if use_mask:
+        want = want * mask.float()
+        wstats = (want.half().float().sum(dim=(0, 1, 2)), (want.half().float() ** 2).sum(dim=(0, 1, 2)))
+    if act == 1:
+        want = want.clamp_min(0)
+    d = lambda t: None if t is None else t.to(dev)
+    got, stats = ops.conv2d(d(x), d(w), 3, 3, x2=d(x2), bias=d(bias), res=d(res), mask=d(mask), pad=1, up1=up1, act=act, want_stats=True)
+    torch.cuda.synchronize()
+    assert stats.shape[0] == N * (Hin // 4) * (Win // 40), "the dispatcher did not route this map to the 160-pixel tile (%d rows)" % stats.shape[0]
+    close(got, want.half())
+    s_ = stats.sum(dim=0).cpu()
+    assert torch.allclose(s_[0], wstats[0], rtol=2e-3, atol=2e-3 * (N * Hin * Win) ** 0.5 + 1e-2)
+    assert torch.allclose(s_[1], wstats[1], rtol=3e-3, atol=1e-2)
+    again, _ = ops.conv2d(d(x), d(w), 3, 3, x2=d(x2), bias=d(bias), res=d(res), mask=d(mask), pad=1, up1=up1, act=act, want_stats=True)
+    assert torch.equal(got, again), "run-to-run identical"
+
+
+@pytest.mark.parametrize("cfg", [18, 19])
+@pytest.mark.parametrize("case", [(1, 8, 40, 128, 128, 64), (2, 32, 40, 256, 256, 128), (1, 12, 80, 128, 64, 0), (1, 10, 44, 64, 128, 64)])
+def test_conv2d_160_pixel_tile_pooled_half_and_skip_half(dev, case, cfg):
+    """out_pool2 on the 160- / 320-pixel tiles (forced through hd_conv_tune_w8(18 / 19): the shared epilogue's 2 x 2 sum with a 40-pixel
+    tile pitch): pooled half against the plain call + hd_concat_up_bwd and the oracle, skip half bit for bit; ragged maps."""
+    from hallucidet_amd import ops, _abi
+    lib = _abi.load()
+    N, H, W, Cin, c_up, c_skip = case
+    Cout = c_up + c_skip
+    x = rnd(N, H, W, Cin, seed=1).to(dev)
+    w = rnd(Cout, 9 * Cin, scale=1.0 / math.sqrt(9 * Cin), seed=3).to(dev)
+    try:
+        lib.hd_conv_tune_w8(cfg, 1)
+        info = dict(c_up=c_up)
+        got = ops.conv2d(x, w, 3, 3, pad=1, pool2=info)
+        assert info["done"] and got.shape == (N, H // 2, W // 2, c_up)
+        plain = ops.conv2d(x, w, 3, 3, pad=1)
+    finally:
+        lib.hd_conv_tune_w8(-1, 0)
+    da, ds = ops.concat_up_bwd(plain, c_up)
+    torch.cuda.synchronize()
+    if c_skip:
+        assert torch.equal(info["skip"], ds)
+    else:
+        assert info["skip"] is None and ds is None
+    assert float((got.float() - da.float()).abs().max()) <= 4e-3 * max(1.0, float(da.float().abs().max()))
+    want, _ = ok.conv2d_nhwc(x.cpu(), w.cpu(), 3, 3, pad=1)
+    close(got, want[..., :c_up].reshape(N, H // 2, 2, W // 2, 2, c_up).sum(dim=(2, 4)).half())
+    close(plain, want.half())
 
 
 GEMM8_CASES = [
@@ -1554,6 +1632,8 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dev, use_z, res
     bs = dict(y=y_u, z=z_u, mean=mean, invstd=invstd, gamma=gamma, beta=beta, relu=True)
     dz = ops.conv2d(dyv, wd, 3, 3, pad=1, res=r, bstat=bs)
     assert bs["part"] is not None, "these 3x3 data gradients run in kernels that implement the sums"
+    if Cc == 256:
+        assert bs["part"].shape[0] == N * (H // 4) * (W // 40), "32x40x256 is the 160-pixel tile's shape (conv3x3_m160.hip, round 6)"
     plain = ops.conv2d(dyv, wd, 3, 3, pad=1, res=r)
     assert torch.equal(dz, plain)
     got = bs["part"].double().sum(0)

@@ -1,0 +1,121 @@
+"""The 160-pixel x 64-channel tile (conv3x3_m160.hip, round 6) against round 5's tile choice on every 3x3 / stride-1 hd_conv2d launch
+signature of one training step that it is eligible for: forced (hd_conv_tune_w8(18 / 19), the faster of the two) vs the cost model without it (-3) vs the shipped
+rule (-1) -- warm graph-replayed duration, max |difference| of the outputs relative to their scale, and the step totals.
+    python tools/probe_m160.py"""
+import collections
+import os
+import sys
+
+os.environ.setdefault("HD_DET_GRAPH", "0")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from hallucidet_amd import _abi, ops, synthetic
+
+lib = _abi.load()
+dev = torch.device("cuda:0")
+
+lit = synthetic.make_module()
+lit.encoder_decoder.runner.enable_graphs(False)
+batch = synthetic.make_batch(8, device="cuda")
+lit.fit_step(batch)
+rec = []
+orig = ops.conv2d
+
+
+def spy(x, w, KH, KW, **kw):
+    out = orig(x, w, KH, KW, **kw)
+    if KH == 3 and kw.get("stride", 1) == 1 and kw.get("in_dil", 1) == 1 and x.shape[3] % 64 == 0 and x.dtype == torch.float16:
+        rec.append((x, w, KH, KW, {k_: (dict(v_) if k_ in ("bstat", "pool2") and v_ is not None else v_) for k_, v_ in kw.items() if k_ not in ("_defer", "out")}))
+    return out
+
+
+ops.conv2d = spy
+lit.fit_step(batch)
+torch.cuda.synchronize()
+ops.conv2d = orig
+
+
+def sig(x, w, kw):
+    return (tuple(x.shape), None if kw.get("x2") is None else tuple(kw["x2"].shape), kw.get("cout") or w.shape[0], bool(kw.get("up1")),
+            bool(kw.get("want_stats")), kw.get("res") is not None, kw.get("mask") is not None, kw.get("bstat") is not None,
+            None if kw.get("pool2") is None else kw["pool2"].get("c_up"), kw.get("act", 0))
+
+
+groups = collections.OrderedDict()
+for x, w, KH, KW, kw in rec:
+    groups.setdefault(sig(x, w, kw), []).append((x, w, KH, KW, kw))
+
+
+def call(x, w, KH, KW, kw):
+    kw = dict(kw)
+    for k_ in ("bstat", "pool2"):
+        if kw.get(k_) is not None:
+            kw[k_] = dict(kw[k_])
+    out = orig(x, w, KH, KW, **kw)
+    extra = []
+    if kw.get("bstat") is not None and kw["bstat"].get("part") is not None:
+        extra.append(kw["bstat"]["part"].sum(0))
+    if kw.get("pool2") is not None and kw["pool2"].get("skip") is not None:
+        extra.append(kw["pool2"]["skip"])
+    return [t.float() for t in (out if isinstance(out, tuple) else (out,)) if torch.is_tensor(t)][:1] + [t.float() for t in extra]
+
+
+def timed(fn, reps=6):
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / reps * 1e3)
+    return best
+
+
+tot = collections.Counter()
+print("%-78s %3s %8s %8s %8s  %s" % ("signature (x, x2, Cout, up1, stats, res, mask, bstat, pool2, act)", "n", "r5 us", "m160 us", "auto us", "max rel diff"))
+for s, lst in groups.items():
+    x, w, KH, KW, kw = lst[0]
+    n = len(lst)
+    lib.hd_conv_tune_w8(-3, 1)
+    o_old = call(x, w, KH, KW, kw)
+    t_old = timed(lambda: call(x, w, KH, KW, kw))
+    o_new, t_new, t_320 = None, float("nan"), float("nan")
+    for cfg in (18, 19):
+        lib.hd_conv_tune_w8(cfg, 1)
+        try:
+            o_c = call(x, w, KH, KW, kw)
+            t_c = timed(lambda: call(x, w, KH, KW, kw))
+        except RuntimeError as ex:
+            continue
+        if cfg == 19:
+            t_320 = t_c
+        if o_new is None or t_c < t_new:
+            o_new, t_new = o_c, t_c
+    lib.hd_conv_tune_w8(-1, 1)
+    t_auto = timed(lambda: call(x, w, KH, KW, kw))
+    d = float("nan")
+    if o_new is not None:
+        d = 0.0
+        for a, b in zip(o_old, o_new):
+            if a.shape != b.shape:          # (BatchNorm rows differ in count between tiles: compared as sums above)
+                d = float("inf")
+                break
+            d = max(d, float((a - b).abs().max()) / (float(a.abs().max()) + 1e-6))
+    tot["old"] += n * t_old
+    tot["new"] += n * (t_new if t_new == t_new else t_old)
+    tot["auto"] += n * t_auto
+    tot["best"] += n * min(t_old, t_new if t_new == t_new else t_old)
+    print("%-78s %3d %8.1f %8.1f %8.1f  %.1e%s" % (str(s), n, t_old, t_new, t_auto, d, "  (320)" if t_new == t_320 else ""))
+lib.hd_conv_tune_w8(-1, 1)
+print("per step (us): round-5 choice %.0f | 160-pixel tile forced wherever eligible %.0f | shipped rule %.0f | per-signature best %.0f" % (
+    tot["old"], tot["new"], tot["auto"], tot["best"]))

@@ -23,7 +23,7 @@ SHAPES = [   # name, N, H, W, Cin, Cout, KH, want_stats
 ]
 CFGS = [int(v) for v in os.environ.get("CFGS", "10,11,12").split(",")]     # tiles of the patch-staged family (conv3x3_w8.hip)
 TILES = [(256, 128), (128, 128), (256, 64), (128, 64), (128, 256), (64, 128), (64, 256), None, None, None, (256, 128), (128, 128), (256, 64), (128, 64),
-         None, (128, 128), (256, 64), (128, 64)]        # 15..17: the step-split main loop (TS) of 11..13
+         None, (128, 128), (256, 64), (128, 64), (160, 64), (320, 64)]        # 15..17: the step-split main loop (TS) of 11..13; 18 / 19: conv3x3_m160.hip
 med = lambda a: float(np.median(a))
 for name, N, H, W, Cin, Cout, KH, stats in SHAPES:
     x = torch.randn(N, H, W, Cin, device=dev, dtype=torch.float16)
