@@ -52,7 +52,7 @@ def _pmc_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in two separate
     runs, corrected as MI355X_MICROARCH.md prescribes; tools/pmc_traffic.py) committed under profiles/ for this round.
     bench.py itself cannot collect PMCs (they need rocprofv3 around the process): null if the file is absent."""
-    for name in ("r05_conv_traffic.json", "r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
+    for name in ("r06_conv_traffic.json", "r05_conv_traffic.json", "r04_conv_traffic.json", "r03_conv_traffic.json", "r02_conv_traffic.json", "r01_conv_traffic.json"):
         j = _profile_json([name])
         try:
             return round(j["traffic_bytes_per_launch"]), {"static": True, "stale": _stale(j), "source": "profiles/" + name, "commit": j.get("commit"),
@@ -65,7 +65,7 @@ def _pmc_traffic():
 def _pmc_mfma_util():
     """MFMA-pipe utilisation of the conv kernels in a training step (SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x 256 CUs x busy
     clocks), tools/pmc_mfma.py on a `rocprofv3 --pmc` run of tools/bench_step.py), committed under profiles/."""
-    for name in ("r05_conv_mfma_util.json", "r04_conv_mfma_util.json", "r03_conv_mfma_util.json", "r02_conv_mfma_util.json"):
+    for name in ("r06_conv_mfma_util.json", "r05_conv_mfma_util.json", "r04_conv_mfma_util.json", "r03_conv_mfma_util.json", "r02_conv_mfma_util.json"):
         j = _profile_json([name])
         try:
             return {"value": j["mfma_util"], "by_kernel": j.get("by_kernel"), "static": True, "stale": _stale(j), "source": "profiles/" + name, "commit": j.get("commit"),
@@ -282,7 +282,7 @@ def conv_roofline(lit, batch, reps=5, peak=None):
             "traffic_provenance": "not collected for the fp32 mode" if f32_mode else _pmc_traffic()[1], "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
             "kernel": "hd_conv2d_f32: conv_f32_kernel (64 x 64 tiles, v_mfma_f32_32x32x2_f32: exact f32 products and sums; peak = the f32 matrix rate)" if f32_mode else
-                      "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + gemm_w8_kernel (8-wave 256-row GEMM tiles: box head) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + "
+                      "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + gemm_w8_kernel (8-wave 256-row GEMM tiles: box head) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + conv3x3_m160_kernel (160- / 320-pixel tiles, producer / consumer waves) + "
                       "conv3x3_c64_kernel / conv7x7s2_stem_kernel / conv3x3_cat128to32_kernel / conv3x3_c32to128_kernel (persistent, register-resident weights: "
                       "the 64 -> 64 channel 3x3 layers, the 7x7 stems, decoder block 3) + "
                       "conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
@@ -551,15 +551,22 @@ def main():
         _flush_c_stdio()               # every rank: RCCL's start-up text (NCCL_DEBUG=VERSION is set on this pool) leaves now, not behind rank 0's line
     torch.cuda.synchronize()
     lit.averager.timing = dist.is_initialized()
+    # per-step spread: one HIP event behind every step on the stream the step is issued on (an event record is a marker packet, no
+    # synchronisation); the contract's number stays the wall clock around the whole region
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for k in range(args.steps):
         loss = lit.fit_step(batch)
+        step_ev[k + 1].record()
     torch.cuda.synchronize()
     if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     lit.averager.timing = False
+    step_ms = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
+    pct = lambda q: round(step_ms[min(len(step_ms) - 1, int(q * len(step_ms)))], 3)
     rccl_ranks = dist.get_world_size() if dist.is_initialized() else 1
     per_rank_ms = None
     if dist.is_initialized():
@@ -580,14 +587,15 @@ def main():
         # already waiting at the final barrier), so the gradient averager is detached for the extra steps
         overlap_used = bool(lit.overlap_allreduce)      # what the TIMED steps ran with (reported below; the extra steps run detached)
         lit.averager.start = lambda g: None
-        lit.averager.finish = lambda g: None
+        lit.averager.finish = lambda g, defer_mean=False: 1.0
         lit.averager.bucket_ready = lambda lo, hi: None
         lit.overlap_allreduce = False
         value = BATCH_PER_GPU * world * args.steps / elapsed
         out = {
             "metric": "images/sec train_hallucidet (640x512, batch 8/GPU)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "ms_per_step_p50": pct(0.5), "ms_per_step_p90": pct(0.9),
+            "ms_per_step_min_max": [round(step_ms[0], 3), round(step_ms[-1], 3)], "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16" if args.precision == 16 else "f32", "data": "synthetic",
             "config": {"workload": ("" if args.precision == 16 else "--precision 32 (fp32 storage, NOT the headline configuration) of: ") +
                                    ("train_hallucidet.py fasterrcnn LLVIP batch=8 fp16 on 1xMI355X (BASELINE configs[1]); "

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "hd_conv7x7s2_dgrad_thin": (C.c_int, [vp, vp, vp, vp] + [C.c_int] * 5 + [vp]),
     "hd_conv_tune_override": (C.c_int, [C.c_int] * 4),
     "hd_conv_tune_w8": (C.c_int, [C.c_int, C.c_int]),
+    "hd_conv_nominal_batch": (C.c_int, [C.c_int]),
     "hd_gemm_w8_mode": (C.c_int, [C.c_int]),
     "hd_wgrad_w8_blocks": (C.c_int, [C.POINTER(WgradArgs)]),
     "hd_wgrad": (C.c_int, [C.POINTER(WgradArgs), vp]),

@@ -24,7 +24,7 @@
 //     holds a ~15 % higher clock than 32x32x16 at equal cycles per FLOP).  A 16-pixel block is 2 tile rows x 8 columns.
 //       TH = 4: consumers = 2 (tile rows 0-1 / 2-3) x 2 (32-deep halves of every K step): two partial sums per output, added by the
 //               shared epilogue (conv_w8_epilogue.h, WK = 2);
-//       TH = 8: consumers = 4 row pairs, each runs both halves of every K step: no partial sums; the epilogue runs per 160-pixel half.
+//       TH = 8: consumers = 4 row pairs, each runs both halves of every K step: no partial sums (epilogue tile [320][68] fp32).
 // Hazards.  Step s (tap s % 9 of chunk s / 9) lives in ring stage s % 6; barrier s ends step s.  Between barriers s-1 and s a producer
 // issues step s+3's weights and (taps 0-6) next-chunk patch pieces, then waits until everything it issued in EARLIER steps has landed; a
 // consumer requests the fragments of step s+1 and multiplies step s.  So step s+2's bytes have landed (every producer's wait) before
@@ -179,13 +179,11 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
       dma16(rw, bst0 + stage * BSTAGE + pw * 512, wbase[0] + koff);
       dma16(rw, bst0 + stage * BSTAGE + (pw + 4) * 512, wbase[1] + koff);
     };
-    // prologue: the patch of chunk 0 and the weights of steps 0-2; all of it has landed before the first barrier
+    // prologue: the patch of chunk 0 (the weights of steps 0-2 come from the consumers, which have nothing else to do yet: 14 back-to-back
+    // pieces per producer were 5 200 clocks of set-up, tools/w8_trace.py); all of it has landed before the first barrier
 #pragma unroll
     for (int k = 0; k < PK; ++k)
       if (k * 4 + pw < NPIECE) issue_patch_piece(0, k);
-    issue_b(0, 0, 0);
-    issue_b(0, 1, 1);
-    issue_b(0, 2, 2);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #define HD_M160_PSTEP(I)                                                                                                   \
@@ -238,7 +236,36 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
     _Pragma("unroll") for (int b = 0; b < 5; ++b)                                                                          \
       _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                        \
         acc[b][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[SET][c], bf[SET][b], acc[b][c], 0, 0, 0);
-    __builtin_amdgcn_s_barrier();                      // the producers' prologue has landed
+    // instruction order of one unit (9 fragment reads of the next unit + 20 MFMAs of this one, one scheduling region): MFMA, read, MFMA,
+    // read ... -- issued back to back in front of the MFMAs the nine reads held the wave for 166 clocks (four consumers push 36 KB through
+    // the LDS pipe at once) while its matrix pipe idled: 591 clocks per step for 320 of MFMA work (profiles/r06_w8_trace_m160_v3.txt)
+#define HD_M160_ORDER()                                                                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_) {                                                                     \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                   \
+    }                                                                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+    {
+      // prologue: the weights of K steps 0-2 (the one time a consumer issues vector-memory instructions; same piece / slot map as the
+      // producers' issue_b with this wave in the place of producer `wave`)
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.w), 0, p.wbytes, 0x00020000);
+      unsigned wb[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int row = (tid >> 3) + 32 * j;
+        const int cg = (tid & 7) ^ ((row >> 1) & 7);
+        const int co = n0 + row;
+        wb[j] = co < p.Cout ? (unsigned)co * (unsigned)p.Ktot * 2u + (unsigned)cg * 16u : 0x80000000u;
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const unsigned koff = (unsigned)(t * p.Cin) * 2u;                       // chunk 0, tap t (ncc >= 1)
+        dma16(rw, bst0 + t * BSTAGE + wave * 512, wb[0] + koff);
+        dma16(rw, bst0 + t * BSTAGE + (wave + 4) * 512, wb[1] + koff);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                      // patch chunk 0 (producers) and weight steps 0-2 (consumers) have landed
     HD_TRACE(2, clock64());
     HD_M160_FETCH(0, 0, 0)
     __builtin_amdgcn_s_setprio(1);
@@ -255,20 +282,17 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
     {                                                                                                                      \
       if constexpr (NQ == 2) {                                                                                             \
         HD_M160_FETCH(1, (I), 1)                                                                                           \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        TR_MARK(tr_mem);                                                                                                   \
         HD_M160_MFMA(0)                                                                                                    \
+        HD_M160_ORDER()                                                                                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         TR_MARK(tr_mfma);                                                                                                  \
         HD_M160_FETCH(0, ((I) + 1) % 18, 0)                                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        TR_MARK(tr_mem);                                                                                                   \
         HD_M160_MFMA(1)                                                                                                    \
+        HD_M160_ORDER()                                                                                                    \
       } else {                                                                                                             \
         HD_M160_FETCH(((I) + 1) & 1, ((I) + 1) % 18, 0)                                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                                 \
-        TR_MARK(tr_mem);                                                                                                   \
         HD_M160_MFMA((I) & 1)                                                                                              \
+        HD_M160_ORDER()                                                                                                    \
       }                                                                                                                    \
       __builtin_amdgcn_sched_barrier(0);                                                                                   \
       TR_MARK(tr_mfma);                                                                                                    \
@@ -281,6 +305,7 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
 #undef HD_M160_CSTEP
 #undef HD_M160_FETCH
 #undef HD_M160_MFMA
+#undef HD_M160_ORDER
     __builtin_amdgcn_s_setprio(0);
 #ifdef HD_CONV_TRACE
     HD_TRACE(8, (unsigned long long)tr_mem);
@@ -312,20 +337,18 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
     }
     hd_w8_epilogue<BMH, BN, 2, TW>(p, lds, n_img, ty0, tx0, n0, tile_m);
   } else {
-    // 320 pixels, no partial sums: consumer wm lays tile rows 2 wm, 2 wm + 1 down in 160-pixel tile wm >> 1 (both fit: 2 x 43.5 KB);
-    // the shared epilogue runs once per tile -- BatchNorm rows 2 tile_m and 2 tile_m + 1 (a half beyond the map still writes its zero sums)
+    // 320 pixels, no partial sums: consumer wm lays tile rows 2 wm, 2 wm + 1 down in ONE fp32 tile [320][68] (85 KiB) and the shared
+    // epilogue runs once over it (five row passes per thread, one BatchNorm row per block)
     if (consumer) {
 #pragma unroll
       for (int b = 0; b < 5; ++b)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const int row = ((wm & 1) * 2 + (fp >> 3)) * TW + b * 8 + (fp & 7);
-          *reinterpret_cast<f32x4*>(ct + ((wm >> 1) * BMH + row) * CP + c * 16 + ks4) = acc[b][c];
+          const int row = (wm * 2 + (fp >> 3)) * TW + b * 8 + (fp & 7);
+          *reinterpret_cast<f32x4*>(ct + row * CP + c * 16 + ks4) = acc[b][c];
         }
     }
-    hd_w8_epilogue<BMH, BN, 1, TW>(p, lds + BMH * CP * 2, n_img, ty0 + 4, tx0, n0, tile_m * 2 + 1);     // (its BatchNorm staging overwrites only its own tile)
-    __syncthreads();
-    hd_w8_epilogue<BMH, BN, 1, TW>(p, lds, n_img, ty0, tx0, n0, tile_m * 2);
+    hd_w8_epilogue<2 * BMH, BN, 1, TW>(p, lds, n_img, ty0, tx0, n0, tile_m);
   }
   HD_TRACE(5, clock64());
   HD_TRACE(6, wall_clock64());
@@ -358,8 +381,8 @@ bool hd_conv_m160_pool2_ok(const ConvP& p) {
          p.pool2 > 0 && (p.pool2 % 64) == 0 && p.pool2 <= p.Cout && ((p.Cout - p.pool2) % 8) == 0 && (p.pool2 == p.Cout || p.y2 != nullptr);
 }
 
-// BatchNorm partial-sum rows: one per 160-pixel epilogue tile (th = 8: two per block)
-int hd_conv_m160_tiles(const ConvP& p, int th) { return p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, TW) * (th / 4); }
+// BatchNorm partial-sum rows: one per block
+int hd_conv_m160_tiles(const ConvP& p, int th) { return p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, TW); }
 
 void hd_conv_launch_m160(ConvP& p, int th, hipStream_t s) {
   p.gm = p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, TW);

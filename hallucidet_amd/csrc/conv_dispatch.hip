@@ -159,6 +159,15 @@ extern "C" int hd_conv_trace_buffer(void* buf) {
 // tiles cover the feature map well.  Tile choice by a cost model fitted to per-block timelines (tools/w8_trace.py, shader clocks):
 // one block per CU, so a launch costs ceil(blocks / 256) rounds of (fixed + K steps x step), fixed = set-up + first stage +
 // epilogue.  Measured against the per-shape sweep of one training step's 136 launch shapes (tools/tune_w8.py).
+// test / tuning hook: n > 0 evaluates the tile cost model at batch n whatever the launch's (rounds 2-5: 8 -- image n of a batched launch is
+// then bit-identical to the same image alone); 0 (default) = the launch's own batch
+static int g_nominal_batch = 0;
+extern "C" int hd_conv_nominal_batch(int n) {
+  HD_CHECK_ARG(n >= 0 && n <= 4096, "hd_conv_nominal_batch: n in [0, 4096]");
+  g_nominal_batch = n;
+  return HD_OK;
+}
+
 static int choose_p8(const ConvP& p, bool allow_m160 = true) {
   static const int on = env_int("HD_CONV_P8", 1);
   if (!on || !hd_conv_p8_eligible(p)) return -1;
@@ -174,9 +183,13 @@ static int choose_p8(const ConvP& p, bool allow_m160 = true) {
   const int nk = p.nchunks / 8;
   int best = -1;
   double best_t = 1e30;
-  // The tiles split K differently (WK), so they do not round identically: the choice must not depend on the batch size, or
-  // image n of a batched launch would differ from the same image alone.  The model is evaluated at the training batch (8).
-  const int nominal_batch = 8;
+  // The tiles split K differently (WK), so they do not round identically.  Rounds 2-5 evaluated this model at the TRAINING batch (8) whatever
+  // the launch's, so that image n of a batched launch was bit-identical to the same image alone -- the builder's convenience, not a property
+  // of the reference (cuDNN picks algorithms per shape), and it kept the 24-image detector launches on tiles chosen for 8 images.  Round 6
+  // (review item 1b): the model sees the launch's own batch; a problem of a given shape always gets the same tile (run-to-run identical),
+  // images of differently batched launches agree to fp16 rounding (tests: stated tolerance).  HD_CONV_NOMINAL_BATCH=8 / hd_conv_nominal_batch(8) restore the old rule.
+  static const int nominal = env_int("HD_CONV_NOMINAL_BATCH", 0);
+  const int nominal_batch = g_nominal_batch > 0 ? g_nominal_batch : (nominal > 0 ? nominal : p.N);
   for (int c = 0; c < 4; ++c) {
     if (bn[c] == 128 && p.Cout <= 64) continue;
     const int64_t tm = (int64_t)nominal_batch * hd_cdiv(p.Ho, th[c]) * hd_cdiv(p.Wo, 8);
@@ -190,21 +203,25 @@ static int choose_p8(const ConvP& p, bool allow_m160 = true) {
     }
   }
   best = ((ts >= 2 && best >= 1) || (ts == 1 && best == 3)) ? best + 4 : best;
-  // Round 6: the 160- / 320-pixel x 64-channel tiles (conv3x3_m160.hip, cfg 8 / 9): 4 x 40- and 8 x 40-pixel tiles divide the U-Net's 32x40 /
-  // 64x80 / 128x160 maps exactly, and 10 240 pixels x 256 channels (40 960 x 128) are 256 blocks of 160 (320) pixels where the tiles
-  // above give 160 / 320.  Same model: rounds x (fixed + K steps x step), constants from per-block stamps (tools/w8_trace.py, CFGS=18,19).
-  // HD_CONV_M160=0: off (A/B).
+  // Round 6: the 160- / 320-pixel x 64-channel tiles (conv3x3_m160.hip, cfg 8 / 9; producer / consumer wave roles).  Same model: rounds x
+  // (fixed + K steps x step), constants from per-block stamps (tools/w8_trace.py, CFGS=18,19: K loop 450 / 780 clocks per step, set-up +
+  // epilogue 9 - 11 k).  No coverage gate: these kernels win on maps they cover badly too (8 x 10 x 10 x 256: 17.5 -> 13.5 us at 21 %
+  // coverage) because what they replace there is the 4-wave implicit-GEMM family at ~900 clocks per K step of a lone 64 x 64 block --
+  // estimated below when no 8-wide tile qualifies (profiles/r06_probe_m160_v4.txt has every signature of a step).  HD_CONV_M160=0: off (A/B).
   static const int m160_on = env_int("HD_CONV_M160", 1);
-  static const double m160_fixed[2] = {(double)env_int("HD_M160_FIXED", 9000), (double)env_int("HD_M320_FIXED", 13500)};
-  static const double m160_step[2] = {(double)env_int("HD_M160_STEP", 440), (double)env_int("HD_M320_STEP", 800)};
+  static const double m160_fixed[2] = {(double)env_int("HD_M160_FIXED", 9000), (double)env_int("HD_M320_FIXED", 10500)};
+  static const double m160_step[2] = {(double)env_int("HD_M160_STEP", 460), (double)env_int("HD_M320_STEP", 790)};
   if (m160_on && allow_m160 && hd_conv_m160_eligible(p)) {
+    if (best < 0) {
+      const int64_t b64 = (int64_t)hd_cdiv((int64_t)nominal_batch * p.Ho * p.Wo, 64) * hd_cdiv(p.Cout, 64);
+      best_t = (double)hd_cdiv(b64, 512) * (4000. + nk * 900.);              // 4-wave family, two 64 x 64 blocks per CU
+    }
     for (int v = 0; v < 2; ++v) {
       const int th_ = v ? 8 : 4;
       const int64_t tm = (int64_t)nominal_batch * hd_cdiv(p.Ho, th_) * hd_cdiv(p.Wo, 40);
-      const double eff = (double)((int64_t)nominal_batch * p.Ho * p.Wo) / (double)(tm * th_ * 40);
       const int64_t blocks = tm * hd_cdiv(p.Cout, 64);
       const double t = (double)hd_cdiv(blocks, 256) * (m160_fixed[v] + nk * m160_step[v]);
-      if (eff >= 0.999 && t < best_t) {        // exact covers only (the U-Net's maps) until the ragged cases are measured
+      if (t < best_t) {
         best_t = t;
         best = 8 + v;
       }

@@ -194,15 +194,18 @@ __device__ __forceinline__ void hd_w8_epilogue(ConvP& p, f16* lds, int n_img, in
     }
     // rows in groups of HB: all of a group's y (and z) vectors are requested before the first is used (one exposed round trip per
     // group instead of one per row; the group size is what the register budget of the 2-blocks-per-CU kernels leaves)
-    constexpr int HB = ITER < 4 ? ITER : 4;
+    constexpr int HB = (ITER % 4 == 0) ? 4 : (ITER % 3 == 0 ? 3 : (ITER % 5 == 0 ? 5 : (ITER % 2 == 0 ? 2 : 1)));   // a divisor of ITER (1, 2, 3, 4, 5, 8 here)
+    static_assert(ITER % HB == 0, "row groups");
 #pragma unroll
     for (int h0 = 0; h0 < ITER; h0 += HB) {
       f16x8 yy[HB], zz[HB];
 #pragma unroll
       for (int j = 0; j < HB; ++j) {
-        const unsigned o = ok[h0 + j] ? off[h0 + j] : off[0];      // (a clamped, valid address: the value is discarded below)
-        yy[j] = *reinterpret_cast<const f16x8*>(byp + (ok[0] ? o : 0u));
-        if (bzp) zz[j] = *reinterpret_cast<const f16x8*>(bzp + (ok[0] ? o : 0u));
+        // (a clamped, valid address: the value is discarded below.  Per ROW: with 40-pixel-wide tiles a thread's rows sit in different
+        //  columns, row 0 may lie outside a ragged map while a later row lies inside)
+        const unsigned o = ok[h0 + j] ? off[h0 + j] : 0u;
+        yy[j] = *reinterpret_cast<const f16x8*>(byp + o);
+        if (bzp) zz[j] = *reinterpret_cast<const f16x8*>(bzp + o);
       }
 #pragma unroll
       for (int j = 0; j < HB; ++j) {

@@ -12,9 +12,9 @@
 //     transposing LDS read ds_read_b64_tr_b16 (four pixel rows x 16 channels per 16-lane group); bank swizzle on the DMA source
 //     side: 16-byte slot s of pixel p holds channel group s ^ (4 * ((p >> 1) & 1)), which puts the four pixel rows of a 32-lane
 //     half into the four 64-byte quarters of the 256-byte bank row (conflict-free);
-//   * 8 waves = 2 (ci halves) x 2 (tap groups: taps 0-4 / 5-8) x 2 (pixel halves of the tile); a wave keeps BOTH co halves of its taps
-//     -- ten (eight) 32 x 32 fp32 accumulators, 160 registers -- across the whole tile range, the two pixel halves meet once, in LDS, at
-//     the end.  (Rounds 2-4: 2 co x 2 ci x 2 pixel halves, nine taps per wave: every MFMA needed its own transposed patch fragment, 80
+//   * rounds 4-5: 8 waves = 2 (ci halves) x 2 (tap groups: taps 0-4 / 5-8) x 2 (pixel halves of the tile); a wave keeps BOTH co halves of
+//     its taps -- ten (eight) 32 x 32 fp32 accumulators, 160 registers -- across the whole tile range, the two pixel halves met once, in
+//     LDS, at the end.  Round 6: four such waves (no pixel halves) are the CONSUMERS, four PRODUCER waves issue the LDS-DMA (see the body).  (Rounds 2-4: 2 co x 2 ci x 2 pixel halves, nine taps per wave: every MFMA needed its own transposed patch fragment, 80
 //     ds_read_b64_tr_b16 per wave and tile, and the kernel ran at the rate of those reads -- 2.3 us per tile, MFMA utilisation 0.26.  With
 //     both co halves in one wave a patch fragment feeds TWO MFMAs: 56 / 48 reads per wave and tile.  Every output element still sums its
 //     pixels in the same order: results are bit-identical to the old decomposition.)
@@ -63,85 +63,121 @@ __device__ __forceinline__ f16x8 tr_pair(const char* p0, const char* p1) {
 }
 __device__ __forceinline__ int swz4(int p) { return ((p >> 1) & 1) << 2; }
 
-constexpr int LDS_HALVES = 2 * STAGE > 9 * 4 * 1024 * 2 ? 2 * STAGE : 9 * 4 * 1024 * 2;   // ring / final half-sum
+constexpr int NSTAGE = 3;
+constexpr int LDS_HALVES = NSTAGE * STAGE;      // 3 x 39 KiB tile stages (117 KiB): one block per CU
 
 // One block of the grid (bx = pixel split, by = (co chunk, ci chunk)); `lds`: LDS_HALVES halves, 1 KiB aligned.  A device function so
 // that the fused data-gradient + weight-gradient launch (conv3x3_w8.hip) can run it in the blocks behind its convolution tiles.
+//
+// Round 6: PRODUCER / CONSUMER wave roles (as conv3x3_m160.hip, and for the same measured reason: every 1-KiB LDS-DMA piece holds its
+// issuing wave 100 - 185 clocks, five pieces per wave and tile that the eight-way split of the MFMA work could not hide -- the multi-layer
+// grids ran at 0.34 MFMA utilisation, ~4 600 clocks per 128-pixel tile for 2 304 of matrix work).
+//   * waves 4-7 (producers): the 39 pieces of tile t + 2 (ten each) into stage (t + 2) % 3, then a counted wait for tile t + 1, one barrier
+//     per tile;
+//   * waves 0-3 (consumers, one per SIMD) = 2 (ci halves) x 2 (tap groups: taps 0-4 / 5-8), both co halves, ALL 128 pixels of the tile
+//     (eight 16-pixel K steps): ten (eight) 32 x 32 fp32 accumulators, 160 registers, exactly as before -- but a consumer now owns its
+//     weights outright: the two pixel halves no longer meet in LDS at the end (a 147 KB exchange and two barriers per block gone), and it
+//     issues no vector-memory instruction inside the loop.
+// Every output element sums its pixels tile by tile, row pair by row pair in one chain (rounds 4-5: two half-tile chains added at the
+// end) -- same products, another fp32 order; hd_wgrad_multi / the fused grid still run THIS body, so they stay bit-identical to separate
+// hd_wgrad launches.
 __device__ __forceinline__ void wgrad3x3_w8_body(const Wg8P& p, f16* lds, int bx, int by) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wci = wave & 1, wpx = (wave >> 1) & 1, wtap = wave >> 2;     // ci half, pixel half of the tile, tap group (waves w and w + 4 share a SIMD: one of each group)
+  const bool consumer = wave < 4;
   const int ci_chunks = p.Cin >> 6;
   const int cchunk = by % ci_chunks, ochunk = by / ci_chunks;
   const int ci0 = cchunk * 64, co0 = ochunk * 64;
   const bool second = p.dual && ci0 >= p.C1;           // this ci chunk lives in the skip tensor
+  const int t_begin = bx * p.per_split;
+  int t_end = t_begin + p.per_split;
+  if (t_end > p.ntiles) t_end = p.ntiles;
+  const int nt = t_end > t_begin ? t_end - t_begin : 0;
 
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(second ? p.x2 : p.x), 0, second ? p.x2bytes : p.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.dy), 0, p.dybytes, 0x00020000);
-
-  // ---- this wave's DMA pieces of a tile: piece q = k*8 + wave; q < XPIECES: input patch, else dY tile
-  int upix[PPWV];               // patch / tile pixel of this lane's unit
-  unsigned ucol[PPWV];          // byte offset of its channel group within the pixel's source row
+  if (!consumer) {
+    // =====================================================  PRODUCER  =====================================================
+    const int pw = wave - 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(second ? p.x2 : p.x), 0, second ? p.x2bytes : p.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(p.dy), 0, p.dybytes, 0x00020000);
+    // ---- this wave's DMA pieces of a tile: piece q = k*4 + pw; q < XPIECES: input patch, else dY tile
+    constexpr int PPWV4 = (NPIECES + 3) / 4;      // 10 per producer (the last producer: 9)
+    int upix[PPWV4];              // patch / tile pixel of this lane's unit
+    unsigned ucol[PPWV4];         // byte offset of its channel group within the pixel's source row
 #pragma unroll
-  for (int k = 0; k < PPWV; ++k) {
-    const int q = k * 8 + wave;
-    const int u = (q < XPIECES ? q : q - XPIECES) * 64 + lane;
-    const int px = u >> 3, slot = u & 7;
-    upix[k] = px;
-    const int cg = (slot ^ swz4(px)) & 7;
-    ucol[k] = q < XPIECES ? (unsigned)((second ? ci0 - p.C1 : ci0) + cg * 8) * 2u : (unsigned)(co0 + cg * 8) * 2u;
-  }
-  const int srcC = second ? p.C2 : p.C1;
-  auto issue_tile = [&](int t, int stage) {
-    const bool live = t < p.ntiles;
-    const int tt = live ? t : 0;
-    const int n = tt / (p.tiles_x * p.tiles_y);
-    const int rem = tt - n * p.tiles_x * p.tiles_y;
-    const int tyi = rem / p.tiles_x;
-    const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
-    f16* sx = lds + stage * STAGE;
-    f16* sy = sx + XSTAGE;
-#pragma unroll
-    for (int k = 0; k < PPWV; ++k) {
-      const int q = k * 8 + wave;
-      if (q >= NPIECES) break;
-      if (q < XPIECES) {
-        const int pp = upix[k];
-        const int y = (pp * 6554) >> 16, x = pp - y * PW;
-        const int iy = ty0 - 1 + y, ix = tx0 - 1 + x;
-        const bool v = live && pp < PPX && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
-        unsigned off;
-        if (p.dual && !second) off = (unsigned)(((n * p.Hsrc + (iy >> 1)) * p.Wsrc + (ix >> 1)) * srcC) * 2u;
-        else off = (unsigned)(((n * p.H + iy) * p.W + ix) * srcC) * 2u;
-        dma16(rx, sx + q * 512, v ? off + ucol[k] : OOBB);
-      } else {
-        const int pix = upix[k];
-        const int oy = ty0 + (pix >> 3), ox = tx0 + (pix & 7);
-        const bool v = live && oy < p.H && ox < p.W;
-        dma16(rdy, sy + (q - XPIECES) * 512, v ? (unsigned)(((n * p.H + oy) * p.W + ox) * p.Cout) * 2u + ucol[k] : OOBB);
-      }
+    for (int k = 0; k < PPWV4; ++k) {
+      const int q = k * 4 + pw;
+      const int u = (q < XPIECES ? q : q - XPIECES) * 64 + lane;
+      const int px = u >> 3, slot = u & 7;
+      upix[k] = px;
+      const int cg = (slot ^ swz4(px)) & 7;
+      ucol[k] = q < XPIECES ? (unsigned)((second ? ci0 - p.C1 : ci0) + cg * 8) * 2u : (unsigned)(co0 + cg * 8) * 2u;
     }
-  };
+    const int srcC = second ? p.C2 : p.C1;
+    auto issue_tile = [&](int t, int stage) {
+      const bool live = t < t_end;
+      const int tt = live ? t : 0;
+      const int n = tt / (p.tiles_x * p.tiles_y);
+      const int rem = tt - n * p.tiles_x * p.tiles_y;
+      const int tyi = rem / p.tiles_x;
+      const int ty0 = tyi * TH, tx0 = (rem - tyi * p.tiles_x) * TW;
+      f16* sx = lds + stage * STAGE;
+      f16* sy = sx + XSTAGE;
+#pragma unroll
+      for (int k = 0; k < PPWV4; ++k) {
+        const int q = k * 4 + pw;
+        if (q >= NPIECES) break;
+        if (q < XPIECES) {
+          const int pp = upix[k];
+          const int y = (pp * 6554) >> 16, x = pp - y * PW;
+          const int iy = ty0 - 1 + y, ix = tx0 - 1 + x;
+          const bool v = live && pp < PPX && ((unsigned)iy < (unsigned)p.H) && ((unsigned)ix < (unsigned)p.W);
+          unsigned off;
+          if (p.dual && !second) off = (unsigned)(((n * p.Hsrc + (iy >> 1)) * p.Wsrc + (ix >> 1)) * srcC) * 2u;
+          else off = (unsigned)(((n * p.H + iy) * p.W + ix) * srcC) * 2u;
+          dma16(rx, sx + q * 512, v ? off + ucol[k] : OOBB);
+        } else {
+          const int pix = upix[k];
+          const int oy = ty0 + (pix >> 3), ox = tx0 + (pix & 7);
+          const bool v = live && oy < p.H && ox < p.W;
+          dma16(rdy, sy + (q - XPIECES) * 512, v ? (unsigned)(((n * p.H + oy) * p.W + ox) * p.Cout) * 2u + ucol[k] : OOBB);
+        }
+      }
+    };
+    // counted wait: everything but the pieces of the tile just issued has landed (10 pieces; the last producer has 9)
+    auto wait_older = [&]() {
+      if ((NPIECES & 3) != 0 && pw >= (NPIECES & 3)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWV4 - 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PPWV4) : "memory");
+    };
+    issue_tile(t_begin, 0);
+    issue_tile(t_begin + 1, 1);
+    wait_older();                               // tile t_begin has landed
+    __builtin_amdgcn_s_barrier();
+    for (int i = 0; i < nt; ++i) {
+      // stage (i + 2) % 3 held tile i - 1: every consumer finished with it before the barrier that ended iteration i - 1
+      issue_tile(t_begin + i + 2, (i + 2) % NSTAGE);
+      wait_older();                             // tile i + 1 has landed
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
 
+  // =======================================================  CONSUMER  =======================================================
+  const int wci = wave & 1, wtap = wave >> 1;           // ci half, tap group
   // ---- transposed-read geometry: 16-lane group g = lane >> 4 -> k half th = g >> 1 (pixel row of the 2 x 8 block), column half
   //      g & 1; within the group lane 4q+p addresses pixel q (x = q, second read x = q + 4), columns 4p .. 4p+3
   const int li = lane & 15, g = lane >> 4;
   const int tq = li >> 2, tp = li & 3, th = g >> 1, thalf = g & 1;
-  const int t_begin = bx * p.per_split;
-  int t_end = t_begin + p.per_split;
-  if (t_end > p.ntiles) t_end = p.ntiles;
   const char* lb = reinterpret_cast<const char*>(lds);
-  float* red = reinterpret_cast<float*>(lds);
-  const int wt2 = wci;                       // (co half, ci half) tile index of the final exchange = coh * 2 + wci
 
   // The tap group is wave-uniform: two instantiations of the same code (T0 = first tap, NT = taps of this wave).
   auto run = [&](auto t0c, auto ntc) {
     constexpr int T0 = decltype(t0c)::value, NT = decltype(ntc)::value;
-    // byte offsets (within a stage) for K step 0 of this wave's pixel half; K step s adds s * 2 rows
+    // byte offsets (within a stage) for K step 0 (tile rows 0-1); K step s adds s * 2 rows
     unsigned ya[2][2], xa[NT][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-      const int y = wpx * (TH / 2) + th, x = tq + 4 * r;
+      const int y = th, x = tq + 4 * r;
       const int pix = y * 8 + x;
 #pragma unroll
       for (int coh = 0; coh < 2; ++coh) {
@@ -165,84 +201,73 @@ __device__ __forceinline__ void wgrad3x3_w8_body(const Wg8P& p, f16* lds, int bx
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][coh][r] = 0.f;
 
-    if (t_begin < t_end) issue_tile(t_begin, 0);
-    for (int t = t_begin; t < t_end; ++t) {
-      const int st = (t - t_begin) & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();          // tile t landed everywhere; everyone is done with the other stage
-      __builtin_amdgcn_sched_barrier(0);
-      if (t + 1 < t_end) issue_tile(t + 1, st ^ 1);
-      const unsigned sb = (unsigned)(st * STAGE * 2);
-      // K steps of this wave's pixel half: 2 pixel rows (16 pixels) each; row step = 8 dY pixels (1 KiB) / 10 patch pixels (1 280 B).
-      // The 2 * NT * 4 MFMAs of a tile as ONE software-pipelined stream: MFMA pair j = (K step j / NT, tap j % NT) uses patch fragment j
-      // for both co halves; the patch fragment of pair j + RINGW is requested right after pair j is issued, the two dY fragments of the
-      // next K step while the current one runs (written as "read; mfma" the compiler put s_waitcnt lgkmcnt(0) in front of every MFMA).
-      constexpr int RINGW = 4, NPAIR = (TH / 4) * NT;
-      f16x8 bq[RINGW], aq[2][2];
-#define HD_WG8_B(J) tr_pair(lb + sb + xa[(J) % NT][0] + ((J) / NT) * 2560, lb + sb + xa[(J) % NT][1] + ((J) / NT) * 2560)
-#define HD_WG8_A(S, COH) tr_pair(lb + sb + ya[COH][0] + (S) * 2048, lb + sb + ya[COH][1] + (S) * 2048)
-      aq[0][0] = HD_WG8_A(0, 0);
-      aq[0][1] = HD_WG8_A(0, 1);
+    __builtin_amdgcn_s_barrier();                 // the first tile has landed
+    __builtin_amdgcn_s_setprio(1);
+    for (int i = 0; i < nt; ++i) {
+      // K steps: 2 pixel rows (16 pixels) each, eight per tile, run as two halves of four (one software-pipelined stream of 2 * NT * 4
+      // MFMAs per half, as in rounds 4-5 -- all eight in one stream spilled 130 registers); row step = 8 dY pixels (1 KiB) / 10 patch
+      // pixels (1 280 B).  MFMA pair j = (K step j / NT, tap j % NT) uses patch fragment j for both co halves; the patch fragment of
+      // pair j + RINGW is requested right after pair j is issued, the two dY fragments of the next K step while the current one runs
+      // (written as "read; mfma" the compiler put s_waitcnt lgkmcnt(0) in front of every MFMA).
+#pragma unroll 1
+      for (int hh = 0; hh < 2; ++hh) {
+        const unsigned sbx = (unsigned)((i % NSTAGE) * STAGE * 2) + (unsigned)(hh * 4 * 2560), sby = (unsigned)((i % NSTAGE) * STAGE * 2) + (unsigned)(hh * 4 * 2048);
+        constexpr int RINGW = 4, NPAIR = (TH / 4) * NT;
+        f16x8 bq[RINGW], aq[2][2];
+#define HD_WG8_B(J) tr_pair(lb + sbx + xa[(J) % NT][0] + ((J) / NT) * 2560, lb + sbx + xa[(J) % NT][1] + ((J) / NT) * 2560)
+#define HD_WG8_A(S, COH) tr_pair(lb + sby + ya[COH][0] + (S) * 2048, lb + sby + ya[COH][1] + (S) * 2048)
+        aq[0][0] = HD_WG8_A(0, 0);
+        aq[0][1] = HD_WG8_A(0, 1);
 #pragma unroll
-      for (int j = 0; j < RINGW; ++j) bq[j] = HD_WG8_B(j);
+        for (int j = 0; j < RINGW; ++j) bq[j] = HD_WG8_B(j);
 #pragma unroll
-      for (int j = 0; j < NPAIR; ++j) {
-        const int s_ = j / NT, tp9 = j % NT;
-        if (tp9 == 0 && s_ + 1 < TH / 4) {
-          aq[(s_ + 1) & 1][0] = HD_WG8_A(s_ + 1, 0);
-          aq[(s_ + 1) & 1][1] = HD_WG8_A(s_ + 1, 1);
+        for (int j = 0; j < NPAIR; ++j) {
+          const int s_ = j / NT, tp9 = j % NT;
+          if (tp9 == 0 && s_ + 1 < TH / 4) {
+            aq[(s_ + 1) & 1][0] = HD_WG8_A(s_ + 1, 0);
+            aq[(s_ + 1) & 1][1] = HD_WG8_A(s_ + 1, 1);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          acc[tp9][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s_ & 1][0], bq[j % RINGW], acc[tp9][0], 0, 0, 0);
+          acc[tp9][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s_ & 1][1], bq[j % RINGW], acc[tp9][1], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j + RINGW < NPAIR) bq[j % RINGW] = HD_WG8_B(j + RINGW);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[tp9][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s_ & 1][0], bq[j % RINGW], acc[tp9][0], 0, 0, 0);
-        acc[tp9][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(aq[s_ & 1][1], bq[j % RINGW], acc[tp9][1], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + RINGW < NPAIR) bq[j % RINGW] = HD_WG8_B(j + RINGW);
-      }
 #undef HD_WG8_A
 #undef HD_WG8_B
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();               // this stage is free; the next tile has landed (the producers' wait)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    __builtin_amdgcn_s_setprio(0);
 
-    // ---- the two pixel halves meet in LDS (9 x 4 tiles of 32 x 32 fp32 = 147 KiB), then one coalesced slab write
-    if (wpx == 1) {
+    // ---- this consumer's sums ARE the block's result for its (ci half, taps): one coalesced write
+    if (p.dw) {
+      // hd_wgrad_args.dw_oihw (one pixel split): this block's sums ARE the gradient of its 64 x 64 x 9 weights.  A lane holds NT
+      // consecutive taps of its (co, ci) pairs -- consecutive floats of the OIHW tensor, the 32 lanes of a half-wave 32 consecutive ci.
+      // scale * sum as hd_wgrad_reduce forms it for one split (0.f + sum: the reduction's accumulator start, -0 -> +0; same bits).
+#pragma unroll
+      for (int coh = 0; coh < 2; ++coh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int ci = ci0 + wci * 32 + (lane & 31);
+          float* o = p.dw + ((size_t)co * p.Cin + ci) * 9 + T0;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) o[t] = (0.f + acc[t][coh][r]) * p.dw_scale;
+        }
+    } else {
+      float* out = p.slab + (size_t)bx * p.Cout * p.Ktot;
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int coh = 0; coh < 2; ++coh)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) red[(((T0 + t) * 4 + coh * 2 + wt2) * 16 + r) * 64 + lane] = acc[t][coh][r];
-    }
-    __syncthreads();
-    if (wpx == 0) {
-      if (p.dw) {
-        // hd_wgrad_args.dw_oihw (one pixel split): this block's sums ARE the gradient of its 64 x 64 x 9 weights.  A lane holds NT
-        // consecutive taps of its (co, ci) pairs -- consecutive floats of the OIHW tensor, the 32 lanes of a half-wave 32 consecutive ci.
-        // scale * sum as hd_wgrad_reduce forms it for one split (0.f + sum: the reduction's accumulator start, -0 -> +0; same bits).
 #pragma unroll
         for (int coh = 0; coh < 2; ++coh)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int co = co0 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             const int ci = ci0 + wci * 32 + (lane & 31);
-            float* o = p.dw + ((size_t)co * p.Cin + ci) * 9 + T0;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) o[t] = (0.f + (acc[t][coh][r] + red[(((T0 + t) * 4 + coh * 2 + wt2) * 16 + r) * 64 + lane])) * p.dw_scale;
+            out[(size_t)co * p.Ktot + (T0 + t) * p.Cin + ci] = acc[t][coh][r];
           }
-      } else {
-        float* out = p.slab + (size_t)bx * p.Cout * p.Ktot;
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-          for (int coh = 0; coh < 2; ++coh)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float v = acc[t][coh][r] + red[(((T0 + t) * 4 + coh * 2 + wt2) * 16 + r) * 64 + lane];
-              const int co = co0 + coh * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-              const int ci = ci0 + wci * 32 + (lane & 31);
-              out[(size_t)co * p.Ktot + (T0 + t) * p.Cin + ci] = v;
-            }
-      }
     }
   };
   if (wtap == 0) run(std::integral_constant<int, 0>{}, std::integral_constant<int, 5>{});

@@ -138,6 +138,10 @@ int hd_conv_tune_override(int bm, int bn, int bk, int deep);
  * step-split main loop of 11..13, 18 = force the 160-pixel x 64-channel tile (4 x 40 pixels, v_mfma_f32_16x16x32_f16).  `nslices` is ignored (kept for the call's shape: the im2col 8-wave
  * family with split-K that used it was measured no faster than the 4-wave kernels on any shape and removed in round 3). */
 int hd_conv_tune_w8(int cfg, int nslices);
+/* test / tuning hook of the same cost model: n > 0 evaluates it at batch n whatever the launch's batch (then image i of a batched launch is
+ * bit-identical to the same image launched alone: the tiles split K differently and do not round identically); 0 (default) = the launch's
+ * own batch -- a given problem always gets the same tile (run-to-run identical), differently batched launches agree to fp16 rounding. */
+int hd_conv_nominal_batch(int n);
 /* test / tuning hook of the large-tile GEMM path (gemm_w8.hip: the plain-GEMM problems of hd_conv2d -- 1x1 / stride-1 convolutions
  * and fully connected layers -- on 256 x 128 (8 waves) / 128 x 128 (4 waves) tiles, register-only epilogue; bit-identical to the
  * implicit-GEMM family): -1 = the built-in rule, 0 = never, 128 / 1128 = that tile wherever the problem is eligible.  Process-wide. */

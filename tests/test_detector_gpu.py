@@ -393,37 +393,75 @@ def test_detector_image_gradient_per_branch(dev, case, branch):
     assert cos >= 0.999 and rel <= 0.03, (branch, cos, rel)
 
 
-def test_batched_three_pass_equals_three_single_passes(dev, case):
-    """eval_forward_fasterrcnn_multi (one trunk over hall+rgb+ir) == three calculate_loss calls: identical losses,
-    detections and image gradient when the sampler permutations are replayed in the same order."""
+@pytest.mark.parametrize("nominal", [8, 0])
+def test_batched_three_pass_equals_three_single_passes(dev, case, nominal):
+    """eval_forward_fasterrcnn_multi (one trunk over hall+rgb+ir) == three calculate_loss calls when the sampler permutations are replayed
+    in the same order.
+    nominal = 8: the convolution tile model evaluated at one batch size for every launch (hd_conv_nominal_batch, rounds 2-5's rule) --
+    the same kernels serve the 2-image and the 6-image launches and losses / detections are IDENTICAL bit for bit: the orchestration of
+    the fused evaluation adds nothing of its own.
+    nominal = 0 (shipped since round 6): the model sees each launch's own batch, a batched launch may run other tiles than a single pass;
+    tiles split K differently, so the two evaluations agree to fp16 rounding -- losses to 2e-3 relative, >= 95 % of the detections
+    matched box for box (IoU >= 0.9, same label, score within 2e-2; measured 576 / 600), image gradient cosine >= 0.99 (0.9951) -- and each of them stays
+    run-to-run identical (second half of the test)."""
+    from hallucidet_amd import _abi
     from hallucidet_amd.models.detector import Detector
     from hallucidet_amd.utils.eval_forward_fasterrcnn import eval_forward_fasterrcnn_multi
+    from oracle import kernels as ok
     det, oracle, images, targets = case
     imgs = [images.to(dev), (images * 0.5 + 0.2).to(dev), images.flip(-1).contiguous().to(dev)]
     tg = _t2d(targets, dev)
-    perms = Perms(33)
-    det.rpn.fg_bg_sampler.randperm_fn = perms
-    det.roi_heads.fg_bg_sampler.randperm_fn = perms
-    x0 = imgs[0].clone().requires_grad_(True)
-    l0, d0 = Detector.calculate_loss(det, x0, tg, model_name="fasterrcnn")
-    with torch.no_grad():
-        _, d1 = Detector.calculate_loss(det, imgs[1], tg, model_name="fasterrcnn")
-        _, d2 = Detector.calculate_loss(det, imgs[2], tg, model_name="fasterrcnn")
-    sum(l0.values()).backward()
-    perms.replay, perms.i = perms.log, 0
-    x1 = imgs[0].clone().requires_grad_(True)
-    (lm, dm0), (_, dm1), (_, dm2) = eval_forward_fasterrcnn_multi(det, [x1, imgs[1], imgs[2]], [tg, tg, tg])
-    sum(lm.values()).backward()
-    det.rpn.fg_bg_sampler.randperm_fn = None
-    det.roi_heads.fg_bg_sampler.randperm_fn = None
-    for k in l0:
-        assert torch.equal(l0[k].detach(), lm[k].detach()), k
-    for a, b in zip(d0 + d1 + d2, dm0 + dm1 + dm2):
-        for key in ("boxes", "scores", "labels"):
-            assert torch.equal(a[key], b[key]), key
+    lib = _abi.load()
+    lib.hd_conv_nominal_batch(nominal)
+    try:
+        perms = Perms(33)
+        det.rpn.fg_bg_sampler.randperm_fn = perms
+        det.roi_heads.fg_bg_sampler.randperm_fn = perms
+        x0 = imgs[0].clone().requires_grad_(True)
+        l0, d0 = Detector.calculate_loss(det, x0, tg, model_name="fasterrcnn")
+        with torch.no_grad():
+            _, d1 = Detector.calculate_loss(det, imgs[1], tg, model_name="fasterrcnn")
+            _, d2 = Detector.calculate_loss(det, imgs[2], tg, model_name="fasterrcnn")
+        sum(l0.values()).backward()
+        perms.replay, perms.i = perms.log, 0
+        x1 = imgs[0].clone().requires_grad_(True)
+        (lm, dm0), (_, dm1), (_, dm2) = eval_forward_fasterrcnn_multi(det, [x1, imgs[1], imgs[2]], [tg, tg, tg])
+        sum(lm.values()).backward()
+        if nominal == 0:
+            # run-to-run: the batched evaluation again, same draws -> the same bits
+            perms.replay, perms.i = perms.log, 0
+            x2 = imgs[0].clone().requires_grad_(True)
+            (lr, dr0), (_, dr1), (_, dr2) = eval_forward_fasterrcnn_multi(det, [x2, imgs[1], imgs[2]], [tg, tg, tg])
+    finally:
+        lib.hd_conv_nominal_batch(0)
+        det.rpn.fg_bg_sampler.randperm_fn = None
+        det.roi_heads.fg_bg_sampler.randperm_fn = None
+    if nominal:
+        for k in l0:
+            assert torch.equal(l0[k].detach(), lm[k].detach()), k
+        for a, b in zip(d0 + d1 + d2, dm0 + dm1 + dm2):
+            for key in ("boxes", "scores", "labels"):
+                assert torch.equal(a[key], b[key]), key
+    else:
+        for k in l0:
+            a, b = float(l0[k]), float(lm[k])
+            assert abs(a - b) <= 2e-3 * abs(a) + 1e-6, (k, a, b)
+            assert torch.equal(lm[k].detach(), lr[k].detach()), ("run-to-run", k)
+        n_det = n_match = 0
+        for a, b in zip(d0 + d1 + d2, dm0 + dm1 + dm2):
+            n_det += max(a["boxes"].shape[0], b["boxes"].shape[0])
+            if a["boxes"].numel() and b["boxes"].numel():
+                best, arg = ok.box_iou(a["boxes"].float().cpu(), b["boxes"].float().cpu()).max(dim=1)
+                n_match += int(((best >= 0.9) & (a["labels"].cpu() == b["labels"].cpu()[arg]) & ((a["scores"].cpu() - b["scores"].cpu()[arg]).abs() <= 2e-2)).sum())
+        print("   batched vs single passes under per-launch tiles: %d / %d detections matched" % (n_match, n_det))
+        assert n_match >= 0.95 * n_det, (n_match, n_det)
+        for a, b in zip(dm0 + dm1 + dm2, dr0 + dr1 + dr2):
+            for key in ("boxes", "scores", "labels"):
+                assert torch.equal(a[key], b[key]), ("run-to-run", key)
     # RoIAlign backward accumulates with fp32 atomics (order varies run to run) before the fp16 trunk gradient
     cos = float(torch.nn.functional.cosine_similarity(x0.grad.flatten(), x1.grad.flatten(), dim=0))
-    assert cos > 0.9999 and float((x0.grad - x1.grad).norm() / x0.grad.norm()) < 1e-2
+    # (per-launch tiles: the two trunk evaluations round differently, ReLUs next to zero flip: measured cosine 0.9951)
+    assert cos > (0.9999 if nominal else 0.99) and float((x0.grad - x1.grad).norm() / x0.grad.norm()) < (1e-2 if nominal else 0.15)
 
 
 def test_batched_heads_equal_list_heads(dev, case):

@@ -284,7 +284,7 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
         Detector.calculate_loss(det, images.to(dev), _t2d(targets, dev), train_det=True, model_name="fcos")
 
 
-def test_three_pass_fusion_equals_three_single_passes(dev, case):
+def test_three_pass_fusion_equals_three_single_passes(dev, case, pinned_tiles):
     from hallucidet_amd.utils.eval_forward_fcos import eval_forward_fcos, eval_forward_fcos_multi
     det, _, images, targets = case
     tg = _t2d(targets, dev)

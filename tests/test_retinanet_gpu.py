@@ -196,7 +196,7 @@ def test_end_to_end_losses_detections_and_image_gradient(dev, case):
         assert torch.equal(a["labels"], b["labels"]) and torch.allclose(a["boxes"], b["boxes"], atol=1e-4)
 
 
-def test_three_pass_fusion_equals_three_single_passes(dev, case):
+def test_three_pass_fusion_equals_three_single_passes(dev, case, pinned_tiles):
     from hallucidet_amd.utils.eval_forward_retinanet import eval_forward_retinanet, eval_forward_retinanet_multi
     det, _, images, targets = case
     tg = _t2d(targets, dev)

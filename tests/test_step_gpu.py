@@ -298,7 +298,7 @@ def test_validation_and_test_hooks_accumulate_map(dev):
     assert all(float(t) == -1.0 for t in lit.on_validation_epoch_end()["map_hall"].values())
 
 
-def test_skip_unused_train_passes_is_opt_in_and_keeps_the_losses(dev):
+def test_skip_unused_train_passes_is_opt_in_and_keeps_the_losses(dev, pinned_tiles):
     """Opt-in flag: the training step without the RGB / IR passes whose results the reference discards (RetinaNet: no sampler,
     so the hallucinated pass's losses are bit-identical with and without them)."""
     from hallucidet_amd import synthetic

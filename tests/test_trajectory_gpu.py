@@ -1,0 +1,211 @@
+"""K-step TRAJECTORY parity (round 6): every other step-level test compares ONE optimiser step.  BatchNorm running statistics, Adam's
+moments and bias correction, the loss scaler and the fp16 weight repack interact over time, and the metric's second half (LLVIP AP@50,
+reference README.md:134-137) needs a dataset this image does not hold -- the nearest stand-in is to take K optimiser steps of the
+product and of the CPU oracle (oracle/step.py: train_hallucidet.py:161-240 forward_step + Lightning's backward / clip_grad_value_(0.5) /
+Adam, train_hallucidet.py:429-445,498-499) from identical weights on identical batches and compare the whole state at the end.
+
+precision=32 (the reference's default, config.py:149), three forms:
+  * RetinaNet, NOTHING shared (no pins, no rounding schedule): a 10-step plain trajectory.  Adam's first steps move every parameter by
+    +-lr whatever the gradient's size, so elements whose gradient sits inside the two evaluations' round-off take opposite steps: the
+    bound on the parameters is the one that dynamics allows (measured values are printed), the per-step LOSSES stay within 3e-3;
+  * Faster R-CNN with the product's discrete decisions handed to the oracle EVERY step (tests/_pins.py, audited as in
+    tests/test_fp32_mode_gpu.py) and the samplers' draws injected on both sides: losses to 1e-3 relative per step, the parameter
+    UPDATE (p_K - p_0) to cosine >= 0.999, running statistics to 1e-3;
+  * the same at BASELINE configs[1]'s size (8 x 512 x 640), fewer steps (the oracle takes ~15 s per step on the box's host cores).
+precision=16 (configs[1] itself): the product's trajectory against the plain fp32 oracle's with stated, looser bounds, and the loss
+scaler's state: no skipped step, the scale it started with (GradScaler grows every 2000 clean steps)."""
+import pytest
+import torch
+
+from oracle import detection as od
+from oracle import retinanet as orn
+from oracle import unet as ou
+from oracle.step import OracleTrainer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+class Draws:
+    """torch.randperm from a private seeded generator (the product's and the oracle's samplers then draw the same permutations for equal
+    populations); logs the population sizes."""
+
+    def __init__(self, seed):
+        self.seed = seed
+        self.reset()
+
+    def reset(self):
+        self.g = torch.Generator().manual_seed(self.seed)
+        self.sizes = []
+
+    def __call__(self, n):
+        self.sizes.append(int(n))
+        return torch.randperm(n, generator=self.g)
+
+
+def _pair(dev, detector_name, seed, precision):
+    """Product at `precision` and the PLAIN fp32 oracle on the same parameters (test_fp32_mode_gpu._pair32's construction)."""
+    from hallucidet_amd import synthetic
+    lit = synthetic.make_module(seed=seed, device=str(dev), precision=precision, detector_name=detector_name)
+    det = lit.detector
+    if detector_name == "retinanet":
+        with torch.no_grad():
+            det.head.classification_head.cls_logits.bias.fill_(-2.0)
+    det.invalidate_packs()
+    ounet = ou.Unet(classes=3)
+    ounet.load_state_dict({k: v.cpu() for k, v in lit.encoder_decoder.state_dict().items()})
+    odet = orn.RetinaNet(num_classes=2, size=300) if detector_name == "retinanet" else od.FasterRCNN(num_classes=2, size=300)
+    odet.load_state_dict({k: v.cpu() for k, v in det.state_dict().items()})
+    tr = OracleTrainer(unet=ounet, detector=odet, lr=lit.lr, clip=0.5)
+    if detector_name == "fasterrcnn":
+        fn = Draws(1)
+        tr.det.rpn.fg_bg_sampler.randperm_fn = fn
+        tr.det.roi_heads.fg_bg_sampler.randperm_fn = fn
+        lit.batch_detector_passes = False          # the reference's per-pass call order (what the oracle replays)
+        lit.detector.fused_passes = False
+        fn = Draws(1)
+        lit.detector.rpn.fg_bg_sampler.randperm_fn = fn
+        lit.detector.roi_heads.fg_bg_sampler.randperm_fn = fn
+    lit.use_detector_graph = False
+    return lit, tr
+
+
+def _to_cpu(batch):
+    rgb, trgb, ir, tir = batch
+    c = lambda ts: [{k: v.cpu() for k, v in t.items()} for t in ts]
+    return rgb.cpu(), c(trgb), ir.cpu(), c(tir)
+
+
+def _reset_draws(lit, tr):
+    for d in (lit.detector, tr.det):
+        fn = getattr(getattr(getattr(d, "rpn", None), "fg_bg_sampler", None), "randperm_fn", None)
+        if fn is not None:
+            fn.reset()
+
+
+def _state_agreement(lit, tr, start):
+    """-> dict of the end-state distances: parameters (rel-L2 over the whole vector), the UPDATE p_K - p_0 (rel-L2, cosine), BatchNorm
+    running mean / variance (worst per-tensor rel-L2), the step counters."""
+    sd = {k: v.detach().float().cpu() for k, v in lit.encoder_decoder.state_dict().items()}
+    osd = {k: v.detach().float() for k, v in tr.unet.state_dict().items()}
+    names = [n for n, _ in tr.unet.named_parameters()]
+    cat = lambda d: torch.cat([d[n].flatten().double() for n in names])
+    p, q, p0 = cat(sd), cat(osd), cat(start)
+    up, uq = p - p0, q - p0
+    out = dict(param_rel=float((p - q).norm() / q.norm()), update_rel=float((up - uq).norm() / uq.norm()),
+               update_cos=float((up * uq).sum() / (up.norm() * uq.norm())), update_norm=float(uq.norm() / p0.norm()))
+    worst_m = worst_v = 0.0
+    for k in osd:
+        if k.endswith("running_mean"):
+            # a shift of the running mean is measured in units of the layer's standard deviation (the mean itself may be ~0)
+            sig = osd[k.replace("running_mean", "running_var")].sqrt()
+            worst_m = max(worst_m, float((sd[k] - osd[k]).norm() / (sig.norm() + 1e-12)))
+        elif k.endswith("running_var"):
+            worst_v = max(worst_v, float((sd[k] - osd[k]).norm() / (osd[k].norm() + 1e-12)))
+        elif k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(osd[k]), (k, int(sd[k]), int(osd[k]))
+    out.update(bn_mean_rel=worst_m, bn_var_rel=worst_v)
+    return out
+
+
+def _run(dev, detector_name, seed, shape, K, share, precision=32):
+    from hallucidet_amd import synthetic
+    from _pins import record, unet_decisions, assert_borrowed_decisions_are_noise
+    lit, tr = _pair(dev, detector_name, seed, precision)
+    N, H, W = shape
+    start = {k: v.detach().float().cpu().clone() for k, v in lit.encoder_decoder.state_dict().items()}
+    rows = []
+    for k in range(K):
+        batch = synthetic.make_batch(N, H, W, seed=seed + 100 + k, device=str(dev))
+        cbatch = _to_cpu(batch)
+        pins = umasks = uvalues = None
+        if share:
+            # the product's discrete decisions at the CURRENT parameters, recorded by a forward pass that leaves no trace: BatchNorm buffers
+            # (running statistics, batch counters) are put back, the samplers' generators rewound
+            lit.encoder_decoder.train()
+            bufs = [b.clone() for b in lit.encoder_decoder.buffers()]
+            _reset_draws(lit, tr)
+            with record(lit.detector, first=True) as rec:
+                lit.forward_step(*batch, 0, step="train")
+            pins = rec.pins(n_images=N)
+            umasks, uvalues = unet_decisions(lit.encoder_decoder.runner)
+            with torch.no_grad():
+                for b, s0 in zip(lit.encoder_decoder.buffers(), bufs):
+                    b.copy_(s0)
+        _reset_draws(lit, tr)
+        loss = lit.fit_step(batch)
+        torch.cuda.synchronize()
+        # oracle: the same step
+        tr.unet.train()
+        tr.unet_q = ou.Ctx(lambda t: t, umasks, uvalues) if share else None
+        # (the draws of the product's step are replayed: its sampler object was rewound before fit_step, the oracle's here)
+        for d in (tr.det,):
+            fn = getattr(getattr(getattr(d, "rpn", None), "fg_bg_sampler", None), "randperm_fn", None)
+            if fn is not None:
+                fn.reset()
+        total, olosses, _ = tr.forward_step(*cbatch, det_pins=pins)
+        if share:
+            assert pins.used == set(pins.masks)
+            if k in (0, K - 1):                                   # the audit of the borrowed decisions, at both ends of the trajectory
+                assert_borrowed_decisions_are_noise(pins, "detector, step %d" % k)
+                assert_borrowed_decisions_are_noise(tr.unet_q, "U-Net, step %d" % k)
+        tr.opt.zero_grad(set_to_none=True)
+        total.backward()
+        torch.nn.utils.clip_grad_value_(tr.unet.parameters(), tr.clip)
+        tr.opt.step()
+        a, b = float(loss), float(total)
+        rows.append((a, b, abs(a - b) / max(abs(b), 1e-12)))
+        print("   step %2d: product loss %.7f oracle %.7f rel %.2e" % (k, a, b, rows[-1][2]))
+    tr.unet_q = None
+    agree = _state_agreement(lit, tr, start)
+    print("   %s %s precision %d, %d steps, decisions %s: %s" % (detector_name, shape, precision, K, "shared" if share else "own",
+                                                                 ", ".join("%s %.3e" % kv for kv in agree.items())))
+    return lit, tr, rows, agree
+
+
+def test_trajectory_fp32_retinanet_nothing_shared(dev):
+    """10 plain steps, nothing shared.  RetinaNet has no sampler and no proposal ranking, so its loss is a continuous function of the
+    parameters (ReLU flips aside) and the two trajectories stay together on their own."""
+    lit, tr, rows, agree = _run(dev, "retinanet", 52, (2, 128, 160), 10, share=False)
+    # measured: per-step losses 3e-7 (step 0) ... 1.1e-3, parameters 1.1e-2, running variance 6e-2, update cosine 0.48 -- Adam's early
+    # steps are +-lr per element whatever the gradient's size, so every element whose gradient lies inside the two evaluations' round-off
+    # (and a random-init network has many: dead ReLU channels, weights in front of a BatchNorm) random-walks apart while the LOSS, which
+    # does not depend on them, stays together.  The sharp statement about the optimiser state is the decisions-shared test below
+    # (parameters 3e-5, update cosine 1.000000); this one pins that two free-running trajectories do not drift in what they compute.
+    assert all(r[2] <= 3e-3 for r in rows), rows
+    assert agree["bn_mean_rel"] <= 0.2 and agree["bn_var_rel"] <= 0.15, agree
+    assert agree["update_cos"] >= 0.3 and agree["param_rel"] <= 3e-2, agree
+    assert not lit.scaler.enabled and lit.optimizer.step_count == 10 and lit.optimizer.skipped_steps == 0
+
+
+@pytest.mark.parametrize("shape,K", [((2, 128, 160), 6), ((8, 512, 640), 3)])          # the second: BASELINE configs[1]'s size
+def test_trajectory_fp32_fasterrcnn_decisions_shared(dev, shape, K):
+    """Faster R-CNN, the product's discrete decisions (ReLU on / off, max-pool winners, post-NMS proposals) handed to the oracle at EVERY
+    step and audited at both ends, sampler draws injected: per-step total loss to 1e-3, end state as the docstring says."""
+    lit, tr, rows, agree = _run(dev, "fasterrcnn", 53, shape, K, share=True)
+    assert all(r[2] <= 1e-3 for r in rows), rows
+    ps, os_ = lit.detector.rpn.fg_bg_sampler.randperm_fn.sizes, tr.det.rpn.fg_bg_sampler.randperm_fn.sizes
+    assert ps[:4 * shape[0]] == os_[:4 * shape[0]], "last step: the samplers drew for different populations"
+    assert agree["bn_mean_rel"] <= 1e-3 and agree["bn_var_rel"] <= 1e-3, agree
+    assert agree["update_cos"] >= 0.999 and agree["update_rel"] <= 5e-2 and agree["param_rel"] <= 1e-3, agree
+    assert lit.optimizer.step_count == K and lit.optimizer.skipped_steps == 0
+
+
+def test_trajectory_fp16_against_the_fp32_oracle(dev):
+    """BASELINE configs[1]'s precision: 6 steps of the fp16 product (loss scaling on) against the plain fp32 oracle.  fp16 storage over
+    ~110 layers moves the losses by ~1e-2 and the gradients by ~10 % (tests/test_step_gpu.py), so the bounds are the stated looser ones;
+    what this test pins over TIME is the loss scaler (no overflow: no skipped step, the scale it started with, inverse scale applied
+    in the optimizer) and that the fp16 weight repack follows every update (a stale repack would freeze the trajectory: the update
+    would stop pointing along the oracle's)."""
+    lit, tr, rows, agree = _run(dev, "retinanet", 54, (2, 128, 160), 6, share=False, precision=16)
+    assert lit.scaler.enabled
+    lit.scaler.resolve()
+    assert lit.optimizer.skipped_steps == 0 and lit.optimizer.step_count == 6 and lit.scaler.scale_value == 2.0 ** 16
+    assert all(r[2] <= 2e-2 for r in rows), rows
+    assert agree["bn_mean_rel"] <= 0.3 and agree["bn_var_rel"] <= 0.2, agree
+    assert agree["update_cos"] >= 0.1 and agree["param_rel"] <= 3e-2, agree       # (free-running, as the fp32 test above: see its comment)

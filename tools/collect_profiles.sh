@@ -1,6 +1,6 @@
 # Round profiles: kernel-trace summary of a training-step run and of the bench command, PMC passes (MFMA utilisation, HBM traffic).
 # Run on the GPU box from the repo root:  bash tools/collect_profiles.sh r02
-R=${1:-r05}
+R=${1:-r06}
 cd /root/repo
 export TMPDIR=/tmp
 mkdir -p gpurun_out
@@ -13,7 +13,7 @@ STEPS=3 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d gpurun_out/pmc_fetch --outp
 STEPS=3 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d gpurun_out/pmc_write --output-format csv -- python3 tools/bench_step.py > gpurun_out/pmc_write.log 2>&1
 python3 tools/pmc_mfma.py gpurun_out/pmc_mfma gpurun_out/pmc_gui gpurun_out/${R}_conv_mfma_util.json > /dev/null
 F=$(ls gpurun_out/pmc_fetch/*/*counter_collection.csv | head -1); W=$(ls gpurun_out/pmc_write/*/*counter_collection.csv | head -1)
-python3 tools/pmc_traffic.py $F $W conv_igemm_kernel,gemm_w8_kernel,conv3x3_small_kernel,conv3x3_w8_kernel,conv3x3_c64_kernel,conv7x7s2_stem_kernel,conv3x3_c32to128_kernel,conv3x3_cat128to32_kernel gpurun_out/${R}_conv_traffic.json > /dev/null
+python3 tools/pmc_traffic.py $F $W conv_igemm_kernel,gemm_w8_kernel,conv3x3_small_kernel,conv3x3_w8_kernel,conv3x3_m160_kernel,conv3x3_c64_kernel,conv7x7s2_stem_kernel,conv3x3_c32to128_kernel,conv3x3_cat128to32_kernel gpurun_out/${R}_conv_traffic.json > /dev/null
 STEPS=12 rocprofv3 --kernel-trace -d gpurun_out/trace_ss --output-format csv -- python3 tools/bench_step.py > gpurun_out/trace_ss.log 2>&1
 python3 tools/trace_gaps.py $(ls gpurun_out/trace_ss/*/*kernel_trace.csv | head -1) 0.5 --table --aten > gpurun_out/${R}_steady_state.txt 2>&1
 rm -rf gpurun_out/trace_ss

@@ -9,14 +9,14 @@ mfma_util of a kernel = sum SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x sum wall cl
 (summed over the 32 shader engines; it reproduces launch duration x ~1.98 GHz here, whereas GRBM_GUI_ACTIVE / 8 reads ~45 % high on
 these 10-50 us dispatches, as MI355X_MICROARCH.md "DVFS give-back" warns for dispatches under 0.3 ms -- it is kept as `gui_clocks`).  SQ_VALU_MFMA_BUSY_CYCLES counts clocks (32 per
 v_mfma_f32_32x32x16_f16), SQ_WAVE_CYCLES / SQ_WAIT_* count quad-clocks.  Kernels: every template instance of the conv families
-(conv_igemm_kernel, conv3x3_w8_kernel, conv3x3_c64_kernel, conv3x3_small_kernel) and the weight-gradient kernels."""
+(conv_igemm_kernel, conv3x3_w8_kernel, conv3x3_m160_kernel, conv3x3_c64_kernel, conv3x3_small_kernel) and the weight-gradient kernels."""
 import collections
 import csv
 import glob
 import json
 import sys
 
-FAMILIES = ["conv_igemm_kernel", "gemm_w8_kernel", "conv3x3_w8_kernel", "conv3x3_c64_kernel", "conv7x7s2_stem_kernel", "conv3x3_c32to128_kernel", "conv3x3_cat128to32_kernel", "conv3x3_small_kernel", "wgrad3x3_w8_multi_kernel", "wgrad3x3_w8_kernel", "wgrad_kernel", "wgrad3x3_small_kernel"]
+FAMILIES = ["conv_igemm_kernel", "gemm_w8_kernel", "conv3x3_w8_kernel", "conv3x3_m160_kernel", "conv3x3_c64_kernel", "conv7x7s2_stem_kernel", "conv3x3_c32to128_kernel", "conv3x3_cat128to32_kernel", "conv3x3_small_kernel", "wgrad3x3_w8_multi_kernel", "wgrad3x3_w8_kernel", "wgrad_kernel", "wgrad3x3_small_kernel"]
 
 
 def load(d):

@@ -15,7 +15,7 @@ if mode == "seg":
     lit.averager.bucket_ready = lambda lo, hi: None
     Dd.is_dist = lambda: True
     lit.averager.start = lambda g: None
-    lit.averager.finish = lambda g: None
+    lit.averager.finish = lambda g, defer_mean=False: 1.0
     lit.averager.begin = lambda g: None
 for _ in range(8): lit.fit_step(batch)
 torch.cuda.synchronize()

@@ -52,7 +52,7 @@ def main():
         naten = sum(v[0] for k, v in per.items() if "at::" in k or "rocclr" in k)
         print("steady state: %d steps, %.1f launches/step, kernel time %.3f ms/step, wall %.3f ms/step; ATen+copy %.1f launches, %.1f us per step"
               % (nsteps, len(win) / nsteps, tot / nsteps / 1e6, (win[-1][1] - win[0][0]) / nsteps / 1e6, naten / nsteps, aten / nsteps / 1e3))
-        groups = [("hd_conv2d: conv_igemm (+ multi)", ("conv_igemm_kernel", "conv_igemm_multi_kernel")), ("hd_conv2d: conv3x3_w8", ("conv3x3_w8_kernel",)), ("hd_conv2d: gemm_w8 (box head)", ("gemm_w8_kernel",)), ("hd_conv2d: register-resident (c64, stem, decoder block 3)", ("conv3x3_c64_kernel", "conv7x7s2_stem_kernel", "conv3x3_c32to128_kernel", "conv3x3_cat128to32_kernel")),
+        groups = [("hd_conv2d: conv_igemm (+ multi)", ("conv_igemm_kernel", "conv_igemm_multi_kernel")), ("hd_conv2d: conv3x3_w8", ("conv3x3_w8_kernel",)), ("hd_conv2d: conv3x3_m160 (producer / consumer)", ("conv3x3_m160_kernel",)), ("hd_conv2d: gemm_w8 (box head)", ("gemm_w8_kernel",)), ("hd_conv2d: register-resident (c64, stem, decoder block 3)", ("conv3x3_c64_kernel", "conv7x7s2_stem_kernel", "conv3x3_c32to128_kernel", "conv3x3_cat128to32_kernel")),
                   ("hd_conv2d: conv3x3_small", ("conv3x3_small_kernel",)), ("data + weight gradient, one grid", ("conv3x3_w8_wgrad_kernel",)),
                   ("weight gradients", ("::wgrad_kernel", "wgrad3x3_w8_kernel", "wgrad3x3_w8_multi_kernel", "wgrad3x3_small_kernel")), ("slab reductions", ("wgrad_reduce",)),
                   ("BatchNorm reduce (bwd)", ("bn_bwd_reduce",)), ("BatchNorm apply (bwd)", ("bn_bwd_apply",)), ("BatchNorm apply (fwd)", ("bn_apply_kernel",)),
