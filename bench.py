@@ -492,6 +492,9 @@ def main():
         #  stdio, i.e. at process exit, behind the JSON line: every rank flushes C stdio after the warm-up steps, see _flush_c_stdio)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        # the gradient arena outlives every collective on it: the allocator need not record the RCCL stream on it (0.1 ms of a 10 ms step at
+        # world size 1, tools/probe_dist_host.py)
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from hallucidet_amd import synthetic

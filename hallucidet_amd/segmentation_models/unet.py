@@ -400,8 +400,18 @@ class UnetRunner:
         return g["out"]
 
     def bucket_ranges(self):
-        """[(lo, hi)] slices of the flat gradient arena in the order the backward pass completes them."""
+        """[(lo, hi)] slices of the flat gradient arena in the order the backward pass completes them.  Cached per arena: the hooked
+        backward asks every step, and walking ~180 parameters in Python between the detector graph and the first backward graph was a
+        160 us hole in every data-parallel step (profiles/r06_forced_dist_steady_state.txt, first collection)."""
         self.flatten_parameters()
+        key = (self._gflat.data_ptr(), self._gflat.numel(), _EXCHANGE_BUCKETS)
+        if getattr(self, "_bucket_ranges_cache", (None, None))[0] == key:
+            return self._bucket_ranges_cache[1]
+        out = self._bucket_ranges_uncached()
+        self._bucket_ranges_cache = (key, out)
+        return out
+
+    def _bucket_ranges_uncached(self):
         off = {id(p): o for p, o in zip(self._params, self._offsets)}
         total = self._gflat.numel()
         first = lambda mod: min(off[id(p)] for p in mod.parameters())
