@@ -15,8 +15,9 @@
 // 659 at 2.07 GHz -- the same 11.4 us): the phase is not LDS-read time, it is the 100 - 185 clocks EACH LDS-DMA piece holds its issuing
 // wave (MI355X_MICROARCH.md, cycle constants) -- 3 - 4 pieces per wave and round that no partner can hide, because the partner's MFMAs
 // end when they end.  So here the waves that multiply issue NO vector-memory instruction:
-//   * waves 4-7 (producers): per K step two 1-KiB weight pieces each (64 x 64 halves = 8 pieces) three steps ahead of the MFMAs, and during
-//     taps 0-6 of a channel chunk two pieces each of the NEXT chunk's input patch; one counted s_waitcnt vmcnt + one s_barrier per K step;
+//   * waves 4-7 (producers): per K step two 1-KiB weight pieces each (64 x 64 halves = 8 pieces) FIVE steps ahead of the MFMAs, and during
+//     taps 0-4 of a channel chunk two or three pieces each of the NEXT chunk's input patch; one counted s_waitcnt vmcnt (two steps' pieces stay
+//     in flight) + one s_barrier per K step;
 //   * waves 0-3 (consumers, one per SIMD): software-pipelined over K steps -- the 9 fragments (4 weight + 5 pixel, ds_read_b128) of the
 //     next 32-deep unit are requested, then the 20 MFMAs of the current unit run from the other register set -- one s_barrier per K step.
 //     A consumer owns 80 pixels x 64 channels = 5 x 4 accumulator blocks of v_mfma_f32_16x16x32_f16 (80 registers; 160 pixels = five
@@ -26,11 +27,11 @@
 //               shared epilogue (conv_w8_epilogue.h, WK = 2);
 //       TH = 8: consumers = 4 row pairs, each runs both halves of every K step: no partial sums (epilogue tile [320][68] fp32).
 // Hazards.  Step s (tap s % 9 of chunk s / 9) lives in ring stage s % 6; barrier s ends step s.  Between barriers s-1 and s a producer
-// issues step s+3's weights and (taps 0-6) next-chunk patch pieces, then waits until everything it issued in EARLIER steps has landed; a
-// consumer requests the fragments of step s+1 and multiplies step s.  So step s+2's bytes have landed (every producer's wait) before
-// barrier s, and are first read after it; the stage written in step s (s+3) was last read in step s-4; the patch buffer of chunk c+1
+// issues step s+5's weights and (taps 0-4) next-chunk patch pieces, then waits until everything it issued TWO OR MORE steps ago has landed; a
+// consumer requests the fragments of step s+1 and multiplies step s.  So step s+3's bytes have landed (every producer's wait) before
+// barrier s, and step s+1's are first read after barrier s-1; the stage written in step s (s+5) is that of step s-1, last read in step s-1; the patch buffer of chunk c+1
 // (chunk parity) was last read in step (c-1, tap 7) -- its tap-8 fragments are requested there -- and is written from step (c, tap 0),
-// two barriers later; it is complete before barrier (c, tap 7) (the weight wait of that step covers every older piece) and first read
+// two barriers later; it is complete before barrier (c, tap 7) (that step's wait covers everything issued in taps <= 5) and first read
 // in step (c, tap 8).  Every consumer waits for its outstanding LDS reads before each barrier.  Both roles execute exactly one barrier
 // per K step plus one in front: the counts match by construction (the same loop table drives both).
 //
@@ -61,13 +62,12 @@ struct M160 {
   static constexpr int PH = TH + 2;
   static constexpr int PPX = PH * PW;                          // 252 / 420 patch pixels
   static constexpr int NPIECE = (PPX * 8 + 63) / 64;           // 32 / 53 one-KiB pieces per patch chunk
-  static constexpr int PK = (NPIECE + 3) / 4;                  // 8 / 14 pieces per producer wave and chunk (two per K step, taps 0 .. PK / 2 - 1)
+  static constexpr int PK = (NPIECE + 3) / 4;                  // 8 / 14 pieces per producer wave and chunk
   static constexpr int PSTAGE = NPIECE * 512;                  // halves per patch stage
   static constexpr int RING = 2 * PSTAGE + NRING * BSTAGE;
   static constexpr int LDS_HALVES = RING > EPI_HALVES ? RING : EPI_HALVES;
   static constexpr int NQ = TH == 8 ? 2 : 1;                   // 32-deep units of a K step a consumer runs
   static_assert(LDS_HALVES * 2 <= 160 * 1024, "LDS");
-  static_assert(PK % 2 == 0 && PK / 2 <= 7, "patch pieces are issued two per step in taps 0-6");
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -179,28 +179,47 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
       dma16(rw, bst0 + stage * BSTAGE + pw * 512, wbase[0] + koff);
       dma16(rw, bst0 + stage * BSTAGE + (pw + 4) * 512, wbase[1] + koff);
     };
-    // prologue: the patch of chunk 0 (the weights of steps 0-2 come from the consumers, which have nothing else to do yet: 14 back-to-back
-    // pieces per producer were 5 200 clocks of set-up, tools/w8_trace.py); all of it has landed before the first barrier
+    // prologue: the patch of chunk 0 and the weights of K steps 3-4 (those of steps 0-2 come from the consumers, which have nothing else to
+    // do yet: 14 back-to-back pieces per producer were 5 200 clocks of set-up, tools/w8_trace.py); all of it has landed before the first barrier
 #pragma unroll
     for (int k = 0; k < PK; ++k)
       if (k * 4 + pw < NPIECE) issue_patch_piece(0, k);
+    issue_b(0, 3, 3);
+    issue_b(0, 4, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // Step I: the weights of step I + 5 (ring stage (I + 5) % 6 = that of step I - 1, whose fragments were fetched during steps I - 2 / I - 1),
+    // during taps 0 .. NPT-1 PPS pieces of the next chunk's patch, then a COUNTED wait that leaves this step's and the previous step's
+    // pieces in flight: everything issued two or more steps ago has landed.  (The first version waited for everything but this step's
+    // pieces: a piece had ONE K step -- 450 clocks -- to arrive, less than a loaded L2 round trip and far less than the Infinity Cache / HBM
+    // latency of a layer's first touch of its weights; the 6-deep ring always had room for this.)  Step s's weights are issued in step
+    // s - 5, guaranteed by the wait of step s - 3 and first read in step s - 1; the patch pieces issued in taps <= 4 are guaranteed by
+    // the wait of tap 7, one barrier before their first read in tap 8.
+    constexpr int NPT = TH == 8 ? 5 : 4, PPS = TH == 8 ? 3 : 2;
+    static_assert(NPT * PPS >= PK && NPT <= 5, "patch pieces of a chunk are issued in taps 0-4");
+    int np_prev = 0;
 #define HD_M160_PSTEP(I)                                                                                                   \
     {                                                                                                                      \
-      constexpr int E = (I) + 3, TAP = (I) % 9;                                                                            \
+      constexpr int E = (I) + 5, TAP = (I) % 9;                                                                            \
       issue_b(2 * P + E / 9, E % 9, E % 6);                                                                                \
       int np = 0;                                                                                                          \
-      if (TAP < PK / 2) {                                                                                                  \
-        _Pragma("unroll") for (int k = 2 * TAP; k < 2 * TAP + 2; ++k)                                                      \
-          if (k * 4 + pw < NPIECE) {                                                                                       \
+      if (TAP < NPT) {                                                                                                     \
+        _Pragma("unroll") for (int k = PPS * TAP; k < PPS * TAP + PPS; ++k)                                                \
+          if (k < PK && k * 4 + pw < NPIECE) {                                                                             \
             issue_patch_piece(2 * P + (I) / 9 + 1, k);                                                                     \
             ++np;                                                                                                          \
           }                                                                                                                \
       }                                                                                                                    \
-      if (np == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                                        \
-      else if (np == 1) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                                   \
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                                                \
+      switch (4 + np + np_prev) {                                                                                          \
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;                                                    \
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;                                                    \
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;                                                    \
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;                                                    \
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;                                                    \
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;                                                    \
+        default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;                                                  \
+      }                                                                                                                    \
+      np_prev = np;                                                                                                        \
       __builtin_amdgcn_s_barrier();                                                                                        \
     }
     HD_M160_LOOP(HD_M160_PSTEP)
