@@ -284,6 +284,11 @@ static TileChoice choose_tile(const ConvP& p) {
     c.use64 = can64_ch && c.bn > 32;
     c.deep = blocks <= 256;
   }
+  // Round 6: the deep ring everywhere.  Rounds 3-5 chose the stage count per shape from WARM back-to-back timings (deep only at <= 1 block
+  // per CU); in STEP ORDER every layer's weights are a first touch from HBM / the Infinity Cache and the extra K tile in flight is worth more
+  // than the third co-resident block: same-box A/B of the whole step, two alternations, HD_CONV_DEEP=0 / rule / 1: 9.860 / 9.773 / 9.713 and
+  // 9.897 / 9.753 / 9.708 ms, detector_conv 4.06 / 3.97 / 3.89 ms.  (Four stages in the 64-deep family: 9.93 -- two blocks per CU are too few.)
+  c.deep = true;
   // experiment knobs: HD_CONV_BK in {0 auto, 32, 64}; HD_CONV_DEEP in {-1 auto, 0, 1}; hd_conv_tune_override
   if (g_ov_bn > 0) c.bn = g_ov_bn;
   if (g_ov_bm > 0) c.bm = g_ov_bm;
