@@ -263,10 +263,11 @@ static TileChoice choose_tile(const ConvP& p) {
   static const int force_bk = env_int("HD_CONV_BK", 0);
   static const int force_deep = env_int("HD_CONV_DEEP", -1);
   static const int old_rules = env_int("HD_CONV_OLD_RULES", 0);     // A/B knob for the rule set below
+  static const int k1_big = env_int("HD_CONV_K1_BIG", 1024), k1_bk64 = env_int("HD_CONV_K1_BK64", 256);     // A/B knobs of the 1x1 rule
   if (!old_rules && p.KH * p.KW == 1 && p.Cout > 64) {
     c.bn = 64;
-    c.bm = ((int64_t)hd_cdiv(p.M, 128) * hd_cdiv(p.Cout, 64) < 1024) ? 64 : 128;
-    c.use64 = can64_ch && p.Cin >= 256;
+    c.bm = ((int64_t)hd_cdiv(p.M, 128) * hd_cdiv(p.Cout, 64) < k1_big) ? 64 : 128;
+    c.use64 = can64_ch && p.Cin >= k1_bk64;
     c.deep = false;
   } else if (!old_rules && p.Cout > 64 && (int64_t)hd_cdiv(p.M, 64) * hd_cdiv(p.Cout, 128) <= 256) {
     c.bm = 64;

@@ -48,12 +48,17 @@ class _GraphedDetector(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_total):
         e = ctx.entry
-        # the graph differentiated loss * s with s = the loss scale at replay time; fit_step's scaler.scale(loss) passes that same
-        # s as grad_total, so the factor is exactly 1.0 there (and the product exact); any other caller gets the chain rule.
-        # Written straight into the static input of the U-Net's backward graphs when they exist (run_backward then skips its copy).
+        # the graph differentiated loss * s with s = the loss scale at replay time.  fit_step seeds the backward pass with the scaler's own
+        # scale tensor (LossScaler.backward): when that very tensor arrives and its value is the one the graph was replayed with, the
+        # factor is exactly 1.0 and the graph's image gradient IS the result -- no launch, and the U-Net's backward graphs read it in
+        # place (UnetRunner.adopt_static_dout).  Any other caller gets the chain rule.
+        sc = e.scaler
+        if sc is not None and sc.__dict__.get("_scale_t") is not None and grad_total.data_ptr() == sc._scale_t.data_ptr() \
+                and sc._scale_t_value == e.scale_value:
+            return e.dimg, None
         f = (grad_total * e.inv_scale).to(e.dimg.dtype)
         dst = e.unet_dout() if e.unet_dout is not None else None
-        if dst is not None and dst.shape == e.dimg.shape and dst.dtype == e.dimg.dtype:
+        if dst is not None and dst.shape == e.dimg.shape and dst.dtype == e.dimg.dtype and dst.data_ptr() != e.dimg.data_ptr():
             return torch.mul(e.dimg, f, out=dst), None
         return e.dimg * f, None
 
@@ -151,6 +156,8 @@ class DetectorStepGraph:
         e.scale = torch.ones((), dtype=torch.float32, device=dev)
         e.inv_scale = torch.ones((), dtype=torch.float32, device=dev)
         e.scale_value = None
+        e.scaler = lit.scaler
+        e.runner = runner
         return e
 
     def _capture(self, e):
@@ -194,6 +201,8 @@ class DetectorStepGraph:
         if self.pool is None:
             self.pool = g.pool()
         e.graph, e.total, e.dimg = g, total, dimg
+        if e.runner is not None:
+            e.runner.adopt_static_dout(dimg)      # the U-Net's backward graphs may take this buffer as their static input
         e.losses = {k: v for k, v in losses_det.items()}
         e.flag = flags[0] if flags else None
         e.det_pads = []

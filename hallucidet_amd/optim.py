@@ -127,6 +127,24 @@ class LossScaler:
         self.runner.grad_scale = self.scale_value
         return loss * self.scale_value
 
+    def scale_tensor(self, like):
+        """The current scale as a persistent 0-dim device tensor (rewritten only when the value changes)."""
+        t = self.__dict__.get("_scale_t")
+        if t is None or t.device != like.device or t.dtype != like.dtype:
+            t = self._scale_t = torch.empty((), dtype=like.dtype, device=like.device)
+            self._scale_t_value = None
+        if self._scale_t_value != self.scale_value:
+            t.fill_(self.scale_value)
+            self._scale_t_value = self.scale_value
+        return t
+
+    def backward(self, loss):
+        """`scale(loss).backward()` without its three launches (loss * scale, the ones_like seed, the seed * scale of MulBackward): the
+        backward pass is seeded with the scale itself, d(scale * loss) / d loss."""
+        self.resolve()
+        self.runner.grad_scale = self.scale_value
+        loss.backward(gradient=self.scale_tensor(loss))
+
     def step(self, optimizer, inv_scale=1.0):
         """Parameter gradients were already divided by the scale in-kernel; only inf/nan detection remains.  `inv_scale`: a factor
         the optimizer applies to every gradient element first (1 / world size of a data-parallel SUM exchange)."""

@@ -189,6 +189,10 @@ _EXCHANGE_BUCKETS = 2 if os.environ.get("HD_EXCHANGE_BUCKETS", "2") != "5" else 
 _WGRAD_MERGE = os.environ.get("HD_WGRAD_MERGE", "1") != "0"     # A/B knob: without an exchange hook, launch the deferred weight gradients of segments 0-2 / 3-4 together
 _WGRAD_DIRECT = os.environ.get("HD_WGRAD_DIRECT", "1") != "0"   # A/B knob: one-split weight gradients written as the OIHW gradient by the kernel
 _WGRAD_DEFER_BLOCKS = int(os.environ.get("HD_WGRAD_DEFER_BLOCKS", "0"))     # > 0: force that grid size (A/B); 0: simulated schedule
+# A/B knob: without an exchange hook the two deferred weight-gradient grids run on a SIDE stream (a parallel branch of the backward graph):
+# group 1 (decoder, layer4, layer3) beside the BatchNorm-backward / data-gradient chain of layer2 and layer1, group 2 beside the max-pool
+# and stem backward.  Same kernels, same operands, same results -- only the order in which the chip sees them changes.
+_WGRAD_SIDE = int(os.environ.get("HD_WGRAD_SIDE", "0"))      # 1: both groups, 2: group 1 only, 3: group 2 only
 _POOL2 = os.environ.get("HD_POOL2", "1") != "0"               # A/B knob: 2x2 sum-pool of the last decoder block's data gradient in its epilogue
 
 def _plan_wgrad_splits(geo, cus=256):
@@ -305,6 +309,9 @@ class UnetRunner:
         self._red = None
         self._wg_plan = None
         self._wg_ready = []
+        self._static_douts = []
+        self._wg_side = None           # side stream of the deferred weight gradients (_fork_wgrads)
+        self._wg_forked = []           # operands of forked launches: kept alive until _join_wgrads (no reuse of their memory before)
         enc, dec = module.encoder, module.decoder
         self.stem = _Unit("encoder.conv1", enc.conv1, enc.bn1)
         self.stages = []
@@ -446,7 +453,12 @@ class UnetRunner:
         per_segment = (hooked and _EXCHANGE_BUCKETS != 2) or not _WGRAD_MERGE
         act = per_segment or k in (2, 4)
         if self._wg_ready and act:
-            self._launch_wgrads()
+            if _WGRAD_SIDE in (1, 2) and not hooked and not per_segment and k == 2:
+                self._fork_wgrads()
+            else:
+                self._launch_wgrads()
+        if k == 4:
+            self._join_wgrads()
         if self._red is not None and (act or not hooked):
             self._red.flush()                   # the segment's gradients are final only after this launch
         if not hooked or (_EXCHANGE_BUCKETS == 2 and k not in (2, 4)):
@@ -456,6 +468,11 @@ class UnetRunner:
         else:
             self.bucket_hook(*self.bucket_ranges()[(0 if k == 2 else 1) if _EXCHANGE_BUCKETS == 2 else k])
 
+    def adopt_static_dout(self, t):
+        """`t` is a buffer some producer rewrites in place before every backward pass (the detector graph's image gradient): if the
+        gradient that arrives when the backward graphs are captured IS this buffer, they read it in place.  The list keeps it alive."""
+        self._static_douts = [u for u in self._static_douts if u.data_ptr() != t.data_ptr()][-7:] + [t]
+
     def run_backward(self, dout):
         if not self.use_graphs:
             return self.backward(dout.contiguous())
@@ -463,8 +480,12 @@ class UnetRunner:
         S = float(self.grad_scale)
         segmented = self.bucket_hook is not None
         if g["bwd"] is None or g["scale"] != S or g.get("segmented") != segmented:
-            g["dout"] = torch.empty(g["out"].shape, dtype=torch.float32, device=g["dev"])
-            g["dout"].copy_(dout)
+            adopted = [t for t in self._static_douts if t.data_ptr() == dout.data_ptr() and t.shape == g["out"].shape and t.dtype == torch.float32 and t.is_contiguous()]
+            if adopted:
+                g["dout"] = adopted[0]          # a producer's static output (det_graph.py): read in place, no copy per step
+            else:
+                g["dout"] = torch.empty(g["out"].shape, dtype=torch.float32, device=g["dev"])
+                g["dout"].copy_(dout)
             self.saved = g["saved"]
             g["bwd"] = None                 # a failed capture must not leave graphs of another (scale, segmentation) behind
             torch.cuda.synchronize()
@@ -755,6 +776,30 @@ class UnetRunner:
         cache[key] = plan
         return plan
 
+    def _fork_wgrads(self):
+        """The ready weight gradients (and the reduction of their slabs) on the side stream, behind everything the current stream has
+        been given so far; the current stream goes on with the next segment's chain.  Their operands stay referenced until the join, so
+        the allocator (eager or a graph's private pool) cannot hand their memory to a later tensor of the main chain."""
+        if not self._wg_ready:
+            return
+        main = torch.cuda.current_stream()
+        if self._wg_side is None:
+            self._wg_side = torch.cuda.Stream()
+        side = self._wg_side
+        self._wg_forked.append(list(self._wg_ready))
+        side.wait_stream(main)
+        red, self._red = self._red, (ops.WgradReduceBatch() if _WRED_MULTI else None)
+        with torch.cuda.stream(side):
+            self._launch_wgrads()
+            if self._red is not None:
+                self._red.flush()
+        self._red = red
+
+    def _join_wgrads(self):
+        if self._wg_forked:
+            torch.cuda.current_stream().wait_stream(self._wg_side)
+            self._wg_forked = []
+
     def _launch_wgrads(self):
         """The planned weight gradients as one grid per <= 24 layers, longest blocks first.  One pixel split: the kernel writes the scaled
         OIHW gradient itself (hd_wgrad_args.dw_oihw), no slab, no reduction."""
@@ -831,6 +876,8 @@ class UnetRunner:
             if si > 0:
                 self._segment_done(4 - si)     # layer4 -> 1, layer3 -> 2, layer2 -> 3
         # d_out = gradient of the max-pooled stem output
+        if _WGRAD_SIDE in (1, 3) and self._cut is None and self.bucket_hook is None and _WGRAD_MERGE:
+            self._fork_wgrads()                # layer2 + layer1 weight gradients beside the max-pool / stem backward
         df1 = ops.maxpool3x3s2_bwd_idx(sv["pool_idx"], d_out, (sv["f1"].shape[1], sv["f1"].shape[2]), add=dfeat[0])
         dx = None
         if need_dx:

@@ -22,6 +22,9 @@ from .utils.eval_forward_retinanet import eval_forward_retinanet_multi
 from .utils.eval_forward_fcos import eval_forward_fcos_multi
 
 
+_SEED_WITH_SCALE = os.environ.get("HD_SEED_WITH_SCALE", "1") != "0"     # A/B knob: LossScaler.backward (no scale / seed launches, image gradient read in place)
+
+
 class _WeightedLosses(torch.autograd.Function):
     """(weighted = stack(losses) * w, total = weighted.sum()) with a ONE-launch backward: d total / d loss_i = w_i, so the incoming
     gradients become one vector and the per-loss gradients are views of it.  Autograd's own backward of stack / mul / sum is seven
@@ -303,7 +306,10 @@ class EncoderDecoderLit(nn.Module):
         # rest of the backward pass; start() covers what no hook reported, finish() waits right before the optimizer
         r.bucket_hook = self.averager.bucket_ready if (is_dist() and self.overlap_allreduce) else None
         self.averager.begin(g)
-        self.scaler.scale(loss).backward()
+        if _SEED_WITH_SCALE:
+            self.scaler.backward(loss)
+        else:
+            self.scaler.scale(loss).backward()
         for d in (self._last_detections or {}).values():       # deferred detector post-processing: queue it behind the backward pass
             if hasattr(d, "flush"):
                 d.flush()

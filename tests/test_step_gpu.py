@@ -409,11 +409,10 @@ def test_eval_step_batch_one_full_size_matches_oracle(dev):
     for side, (sc, other_sc, lab, other_lab, m) in (("oracle->product", (os_, ps, ol, pl, iou)), ("product->oracle", (ps, os_, pl, ol, iou.t()))):
         conf = sc >= 0.1
         best, j = m.max(dim=1)
-        # scores agree to 2e-2, or -- on the slope of the softmax, where this test's x30 amplification of the class logits turns a 5e-3
-        # difference of the un-amplified logit into 0.03 of score -- to 0.2 in the amplified logit log(s / (1 - s)) (= 6.7e-3 un-amplified,
-        # the order of the 5e-3 relative bound on the classification loss above; measured 0.14 on one 0.756 / 0.729 detection)
-        lg = lambda t: torch.log(t.clamp(1e-6, 1 - 1e-6) / (1 - t.clamp(1e-6, 1 - 1e-6)))
-        close = ((other_sc[j] - sc).abs() <= 2e-2) | ((lg(other_sc[j]) - lg(sc)).abs() <= 0.2)
+        # scores agree to 2e-2.  This test amplifies the class logits x30, so on the slope of the softmax a 5e-3 difference of the
+        # un-amplified logit is 0.03 of score (seen once: 0.756 / 0.729): ONE such detection per direction is absorbed by the count budget
+        # below (the 5 % budget is zero when fewer than 20 detections are confident) instead of a wider score criterion
+        close = (other_sc[j] - sc).abs() <= 2e-2
         bad = conf & ~((best >= 0.9) & close & (other_lab[j] == lab))
         detail = [(round(float(sc[i]), 4), int(lab[i]), round(float(best[i]), 3), round(float(other_sc[j[i]]), 4), int(other_lab[j[i]])) for i in torch.nonzero(bad).flatten().tolist()]
-        assert int(bad.sum()) <= int(conf.sum()) // 20, (side, int(bad.sum()), int(conf.sum()), "(score, label, best IoU, matched score, matched label)", detail)
+        assert int(bad.sum()) <= max(1, int(conf.sum()) // 20), (side, int(bad.sum()), int(conf.sum()), "(score, label, best IoU, matched score, matched label)", detail)

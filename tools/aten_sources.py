@@ -18,9 +18,11 @@ if os.environ.get("UNET_GRAPHS", "1") == "0":        # also log the U-Net's own 
     lit.use_graphs = False
     lit.encoder_decoder.runner.enable_graphs(False)
 batch = synthetic.make_batch(int(os.environ.get("N", 8)), device="cuda")
-for _ in range(3):
-    lit.fit_step(batch)
-torch.cuda.synchronize()
+CAPTURE = os.environ.get("ATEN_CAPTURE", "0") == "1"     # HD_DET_GRAPH=1 ATEN_CAPTURE=1: log from the first step on -- the step that captures the
+if not CAPTURE:                                          # graphs logs what they hold, the steps after it log what is still issued eagerly
+    for _ in range(3):
+        lit.fit_step(batch)
+    torch.cuda.synchronize()
 SKIP = ("aten.view", "aten.reshape", "aten._unsafe_view", "aten.detach", "aten.slice", "aten.select", "aten.unsqueeze", "aten.squeeze", "aten.expand",
         "aten.permute", "aten.transpose", "aten.t.", "aten.alias", "aten.as_strided", "aten.split", "aten.unbind", "aten.empty", "aten.is_", "aten.sym_",
         "aten.stride", "aten.size", "aten.dim", "aten.numel", "aten.lift_fresh", "aten._local_scalar", "aten.unfold", "aten.narrow", "aten.chunk",
@@ -45,12 +47,18 @@ class Log(TorchDispatchMode):
 
 
 torch.autograd.set_multithreading_enabled(False)
-with Log():
-    lit.fit_step(batch)
-torch.cuda.synchronize()
-per_line = collections.defaultdict(list)
-for (where, name), n in log.items():
-    per_line[where].append((n, name))
-print("%d device-side ATen calls in one step, %d source lines" % (sum(log.values()), len(per_line)))
-for where, ops_ in sorted(per_line.items(), key=lambda kv: -sum(n for n, _ in kv[1])):
-    print("%4d  %-58s %s" % (sum(n for n, _ in ops_), where, " ".join("%s x%d" % (nm, n) for n, nm in sorted(ops_, reverse=True))[:150]))
+for step in range(4 if CAPTURE else 1):
+    log.clear()
+    with Log():
+        lit.fit_step(batch)
+    torch.cuda.synchronize()
+    if CAPTURE:
+        print("step %d: %d device-side ATen calls" % (step, sum(log.values())))
+        if step in (1, 2):
+            continue
+    per_line = collections.defaultdict(list)
+    for (where, name), n in log.items():
+        per_line[where].append((n, name))
+    print("%d device-side ATen calls in one step, %d source lines" % (sum(log.values()), len(per_line)))
+    for where, ops_ in sorted(per_line.items(), key=lambda kv: -sum(n for n, _ in kv[1])):
+        print("%4d  %-58s %s" % (sum(n for n, _ in ops_), where, " ".join("%s x%d" % (nm, n) for n, nm in sorted(ops_, reverse=True))[:150]))
