@@ -50,17 +50,24 @@
 
 namespace {
 
-constexpr int TW = 40, PW = TW + 2;
-constexpr int BMH = 4 * TW, BN = 64;                  // the epilogue's unit: 160 pixels x 64 channels
+constexpr int BN = 64;
 constexpr int BSTAGE = BN * 64;                       // halves per weight stage (8 KiB)
-constexpr int NRING = 6;
 constexpr int CP = BN + 4;
-constexpr int EPI_HALVES = 2 * BMH * CP * 2;
 
-template <int TH>
+// TW = 40: the U-Net maps (and every map the 40-pixel width covers well); TW = 24 (TH = 4 only: 96 pixels x 64 channels): the detector's
+// 19 x 19 maps, which a 40-wide tile covers to 47 % -- three 8-column blocks per row pair instead of five, same roles, same swizzle
+// (tools/search_swizzle_m160.py: slot ^ (x & 7) is conflict-free at the 26-pixel pitch too).
+template <int TH, int TW>
 struct M160 {
+  static constexpr int PW = TW + 2, NB = TW / 8;               // patch pitch in pixels; 8-column blocks per row pair
+  // weight ring: 6 stages (a compile-time stage per step of the 18-step period); the 24-wide tile takes 5 -- 2 x 20 KiB of patch + 5 x 8 KiB
+  // = 80 KiB: TWO blocks per CU (its consumers hold 12 accumulator blocks: 128 registers), each hiding the other's set-up and epilogue.
+  // Five does not divide the period, so there the ring stage is a run-time counter (one scalar add per step in either role).
+  static constexpr int NRING = TW == 24 ? 5 : 6;
+  static constexpr int BMH = 4 * TW;                           // the epilogue's unit: 4 tile rows x 64 channels
+  static constexpr int EPI_HALVES = 2 * BMH * CP * 2;
   static constexpr int PH = TH + 2;
-  static constexpr int PPX = PH * PW;                          // 252 / 420 patch pixels
+  static constexpr int PPX = PH * PW;                          // 252 / 420 patch pixels (TW = 40)
   static constexpr int NPIECE = (PPX * 8 + 63) / 64;           // 32 / 53 one-KiB pieces per patch chunk
   static constexpr int PK = (NPIECE + 3) / 4;                  // 8 / 14 pieces per producer wave and chunk
   static constexpr int PSTAGE = NPIECE * 512;                  // halves per patch stage
@@ -76,10 +83,13 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, f16* lds_dst, un
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_dst, 16, voff, 0, 0, 0);
 }
 
-template <int TH, bool DUAL>
+template <int TH, int TW, bool DUAL>
 __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in, int nwg_in) {
-  using G = M160<TH>;
-  constexpr int PPX = G::PPX, NPIECE = G::NPIECE, PK = G::PK, PSTAGE = G::PSTAGE, NQ = G::NQ;
+  using G = M160<TH, TW>;
+  constexpr int PPX = G::PPX, NPIECE = G::NPIECE, PK = G::PK, PSTAGE = G::PSTAGE, NQ = G::NQ, PW = G::PW, NB = G::NB, BMH = G::BMH;
+  constexpr int NRING = G::NRING, AHEAD = NRING - 1;          // a step's weights are issued AHEAD steps before its MFMAs
+  constexpr bool RT_RING = NRING != 6;
+  static_assert(!RT_RING || NQ == 1, "run-time ring stage: one 32-deep unit per consumer and step");
   f16* const patch0 = lds;
   f16* const bst0 = lds + 2 * PSTAGE;
 
@@ -110,9 +120,9 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
   const int wm = TH == 8 ? (wave & 3) : ((wave >> 1) & 1);   // tile rows 2 wm, 2 wm + 1
   const int wq = TH == 8 ? 0 : (wave & 1);                   // TH = 4: the 32-deep half of every K step this consumer multiplies
   const int fp = lane & 15;
-  f32x4 acc[5][4];
+  f32x4 acc[NB][4];
 #pragma unroll
-  for (int b = 0; b < 5; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[b][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -145,7 +155,7 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
     for (int k = 0; k < PK; ++k) {
       const int u = (k * 4 + pw) * 64 + lane;
       const int pp = u >> 3, slot = u & 7;
-      const int y = (pp * 1561) >> 16, x = pp - y * PW;       // pp / 42 (exact for pp < 1 000: tools/search_swizzle_m160.py checks it)
+      const int y = pp / PW, x = pp - y * PW;                 // (a constant divisor: multiply + shift)
       const int iy = ty0 - 1 + y, ix = tx0 - 1 + x;
       const bool v = (u < PPX * 8) && ((unsigned)iy < (unsigned)p.Hin) && ((unsigned)ix < (unsigned)p.Win);
       const unsigned cg16 = (unsigned)((slot ^ x) & 7) * 16u;
@@ -184,8 +194,8 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
 #pragma unroll
     for (int k = 0; k < PK; ++k)
       if (k * 4 + pw < NPIECE) issue_patch_piece(0, k);
-    issue_b(0, 3, 3);
-    issue_b(0, 4, 4);
+#pragma unroll
+    for (int t = 3; t < AHEAD; ++t) issue_b(0, t, t);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     // Step I: the weights of step I + 5 (ring stage (I + 5) % 6 = that of step I - 1, whose fragments were fetched during steps I - 2 / I - 1),
@@ -198,10 +208,16 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
     constexpr int NPT = TH == 8 ? 5 : 4, PPS = TH == 8 ? 3 : 2;
     static_assert(NPT * PPS >= PK && NPT <= 5, "patch pieces of a chunk are issued in taps 0-4");
     int np_prev = 0;
+    int pst = AHEAD;                           // (RT_RING) ring stage of the step whose weights are issued next
 #define HD_M160_PSTEP(I)                                                                                                   \
     {                                                                                                                      \
-      constexpr int E = (I) + 5, TAP = (I) % 9;                                                                            \
-      issue_b(2 * P + E / 9, E % 9, E % 6);                                                                                \
+      constexpr int E = (I) + AHEAD, TAP = (I) % 9;                                                                        \
+      if constexpr (RT_RING) {                                                                                             \
+        issue_b(2 * P + E / 9, E % 9, pst);                                                                                \
+        pst = pst + 1 == NRING ? 0 : pst + 1;                                                                              \
+      } else {                                                                                                             \
+        issue_b(2 * P + E / 9, E % 9, E % 6);                                                                              \
+      }                                                                                                                    \
       int np = 0;                                                                                                          \
       if (TAP < NPT) {                                                                                                     \
         _Pragma("unroll") for (int k = PPS * TAP; k < PPS * TAP + PPS; ++k)                                                \
@@ -241,29 +257,34 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
     }
     const unsigned tA = (unsigned)(2 * PSTAGE * 2 + fp * 128 + ((fks ^ (fp >> 1)) & 7) * 16);
     const char* lb = reinterpret_cast<const char*>(lds);
-    f16x8 af[2][4], bf[2][5];        // two register sets: the unit being multiplied and the one being fetched
+    f16x8 af[2][4], bf[2][NB];        // two register sets: the unit being multiplied and the one being fetched
+    int cst = 0;                      // (RT_RING) ring stage of the step whose fragments are fetched next
     // fragments of K step S (tap S % 9, patch stage (S / 9) & 1, ring stage S % 6), 32-deep half Q (TH = 8; TH = 4: the consumer's own) -> SET
 #define HD_M160_FETCH(SET, S, Q)                                                                                           \
     {                                                                                                                      \
-      constexpr int TAP_ = (S) % 9, KY_ = TAP_ / 3, KX_ = TAP_ % 3, PST_ = ((S) / 9) & 1, RST_ = (S) % 6;                   \
+      constexpr int TAP_ = (S) % 9, KY_ = TAP_ / 3, KX_ = TAP_ % 3, PST_ = ((S) / 9) & 1, RST_ = RT_RING ? 0 : (S) % 6;     \
       const unsigned tb_ = tB[KX_][PST_] ^ (unsigned)((Q) << 6);                                                           \
-      const unsigned ta_ = tA ^ (unsigned)((Q) << 6);                                                                      \
+      unsigned ta_ = tA ^ (unsigned)((Q) << 6);                                                                            \
+      if constexpr (RT_RING) {                                                                                             \
+        ta_ += (unsigned)(cst * BSTAGE * 2);                                                                               \
+        cst = cst + 1 == NRING ? 0 : cst + 1;                                                                              \
+      }                                                                                                                    \
       _Pragma("unroll") for (int c = 0; c < 4; ++c) af[SET][c] = *reinterpret_cast<const f16x8*>(lb + ta_ + RST_ * BSTAGE * 2 + c * 2048);   \
-      _Pragma("unroll") for (int b = 0; b < 5; ++b) bf[SET][b] = *reinterpret_cast<const f16x8*>(lb + tb_ + KY_ * PW * 128 + b * 1024);      \
+      _Pragma("unroll") for (int b = 0; b < NB; ++b) bf[SET][b] = *reinterpret_cast<const f16x8*>(lb + tb_ + KY_ * PW * 128 + b * 1024);      \
     }
 #define HD_M160_MFMA(SET)                                                                                                  \
-    _Pragma("unroll") for (int b = 0; b < 5; ++b)                                                                          \
+    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                                         \
       _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                        \
         acc[b][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[SET][c], bf[SET][b], acc[b][c], 0, 0, 0);
     // instruction order of one unit (9 fragment reads of the next unit + 20 MFMAs of this one, one scheduling region): MFMA, read, MFMA,
     // read ... -- issued back to back in front of the MFMAs the nine reads held the wave for 166 clocks (four consumers push 36 KB through
     // the LDS pipe at once) while its matrix pipe idled: 591 clocks per step for 320 of MFMA work (profiles/r06_w8_trace_m160_v3.txt)
 #define HD_M160_ORDER()                                                                                                    \
-    _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_) {                                                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4 + NB; ++i_) {                                                                \
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                                   \
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                                   \
     }                                                                                                                      \
-    __builtin_amdgcn_sched_group_barrier(0x008, 11, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NB - (4 + NB), 0);
     {
       // prologue: the weights of K steps 0-2 (the one time a consumer issues vector-memory instructions; same piece / slot map as the
       // producers' issue_b with this wave in the place of producer `wave`)
@@ -347,7 +368,7 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
   if constexpr (TH == 4) {
     if (consumer) {              // partial tile wq = this consumer's half of every K step
 #pragma unroll
-      for (int b = 0; b < 5; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int row = (wm * 2 + (fp >> 3)) * TW + b * 8 + (fp & 7);
@@ -360,7 +381,7 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
     // epilogue runs once over it (five row passes per thread, one BatchNorm row per block)
     if (consumer) {
 #pragma unroll
-      for (int b = 0; b < 5; ++b)
+      for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int row = (wm * 2 + (fp >> 3)) * TW + b * 8 + (fp & 7);
@@ -374,10 +395,10 @@ __device__ __forceinline__ void conv3x3_m160_body(ConvP& p, f16* lds, int bid_in
   HD_TRACE(7, hw_ids());
 }
 
-template <int TH, bool DUAL>
+template <int TH, bool DUAL, int TW = 40>
 __global__ __launch_bounds__(512, 2) void conv3x3_m160_kernel(ConvP p) {
-  __shared__ __attribute__((aligned(1024))) f16 lds[M160<TH>::LDS_HALVES];
-  conv3x3_m160_body<TH, DUAL>(p, lds, blockIdx.x, gridDim.x);
+  __shared__ __attribute__((aligned(1024))) f16 lds[M160<TH, TW>::LDS_HALVES];
+  conv3x3_m160_body<TH, TW, DUAL>(p, lds, blockIdx.x, gridDim.x);
 }
 
 }  // namespace
@@ -401,13 +422,16 @@ bool hd_conv_m160_pool2_ok(const ConvP& p) {
 }
 
 // BatchNorm partial-sum rows: one per block
-int hd_conv_m160_tiles(const ConvP& p, int th) { return p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, TW); }
+int hd_conv_m160_tiles(const ConvP& p, int th, int tw) { return p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, tw); }
 
-void hd_conv_launch_m160(ConvP& p, int th, hipStream_t s) {
-  p.gm = p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, TW);
+// (th, tw) in {(4, 40), (8, 40), (4, 24)}; the 24-wide tile takes single-source problems only
+void hd_conv_launch_m160(ConvP& p, int th, int tw, hipStream_t s) {
+  p.gm = p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, tw);
   p.gn = hd_cdiv(p.Cout, BN);
   dim3 grid(p.gm * p.gn);
-  if (th == 8) {
+  if (tw == 24) {
+    hipLaunchKernelGGL((conv3x3_m160_kernel<4, false, 24>), grid, dim3(512), 0, s, p);
+  } else if (th == 8) {
     if (p.x2) hipLaunchKernelGGL((conv3x3_m160_kernel<8, true>), grid, dim3(512), 0, s, p);
     else hipLaunchKernelGGL((conv3x3_m160_kernel<8, false>), grid, dim3(512), 0, s, p);
   } else {

@@ -216,11 +216,24 @@ static int choose_p8(const ConvP& p, bool allow_m160 = true) {
       const int64_t b64 = (int64_t)hd_cdiv((int64_t)nominal_batch * p.Ho * p.Wo, 64) * hd_cdiv(p.Cout, 64);
       best_t = (double)hd_cdiv(b64, 512) * (4000. + nk * 900.);              // 4-wave family, two 64 x 64 blocks per CU
     }
-    for (int v = 0; v < 2; ++v) {
-      const int th_ = v ? 8 : 4;
-      const int64_t tm = (int64_t)nominal_batch * hd_cdiv(p.Ho, th_) * hd_cdiv(p.Wo, 40);
+    // cfg 10: the 96-pixel tile (4 x 24: the detector's 19 x 19 / 10 x 10 / 5 x 5 maps, which the 40-wide tiles cover to 47 % and less); single-source
+    // problems only.  TWO blocks per CU (80 KiB of LDS, 116 registers): up to 256 blocks run alone (per-block stamps, tools/w8_trace.py CFGS=20:
+    // set-up + epilogue 6.6 k clocks, 350 per K step), more than that in co-resident pairs, 512 per round (11 k, 420 per step each: fitted to whole launches, tools/probe_m160.py -- a full chip of pairs clocks lower than the stamps of one launch say).
+    static const double m96_fixed[2] = {(double)env_int("HD_M96_FIXED", 6600), (double)env_int("HD_M96_FIXED2", 11000)};
+    static const double m96_step[2] = {(double)env_int("HD_M96_STEP", 350), (double)env_int("HD_M96_STEP2", 420)};
+    static const int m96_on = env_int("HD_CONV_M96", 1);
+    for (int v = 0; v < 3; ++v) {
+      if (v == 2 && (!m96_on || p.x2)) continue;
+      const int th_ = v == 1 ? 8 : 4, tw_ = v == 2 ? 24 : 40;
+      const int64_t tm = (int64_t)nominal_batch * hd_cdiv(p.Ho, th_) * hd_cdiv(p.Wo, tw_);
       const int64_t blocks = tm * hd_cdiv(p.Cout, 64);
-      const double t = (double)hd_cdiv(blocks, 256) * (m160_fixed[v] + nk * m160_step[v]);
+      double t;
+      if (v == 2) {
+        const int pair = blocks > 256;
+        t = (double)(pair ? hd_cdiv(blocks, 512) : 1) * (m96_fixed[pair] + nk * m96_step[pair]);
+      } else {
+        t = (double)hd_cdiv(blocks, 256) * (m160_fixed[v] + nk * m160_step[v]);
+      }
       if (t < best_t) {
         best_t = t;
         best = 8 + v;
@@ -238,12 +251,12 @@ struct TileChoice {
 
 // tuning hook of the 8-wave patch-staged family (tools/tune_w8.py): cfg -1 = cost model, -2 = never, -3 = cost model without the 160-pixel tile
 // (round 5's choice: A/B of conv3x3_m160.hip inside one process, tools/probe_m160.py), 10..13 = force that tile, 15..17 = force
-// the step-split main loop (TS) of tiles 11..13, 18 / 19 = force the 160- / 320-pixel x 64-channel tile (conv3x3_m160.hip)
+// the step-split main loop (TS) of tiles 11..13, 18 / 19 / 20 = force the 160- / 320- / 96-pixel x 64-channel tile (conv3x3_m160.hip)
 // wherever the family is eligible
 static int g_w8_cfg = -1;
 extern "C" int hd_conv_tune_w8(int cfg, int nslices) {
   (void)nslices;
-  HD_CHECK_ARG(cfg == -1 || cfg == -2 || cfg == -3 || (cfg >= 10 && cfg <= 13) || (cfg >= 15 && cfg <= 19), "hd_conv_tune_w8: cfg in {-1, -2, -3, 10..13, 15..19}");
+  HD_CHECK_ARG(cfg == -1 || cfg == -2 || cfg == -3 || (cfg >= 10 && cfg <= 13) || (cfg >= 15 && cfg <= 20), "hd_conv_tune_w8: cfg in {-1, -2, -3, 10..13, 15..20}");
   g_w8_cfg = cfg;
   return HD_OK;
 }
@@ -301,7 +314,7 @@ static TileChoice choose_tile(const ConvP& p) {
   if (g_ov_deep >= 0) c.deep = g_ov_deep != 0;
   c.p8cfg = -1;
   if (g_w8_cfg >= 10 && g_w8_cfg < 18 && hd_conv_p8_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
-  if (g_w8_cfg >= 18 && hd_conv_m160_eligible(p) && g_small_ok) c.p8cfg = g_w8_cfg - 10;
+  if (g_w8_cfg >= 18 && hd_conv_m160_eligible(p) && g_small_ok && !(g_w8_cfg == 20 && p.x2)) c.p8cfg = g_w8_cfg - 10;
   if ((g_w8_cfg == -1 || g_w8_cfg == -3) && g_small_ok && g_ov_bm < 0 && g_ov_bn < 0 && g_ov_bk < 0) c.p8cfg = choose_p8(p, g_w8_cfg == -1);
   return c;
 }
@@ -316,7 +329,7 @@ extern "C" int hd_conv2d_stats_rows(const hd_conv_args* a) {
   if (use_stem(p)) return hd_conv_stem_rows(p);
   if (use_cat(p)) return hd_conv_cat128to32_rows(p);
   const TileChoice c = choose_tile(p);
-  if (c.p8cfg >= 8) return hd_conv_m160_tiles(p, c.p8cfg == 9 ? 8 : 4);
+  if (c.p8cfg >= 8) return hd_conv_m160_tiles(p, c.p8cfg == 9 ? 8 : 4, c.p8cfg == 10 ? 24 : 40);
   if (c.p8cfg >= 0) return hd_conv_p8_tiles(p, c.p8cfg);
   return hd_cdiv(p.M, c.bm);
 }
@@ -488,7 +501,7 @@ extern "C" int hd_conv2d(const hd_conv_args* a, void* stream) {
     p.M = M_full;
   }
   if (c.p8cfg >= 8) {
-    hd_conv_launch_m160(p, c.p8cfg == 9 ? 8 : 4, s);
+    hd_conv_launch_m160(p, c.p8cfg == 9 ? 8 : 4, c.p8cfg == 10 ? 24 : 40, s);
   } else if (c.p8cfg >= 0) {
     hd_conv_launch_p8(p, c.p8cfg, s);
   } else if (use64) hd_conv_launch_bk64(p, bm, bn, deep, s);

@@ -110,7 +110,7 @@ W8_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 15, 16, 17, 18, 19])
+@pytest.mark.parametrize("cfg", [10, 11, 12, 13, 15, 16, 17, 18, 19, 20])
 def test_conv2d_eight_wave_families(dev, cfg):
     """Every tile of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip: cfg 10-13; 15-17 = the step-split main loop of 11-13, shipped
     for 13; 18 / 19 = the 160- / 320-pixel x 64-channel tiles of conv3x3_m160.hip on v_mfma_f32_16x16x32_f16, round 6), forced through hd_conv_tune_w8 wherever it is eligible (the other cases fall through to the 4-wave family), against the
@@ -207,6 +207,52 @@ def test_conv2d_160_pixel_tile_on_the_unet_maps(dev, case, cfg):
     assert torch.equal(got, again), "run-to-run identical"
 
 
+M96_CASES = [
+    # N, H, W, Cin, Cout, act, bias, res, mask   (3x3 / s1 / p1; the 4 x 24-pixel x 64-channel tile, cfg 20)
+    (3, 19, 19, 256, 256, 1, True, False, False),          # the detector's layer3 bottleneck conv2: ragged in both directions (19 = 4 * 4 + 3, 24 - 5)
+    (2, 19, 19, 256, 256, 0, False, True, True),           # its data gradient form: residual + ReLU mask
+    (2, 10, 10, 512, 512, 1, True, False, False),          # layer4: 8 chunks, 10 of 24 columns live
+    (1, 38, 38, 128, 136, 0, False, False, False),         # two column tiles (24 + 14), Cout not a multiple of 64
+    (1, 8, 48, 64, 128, 1, True, True, False),             # exact cover, one chunk only (prologue + tail)
+    (2, 5, 5, 192, 128, 0, False, False, False),           # the P6-sized map, 3 chunks (odd tail)
+]
+
+
+@pytest.mark.parametrize("case", M96_CASES)
+def test_conv2d_96_pixel_tile_on_the_detector_maps(dev, case):
+    """conv3x3_m160.hip's 4 x 24-pixel x 64-channel instance (cfg 20; three 8-column blocks per row pair, same producer / consumer roles and
+    swizzle) forced through hd_conv_tune_w8 on the detector's small maps: outputs, one BatchNorm row per block, every epilogue option against
+    the oracle, run-to-run identical."""
+    from hallucidet_amd import ops, _abi
+    lib = _abi.load()
+    N, H, W, Cin, Cout, act, use_bias, use_res, use_mask = case
+    x = rnd(N, H, W, Cin, seed=1)
+    w = rnd(Cout, 9 * Cin, scale=1.0 / math.sqrt(9 * Cin), seed=3)
+    bias = torch.randn(Cout, generator=torch.Generator().manual_seed(4)) if use_bias else None
+    res = rnd(N, H, W, Cout, seed=5) if use_res else None
+    mask = (torch.rand(N, H, W, Cout, generator=torch.Generator().manual_seed(6)) > 0.4).half() if use_mask else None
+    want, wstats = ok.conv2d_nhwc(x, w, 3, 3, bias=bias, res=res, pad=1, act=0)
+    if use_mask:
+        want = want * mask.float()
+        wstats = (want.half().float().sum(dim=(0, 1, 2)), (want.half().float() ** 2).sum(dim=(0, 1, 2)))
+    if act == 1:
+        want = want.clamp_min(0)
+    d = lambda t: None if t is None else t.to(dev)
+    try:
+        lib.hd_conv_tune_w8(20, 1)
+        got, stats = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), mask=d(mask), pad=1, act=act, want_stats=True)
+        again, _ = ops.conv2d(d(x), d(w), 3, 3, bias=d(bias), res=d(res), mask=d(mask), pad=1, act=act, want_stats=True)
+    finally:
+        lib.hd_conv_tune_w8(-1, 0)
+    torch.cuda.synchronize()
+    assert stats.shape[0] == N * ((H + 3) // 4) * ((W + 23) // 24), "not the 4 x 24-pixel tile (%d rows)" % stats.shape[0]
+    close(got, want.half())
+    s_ = stats.sum(dim=0).cpu()
+    assert torch.allclose(s_[0], wstats[0], rtol=2e-3, atol=2e-3 * (N * H * W) ** 0.5 + 1e-2)
+    assert torch.allclose(s_[1], wstats[1], rtol=3e-3, atol=1e-2)
+    assert torch.equal(got, again), "run-to-run identical"
+
+
 def test_conv_dispatcher_routes_the_unet_layers_to_the_160_and_320_pixel_tiles(dev):
     """The shipped rule at the training batch (hd_conv2d_stats_rows answers without launching: one BatchNorm row per block): ResNet-34
     layer3 (8 x 32 x 40 x 256) on 4 x 40-pixel tiles -- 64 x 4 = 256 blocks --, layer2 (8 x 64 x 80 x 128) on 8 x 40-pixel tiles -- 128 x 2 =
@@ -224,7 +270,7 @@ def test_conv_dispatcher_routes_the_unet_layers_to_the_160_and_320_pixel_tiles(d
     assert rows(1, 32, 40, 256, 256) in (1 * 2 * 5, 1 * 1 * 5)          # 16 x 8- or 32 x 8-pixel tiles
 
 
-@pytest.mark.parametrize("cfg", [18, 19])
+@pytest.mark.parametrize("cfg", [18, 19, 20])
 @pytest.mark.parametrize("case", [(1, 8, 40, 128, 128, 64), (2, 32, 40, 256, 256, 128), (1, 12, 80, 128, 64, 0), (1, 10, 44, 64, 128, 64)])
 def test_conv2d_160_pixel_tile_pooled_half_and_skip_half(dev, case, cfg):
     """out_pool2 on the 160- / 320-pixel tiles (forced through hd_conv_tune_w8(18 / 19): the shared epilogue's 2 x 2 sum with a 40-pixel
@@ -1691,7 +1737,7 @@ def test_batchnorm_backward_sums_from_the_data_gradient_epilogue(dev, use_z, res
     assert torch.allclose(a[2], b[2], rtol=1e-4, atol=1e-4 * float(b[2].abs().max())) and torch.allclose(a[3], b[3], rtol=1e-4, atol=1e-4 * float(b[3].abs().max()))
 
 
-@pytest.mark.parametrize("cfg", [18, 19])
+@pytest.mark.parametrize("cfg", [18, 19, 20])
 def test_batchnorm_backward_sums_on_ragged_160_pixel_tiles(dev, cfg):
     """The bs_* epilogue on maps the 40-pixel-wide tiles cover raggedly (3 x 19 x 21 and 2 x 10 x 10 on 256 channels, residual + ReLU mask from
     z): a thread's rows sit in different COLUMNS there, so a row inside the map can follow one outside it (a bug of the first version:
@@ -1714,8 +1760,8 @@ def test_batchnorm_backward_sums_on_ragged_160_pixel_tiles(dev, cfg):
             dz = ops.conv2d(dyv, wd, 3, 3, pad=1, res=r, bstat=bs)
         finally:
             lib.hd_conv_tune_w8(-1, 0)
-        th = 4 if cfg == 18 else 8
-        assert bs["part"] is not None and bs["part"].shape[0] == N * ((H + th - 1) // th) * ((W + 39) // 40)
+        th, tw = (8 if cfg == 19 else 4), (24 if cfg == 20 else 40)
+        assert bs["part"] is not None and bs["part"].shape[0] == N * ((H + th - 1) // th) * ((W + tw - 1) // tw)
         rows = 64
         part = torch.empty(rows, 2 * Cc, device=dev)
         ops.check(lib.hd_bn_bwd_reduce(ops.ptr(dz), ops.ptr(z_u), ops.ptr(y_u), ops.ptr(mean), ops.ptr(invstd), ops.ptr(gamma), ops.ptr(beta),

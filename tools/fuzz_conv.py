@@ -173,7 +173,7 @@ def run_w8_tiles(ops, c, gen):
     want = pre.clamp_min(0) if c["act"] == 1 else torch.sigmoid(pre) if c["act"] == 2 else pre
     msgs = []
     try:
-        for cfg in (10, 11, 12, 13, 15, 16, 17, 18, 19):          # 18 / 19: the 160- / 320-pixel x 64-channel tiles (conv3x3_m160.hip)
+        for cfg in (10, 11, 12, 13, 15, 16, 17, 18, 19, 20):      # 18 / 19 / 20: the 160- / 320- / 96-pixel x 64-channel tiles (conv3x3_m160.hip)
             lib.hd_conv_tune_w8(cfg, 1)
             got, stats = ops.conv2d(x, w, 3, 3, x2=x2, bias=bias, res=res, pad=1, up1=c["up1"], act=c["act"], want_stats=True)
             torch.cuda.synchronize()

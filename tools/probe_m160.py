@@ -89,8 +89,8 @@ for s, lst in groups.items():
     lib.hd_conv_tune_w8(-3, 1)
     o_old = call(x, w, KH, KW, kw)
     t_old = timed(lambda: call(x, w, KH, KW, kw))
-    o_new, t_new, t_320 = None, float("nan"), float("nan")
-    for cfg in (18, 19):
+    o_new, t_new, t_320, t_96 = None, float("nan"), float("nan"), float("nan")
+    for cfg in (18, 19, 20):
         lib.hd_conv_tune_w8(cfg, 1)
         try:
             o_c = call(x, w, KH, KW, kw)
@@ -99,6 +99,8 @@ for s, lst in groups.items():
             continue
         if cfg == 19:
             t_320 = t_c
+        if cfg == 20:
+            t_96 = t_c
         if o_new is None or t_c < t_new:
             o_new, t_new = o_c, t_c
     lib.hd_conv_tune_w8(-1, 1)
@@ -115,7 +117,7 @@ for s, lst in groups.items():
     tot["new"] += n * (t_new if t_new == t_new else t_old)
     tot["auto"] += n * t_auto
     tot["best"] += n * min(t_old, t_new if t_new == t_new else t_old)
-    print("%-78s %3d %8.1f %8.1f %8.1f  %.1e%s" % (str(s), n, t_old, t_new, t_auto, d, "  (320)" if t_new == t_320 else ""))
+    print("%-78s %3d %8.1f %8.1f %8.1f  %.1e%s" % (str(s), n, t_old, t_new, t_auto, d, "  (320)" if t_new == t_320 else ("  (96)" if t_new == t_96 else "")))
 lib.hd_conv_tune_w8(-1, 1)
 print("per step (us): round-5 choice %.0f | 160-pixel tile forced wherever eligible %.0f | shipped rule %.0f | per-signature best %.0f" % (
     tot["old"], tot["new"], tot["auto"], tot["best"]))

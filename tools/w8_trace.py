@@ -20,10 +20,13 @@ SHAPES = [   # name, N, H, W, Cin, Cout, KH, want_stats
     ("layer3 256->256 @32x40", 8, 32, 40, 256, 256, 3, True),
     ("layer2 128->128 @64x80", 8, 64, 80, 128, 128, 3, True),
     ("layer1 64->64 @128x160", 8, 128, 160, 64, 64, 3, True),
-]
+    ("det 256->256 @19x19 x24", 24, 19, 19, 256, 256, 3, False),
+    ("det 256->256 @19x19 x8", 8, 19, 19, 256, 256, 3, False),
+    ("det 512->512 @10x10 x24", 24, 10, 10, 512, 512, 3, False),
+][int(os.environ.get("SHAPE_LO", 0)):]
 CFGS = [int(v) for v in os.environ.get("CFGS", "10,11,12").split(",")]     # tiles of the patch-staged family (conv3x3_w8.hip)
 TILES = [(256, 128), (128, 128), (256, 64), (128, 64), (128, 256), (64, 128), (64, 256), None, None, None, (256, 128), (128, 128), (256, 64), (128, 64),
-         None, (128, 128), (256, 64), (128, 64), (160, 64), (320, 64)]        # 15..17: the step-split main loop (TS) of 11..13; 18 / 19: conv3x3_m160.hip
+         None, (128, 128), (256, 64), (128, 64), (160, 64), (320, 64), (96, 64)]        # 15..17: the step-split main loop (TS) of 11..13; 18 / 19 / 20: conv3x3_m160.hip
 med = lambda a: float(np.median(a))
 for name, N, H, W, Cin, Cout, KH, stats in SHAPES:
     x = torch.randn(N, H, W, Cin, device=dev, dtype=torch.float16)
