@@ -44,6 +44,9 @@
 //     COLUMN only and a block is 8 columns wide, so a lane's swizzle is the same for its five blocks and three tap rows: THREE address
 //     registers per consumer (tap column), everything else an instruction offset (block b: + b KiB, tap row: + ky * 5 376, stage).
 // LDS: TH = 4: 2 x 32 KiB patch + 6 x 8 KiB weights = 112 KiB; TH = 8: 2 x 53 KiB + 48 KiB = 154 KiB (epilogue tile 85 KiB): one block per CU.
+// The 4 x 24-pixel instance (TW = 24: the detector's 19 x 19 / 10 x 10 / 5 x 5 maps, ResNet-34 layer4): three 8-column blocks per row pair,
+// 2 x 20 KiB patch + FIVE 8-KiB weight stages = 80 KiB and 116 registers -> TWO blocks per CU; the ring stage is a run-time counter there
+// (s % 5, weights four steps ahead; five does not divide the 18-step table), everything else -- roles, hazards, swizzle -- as above.
 #include "hd_common.h"
 #include "conv_params.h"
 #include "conv_w8_epilogue.h"

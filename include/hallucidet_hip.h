@@ -135,7 +135,8 @@ int hd_conv7x7s2_dgrad_thin(const void* dy, const void* mask_z, const void* w16,
 int hd_conv_tune_override(int bm, int bn, int bk, int deep);
 /* tuning hook of the 8-wave patch-staged 3x3 family (conv3x3_w8.hip, conv3x3_m160.hip): cfg -1 = the built-in cost model, -2 = never,
  * -3 = the cost model without the 160-pixel tile, 10..13 = force tile {256x128, 128x128, 256x64, 128x64} wherever eligible, 15..17 = the
- * step-split main loop of 11..13, 18 = force the 160-pixel x 64-channel tile (4 x 40 pixels, v_mfma_f32_16x16x32_f16).  `nslices` is ignored (kept for the call's shape: the im2col 8-wave
+ * step-split main loop of 11..13, 18 / 19 / 20 = force the 160- / 320- / 96-pixel x 64-channel tile (4 x 40, 8 x 40, 4 x 24 pixels,
+ * v_mfma_f32_16x16x32_f16; 20: single-source problems).  `nslices` is ignored (kept for the call's shape: the im2col 8-wave
  * family with split-K that used it was measured no faster than the 4-wave kernels on any shape and removed in round 3). */
 int hd_conv_tune_w8(int cfg, int nslices);
 /* test / tuning hook of the same cost model: n > 0 evaluates it at batch n whatever the launch's batch (then image i of a batched launch is

@@ -256,7 +256,7 @@ def test_conv2d_96_pixel_tile_on_the_detector_maps(dev, case):
 def test_conv_dispatcher_routes_the_unet_layers_to_the_160_and_320_pixel_tiles(dev):
     """The shipped rule at the training batch (hd_conv2d_stats_rows answers without launching: one BatchNorm row per block): ResNet-34
     layer3 (8 x 32 x 40 x 256) on 4 x 40-pixel tiles -- 64 x 4 = 256 blocks --, layer2 (8 x 64 x 80 x 128) on 8 x 40-pixel tiles -- 128 x 2 =
-    256 blocks --, decoder block 0's conv1 likewise; a single image stays on the 8-pixel-wide tiles (fewer, cheaper blocks)."""
+    256 blocks --, decoder block 0's conv1 likewise; a single image goes to fewer, cheaper blocks; the detector's 19 x 19 maps to 4 x 24-pixel tiles."""
     import ctypes as C
     from hallucidet_amd import _abi
     lib = _abi.load()
@@ -267,7 +267,9 @@ def test_conv_dispatcher_routes_the_unet_layers_to_the_160_and_320_pixel_tiles(d
         return lib.hd_conv2d_stats_rows(C.byref(a))
     assert rows(8, 32, 40, 256, 256) == 8 * 8 * 1
     assert rows(8, 64, 80, 128, 128) == 8 * 8 * 2
-    assert rows(1, 32, 40, 256, 256) in (1 * 2 * 5, 1 * 1 * 5)          # 16 x 8- or 32 x 8-pixel tiles
+    assert rows(1, 32, 40, 256, 256) in (1 * 2 * 5, 1 * 1 * 5, 1 * 8 * 2)   # 16 x 8- or 32 x 8-pixel tiles, or the 4 x 24-pixel tile (64 blocks, two per CU)
+    assert rows(24, 19, 19, 256, 256) == 24 * 5 * 1                     # the detector's layer3 at batch 24: 4 x 24-pixel tiles, 480 blocks in co-resident pairs
+    assert rows(8, 19, 19, 256, 256) == 8 * 5 * 1
 
 
 @pytest.mark.parametrize("cfg", [18, 19, 20])
