@@ -100,6 +100,11 @@ class DetectorStepGraph:
     def _stage_targets(self, e, targets):
         """Real target lists -> the entry's static [M, G, 4] / [M, G] buffers (one concatenation + one gather each)."""
         dev = e.tb.device
+        # targets that are the very tensors staged last time, unmodified since (a resident batch re-used step after step), are not staged
+        # again -- the rule the image batches follow (step()); the references held in e.tsrc keep their storage from being recycled
+        sig = [(t["boxes"], t["boxes"]._version, t["labels"], t["labels"]._version) for t in targets]
+        if e.tsrc is not None and len(e.tsrc) == len(sig) and all(a[0] is b[0] and a[1] == b[1] and a[2] is b[2] and a[3] == b[3] for a, b in zip(e.tsrc, sig)):
+            return
         lens = tuple(int(t["boxes"].shape[0]) for t in targets)
         idx, live = self._stage_table(lens, e.G, dev)
         boxes = torch.cat([t["boxes"].to(torch.float32).reshape(-1, 4) for t in targets] + [e.zero_box], dim=0)
@@ -107,13 +112,16 @@ class DetectorStepGraph:
         torch.index_select(boxes, 0, idx, out=e.tb.view(-1, 4))
         torch.index_select(labels, 0, idx, out=e.tl.view(-1))
         e.live.copy_(live)
+        # the reference's degenerate-box flag (eval_forward_fasterrcnn.py:41-53) of these rows, once per staging: the graph reads it
+        e.deg.copy_(((e.tb[..., 2:] <= e.tb[..., :2]).any(dim=-1) & e.live).any().reshape(1))
+        e.tsrc = sig
 
     # -------------------------------------------------------------------------------------------------------- capture
     def _section(self, e, x):
         lit, N = self.lit, e.N
         # rows [0, N) = IR targets (hallucinated pass), [N, 2N) = RGB, [2N, 3N) = IR again: the order the fused evaluation
         # concatenates the passes in, so that its stacks of these rows are views (detection.stack_rows), not copies
-        t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i]} for i in range(3 * N)]
+        t = [{"boxes": e.tb[i], "labels": e.tl[i], "_rows": e.live[i], "_flag": e.deg} for i in range(3 * N)]
         t_ir, t_rgb, t_ir2 = t[:N], t[N:2 * N], t[2 * N:]
         ir3 = e.ir.expand(-1, e.x.shape[1], -1, -1) if e.ir.shape[1] == 1 and e.x.shape[1] != 1 else e.ir
         return lit._detector_section(x, e.rgb, ir3, t_rgb, t_ir, 'train', False, targets_ir_pass=t_ir2)
@@ -151,6 +159,8 @@ class DetectorStepGraph:
         e.tb = torch.zeros((3 * e.N, G, 4), dtype=torch.float32, device=dev)
         e.tl = torch.zeros((3 * e.N, G), dtype=torch.int64, device=dev)
         e.live = torch.zeros((3 * e.N, G), dtype=torch.bool, device=dev)
+        e.deg = torch.zeros((1,), dtype=torch.uint8, device=dev)
+        e.tsrc = None
         e.zero_box = torch.zeros((1, 4), dtype=torch.float32, device=dev)
         e.zero_label = torch.zeros((1,), dtype=torch.int64, device=dev)
         e.scale = torch.ones((), dtype=torch.float32, device=dev)

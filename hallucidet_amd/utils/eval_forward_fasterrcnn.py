@@ -25,6 +25,8 @@ def _degenerate_flag(targets):
     if targets and "_rows" in targets[0]:
         # staged targets (det_graph.py): every image carries the same number of rows, `_rows` marks the real ones (the rest is
         # zero padding, which must not trip the check)
+        if "_flag" in targets[0]:
+            return targets[0]["_flag"]          # computed when the rows were staged (det_graph.py)
         from ..models.detection import stack_rows
         allb = stack_rows([t["boxes"] for t in targets])
         live = stack_rows([t["_rows"] for t in targets])
