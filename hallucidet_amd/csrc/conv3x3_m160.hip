@@ -404,6 +404,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_m160_kernel(ConvP p) {
   conv3x3_m160_body<TH, TW, DUAL>(p, lds, blockIdx.x, gridDim.x);
 }
 
+// Several 96-pixel-tile problems in ONE grid (the pyramid levels of an FPN / RPN-head convolution: 19 x 19, 10 x 10, 5 x 5 maps are 64 - 480
+// blocks each, a fraction of the chip's 512 slots): blocks [first[i], first[i + 1]) run problem i exactly as its own launch would.
+__global__ __launch_bounds__(512, 2) void conv3x3_m96_multi_kernel(ConvMulti mp) {
+  __shared__ __attribute__((aligned(1024))) f16 lds[M160<4, 24>::LDS_HALVES];
+  int pi = 0;
+  for (int i = 1; i < mp.n; ++i)
+    if ((int)blockIdx.x >= mp.first[i]) pi = i;
+  ConvP p = mp.p[pi];
+  conv3x3_m160_body<4, 24, false>(p, lds, (int)blockIdx.x - mp.first[pi], mp.first[pi + 1] - mp.first[pi]);
+}
+
 }  // namespace
 
 // 3x3 / s1 / p1, same extent in and out, Cin % 64 == 0 (both sources of a decoder concat), NHWC f16 out, Cout % 8 == 0; an upsampled
@@ -426,6 +437,19 @@ bool hd_conv_m160_pool2_ok(const ConvP& p) {
 
 // BatchNorm partial-sum rows: one per block
 int hd_conv_m160_tiles(const ConvP& p, int th, int tw) { return p.N * hd_cdiv(p.Ho, th) * hd_cdiv(p.Wo, tw); }
+
+void hd_conv_launch_m96_multi(ConvMulti& mp, hipStream_t s) {
+  int total = 0;
+  for (int i = 0; i < mp.n; ++i) {
+    ConvP& p = mp.p[i];
+    p.gm = p.N * hd_cdiv(p.Ho, 4) * hd_cdiv(p.Wo, 24);
+    p.gn = hd_cdiv(p.Cout, BN);
+    mp.first[i] = total;
+    total += p.gm * p.gn;
+  }
+  mp.first[mp.n] = total;
+  hipLaunchKernelGGL(conv3x3_m96_multi_kernel, dim3(total), dim3(512), 0, s, mp);
+}
 
 // (th, tw) in {(4, 40), (8, 40), (4, 24)}; the 24-wide tile takes single-source problems only
 void hd_conv_launch_m160(ConvP& p, int th, int tw, hipStream_t s) {

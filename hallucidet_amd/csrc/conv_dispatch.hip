@@ -431,7 +431,36 @@ extern "C" int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream) {
       return HD_OK;
     }
   }
+  // Not one igemm grid: the members the tile model sends to the 96-pixel tile (conv3x3_m160.hip, cfg 10: the small pyramid levels) still share
+  // ONE grid -- the same blocks their own launches would run, bit for bit -- the others are launched one by one.  HD_CONV_M96_MULTI=0: off (A/B).
+  static const int m96_multi_on = env_int("HD_CONV_M96_MULTI", 1);
+  bool taken[HD_CONV_MULTI_MAX] = {};
+  if (multi_on && m96_multi_on && n >= 2 && n <= HD_CONV_MULTI_MAX && g_small_ok && g_w8_cfg < 0) {
+    static ConvMulti m96;
+    m96.n = 0;
+    for (int i = 0; i < n; ++i) {
+      ConvP& p = m96.p[m96.n];
+      int rc = fill_params(&args[i], p);
+      if (rc) return rc;
+      if (use_small(p) || use_c64(p) || use_stem(p) || use_c32(p) || use_cat(p) || choose_gemm8(p) || p.pool2 || p.x2) continue;
+      if (choose_tile(p).p8cfg != 10) continue;
+      HD_CHECK_ARG(!p.bs_y || bstat_kernel(p), "hd_conv2d_multi: bs_* on a problem whose kernel does not implement them");
+#ifdef HD_CONV_TRACE
+      p.trace = nullptr;
+      p.trace_tid = 0;
+#endif
+      taken[i] = true;
+      ++m96.n;
+    }
+    if (m96.n >= 2) {
+      hd_conv_launch_m96_multi(m96, (hipStream_t)stream);
+      HD_CHECK_LAUNCH();
+    } else {
+      for (int i = 0; i < n; ++i) taken[i] = false;
+    }
+  }
   for (int i = 0; i < n; ++i) {
+    if (taken[i]) continue;
     int rc = hd_conv2d(&args[i], stream);
     if (rc) return rc;
   }

@@ -166,6 +166,7 @@ bool hd_conv_m160_eligible(const ConvP& p);
 bool hd_conv_m160_pool2_ok(const ConvP& p);
 int hd_conv_m160_tiles(const ConvP& p, int th, int tw);
 void hd_conv_launch_m160(ConvP& p, int th, int tw, hipStream_t s);      // (th, tw) in {(4, 40), (8, 40), (4, 24)}
+void hd_conv_launch_m96_multi(ConvMulti& mp, hipStream_t s);              // several 4 x 24-pixel-tile problems in one grid
 // the same tile grid with the blocks of an 8-wave weight gradient behind it (one launch; conv3x3_w8.hip)
 void hd_conv_launch_p8_wgrad(ConvP& p, int cfg, const hd_wgrad_args* wa, hipStream_t s);
 // wgrad.hip: would hd_wgrad run this weight gradient in the 8-wave patch-staged kernel?

@@ -192,8 +192,9 @@ int hd_wgrad_tune_override(int tm);
 /* n independent hd_conv2d problems (an array of argument blocks) as ONE grid where they all run in the same 4-wave implicit-GEMM
  * variant, n separate launches otherwise: the same Conv2d applied per feature level -- torchvision FeaturePyramidNetwork inner_blocks /
  * layer_blocks, RPNHead.conv / cls_logits / bbox_pred, the RetinaNet / FCOS towers [EXT], called per level from
- * src/utils/eval_forward_*.py via model.backbone / model.rpn.head / model.head -- and their data gradients.  Results are bit-identical to
- * n hd_conv2d calls.  n <= 10 for the single grid. */
+ * src/utils/eval_forward_*.py via model.backbone / model.rpn.head / model.head -- and their data gradients.  Where that is not the case, the
+ * members the tile model sends to the 4 x 24-pixel tile (the small pyramid levels) still share one grid.  Results are bit-identical to
+ * n hd_conv2d calls.  n <= 10 for a single grid. */
 int hd_conv2d_multi(const hd_conv_args* args, int n, void* stream);
 
 /* The data gradient (an hd_conv2d over dY with the flipped weights) and the weight gradient of ONE layer -- the two consumers of the
