@@ -282,7 +282,7 @@ def conv_roofline(lit, batch, reps=5, peak=None):
             "traffic_provenance": "not collected for the fp32 mode" if f32_mode else _pmc_traffic()[1], "traffic_unit": "HBM bytes per launch (PMC)",
             "alg_bytes_per_launch": round(tot_by / max(n, 1)),
             "kernel": "hd_conv2d_f32: conv_f32_kernel (64 x 64 tiles, v_mfma_f32_32x32x2_f32: exact f32 products and sums; peak = the f32 matrix rate)" if f32_mode else
-                      "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + gemm_w8_kernel (8-wave 256-row GEMM tiles: box head) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + conv3x3_m160_kernel (160- / 320-pixel tiles, producer / consumer waves) + "
+                      "hd_conv2d: conv_igemm_kernel (4-wave implicit GEMM: conv / dgrad / FC) + gemm_w8_kernel (8-wave 256-row GEMM tiles: box head) + conv3x3_w8_kernel (8-wave patch-staged 3x3) + conv3x3_m160_kernel (160- / 320- / 96-pixel tiles, producer / consumer waves) + "
                       "conv3x3_c64_kernel / conv7x7s2_stem_kernel / conv3x3_cat128to32_kernel / conv3x3_c32to128_kernel (persistent, register-resident weights: "
                       "the 64 -> 64 channel 3x3 layers, the 7x7 stems, decoder block 3) + "
                       "conv3x3_small_kernel (16/32-channel 3x3 layers)", "launches_per_step": n,
