@@ -252,6 +252,7 @@ class _BackboneFn(torch.autograd.Function):
         outs, saved = bb._forward(x, save=True, n_active=n_active)
         ctx.bb, ctx.saved, ctx.n_active, ctx.n = bb, saved, n_active, x.shape[0]
         ctx.need_dx = x.requires_grad
+        ctx.xmeta = (tuple(x.shape), x.dtype, x.device)
         ctx.nout = len(outs)
         ctx.set_materialize_grads(False)          # unused levels arrive as None, not as zero-filled maps
         if n_active < x.shape[0] and _ACTIVE_VIEWS:
@@ -266,14 +267,29 @@ class _BackboneFn(torch.autograd.Function):
             grads = list(grads[ctx.nout:])
         else:
             grads = [None if g is None else g[:na] for g in grads]
-        dx = ctx.bb._backward(ctx.saved, grads, need_dx=ctx.need_dx)
+        # The gradient of the whole [n] batch with rows >= n_active zero: a buffer kept per (shape, n_active) and zeroed ONCE -- the
+        # stem's data gradient writes rows [0, n_active) in place every pass, nothing ever writes the others (was: a zero fill of the whole
+        # batch + a copy per pass).  Created outside stream capture only (a graph's warm-up passes do that).
+        full = None
+        if na < ctx.n and ctx.need_dx:
+            shape, dtype, dev = ctx.xmeta
+            pads = ctx.bb.__dict__.setdefault("_dx_pads", {})
+            key = (shape, dtype, str(dev), na)
+            full = pads.get(key)
+            if full is None and dtype == torch.float16 and not torch.cuda.is_current_stream_capturing():
+                if len(pads) >= 4:
+                    pads.pop(next(iter(pads)))
+                full = pads[key] = torch.zeros(shape, dtype=dtype, device=dev)
+        dx = ctx.bb._backward(ctx.saved, grads, need_dx=ctx.need_dx, dx_out=None if full is None else full[:na])
         ctx.saved = None
         if dx is None:
             return None, None, None, None
         if na < ctx.n:
-            full = torch.zeros((ctx.n,) + tuple(dx.shape[1:]), dtype=dx.dtype, device=dx.device)
-            full[:na] = dx
-            dx = full
+            if full is not None and dx.data_ptr() == full.data_ptr():
+                return full, None, None, None
+            pad = torch.zeros((ctx.n,) + tuple(dx.shape[1:]), dtype=dx.dtype, device=dx.device)
+            pad[:na] = dx
+            dx = pad
         return dx, None, None, None
 
 
@@ -361,7 +377,7 @@ class BackboneWithFPN(nn.Module):
                        p6=extra[0][:na] if self.p6p7 else None)
         return outs + extra, rec
 
-    def _backward(self, rec, grads, need_dx=True):
+    def _backward(self, rec, grads, need_dx=True, dx_out=None):
         P = self.pack()
         tp = self.train_params
         inv = 1.0 / self.grad_scale
@@ -444,7 +460,9 @@ class BackboneWithFPN(nn.Module):
             # the gradient handed to the hallucination network: sub-pixel form of the stem's data gradient, its ReLU backward in the staging
             if "wsub" not in e:
                 e["wsub"] = ops.stem_dgrad_weights(e["wf"], e["cin_p"])
-            return ops.conv7x7s2_dgrad_thin(ds_, e["wsub"], (x.shape[1], x.shape[2]), mask_z=rec["stem"])
+            if dx_out is not None and (tuple(dx_out.shape) != (ds_.shape[0], x.shape[1], x.shape[2], 8) or dx_out.dtype != torch.float16):
+                dx_out = None
+            return ops.conv7x7s2_dgrad_thin(ds_, e["wsub"], (x.shape[1], x.shape[2]), mask_z=rec["stem"], out=dx_out)
         ds_ = ops.relu_bwd(ds_, rec["stem"])
         return _dgrad(P["stem"], ds_, (x.shape[1], x.shape[2]))
 

@@ -214,14 +214,17 @@ def stem_dgrad_weights(wf, cin_p=8):
     return out.view(16, 1024).half().contiguous()
 
 
-def conv7x7s2_dgrad_thin(dy, w16, in_hw, mask_z=None):
-    """Data gradient of the ResNet stem convolution in sub-pixel form (hd_conv7x7s2_dgrad_thin): dy [N,Hl,Wl,64] f16 -> [N,H,W,8] f16."""
+def conv7x7s2_dgrad_thin(dy, w16, in_hw, mask_z=None, out=None):
+    """Data gradient of the ResNet stem convolution in sub-pixel form (hd_conv7x7s2_dgrad_thin): dy [N,Hl,Wl,64] f16 -> [N,H,W,8] f16
+    (`out`: written in place when given)."""
     _need_cuda(dy, w16, mask_z)
     N, Hl, Wl, C_ = dy.shape
     H, W = in_hw
     assert C_ == 64 and dy.dtype == torch.float16 and dy.is_contiguous() and w16.shape == (16, 1024) and w16.dtype == torch.float16
     assert mask_z is None or (mask_z.shape == dy.shape and mask_z.dtype == dy.dtype and mask_z.is_contiguous())
-    dx = torch.empty((N, H, W, 8), dtype=torch.float16, device=dy.device)
+    if out is not None:
+        assert out.shape == (N, H, W, 8) and out.dtype == torch.float16 and out.is_contiguous() and out.device == dy.device
+    dx = out if out is not None else torch.empty((N, H, W, 8), dtype=torch.float16, device=dy.device)
     check(_abi.load().hd_conv7x7s2_dgrad_thin(ptr(dy), ptr(mask_z), ptr(w16), ptr(dx), N, Hl, Wl, H, W, _stream()), "hd_conv7x7s2_dgrad_thin")
     return dx
 
