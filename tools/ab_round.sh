@@ -1,5 +1,7 @@
 # Same-box A/B of two checkouts (round 5 in ab_r5/, this tree), alternating processes; then the data-parallel code path at world size 1.
 #   bash tools/ab_round.sh   (on the GPU box, from the repo root)
+#   Needs a built checkout of the other round in ab_r5/ (git-ignored):  git worktree add ab_r5 74ba14c && (cd ab_r5 && python -c "import __graft_entry__ as g; g.build()")
+#   and remove it afterwards (git worktree remove ab_r5 --force): gpurun ships it to the box with the snapshot.
 cd /root/repo; export TMPDIR=/tmp; mkdir -p gpurun_out/ab
 line() { python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(sys.argv[2], d['value'], 'images/s', d['ms_per_step'], 'ms/step', 'frac', d.get('roofline',{}).get('frac'), 'p50', d.get('ms_per_step_p50'))" $1 "$2"; }
 for i in 1 2; do
