@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* running_mean, float* running_var, float momentum, float eps,
                                                           float* mean, float* invstd, float* scale, float* shift) {
-  __shared__ double red[2][64][4];
+  __shared__ double red[2][4][4];
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   double s1 = 0.0, s2 = 0.0;
@@ -59,16 +59,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
       s2 += (double)part[(size_t)r * 2 * C + C + c];
     }
   }
-  red[0][rl][cl] = s1;
-  red[1][rl][cl] = s2;
+  // 64 row lanes -> one value per channel: inside a wave (16 row lanes x 4 channels) by four xor-shuffles, then the four waves' values through
+  // LDS -- a fixed order (deterministic); the 64-step serial loop over red[][64][4] this replaces was ~0.5 us of a ~4 us dependent launch
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if ((threadIdx.x & 63) < 4) {
+    red[0][threadIdx.x >> 6][cl] = s1;
+    red[1][threadIdx.x >> 6][cl] = s2;
+  }
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  s1 = s2 = 0.0;
-#pragma unroll
-  for (int q = 0; q < 64; ++q) {
-    s1 += red[0][q][cl];
-    s2 += red[1][q][cl];
-  }
+  s1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  s2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   double m = s1 / count;
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float invM, float gscale, int accumulate,
                                                           float* dgamma, float* dbeta, float* __restrict__ coef) {
-  __shared__ float red[2][64][4];
+  __shared__ float red[2][4][4];
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   float s1 = 0.f, s2 = 0.f;
@@ -273,16 +278,19 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
       s2 += part[(size_t)r * 2 * C + C + c];
     }
   }
-  red[0][rl][cl] = s1;
-  red[1][rl][cl] = s2;
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) {          // (as in bn_finalize_kernel: wave-level xor-shuffles, then the four waves' values)
+    s1 += __shfl_xor(s1, o, 64);
+    s2 += __shfl_xor(s2, o, 64);
+  }
+  if ((threadIdx.x & 63) < 4) {
+    red[0][threadIdx.x >> 6][cl] = s1;
+    red[1][threadIdx.x >> 6][cl] = s2;
+  }
   __syncthreads();
   if (rl != 0 || c >= C) return;
-  float sg = 0.f, sgx = 0.f;
-#pragma unroll
-  for (int q = 0; q < 64; ++q) {
-    sg += red[0][q][cl];
-    sgx += red[1][q][cl];
-  }
+  const float sg = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+  const float sgx = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   const float dg = sgx * gscale, db = sg * gscale;
   if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
