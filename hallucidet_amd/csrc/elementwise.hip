@@ -44,6 +44,17 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   double s1 = 0.0, s2 = 0.0;
+  // the four threads that finish a channel ask for its parameters NOW, beside the row loads: read behind the reduction they were a second
+  // dependent memory round trip (cold in step order: last touched by the previous step's optimizer) in a launch that is two round trips long
+  float g = 1.f, b = 0.f, rm_old = 0.f, rv_old = 0.f;
+  if (rl == 0 && c < C) {
+    if (gamma) g = gamma[c];
+    if (beta) b = beta[c];
+    if (running_mean) {
+      rm_old = running_mean[c];
+      rv_old = running_var[c];
+    }
+  }
   if (c < C) {
     int r = rl;
     for (; r + 192 < rows; r += 256) {           // four loads of each kind in flight
@@ -78,15 +89,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   double var = s2 / count - m * m;
   if (var < 0.0) var = 0.0;
   float is = (float)(1.0 / sqrt(var + (double)eps));
-  float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
   if (mean) mean[c] = (float)m;
   if (invstd) invstd[c] = is;
   scale[c] = g * is;
   shift[c] = b - (float)m * g * is;
   if (running_mean) {
     double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    running_mean[c] = (1.f - momentum) * rm_old + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * rv_old + momentum * (float)unbiased;
   }
 }
 
@@ -263,6 +273,18 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
   const int cl = threadIdx.x & 3, rl = threadIdx.x >> 2;
   const int c = blockIdx.x * 4 + cl;
   float s1 = 0.f, s2 = 0.f;
+  // (as in bn_finalize_kernel: the finishing threads' per-channel loads are issued beside the row loads)
+  float ga = 1.f, be = 0.f, is = 0.f, mu = 0.f, dg_old = 0.f, db_old = 0.f;
+  if (rl == 0 && c < C) {
+    if (gamma) ga = gamma[c];
+    if (beta) be = beta[c];
+    is = invstd[c];
+    mu = mean[c];
+    if (accumulate) {
+      if (dgamma) dg_old = dgamma[c];
+      if (dbeta) db_old = dbeta[c];
+    }
+  }
   if (c < C) {
     int r = rl;
     for (; r + 192 < rows; r += 256) {
@@ -292,9 +314,8 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const float* __restric
   const float sg = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
   const float sgx = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
   const float dg = sgx * gscale, db = sg * gscale;
-  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
-  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
-  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f, is = invstd[c], mu = mean[c];
+  if (dgamma) dgamma[c] = accumulate ? dg_old + dg : dg;
+  if (dbeta) dbeta[c] = accumulate ? db_old + db : db;
   const float a_ = ga * is;
   const float b_ = -a_ * is * sgx * invM;
   coef[c] = a_;
