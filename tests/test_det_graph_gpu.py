@@ -128,6 +128,44 @@ def test_degenerate_box_still_raises_one_call_later():
         flush_degenerate(lit.detector, block=True)
 
 
+def test_unchanged_batches_are_not_staged_again_and_changed_ones_are():
+    """Round 6: a batch that IS the tensors staged last time (same objects, same version counters) is neither copied into the graphs'
+    static inputs nor re-staged; an in-place edit of an image or of a target box, or a new tensor, is picked up by the next step."""
+    from hallucidet_amd import synthetic
+    lit = _lit("fasterrcnn")
+    b = synthetic.make_batch(2, H, W, seed=9, device="cuda")
+
+    def total(batch):
+        lit.encoder_decoder.train()
+        torch.manual_seed(123)
+        out = lit.forward_step(batch[0], batch[1], batch[2], batch[3], 0, step='train')
+        torch.cuda.synchronize()
+        return float(out['loss']['total'].detach())
+
+    total(b)                                   # capture
+    base = total(b)
+    g = lit._detector_graph()
+    e = next(iter(g.entries.values()))
+    assert e.tsrc is not None and all(s[0] is t["boxes"] for s, t in zip(e.tsrc, list(b[3]) + list(b[1]) + list(b[3])))
+    assert total(b) == base                    # a replay on resident inputs: nothing staged, same seeded draws, same loss
+    # an in-place edit of a target box bumps its version counter: staged again
+    b[3][0]["boxes"][0, 2:] += 9.0
+    moved = total(b)
+    assert moved != base
+    b[3][0]["boxes"][0, 2:] -= 9.0
+    assert total(b) == base
+    # an in-place edit of the IR images: copied again into the U-Net graph's static input
+    b[2].mul_(0.5)
+    dimmed = total(b)
+    assert dimmed != base
+    b[2].mul_(2.0)
+    assert total(b) == base
+    # new tensors with the same content: staged, same result
+    b2 = (b[0].clone(), [dict(boxes=t["boxes"].clone(), labels=t["labels"].clone()) for t in b[1]], b[2].clone(),
+          [dict(boxes=t["boxes"].clone(), labels=t["labels"].clone()) for t in b[3]])
+    assert total(b2) == base
+
+
 def test_image_without_boxes_and_a_smaller_last_batch():
     """An image with NO ground-truth boxes (all its staged rows are padding) and a last batch of another size (its own graph): the
     replayed losses equal the eagerly issued ones on the same staged targets, bit for bit."""

@@ -246,3 +246,25 @@ def test_bench_rank_validation_through_the_launcher(tmp_path):
     # (3) a rank outside the world
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=dict(env, WORLD_SIZE="2", RANK="2", LOCAL_RANK="2"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "outside WORLD_SIZE=2" in r.stderr
+
+
+def test_loss_scaler_backward_seeds_with_the_scale():
+    """LossScaler.backward(loss) == scale(loss).backward(): the backward pass seeded with the scale itself (round 6: no loss * scale,
+    ones_like, MulBackward launches); the persistent scale tensor follows the scale value."""
+    from hallucidet_amd.optim import LossScaler, ParamArena
+    torch.manual_seed(0)
+    net = torch.nn.Linear(5, 3)
+    arena = ParamArena(net.parameters())
+    scaler = LossScaler(arena, init_scale=512.0)
+    x = torch.randn(4, 5)
+    loss = net(x).square().mean()
+    scaler.scale(loss).backward()
+    want = arena._gflat.clone()
+    arena._gflat.zero_()
+    loss = net(x).square().mean()
+    scaler.backward(loss)
+    assert torch.equal(arena._gflat, want) and arena.grad_scale == 512.0
+    t = scaler.scale_tensor(loss)
+    assert float(t) == 512.0 and scaler.scale_tensor(loss) is t
+    scaler.scale_value = 256.0
+    assert float(scaler.scale_tensor(loss)) == 256.0
