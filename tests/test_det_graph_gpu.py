@@ -149,10 +149,11 @@ def test_unchanged_batches_are_not_staged_again_and_changed_ones_are():
     assert e.tsrc is not None and all(s[0] is t["boxes"] for s, t in zip(e.tsrc, list(b[3]) + list(b[1]) + list(b[3])))
     assert total(b) == base                    # a replay on resident inputs: nothing staged, same seeded draws, same loss
     # an in-place edit of a target box bumps its version counter: staged again
+    keep = b[3][0]["boxes"].clone()
     b[3][0]["boxes"][0, 2:] += 9.0
     moved = total(b)
     assert moved != base
-    b[3][0]["boxes"][0, 2:] -= 9.0
+    b[3][0]["boxes"].copy_(keep)               # (restored exactly: x + 9 - 9 need not be x in fp32)
     assert total(b) == base
     # an in-place edit of the IR images: copied again into the U-Net graph's static input
     b[2].mul_(0.5)
